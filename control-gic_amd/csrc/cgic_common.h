@@ -1,0 +1,99 @@
+// cgic_common.h -- shared host/device helpers of libcgic_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/cgic_hip.h"
+
+namespace cgic {
+
+constexpr int kWave = 64;  // gfx950 wavefront width
+
+// ---- host-side error plumbing ------------------------------------------------
+void set_error(const char *fmt, ...);
+int hip_fail(hipError_t e, const char *what, const char *file, int line);
+
+#define CGIC_HIP_TRY(expr)                                                      \
+    do {                                                                        \
+        hipError_t _e = (expr);                                                 \
+        if (_e != hipSuccess) return ::cgic::hip_fail(_e, #expr, __FILE__, __LINE__); \
+    } while (0)
+
+#define CGIC_REQUIRE(cond, code, ...)                                           \
+    do {                                                                        \
+        if (!(cond)) {                                                          \
+            ::cgic::set_error(__VA_ARGS__);                                     \
+            return (code);                                                      \
+        }                                                                       \
+    } while (0)
+
+inline int launch_check(const char *kernel)
+{
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        set_error("launch of %s failed: %s", kernel, hipGetErrorString(e));
+        return CGIC_ERR_HIP;
+    }
+    return CGIC_OK;
+}
+
+// ---- device-side table view ----------------------------------------------------
+struct TableDev {
+    const int32_t *len;    // [n] code length in bits
+    const uint32_t *code;  // [n * words] MSB-first code words
+    const uint32_t *lut;   // [1 << lut_bits] decode LUT (see cgic_table.hip)
+    const int32_t *child;  // [2 * nodes] decode trie: >=0 node id, <0 = ~symbol
+    int n;
+    int words;
+    int max_len;
+    int lut_bits;
+};
+
+struct Table;  // host object behind cgic_table
+int table_device_view(const cgic_table *t, TableDev *out);  // uploads lazily
+
+#if defined(__HIPCC__)
+// ---- wave / block primitives ---------------------------------------------------
+__device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & (kWave - 1)); }
+
+// inclusive scan across the 64 lanes of a wave (Hillis-Steele over DPP-able shuffles)
+template <typename T>
+__device__ __forceinline__ T wave_inclusive_scan(T v)
+{
+    const int lane = lane_id();
+#pragma unroll
+    for (int d = 1; d < kWave; d <<= 1) {
+        T o = __shfl_up(v, d, kWave);
+        if (lane >= d) v += o;
+    }
+    return v;
+}
+
+// Block-wide exclusive scan of one value per thread (blockDim.x multiple of 64,
+// <= 1024).  `smem` needs blockDim.x/64 + 1 elements.  Returns the exclusive
+// prefix; *total receives the block total.  Contains two __syncthreads().
+template <typename T>
+__device__ __forceinline__ T block_exclusive_scan(T v, T *smem, T *total)
+{
+    const int lane = lane_id();
+    const int wid = (int)(threadIdx.x >> 6);
+    const int nw = (int)(blockDim.x >> 6);
+    T inc = wave_inclusive_scan(v);
+    if (lane == kWave - 1) smem[wid] = inc;
+    __syncthreads();
+    if (wid == 0) {
+        T w = lane < nw ? smem[lane] : T(0);
+        T winc = wave_inclusive_scan(w);
+        if (lane < nw) smem[lane] = winc - w;  // exclusive offset of each wave
+        if (lane == nw - 1) smem[nw] = winc;
+    }
+    __syncthreads();
+    T res = smem[wid] + (inc - v);
+    *total = smem[nw];
+    return res;
+}
+#endif
+
+}  // namespace cgic

@@ -1,0 +1,177 @@
+// cgic_entropy.hip -- per-patch soft-histogram Shannon entropy maps for patch
+// sizes 8 and 16 in ONE pass over the image (reference: Entropy,
+// CGIC/models/model.py:433-483; CGIC.encode runs it twice, model.py:100-101,
+// each time materialising a [patches, p*p, 32] fp32 temp).
+//
+// Layout: a 256-thread block owns a 16-row x 64-column strip of one image =
+// four 16x16 patches side by side; each wave owns one of them.  The strip is
+// read once with coalesced float4 loads (256 B per row per channel), turned
+// into gray in registers and parked in LDS.  Per 8x8 sub-patch a wave does
+// lane = pixel: only the bins within +-2 of the pixel's own bin can be non-zero
+// in fp32 (exp underflows to exactly 0 beyond 14.42 sigma = 2.24 bin widths,
+// in the reference too), so 5 exps per pixel instead of 32; the 64x32 kernel
+// values are deposited in a wave-private LDS tile and summed per bin in a
+// fixed order (lane = bin) -- deterministic, no float atomics.  The four 8x8
+// sums accumulate into the 16x16 patch's histogram.
+//
+// fp32 throughout, denormals kept (epsilon = 1e-40 is an fp32 denormal,
+// model.py:451).  exp/log are OCML's => agrees with the CPU reference to ~1e-6.
+#include "cgic_common.h"
+
+namespace cgic {
+
+constexpr int kEntThreads = 256;
+constexpr int kBins = 32;
+constexpr int kTileStride = 68;  // 64 pixels + 4 pad dwords: conflict-free b128 column reads
+
+struct BinsArg { float v[kBins]; };   // passed by value in the kernarg segment
+
+__device__ __forceinline__ float bfly_sum32(float v)
+{
+    // butterfly over the 32 bins held by lanes {0..31} (and, mirrored, {32..63});
+    // every lane ends with the same total, summed in the same order
+#pragma unroll
+    for (int off = 1; off < 32; off <<= 1) v += __shfl_xor(v, off, kWave);
+    return v;
+}
+
+// entropy of one histogram: lane (b = lane&31) holds sum over pixels of bin b
+__device__ __forceinline__ float patch_entropy(float s, float npix)
+{
+    const float eps = 1e-40f;
+    float pdf = s / npix;                       // torch.mean over pixels      (:456)
+    float norm = bfly_sum32(pdf) + eps;         // sum over bins + epsilon     (:457)
+    pdf = pdf / norm + eps;                     //                             (:458)
+    float t = pdf * logf(pdf);
+    return -bfly_sum32(t);                      //                             (:459)
+}
+
+__global__ __launch_bounds__(kEntThreads) void entropy_maps_kernel(
+    const float *__restrict__ x, int64_t H, int64_t W, float sigma, float *__restrict__ e8,
+    float *__restrict__ e16, BinsArg bins_arg)
+{
+    __shared__ __attribute__((aligned(16))) float gray[16][64 + 4];
+    __shared__ __attribute__((aligned(16))) float tile[4][kBins * kTileStride];
+    __shared__ float bins[kBins];
+
+    const int64_t b = blockIdx.z;
+    const int64_t row0 = (int64_t)blockIdx.y * 16;
+    const int64_t col0 = (int64_t)blockIdx.x * 64;
+    const int tid = threadIdx.x;
+    const int lane = lane_id();
+    const int wave = tid >> 6;
+
+    if (tid < kBins) bins[tid] = bins_arg.v[tid];
+    for (int i = tid; i < 4 * kBins * kTileStride; i += kEntThreads) (&tile[0][0])[i] = 0.f;
+
+    // ---- load 16 x 64 pixels, gray = 0.2989 R + 0.5870 G + 0.1140 B  (:471)
+    {
+        const int r = tid >> 4;          // 0..15
+        const int c4 = (tid & 15) * 4;   // 0..60
+        const int64_t col = col0 + c4;
+        float4 g4 = {0.f, 0.f, 0.f, 0.f};
+        if (col < W) {   // W % 16 == 0 => a float4 is entirely inside or outside
+            const int64_t plane = H * W;
+            const float *p = x + (b * 3) * plane + (row0 + r) * W + col;
+            float4 R = *reinterpret_cast<const float4 *>(p);
+            float4 G = *reinterpret_cast<const float4 *>(p + plane);
+            float4 Bl = *reinterpret_cast<const float4 *>(p + 2 * plane);
+            g4.x = (0.2989f * R.x + 0.5870f * G.x) + 0.1140f * Bl.x;
+            g4.y = (0.2989f * R.y + 0.5870f * G.y) + 0.1140f * Bl.y;
+            g4.z = (0.2989f * R.z + 0.5870f * G.z) + 0.1140f * Bl.z;
+            g4.w = (0.2989f * R.w + 0.5870f * G.w) + 0.1140f * Bl.w;
+        }
+        *reinterpret_cast<float4 *>(&gray[r][c4]) = g4;
+    }
+    __syncthreads();
+
+    if (col0 + wave * 16 >= W) return;   // this wave's 16x16 patch is outside the image (whole wave)
+
+    float *T = tile[wave];
+    const int bin = lane & 31;
+    const int half = lane >> 5;
+    const float bin0 = bins[0];
+    const float inv_step = 15.5f;        // (nbins-1)/2 bins per unit; only picks the candidate window
+    float s16 = 0.f;
+
+#pragma unroll 1
+    for (int sp = 0; sp < 4; ++sp) {     // 8x8 sub-patches, row-major: (0,0) (0,1) (1,0) (1,1)
+        const int sy = sp >> 1, sx = sp & 1;
+        // lane = pixel (row-major inside the 8x8 patch, like nn.Unfold)
+        const int py = lane >> 3, px = lane & 7;
+        const float gv = gray[sy * 8 + py][wave * 16 + sx * 8 + px];
+        // candidate window: nearest bin +-2 covers every fp32-nonzero kernel value
+        float fc = rintf((gv - bin0) * inv_step);
+        fc = fminf(fmaxf(fc, 0.f), 31.f);
+        int jc = (gv == gv) ? (int)fc : 0;
+        int jlo = jc - 2 < 0 ? 0 : jc - 2;
+        jlo = jlo > kBins - 5 ? kBins - 5 : jlo;
+#pragma unroll
+        for (int q = 0; q < 5; ++q) {
+            const int jb = jlo + q;
+            float res = gv - bins[jb];                   // residuals          (:453)
+            float t = res / sigma;
+            float kv = expf(-0.5f * (t * t));            // kernel_values      (:454)
+            T[jb * kTileStride + lane] = kv;
+        }
+        __builtin_amdgcn_wave_barrier();
+        // lane = (bin, half): sum 32 pixels in order, then the two halves
+        float s = 0.f;
+        const float4 *row = reinterpret_cast<const float4 *>(&T[bin * kTileStride + half * 32]);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            float4 v = row[q];
+            s += v.x; s += v.y; s += v.z; s += v.w;
+        }
+        s += __shfl_xor(s, 32, kWave);
+        __builtin_amdgcn_wave_barrier();
+        // clear what this pixel deposited, ready for the next sub-patch
+#pragma unroll
+        for (int q = 0; q < 5; ++q) T[(jlo + q) * kTileStride + lane] = 0.f;
+        s16 += s;
+        if (e8) {
+            float ent = patch_entropy(s, 64.f);
+            if (lane == 0) {
+                const int64_t h8 = H / 8, w8 = W / 8;
+                e8[(b * h8 + (row0 / 8 + sy)) * w8 + (col0 / 8 + wave * 2 + sx)] = ent;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    if (e16) {
+        float ent = patch_entropy(s16, 256.f);
+        if (lane == 0) {
+            const int64_t h16 = H / 16, w16 = W / 16;
+            e16[(b * h16 + row0 / 16) * w16 + (col0 / 16 + wave)] = ent;
+        }
+    }
+}
+
+}  // namespace cgic
+
+using namespace cgic;
+
+extern "C" int cgic_entropy_maps_f32(const float *x, int64_t B, int64_t H, int64_t W, const float *bins,
+                                     int nbins, float sigma, float *e8, float *e16, cgic_stream_t stream)
+{
+    CGIC_REQUIRE(x && bins, CGIC_ERR_INVALID, "entropy: x and bins must not be NULL");
+    CGIC_REQUIRE(nbins == kBins, CGIC_ERR_UNSUPPORTED, "entropy: nbins=%d; the reference uses 32 (model.py:480)", nbins);
+    CGIC_REQUIRE(B >= 0 && H > 0 && W > 0 && H % 16 == 0 && W % 16 == 0, CGIC_ERR_INVALID,
+                 "entropy: H=%lld W=%lld must be positive multiples of 16", (long long)H, (long long)W);
+    CGIC_REQUIRE(B <= 65535 && H / 16 <= 65535, CGIC_ERR_UNSUPPORTED, "entropy: batch/height exceed the grid limits");
+    // The +-2-bin candidate window is exact only when 2.5 bin widths >= the fp32
+    // underflow radius of the Gaussian: 14.42 * sigma <= 2.5 * (2/31)
+    CGIC_REQUIRE(sigma > 0.f && sigma <= 0.0111f, CGIC_ERR_UNSUPPORTED,
+                 "entropy: sigma=%g; the 5-bin window assumes the reference's sigma=0.01 (model.py:481)", sigma);
+    for (int i = 1; i < kBins; ++i)
+        CGIC_REQUIRE(fabsf((bins[i] - bins[i - 1]) - 2.0f / 31.0f) < 1e-5f, CGIC_ERR_UNSUPPORTED,
+                     "entropy: bins are not linspace(-1, 1, 32)");
+    if (B == 0 || (!e8 && !e16)) return CGIC_OK;
+
+    BinsArg ba;
+    memcpy(ba.v, bins, sizeof(ba.v));
+    hipStream_t s = (hipStream_t)stream;
+    dim3 grid((unsigned)((W + 63) / 64), (unsigned)(H / 16), (unsigned)B);
+    hipLaunchKernelGGL(entropy_maps_kernel, grid, dim3(kEntThreads), 0, s, x, H, W, sigma, e8, e16, ba);
+    return launch_check("entropy_maps_kernel");
+}

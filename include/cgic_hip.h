@@ -1,0 +1,216 @@
+/*
+ * cgic_hip.h -- C ABI of libcgic_hip.so: the MI355X (gfx950) implementation of
+ * Control-GIC's granularity-adaptive VQ + router + entropy-coder hot path.
+ *
+ * The reference (lianqi1008/Control-GIC) is pure Python and has no FFI layer;
+ * its boundary for this path is a set of Python classes.  Each entry point
+ * below replaces the body of one of those reference methods (cited as
+ * file:line relative to the reference root) and is what a binding for that
+ * method would call -- see INTEGRATION.md for the ctypes stubs.
+ *
+ * Conventions
+ *  - Plain C: pointers + sizes, no torch / HIP types.  `stream` is a
+ *    hipStream_t passed as void* (NULL = the default stream).
+ *  - Pointers documented "device" must be device-accessible allocations on
+ *    the current HIP device; everything else is host memory.
+ *  - All device work is enqueued on `stream`; no entry point synchronises the
+ *    host unless its comment says so.  Outputs are written by the kernels on
+ *    that stream; inputs are never modified.
+ *  - Return value: CGIC_OK (0) or a negative CGIC_ERR_* code; a message for
+ *    the calling thread's last error is available from cgic_last_error().
+ *  - Tensors are dense row-major ("contiguous") in the layouts the reference
+ *    uses (NCHW images/latents, [K,C] codebook).
+ */
+#ifndef CGIC_HIP_H
+#define CGIC_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CGIC_ABI_VERSION 1
+
+#define CGIC_OK 0
+#define CGIC_ERR_INVALID (-1)     /* bad argument (shape, ratio, NULL pointer ...) */
+#define CGIC_ERR_UNSUPPORTED (-2) /* valid for the reference, not built here (e.g. e_dim != 4) */
+#define CGIC_ERR_HIP (-3)         /* a HIP runtime call failed (no device, launch error ...) */
+#define CGIC_ERR_NOMEM (-4)
+#define CGIC_ERR_CAPACITY (-5)    /* an output / workspace buffer is too small */
+
+typedef void *cgic_stream_t;
+
+/* number of .bin streams compress() can write per image, in this order
+ * (CGIC/models/model.py:226-231): indices_coarse, indices_medium,
+ * indices_fine, mask_coarse, mask_medium */
+#define CGIC_NUM_STREAMS 5
+
+const char *cgic_last_error(void);
+int cgic_abi_version(void);
+/* number of visible HIP devices, or CGIC_ERR_HIP; never throws, never aborts */
+int cgic_device_count(void);
+
+/* ---------------------------------------------------------------------------
+ * A. VectorQuantize2.forward -- CGIC/modules/vqvae/quantize.py:69-97
+ *
+ *   z        device [B, 4, hw]  fp32 (NCHW latent, hw = h*w)
+ *   codebook device [K, 4]      fp32 (embedding.weight; K % 16 == 0, K <= 8192)
+ *   indices  device [B*hw]      int64   argmin_k ||z - e_k||^2 with the CPU
+ *            reference's fp32 rounding sequence; lowest index on exact ties
+ *   z_q      device [B, 4, hw]  fp32 or NULL   = z + (e[idx] - z)      (:93)
+ *   loss     device [1]         fp32 or NULL   = m + beta*m, m = mean((e[idx]-z)^2)
+ *            (:85-90; legacy=1 -> m + beta*m, legacy=0 -> beta*m + m)
+ *   hist     device [K]         int64 or NULL  += occurrences of each index
+ *            (the usage counter of quantize.py:28,79-81, exact integers)
+ *   workspace device, cgic_vq_workspace_bytes(B*hw) bytes, or NULL iff loss==NULL
+ * ------------------------------------------------------------------------- */
+size_t cgic_vq_workspace_bytes(int64_t n_vectors);
+int cgic_vq_forward_f32(const float *z, int64_t B, int64_t hw, const float *codebook, int K, int e_dim,
+                        float beta, int legacy, int64_t *indices, float *z_q, float *loss,
+                        int64_t *hist, void *workspace, cgic_stream_t stream);
+/* same contract, plain-VALU kernel (no MFMA); kept as an independent
+ * implementation for cross-checking the MFMA kernel's rounding */
+int cgic_vq_forward_valu_f32(const float *z, int64_t B, int64_t hw, const float *codebook, int K,
+                             int e_dim, float beta, int legacy, int64_t *indices, float *z_q,
+                             float *loss, int64_t *hist, void *workspace, cgic_stream_t stream);
+
+/* usage histogram of an index tensor (quantize.py:79-81): hist[idx[i]] += 1 */
+int cgic_index_histogram(const int64_t *indices, int64_t n, int K, int64_t *hist, cgic_stream_t stream);
+
+/* ---------------------------------------------------------------------------
+ * C'. Entropy.forward -- CGIC/models/model.py:433-483, patch sizes 8 and 16 in
+ * one pass over the image (CGIC.encode computes both, model.py:100-101).
+ *
+ *   x     device [B, 3, H, W] fp32, H % 16 == 0, W % 16 == 0
+ *   bins  host   [32] fp32  (torch.linspace(-1, 1, 32), model.py:480)
+ *   e8    device [B, H/8,  W/8 ] fp32 or NULL
+ *   e16   device [B, H/16, W/16] fp32 or NULL
+ * fp32 throughout; exp/log are OCML's, so results match the CPU reference to
+ * ~1e-6, not bit-for-bit (SURVEY.md section 7 "hard parts").
+ * ------------------------------------------------------------------------- */
+int cgic_entropy_maps_f32(const float *x, int64_t B, int64_t H, int64_t W, const float *bins,
+                          int nbins, float sigma, float *e8, float *e16, cgic_stream_t stream);
+
+/* ---------------------------------------------------------------------------
+ * C. TripleGrainFixedEntropyRouter -- CGIC/modules/vqvae/RouterTriple.py:8-95
+ *
+ * cgic_router_mode: the 7-way mode from the zero-ness of the ratios, with
+ * fine = 1 - coarse - medium evaluated in float64 (:13,19,36,72).
+ *
+ * cgic_router_f32:
+ *   e16 device [B, h16, w16] fp32;  e8 device [B, 2*h16, 2*w16] fp32
+ *   per_image = 0: thresholds over the flattened batch (the reference, :21,40,52,63)
+ *   per_image = 1: one threshold set per image == B independent B=1 calls
+ *   mask_c device [B, h16, w16], mask_m [B, 2h16, 2w16], mask_f [B, 4h16, 4w16] int32
+ *   gate   device [B, 4h16, 3*4w16] fp32 or NULL  (cat(up4(gc), up2(gm), gf), :93)
+ *   mode_out host int or NULL
+ * k = round(n*ratio) uses Python's round-half-even on the float64 product.
+ * CGIC_ERR_INVALID if k > n (the reference raises IndexError there).
+ * ------------------------------------------------------------------------- */
+int cgic_router_mode(double coarse_ratio, double medium_ratio);
+int cgic_router_f32(const float *e16, const float *e8, int64_t B, int64_t h16, int64_t w16,
+                    double coarse_ratio, double medium_ratio, int per_image, int32_t *mask_c,
+                    int32_t *mask_m, int32_t *mask_f, float *gate, int *mode_out,
+                    cgic_stream_t stream);
+
+/* ---------------------------------------------------------------------------
+ * D. HuffmanCoding.__init__ / make_heap / merge_nodes / make_codes --
+ * CGIC/tools/indices_coding.py:10-17,46-75 (host side; CPython heapq
+ * tie-breaking reproduced exactly).
+ *
+ *   freq  host [n] int64  int(value.item()) per symbol
+ *   order host [n] int32 or NULL: order[i] = symbol pushed i-th = iteration
+ *         order of the `frequency` mapping (NULL = 0,1,2,...).  NB the
+ *         reference's mapping is an nn.ParameterDict built from a plain dict
+ *         (quantize.py:28) and therefore iterates its keys sorted AS STRINGS.
+ * The table owns host copies and (lazily, per device) device copies.
+ * cgic_table_binary(): the fixed table {0:'0', 1:'1'} of BinaryCoding
+ * (CGIC/tools/mask_coding.py:11-12).
+ * ------------------------------------------------------------------------- */
+typedef struct cgic_table cgic_table;
+int cgic_table_create(const int64_t *freq, const int32_t *order, int n, cgic_table **out);
+int cgic_table_binary(cgic_table **out);
+void cgic_table_destroy(cgic_table *t);
+int cgic_table_num_symbols(const cgic_table *t);
+int cgic_table_max_len(const cgic_table *t);
+int cgic_table_words(const cgic_table *t); /* 32-bit words per code = ceil(max_len/32) */
+/* host copies: len [n] int32 bits; code [n*words] uint32, bit i of a code is
+ * bit 31-(i%32) of word i/32 (MSB first) */
+int cgic_table_get(const cgic_table *t, int32_t *len, uint32_t *code);
+
+/* ---------------------------------------------------------------------------
+ * E/F. single-stream coders: HuffmanCoding.compress / decompress_string
+ * (indices_coding.py:113-126,153-168) and BinaryCoding.compress /
+ * decompress_string (mask_coding.py:40-55,81-96), minus the file I/O which
+ * stays in the Python host.
+ *
+ * cgic_encode_stream:
+ *   syms   device [n] int64 (a table with 2 symbols also accepts int32 via
+ *          elem_bytes = 4: BinaryCoding is fed int32 masks, model.py:230)
+ *   out    device [cap] uint8; framing: 1 byte pad count (1..8), code bits
+ *          MSB-first, pad zero bits; n == 0 -> 0 bytes (empty file)
+ *   nbytes device [1] int32: bytes produced, or CGIC_ERR_* (<0) if a symbol
+ *          is outside the table (KeyError in the reference) / cap too small
+ * cgic_decode_stream:
+ *   in     device [nbytes] uint8 (+ >= 8 readable bytes of slack after it)
+ *   syms   device [cap] int64; count device [1] int64: symbols decoded, or -1
+ *          for an empty input (the reference returns None)
+ * Workspace: cgic_stream_workspace_bytes(n) for encode; decode needs none.
+ * ------------------------------------------------------------------------- */
+size_t cgic_stream_capacity(const cgic_table *t, int64_t n_symbols);
+size_t cgic_stream_workspace_bytes(int64_t n_symbols);
+int cgic_encode_stream(const cgic_table *t, const void *syms, int elem_bytes, int64_t n, uint8_t *out,
+                       int64_t cap, int32_t *nbytes, void *workspace, cgic_stream_t stream);
+int cgic_decode_stream(const cgic_table *t, const uint8_t *in, int64_t nbytes, int64_t *syms,
+                       int64_t cap, int64_t *count, cgic_stream_t stream);
+
+/* ---------------------------------------------------------------------------
+ * G. CGIC.compress glue, batched -- CGIC/models/model.py:217-260 (encode side)
+ * and :269-397 (decode side).  Bit-identical to looping the reference over
+ * the batch at B=1.
+ *
+ * cgic_compress_streams:
+ *   ind     device [B, h, w] int64   (VQ indices on the 1/4-resolution grid)
+ *   mask_c  device [B, h/4, w/4], mask_m [B, h/2, w/2], mask_f [B, h, w] int32
+ *   mode    0..6 (cgic_router_mode)
+ *   out     device [B, 5, slot] uint8, slot = cgic_compress_slot_bytes(t, h, w)
+ *   nbytes  device [B, 5] int32: length of each stream; -1 = the mode does not
+ *           write that stream (model.py:225-260); 0 = written but empty file;
+ *           < -1 = CGIC_ERR_* for that stream
+ *   Streams are produced by: masked select in row-major order of each
+ *   granularity's own grid (ind[:, ::4, ::4][mask_c==1] ..., :219-221),
+ *   Huffman coding with `t`, 1-bit packing of mask_c / mask_m (:230-231).
+ *
+ * cgic_decompress_streams: inverse (model.py:269-397)
+ *   in / nbytes as produced above (device)
+ *   ind_out device [B, h, w] int64; mask_*_out device int32 (any may be NULL)
+ *   codebook device [K, 4] + z_q device [B, 4, h, w] fp32: optional fused
+ *           embedding gather (model.py:391-392), exact codebook rows
+ *   status  device [B] int32: 0, or CGIC_ERR_INVALID when a stream's symbol
+ *           count does not match its mask / a mask stream has the wrong length
+ *           / an index is outside the codebook (the reference raises there)
+ * ------------------------------------------------------------------------- */
+size_t cgic_compress_slot_bytes(const cgic_table *t, int64_t h, int64_t w);
+size_t cgic_compress_workspace_bytes(int64_t B, int64_t h, int64_t w);
+int cgic_mode_streams(int mode); /* bit i set = stream i is written in this mode */
+int cgic_compress_streams(const cgic_table *t, const int64_t *ind, const int32_t *mask_c,
+                          const int32_t *mask_m, const int32_t *mask_f, int64_t B, int64_t h,
+                          int64_t w, int mode, uint8_t *out, int64_t slot, int32_t *nbytes,
+                          void *workspace, cgic_stream_t stream);
+size_t cgic_decompress_workspace_bytes(int64_t B, int64_t h, int64_t w);
+int cgic_decompress_streams(const cgic_table *t, const uint8_t *in, int64_t slot, const int32_t *nbytes,
+                            int64_t B, int64_t h, int64_t w, int mode, int64_t *ind_out,
+                            int32_t *mask_c_out, int32_t *mask_m_out, int32_t *mask_f_out,
+                            const float *codebook, int K, int e_dim, float *z_q, int32_t *status,
+                            void *workspace, cgic_stream_t stream);
+
+/* embedding gather on its own (model.py:121,391-392): out[b, c, p] = codebook[ind[b, p], c] */
+int cgic_embedding_gather_f32(const int64_t *ind, int64_t B, int64_t hw, const float *codebook, int K,
+                              int e_dim, float *out, int32_t *status, cgic_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CGIC_HIP_H */
