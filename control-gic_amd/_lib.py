@@ -1,0 +1,106 @@
+"""ctypes binding of libcgic_hip.so (include/cgic_hip.h).
+
+There is no CPU fallback anywhere in this package: if the shared library is
+missing or a call fails, the caller gets an exception, never a silently
+different code path.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libcgic_hip.so")
+
+OK, ERR_INVALID, ERR_UNSUPPORTED, ERR_HIP, ERR_NOMEM, ERR_CAPACITY = 0, -1, -2, -3, -4, -5
+NUM_STREAMS = 5
+STREAM_NAMES = ("indices_coarse", "indices_medium", "indices_fine", "mask_coarse", "mask_medium")
+
+
+class CgicError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"libcgic_hip error {code}: {msg}")
+        self.code = code
+
+
+_vp, _i64, _i32, _int, _f32, _f64, _sz = C.c_void_p, C.c_int64, C.c_int32, C.c_int, C.c_float, C.c_double, C.c_size_t
+
+# name -> (restype, argtypes); every function include/cgic_hip.h declares
+PROTOTYPES = {
+    "cgic_last_error": (C.c_char_p, []),
+    "cgic_abi_version": (_int, []),
+    "cgic_device_count": (_int, []),
+    "cgic_vq_workspace_bytes": (_sz, [_i64]),
+    "cgic_vq_forward_f32": (_int, [_vp, _i64, _i64, _vp, _int, _int, _f32, _int, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "cgic_vq_forward_valu_f32": (_int, [_vp, _i64, _i64, _vp, _int, _int, _f32, _int, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "cgic_index_histogram": (_int, [_vp, _i64, _int, _vp, _vp]),
+    "cgic_entropy_maps_f32": (_int, [_vp, _i64, _i64, _i64, C.POINTER(_f32), _int, _f32, _vp, _vp, _vp]),
+    "cgic_router_mode": (_int, [_f64, _f64]),
+    "cgic_router_f32": (_int, [_vp, _vp, _i64, _i64, _i64, _f64, _f64, _int, _vp, _vp, _vp, _vp, C.POINTER(_int), _vp]),
+    "cgic_table_create": (_int, [C.POINTER(_i64), C.POINTER(_i32), _int, C.POINTER(_vp)]),
+    "cgic_table_binary": (_int, [C.POINTER(_vp)]),
+    "cgic_table_destroy": (None, [_vp]),
+    "cgic_table_num_symbols": (_int, [_vp]),
+    "cgic_table_max_len": (_int, [_vp]),
+    "cgic_table_words": (_int, [_vp]),
+    "cgic_table_get": (_int, [_vp, C.POINTER(_i32), C.POINTER(C.c_uint32)]),
+    "cgic_stream_capacity": (_sz, [_vp, _i64]),
+    "cgic_stream_workspace_bytes": (_sz, [_i64]),
+    "cgic_encode_stream": (_int, [_vp, _vp, _int, _i64, _vp, _i64, _vp, _vp, _vp]),
+    "cgic_decode_stream": (_int, [_vp, _vp, _i64, _vp, _i64, _vp, _vp]),
+    "cgic_compress_slot_bytes": (_sz, [_vp, _i64, _i64]),
+    "cgic_compress_workspace_bytes": (_sz, [_i64, _i64, _i64]),
+    "cgic_mode_streams": (_int, [_int]),
+    "cgic_compress_streams": (_int, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _int, _vp, _i64, _vp, _vp, _vp]),
+    "cgic_decompress_workspace_bytes": (_sz, [_i64, _i64, _i64]),
+    "cgic_decompress_streams": (_int, [_vp, _vp, _i64, _vp, _i64, _i64, _i64, _int, _vp, _vp, _vp, _vp, _vp, _int,
+                                       _int, _vp, _vp, _vp, _vp]),
+    "cgic_embedding_gather_f32": (_int, [_vp, _i64, _i64, _vp, _int, _int, _vp, _vp, _vp]),
+}
+
+_lib = None
+
+
+def lib():
+    """Load libcgic_hip.so (once).  Raises if it has not been built -- run
+    `python -c "import __graft_entry__ as g; g.build()"` or `make -C control-gic_amd/csrc`."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                f"{LIB_PATH} is missing: the HIP extension has not been built "
+                "(make -C control-gic_amd/csrc).  There is no CPU fallback.")
+        l = C.CDLL(LIB_PATH)
+        for name, (res, args) in PROTOTYPES.items():
+            fn = getattr(l, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = l
+    return _lib
+
+
+def check(rc):
+    if rc < 0:
+        raise CgicError(rc, lib().cgic_last_error().decode(errors="replace"))
+    return rc
+
+
+def call(name, *args):
+    return check(getattr(lib(), name)(*args))
+
+
+def ptr(t):
+    """device/host pointer of a torch tensor (None -> NULL)"""
+    return None if t is None else t.data_ptr()
+
+
+def current_stream(device=None):
+    import torch
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+def require_device(*tensors):
+    """The product path is HIP-only: refuse CPU tensors loudly."""
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError(
+                "control_gic_amd ops run on an MI355X (HIP) device only; got a CPU tensor. "
+                "There is deliberately no CPU fallback -- the CPU oracle lives in oracle/ and is test-only.")

@@ -1,0 +1,778 @@
+// cgic_coder.hip -- the entropy-coder half of CGIC.compress:
+//   encode: masked select + static-Huffman bit packing + 1-bit mask packing
+//           (reference: CGIC/models/model.py:217-260, CGIC/tools/indices_coding.py:78-126,
+//            CGIC/tools/mask_coding.py:14-55)
+//   decode: prefix decoding, mask -> index scatter, x2/x4 merge, embedding gather
+//           (reference: indices_coding.py:131-168, mask_coding.py:59-96, model.py:269-397)
+//
+// The reference does this per image on the host: .tolist() (device sync), Python
+// string concatenation bit by bit, one file per stream.  Here every (image, stream)
+// pair is one workgroup and nothing leaves the device:
+//
+//  encode  phase A: wave prefix sums (count | bit-length packed in one u64) compact the
+//                   selected symbols and give each its end bit offset;
+//          phase B: GATHER formulation -- one thread per 32-bit output word binary-searches
+//                   the symbol that covers its first bit and ORs the overlapping code bits
+//                   together.  No atomics, no pre-zeroed output, deterministic, and codes of
+//                   any length (the reference's table can reach 1023 bits) need no special case.
+//          masks:   64 positions per wave -> one __ballot -> 8 bit-reversed bytes.
+//  decode  one wave per stream: every lane speculatively decodes "a codeword starting at
+//          bit base+lane" through a 12-bit LUT in LDS (64 starts in one LDS round trip); a
+//          wave-uniform scalar chain (v_readlane) then walks the true codeword boundaries,
+//          ~10 cycles per symbol instead of a dependent LDS/HBM lookup per symbol.  Codes
+//          longer than 12 bits fall back to a trie walk at the point the chain reaches them.
+//  merge   rank = prefix popcount of the bit-packed masks (read straight from the mask
+//          streams); one block per image scatters the three symbol lists, sums the x1/x2/x4
+//          grids and gathers codebook rows.
+// All integer / bit work: outputs are bit-identical to the reference by construction and
+// checked against it through the oracle + tests/golden/{coders,compress_cfg1}.npz.
+#include "cgic_common.h"
+
+namespace cgic {
+
+constexpr int kEncThreads = 256;
+constexpr int kEncItems = 4;            // consecutive positions per thread per scan round
+constexpr int kLdsPos = 8192;           // streams up to this many positions keep phase-A results in LDS
+constexpr int kDecLutMax = 4096;        // 12-bit LUT
+
+// -------------------------------------------------------------------------------------------
+// encode
+// -------------------------------------------------------------------------------------------
+struct EncStorage {
+    uint32_t *cend;   // inclusive end bit of each selected symbol
+    uint16_t *csym;   // the symbol
+};
+
+// code bits [off, off+nb) of symbol s, right-aligned; 1 <= nb <= 32
+__device__ __forceinline__ uint32_t code_bits(const TableDev &t, int s, uint32_t off, uint32_t nb)
+{
+    const uint32_t j = off >> 5;
+    const uint32_t *c = t.code + (size_t)s * t.words;
+    uint64_t w = (uint64_t)c[j] << 32;
+    if ((int)(j + 1) < t.words) w |= c[j + 1];
+    return (uint32_t)((w << (off & 31)) >> (64 - nb));
+}
+
+// Phase A + B for one Huffman-coded stream.  sym_at(i, &flag) returns the symbol at linear
+// position i and whether it is selected.  Returns bytes written (0 = empty file) or CGIC_ERR_*.
+template <typename SymAt>
+__device__ int encode_huffman_stream(const TableDev &t, int64_t npos, SymAt sym_at, EncStorage st,
+                                     uint8_t *out, int64_t cap)
+{
+    __shared__ unsigned long long scan_smem[kEncThreads / kWave + 1];
+    __shared__ int s_err;
+    const int tid = threadIdx.x;
+    if (tid == 0) s_err = 0;
+    __syncthreads();
+
+    unsigned long long carry = 0;   // (count << 32) | bits, uniform
+    for (int64_t base = 0; base < npos; base += (int64_t)kEncThreads * kEncItems) {
+        int sym[kEncItems];
+        uint32_t len[kEncItems];
+        unsigned long long local = 0;
+#pragma unroll
+        for (int k = 0; k < kEncItems; ++k) {
+            const int64_t i = base + (int64_t)tid * kEncItems + k;
+            bool flag = false;
+            int64_t s = 0;
+            if (i < npos) s = sym_at(i, &flag);
+            uint32_t l = 0;
+            if (flag) {
+                if (s < 0 || s >= t.n) { s_err = CGIC_ERR_INVALID; s = 0; }   // KeyError in the reference
+                l = (uint32_t)t.len[s];
+            }
+            sym[k] = flag ? (int)s : -1;
+            len[k] = l;
+            local += flag ? ((1ull << 32) | l) : 0ull;
+        }
+        unsigned long long total;
+        unsigned long long excl = block_exclusive_scan(local, scan_smem, &total) + carry;
+#pragma unroll
+        for (int k = 0; k < kEncItems; ++k) {
+            if (sym[k] >= 0) {
+                const uint32_t ci = (uint32_t)(excl >> 32);
+                excl += (1ull << 32) | len[k];
+                st.cend[ci] = (uint32_t)excl;
+                st.csym[ci] = (uint16_t)sym[k];
+            }
+        }
+        carry += total;
+    }
+    __syncthreads();   // phase-A stores (LDS or global, same workgroup) visible to phase B
+    if (s_err) return s_err;
+
+    const uint32_t count = (uint32_t)(carry >> 32);
+    const uint32_t total_bits = (uint32_t)carry;
+    if (count == 0) return 0;                                   // `if not text: write b''`  (:116-118)
+    const uint32_t pad = 8 - (total_bits & 7);                  // 1..8                      (:92)
+    const int64_t nbytes = 1 + (int64_t)((total_bits + pad) >> 3);
+    if (nbytes > cap) return CGIC_ERR_CAPACITY;
+    const int64_t nwords = (nbytes + 3) >> 2;
+    uint32_t *out32 = reinterpret_cast<uint32_t *>(out);        // slot bases are 16-byte aligned
+    for (int64_t q = tid; q < nwords; q += kEncThreads) {
+        // stream bits [32q, 32q+32); stream bit = 8 (header byte) + payload bit
+        const int64_t lo = 32 * q - 8, hi = lo + 32;
+        uint32_t acc = q == 0 ? (pad << 24) : 0u;               // "{0:08b}".format(extra_padding) (:96)
+        const uint32_t p0 = lo < 0 ? 0u : (uint32_t)lo;
+        if (p0 < total_bits) {
+            // first symbol whose end bit is > p0
+            uint32_t a = 0, b = count;
+            while (a < b) {
+                uint32_t m = (a + b) >> 1;
+                if (st.cend[m] > p0) b = m; else a = m + 1;
+            }
+            uint32_t c = a;
+            uint32_t start = c ? st.cend[c - 1] : 0u;
+            while (c < count && (int64_t)start < hi) {
+                const uint32_t end = st.cend[c];
+                const int s = st.csym[c];
+                const uint32_t from = start > p0 ? start : p0;
+                const uint32_t to = (int64_t)end < hi ? end : (uint32_t)hi;
+                if (to > from) acc |= code_bits(t, s, from - start, to - from) << (uint32_t)(hi - to);
+                start = end;
+                ++c;
+            }
+        }
+        out32[q] = __builtin_bswap32(acc);                       // MSB-first bytes (:108)
+    }
+    return (int)nbytes;
+}
+
+// 1-bit stream (BinaryCoding): bit_at(i) in {0,1}; other values are a KeyError in the reference
+template <typename BitAt>
+__device__ int encode_binary_stream(int64_t npos, BitAt bit_at, uint8_t *out, int64_t cap)
+{
+    if (npos == 0) return 0;
+    const uint32_t pad = 8 - (uint32_t)(npos & 7);
+    const int64_t payload = (npos >> 3) + 1;
+    const int64_t nbytes = 1 + payload;
+    if (nbytes > cap) return CGIC_ERR_CAPACITY;
+    __shared__ int b_err;
+    const int tid = threadIdx.x, lane = lane_id();
+    if (tid == 0) { b_err = 0; out[0] = (uint8_t)pad; }
+    __syncthreads();
+    const int64_t rounded = (npos + 8 + 63) & ~(int64_t)63;     // cover the pad byte too
+    for (int64_t i = tid; i < rounded; i += kEncThreads) {
+        int v = 0;
+        if (i < npos) {
+            v = bit_at(i);
+            if (v != 0 && v != 1) { b_err = CGIC_ERR_INVALID; v = 0; }
+        }
+        const unsigned long long bal = __ballot(v == 1);
+        if (lane < 8) {
+            const int64_t byte = ((i - lane) >> 3) + lane;
+            if (byte < payload) out[1 + byte] = (uint8_t)(__brev((uint32_t)((bal >> (8 * lane)) & 0xFF)) >> 24);
+        }
+    }
+    __syncthreads();
+    return b_err ? b_err : (int)nbytes;
+}
+
+struct CompressArgs {
+    TableDev tab;
+    const int64_t *ind;
+    const int32_t *mc, *mm, *mf;
+    int64_t h, w;
+    int stream_mask;        // bit s set = stream s written in this mode
+    uint8_t *out;
+    int64_t slot;
+    int32_t *nbytes;        // [B, 5]
+    uint32_t *ws_end;       // global phase-A storage for streams > kLdsPos positions
+    uint16_t *ws_sym;
+    int64_t ws_stride;      // positions reserved per (image, stream) in the workspace
+};
+
+__global__ __launch_bounds__(kEncThreads) void compress_streams_kernel(CompressArgs a)
+{
+    __shared__ __attribute__((aligned(16))) uint32_t lds_end[kLdsPos];
+    __shared__ uint16_t lds_sym[kLdsPos];
+    const int s = blockIdx.x;
+    const int64_t b = blockIdx.y;
+    int32_t *nb = a.nbytes + b * CGIC_NUM_STREAMS + s;
+    if (!((a.stream_mask >> s) & 1)) {
+        if (threadIdx.x == 0) *nb = -1;
+        return;
+    }
+    uint8_t *out = a.out + (b * CGIC_NUM_STREAMS + s) * a.slot;
+    const int64_t h = a.h, w = a.w;
+    int rc;
+    if (s < 3) {
+        const int sh = 2 - s;                                   // stride 4, 2, 1
+        const int64_t gh = h >> sh, gw = w >> sh, npos = gh * gw;
+        const int32_t *mask = (s == 0 ? a.mc : s == 1 ? a.mm : a.mf) + b * npos;
+        const int64_t *ind = a.ind + b * h * w;
+        EncStorage st;
+        if (npos <= kLdsPos) { st.cend = lds_end; st.csym = lds_sym; }
+        else {
+            st.cend = a.ws_end + (b * 3 + s) * a.ws_stride;
+            st.csym = a.ws_sym + (b * 3 + s) * a.ws_stride;
+        }
+        // ind[:, ::4, ::4][mask_c == 1] etc.: row-major over the granularity's own grid (:219-221)
+        auto sym_at = [&](int64_t i, bool *flag) -> int64_t {
+            *flag = mask[i] == 1;
+            if (!*flag) return 0;
+            const int64_t y = i / gw, x = i - y * gw;
+            return ind[((y << sh) * w) + (x << sh)];
+        };
+        rc = encode_huffman_stream(a.tab, npos, sym_at, st, out, a.slot);
+    } else {
+        const int sh = s == 3 ? 2 : 1;
+        const int64_t npos = (h >> sh) * (w >> sh);
+        const int32_t *mask = (s == 3 ? a.mc : a.mm) + b * npos;   // grain_mask[k].flatten() (:230-231)
+        rc = encode_binary_stream(npos, [&](int64_t i) { return (int)mask[i]; }, out, a.slot);
+    }
+    if (threadIdx.x == 0) *nb = rc < 0 ? rc - 10 : rc;     // errors are CGIC_ERR_* - 10 (-1 means "not written")
+}
+
+struct EncodeOneArgs {
+    TableDev tab;
+    const void *syms;
+    int elem_bytes;
+    int64_t n;
+    uint8_t *out;
+    int64_t cap;
+    int32_t *nbytes;
+    uint32_t *ws_end;
+    uint16_t *ws_sym;
+};
+
+__global__ __launch_bounds__(kEncThreads) void encode_stream_kernel(EncodeOneArgs a)
+{
+    __shared__ __attribute__((aligned(16))) uint32_t lds_end[kLdsPos];
+    __shared__ uint16_t lds_sym[kLdsPos];
+    EncStorage st;
+    if (a.n <= kLdsPos) { st.cend = lds_end; st.csym = lds_sym; }
+    else { st.cend = a.ws_end; st.csym = a.ws_sym; }
+    auto sym_at = [&](int64_t i, bool *flag) -> int64_t {
+        *flag = true;
+        return a.elem_bytes == 8 ? reinterpret_cast<const int64_t *>(a.syms)[i]
+                                 : (int64_t) reinterpret_cast<const int32_t *>(a.syms)[i];
+    };
+    int rc;
+    if (a.tab.n == 2 && a.tab.max_len == 1) {
+        // BinaryCoding's fixed table: ballot path (symbol v <-> bit v)
+        rc = encode_binary_stream(a.n, [&](int64_t i) { bool f; return (int)sym_at(i, &f); }, a.out, a.cap);
+    } else {
+        rc = encode_huffman_stream(a.tab, a.n, sym_at, st, a.out, a.cap);
+    }
+    if (threadIdx.x == 0) *a.nbytes = rc;
+}
+
+// -------------------------------------------------------------------------------------------
+// decode
+// -------------------------------------------------------------------------------------------
+// 32 payload bits starting at payload bit p (MSB first).  `in` points at the header byte.
+__device__ __forceinline__ uint32_t fetch32(const uint8_t *in, int64_t p)
+{
+    const uintptr_t addr = reinterpret_cast<uintptr_t>(in) + 1 + (uintptr_t)(p >> 3);
+    const uint32_t *al = reinterpret_cast<const uint32_t *>(addr & ~(uintptr_t)3);
+    const uint32_t o = (uint32_t)(addr & 3);
+    const uint64_t w = ((uint64_t)__builtin_bswap32(al[0]) << 32) | __builtin_bswap32(al[1]);
+    return (uint32_t)((w << (8 * o + (uint32_t)(p & 7))) >> 32);
+}
+
+// One wave decodes one stream.  lut: LDS copy of the table's LUT.  put(k, sym) stores the
+// k-th symbol.  Returns the symbol count, -1 for an empty input (None in the reference).
+template <typename Put>
+__device__ int64_t decode_stream_wave(const TableDev &t, const uint32_t *lut, const uint8_t *in,
+                                      int64_t nbytes, int64_t cap, Put put, int *overflow)
+{
+    if (nbytes <= 0) return -1;                                  // :158-159
+    const int lane = lane_id();
+    const int pad = in[0];                                       // remove_padding :131-138
+    const int64_t total = (nbytes - 1) * 8;
+    int64_t nbits = pad == 0 ? 0 : total - pad;                  // text[:-0] is empty in Python
+    if (nbits < 0) nbits = 0;
+    const int LB = t.lut_bits;
+    int64_t pos = 0, count = 0;
+    bool done = false;
+    for (int64_t base = 0; base < nbits && !done; base += kWave) {
+        const int64_t p = base + lane;
+        uint32_t e = 0xFFFFFF00u;
+        if (p < nbits) e = lut[fetch32(in, p) >> (32 - LB)];
+        int L = (int)(e & 0xFF);
+        int S = (int)(e >> 8);
+        unsigned long long starts = 0;
+        while (pos < base + kWave) {
+            const int i = (int)(pos - base);
+            int Li = __builtin_amdgcn_readlane(L, i);
+            const int Si = __builtin_amdgcn_readlane(S, i);
+            if (Li == 0) {
+                // code longer than the LUT window: continue in the trie from node Si
+                if (Si == 0xFFFFFF) { done = true; break; }
+                int node = Si, sym = -1;
+                int64_t q = pos + LB;
+                while (q < nbits) {
+                    const int bit = (in[1 + (q >> 3)] >> (7 - (int)(q & 7))) & 1;
+                    const int c = t.child[2 * node + bit];
+                    ++q;
+                    if (c == INT32_MIN) break;
+                    if (c < 0) { sym = ~c; break; }
+                    node = c;
+                }
+                if (sym < 0) { done = true; break; }             // ran out of bits: trailing partial code is dropped
+                Li = (int)(q - pos);
+                S = lane == i ? sym : S;
+            }
+            if (pos + Li > nbits) { done = true; break; }
+            starts |= 1ull << i;
+            pos += Li;
+        }
+        if (starts) {
+            const int rank = __popcll(starts & ((1ull << lane) - 1ull));
+            if ((starts >> lane) & 1ull) {
+                if (count + rank < cap) put(count + rank, S);
+                else *overflow = 1;
+            }
+            count += __popcll(starts);
+        }
+    }
+    return count;
+}
+
+__device__ __forceinline__ void load_lut(const TableDev &t, uint32_t *lut)
+{
+    const int n = 1 << t.lut_bits;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) lut[i] = t.lut[i];
+    __syncthreads();
+}
+
+struct DecodeArgs {
+    TableDev tab;
+    const uint8_t *in;
+    int64_t slot;
+    const int32_t *nbytes;   // [B, 5]
+    int64_t h, w;
+    int stream_mask;
+    int32_t *dsym;           // [B, n_c + n_m + n_f] decoded symbols
+    int64_t *dcount;         // [B, 3]: count, -1 = empty file, -2 = not sent, -3 = overflow
+};
+
+__global__ __launch_bounds__(kWave) void decode_streams_kernel(DecodeArgs a)
+{
+    __shared__ uint32_t lut[kDecLutMax];
+    const int s = blockIdx.x;
+    const int64_t b = blockIdx.y;
+    int64_t *dc = a.dcount + b * 3 + s;
+    if (!((a.stream_mask >> s) & 1)) {
+        if (threadIdx.x == 0) *dc = -2;
+        return;
+    }
+    load_lut(a.tab, lut);
+    const int64_t n_c = (a.h >> 2) * (a.w >> 2), n_m = (a.h >> 1) * (a.w >> 1), n_f = a.h * a.w;
+    const int64_t off = s == 0 ? 0 : (s == 1 ? n_c : n_c + n_m);
+    const int64_t cap = s == 0 ? n_c : (s == 1 ? n_m : n_f);
+    int32_t *dst = a.dsym + b * (n_c + n_m + n_f) + off;
+    const int32_t nb = a.nbytes[b * CGIC_NUM_STREAMS + s];
+    int overflow = 0;
+    int64_t cnt = decode_stream_wave(a.tab, lut, a.in + (b * CGIC_NUM_STREAMS + s) * a.slot, nb, cap,
+                                     [&](int64_t k, int sym) { dst[k] = sym; }, &overflow);
+    overflow = __any(overflow);
+    if (threadIdx.x == 0) *dc = overflow ? -3 : cnt;
+}
+
+struct DecodeOneArgs {
+    TableDev tab;
+    const uint8_t *in;
+    int64_t nbytes;
+    int64_t *syms;
+    int64_t cap;
+    int64_t *count;
+};
+
+__global__ __launch_bounds__(kWave) void decode_stream_kernel(DecodeOneArgs a)
+{
+    __shared__ uint32_t lut[kDecLutMax];
+    load_lut(a.tab, lut);
+    int overflow = 0;
+    int64_t *dst = a.syms;
+    int64_t cnt = decode_stream_wave(a.tab, lut, a.in, a.nbytes, a.cap,
+                                     [&](int64_t k, int sym) { dst[k] = sym; }, &overflow);
+    overflow = __any(overflow);
+    if (threadIdx.x == 0) *a.count = overflow ? (int64_t)CGIC_ERR_CAPACITY : cnt;
+}
+
+// -------------------------------------------------------------------------------------------
+// merge: masks + symbol lists -> index grid (+ masks, + z_q)         model.py:269-397
+// -------------------------------------------------------------------------------------------
+constexpr int kMergeThreads = 256;
+constexpr int kMergeItems = 4;
+
+struct MergeArgs {
+    const uint8_t *in;
+    int64_t slot;
+    const int32_t *nbytes;
+    int64_t h, w;
+    int mode;
+    const int32_t *dsym;
+    const int64_t *dcount;
+    int64_t *ind_out;
+    int32_t *mc_out, *mm_out, *mf_out;
+    const float *codebook;
+    int K;
+    float *zq;
+    int32_t *status;
+};
+
+// LSB-first bit array word `wi` (bits 32wi..32wi+31) of an MSB-first mask stream
+__device__ __forceinline__ uint32_t mask_stream_word(const uint8_t *in, int64_t wi, int64_t nbits)
+{
+    uint32_t v = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int64_t byte = wi * 4 + k;
+        if (byte * 8 < nbits) v |= (uint32_t)(__brev((uint32_t)in[1 + byte]) >> 24) << (8 * k);
+    }
+    const int64_t rem = nbits - wi * 32;
+    if (rem < 32) v &= rem <= 0 ? 0u : ((1u << rem) - 1u);
+    return v;
+}
+
+__global__ __launch_bounds__(kMergeThreads) void merge_kernel(MergeArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t sm[];
+    __shared__ uint32_t scan_smem[kMergeThreads / kWave + 1];
+    __shared__ int s_status;
+    const int tid = threadIdx.x;
+    const int64_t b = blockIdx.x;
+    const int64_t h = a.h, w = a.w, h2 = h >> 1, w2 = w >> 1, h4 = h >> 2, w4 = w >> 2;
+    const int64_t n_c = h4 * w4, n_m = h2 * w2, n_f = h * w;
+    const int64_t wc = (n_c + 31) >> 5, wm = (n_m + 31) >> 5;
+    uint32_t *mcb = sm;                 // [wc] coarse mask bits, LSB first
+    uint32_t *mmb = mcb + wc;           // [wm]
+    uint32_t *pcb = mmb + wm;           // [wc] exclusive popcount prefix
+    uint32_t *pmb = pcb + wc;           // [wm]
+    const int mode = a.mode;
+    if (tid == 0) s_status = 0;
+    __syncthreads();
+
+    const bool send_mc = mode == 0 || mode == 2 || mode == 3;
+    const bool send_mm = mode == 0 || mode == 1;
+    const uint8_t *in_mc = a.in + (b * CGIC_NUM_STREAMS + 3) * a.slot;
+    const uint8_t *in_mm = a.in + (b * CGIC_NUM_STREAMS + 4) * a.slot;
+    // a mask stream must be exactly 1 + n/8 + 1 bytes with pad = 8 - n%8 (mask_coding.py:19-26)
+    if (tid == 0) {
+        if (send_mc) {
+            const int32_t nb = a.nbytes[b * CGIC_NUM_STREAMS + 3];
+            if (nb != 2 + (n_c >> 3) || in_mc[0] != 8 - (n_c & 7)) s_status = CGIC_ERR_INVALID;
+        }
+        if (send_mm) {
+            const int32_t nb = a.nbytes[b * CGIC_NUM_STREAMS + 4];
+            if (nb != 2 + (n_m >> 3) || in_mm[0] != 8 - (n_m & 7)) s_status = CGIC_ERR_INVALID;
+        }
+    }
+    __syncthreads();
+    if (s_status) {
+        if (tid == 0 && a.status) a.status[b] = s_status;
+        return;
+    }
+    for (int64_t i = tid; i < wc; i += kMergeThreads) {
+        uint32_t v;
+        if (send_mc) v = mask_stream_word(in_mc, i, n_c);
+        else {
+            v = mode == 4 ? 0xFFFFFFFFu : 0u;                                   // :355 / zeros
+            const int64_t rem = n_c - i * 32;
+            if (rem < 32) v &= (1u << rem) - 1u;
+        }
+        mcb[i] = v;
+    }
+    __syncthreads();
+    for (int64_t i = tid; i < wm; i += kMergeThreads) {
+        uint32_t v = 0;
+        if (send_mm) v = mask_stream_word(in_mm, i, n_m);
+        else if (mode == 3 || mode == 5) {
+            for (int k = 0; k < 32; ++k) {
+                const int64_t j = i * 32 + k;
+                if (j >= n_m) break;
+                bool bit = true;                                                // mode 5: ones (:368)
+                if (mode == 3) {                                                // 1 - up2(mask_coarse) (:332)
+                    const int64_t y = j / w2, x = j - y * w2, c = (y >> 1) * w4 + (x >> 1);
+                    bit = !((mcb[c >> 5] >> (c & 31)) & 1u);
+                }
+                v |= (uint32_t)bit << k;
+            }
+        }
+        mmb[i] = v;
+    }
+    __syncthreads();
+    // exclusive popcount prefixes of both bit arrays
+    uint32_t carry = 0, total;
+    for (int64_t base = 0; base < wc; base += kMergeThreads) {
+        const int64_t i = base + tid;
+        const uint32_t c = i < wc ? __popc(mcb[i]) : 0u;
+        const uint32_t ex = block_exclusive_scan(c, scan_smem, &total);
+        if (i < wc) pcb[i] = carry + ex;
+        carry += total;
+    }
+    const uint32_t cnt_c = carry;
+    carry = 0;
+    for (int64_t base = 0; base < wm; base += kMergeThreads) {
+        const int64_t i = base + tid;
+        const uint32_t c = i < wm ? __popc(mmb[i]) : 0u;
+        const uint32_t ex = block_exclusive_scan(c, scan_smem, &total);
+        if (i < wm) pmb[i] = carry + ex;
+        carry += total;
+    }
+    const uint32_t cnt_m = carry;
+    __syncthreads();
+
+    const int32_t *ds_c = a.dsym + b * (n_c + n_m + n_f), *ds_m = ds_c + n_c, *ds_f = ds_m + n_m;
+    const int64_t dc_c = a.dcount[b * 3 + 0], dc_m = a.dcount[b * 3 + 1], dc_f = a.dcount[b * 3 + 2];
+    const bool has_c = mode == 0 || mode == 2 || mode == 3 || mode == 4;
+    const bool has_m = mode == 0 || mode == 1 || mode == 3 || mode == 5;
+    const bool has_f = mode == 0 || mode == 1 || mode == 2 || mode == 6;
+    // an empty index file (None) means "all zeros" for coarse/medium (:283-290); any other
+    // count must equal the number of mask ones (the reference raises a shape mismatch)
+    int st = 0;
+    if (dc_c == -3 || dc_m == -3 || dc_f == -3) st = CGIC_ERR_INVALID;
+    if (has_c && dc_c >= 0 && dc_c != cnt_c) st = CGIC_ERR_INVALID;
+    if (has_m && dc_m >= 0 && dc_m != cnt_m) st = CGIC_ERR_INVALID;
+    const bool use_c = has_c && dc_c >= 0, use_m = has_m && dc_m >= 0, use_f = has_f && dc_f >= 0;
+
+    int64_t *ind_out = a.ind_out ? a.ind_out + b * n_f : nullptr;
+    float *zq = a.zq ? a.zq + b * 4 * n_f : nullptr;
+    uint32_t fcarry = 0;
+    int bad_index = 0;
+    for (int64_t base = 0; base < n_f; base += (int64_t)kMergeThreads * kMergeItems) {
+        uint32_t fl = 0;       // fine flags of my items
+        int64_t i0 = base + (int64_t)tid * kMergeItems;
+        int64_t vals[kMergeItems];
+#pragma unroll
+        for (int k = 0; k < kMergeItems; ++k) {
+            const int64_t i = i0 + k;
+            vals[k] = 0;
+            if (i >= n_f) continue;
+            const int64_t y = i / w, x = i - y * w;
+            const int64_t j2 = (y >> 1) * w2 + (x >> 1), j4 = (y >> 2) * w4 + (x >> 2);
+            const bool bc = (mcb[j4 >> 5] >> (j4 & 31)) & 1u;
+            const bool bm = (mmb[j2 >> 5] >> (j2 & 31)) & 1u;
+            bool bf;
+            switch (mode) {
+            case 0: bf = (1 - (int)bm - (int)bc) == 1; break;                   // :280
+            case 1: bf = !bm; break;                                            // :302
+            case 2: bf = !bc; break;                                            // :320
+            case 6: bf = true; break;                                           // :380
+            default: bf = false; break;
+            }
+            fl |= (uint32_t)bf << k;
+            int64_t v = 0;
+            if (bc && use_c) v += ds_c[pcb[j4 >> 5] + __popc(mcb[j4 >> 5] & ((1u << (j4 & 31)) - 1u))];
+            if (bm && use_m) v += ds_m[pmb[j2 >> 5] + __popc(mmb[j2 >> 5] & ((1u << (j2 & 31)) - 1u))];
+            vals[k] = v;
+            if (a.mc_out && (y & 3) == 0 && (x & 3) == 0) a.mc_out[b * n_c + j4] = bc;
+            if (a.mm_out && (y & 1) == 0 && (x & 1) == 0) a.mm_out[b * n_m + j2] = bm;
+            if (a.mf_out) a.mf_out[b * n_f + i] = bf;
+        }
+        uint32_t ftotal;
+        uint32_t frank = block_exclusive_scan((uint32_t)__popc(fl), scan_smem, &ftotal) + fcarry;
+#pragma unroll
+        for (int k = 0; k < kMergeItems; ++k) {
+            const int64_t i = i0 + k;
+            if (i >= n_f) continue;
+            int64_t v = vals[k];
+            if ((fl >> k) & 1u) {
+                if (use_f && (int64_t)frank < dc_f) v += ds_f[frank];           // t[t==1] = decoded (:292)
+                ++frank;
+            }
+            if (ind_out) ind_out[i] = v;                                        // sum of the three grids (:293)
+            if (zq) {
+                if (v < 0 || v >= a.K) { bad_index = 1; v = 0; }
+                const float4 e = reinterpret_cast<const float4 *>(a.codebook)[v];   // exact rows (:391-392)
+                zq[i] = e.x; zq[n_f + i] = e.y; zq[2 * n_f + i] = e.z; zq[3 * n_f + i] = e.w;
+            }
+        }
+        fcarry += ftotal;
+    }
+    if (has_f && (dc_f >= 0 ? dc_f != (int64_t)fcarry : fcarry != 0)) st = CGIC_ERR_INVALID;
+    if (bad_index) s_status = CGIC_ERR_INVALID;
+    __syncthreads();
+    if (tid == 0 && a.status) a.status[b] = st ? st : s_status;
+}
+
+__global__ void gather_kernel(const int64_t *__restrict__ ind, int64_t B, int64_t hw,
+                              const float *__restrict__ cb, int K, float *__restrict__ out,
+                              int32_t *__restrict__ status)
+{
+    const int64_t n = B * hw;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        int64_t v = ind[i];
+        const int64_t b = i / hw, p = i - b * hw;
+        if (v < 0 || v >= K) { if (status) status[b] = CGIC_ERR_INVALID; v = 0; }
+        const float4 e = reinterpret_cast<const float4 *>(cb)[v];
+        float *o = out + b * 4 * hw + p;
+        o[0] = e.x; o[hw] = e.y; o[2 * hw] = e.z; o[3 * hw] = e.w;
+    }
+}
+
+static const int kModeStreams[7] = {0x1f, 0x16, 0x0d, 0x0b, 0x01, 0x02, 0x04};  // model.py:225-260
+
+static size_t align16(size_t v) { return (v + 15) & ~(size_t)15; }
+
+}  // namespace cgic
+
+using namespace cgic;
+
+extern "C" int cgic_mode_streams(int mode)
+{
+    CGIC_REQUIRE(mode >= 0 && mode <= 6, CGIC_ERR_INVALID, "mode %d outside 0..6", mode);
+    return kModeStreams[mode];
+}
+
+extern "C" size_t cgic_stream_capacity(const cgic_table *t, int64_t n)
+{
+    if (!t || n < 0) return 0;
+    const uint64_t bits = (uint64_t)cgic_table_max_len(t) * (uint64_t)n;
+    return align16((size_t)(bits / 8 + 2) + 8);    // header + pad byte + word-store/fetch slack
+}
+
+extern "C" size_t cgic_stream_workspace_bytes(int64_t n)
+{
+    return n > kLdsPos ? align16((size_t)n * 4) + align16((size_t)n * 2) : 0;
+}
+
+extern "C" size_t cgic_compress_slot_bytes(const cgic_table *t, int64_t h, int64_t w)
+{
+    if (!t || h <= 0 || w <= 0) return 0;
+    const size_t a = cgic_stream_capacity(t, h * w);
+    const size_t m = align16((size_t)((h / 2) * (w / 2) / 8 + 2) + 8);
+    return a > m ? a : m;
+}
+
+static size_t ws_stride(int64_t h, int64_t w) { return ((size_t)(h * w) + 7) & ~(size_t)7; }
+
+extern "C" size_t cgic_compress_workspace_bytes(int64_t B, int64_t h, int64_t w)
+{
+    if (B <= 0 || h * w <= kLdsPos) return 0;
+    return (size_t)B * 3 * ws_stride(h, w) * (sizeof(uint32_t) + sizeof(uint16_t));
+}
+
+static int check_grid(int64_t B, int64_t h, int64_t w, int mode)
+{
+    CGIC_REQUIRE(B >= 0 && h > 0 && w > 0 && h % 4 == 0 && w % 4 == 0, CGIC_ERR_INVALID,
+                 "latent grid %lldx%lld must be positive multiples of 4", (long long)h, (long long)w);
+    CGIC_REQUIRE(mode >= 0 && mode <= 6, CGIC_ERR_INVALID, "mode %d outside 0..6", mode);
+    CGIC_REQUIRE(B <= 65535, CGIC_ERR_UNSUPPORTED, "batch %lld exceeds the grid limit", (long long)B);
+    CGIC_REQUIRE(h * w < ((int64_t)1 << 26), CGIC_ERR_UNSUPPORTED, "latent grid too large");
+    return CGIC_OK;
+}
+
+extern "C" int cgic_compress_streams(const cgic_table *t, const int64_t *ind, const int32_t *mask_c,
+                                     const int32_t *mask_m, const int32_t *mask_f, int64_t B, int64_t h,
+                                     int64_t w, int mode, uint8_t *out, int64_t slot, int32_t *nbytes,
+                                     void *workspace, cgic_stream_t stream)
+{
+    int rc = check_grid(B, h, w, mode);
+    if (rc) return rc;
+    CGIC_REQUIRE(t && ind && mask_c && mask_m && mask_f && out && nbytes, CGIC_ERR_INVALID, "compress_streams: NULL argument");
+    CGIC_REQUIRE(slot % 16 == 0 && (size_t)slot >= cgic_compress_slot_bytes(t, h, w), CGIC_ERR_CAPACITY,
+                 "compress_streams: slot=%lld, need a multiple of 16 >= %zu", (long long)slot, cgic_compress_slot_bytes(t, h, w));
+    CGIC_REQUIRE(cgic_table_num_symbols(t) <= 65536, CGIC_ERR_UNSUPPORTED, "table too large");
+    CGIC_REQUIRE((uint64_t)cgic_table_max_len(t) * (uint64_t)(h * w) < 0xFFFFFF00ull, CGIC_ERR_UNSUPPORTED,
+                 "compress_streams: a stream could exceed 2^32 bits");
+    CGIC_REQUIRE(workspace || cgic_compress_workspace_bytes(B, h, w) == 0, CGIC_ERR_INVALID,
+                 "compress_streams: workspace required for %lldx%lld grids", (long long)h, (long long)w);
+    if (B == 0) return CGIC_OK;
+    CompressArgs a;
+    rc = table_device_view(t, &a.tab);
+    if (rc) return rc;
+    a.ind = ind; a.mc = mask_c; a.mm = mask_m; a.mf = mask_f; a.h = h; a.w = w;
+    a.stream_mask = kModeStreams[mode];
+    a.out = out; a.slot = slot; a.nbytes = nbytes;
+    a.ws_stride = (int64_t)ws_stride(h, w);
+    a.ws_end = (uint32_t *)workspace;
+    a.ws_sym = workspace ? (uint16_t *)((char *)workspace + (size_t)B * 3 * ws_stride(h, w) * sizeof(uint32_t)) : nullptr;
+    hipLaunchKernelGGL(compress_streams_kernel, dim3(CGIC_NUM_STREAMS, (unsigned)B), dim3(kEncThreads), 0,
+                       (hipStream_t)stream, a);
+    return launch_check("compress_streams_kernel");
+}
+
+extern "C" int cgic_encode_stream(const cgic_table *t, const void *syms, int elem_bytes, int64_t n, uint8_t *out,
+                                  int64_t cap, int32_t *nbytes, void *workspace, cgic_stream_t stream)
+{
+    CGIC_REQUIRE(t && out && nbytes && (syms || n == 0), CGIC_ERR_INVALID, "encode_stream: NULL argument");
+    CGIC_REQUIRE(elem_bytes == 8 || elem_bytes == 4, CGIC_ERR_INVALID, "encode_stream: elem_bytes must be 4 or 8");
+    CGIC_REQUIRE(n >= 0 && n < ((int64_t)1 << 26), CGIC_ERR_UNSUPPORTED, "encode_stream: n out of range");
+    CGIC_REQUIRE(((uintptr_t)out & 3) == 0, CGIC_ERR_INVALID, "encode_stream: out must be 4-byte aligned");
+    CGIC_REQUIRE(workspace || n <= kLdsPos, CGIC_ERR_INVALID, "encode_stream: workspace required for n > %d", kLdsPos);
+    CGIC_REQUIRE((uint64_t)cgic_table_max_len(t) * (uint64_t)n < 0xFFFFFF00ull, CGIC_ERR_UNSUPPORTED,
+                 "encode_stream: the stream could exceed 2^32 bits");
+    EncodeOneArgs a;
+    int rc = table_device_view(t, &a.tab);
+    if (rc) return rc;
+    a.syms = syms; a.elem_bytes = elem_bytes; a.n = n; a.out = out; a.cap = cap; a.nbytes = nbytes;
+    a.ws_end = (uint32_t *)workspace;
+    a.ws_sym = workspace ? (uint16_t *)((char *)workspace + align16((size_t)n * 4)) : nullptr;
+    hipLaunchKernelGGL(encode_stream_kernel, dim3(1), dim3(kEncThreads), 0, (hipStream_t)stream, a);
+    return launch_check("encode_stream_kernel");
+}
+
+extern "C" int cgic_decode_stream(const cgic_table *t, const uint8_t *in, int64_t nbytes, int64_t *syms,
+                                  int64_t cap, int64_t *count, cgic_stream_t stream)
+{
+    CGIC_REQUIRE(t && count && (in || nbytes == 0) && (syms || cap == 0), CGIC_ERR_INVALID, "decode_stream: NULL argument");
+    CGIC_REQUIRE(nbytes >= 0 && cap >= 0, CGIC_ERR_INVALID, "decode_stream: negative size");
+    DecodeOneArgs a;
+    int rc = table_device_view(t, &a.tab);
+    if (rc) return rc;
+    a.in = in; a.nbytes = nbytes; a.syms = syms; a.cap = cap; a.count = count;
+    hipLaunchKernelGGL(decode_stream_kernel, dim3(1), dim3(kWave), 0, (hipStream_t)stream, a);
+    return launch_check("decode_stream_kernel");
+}
+
+extern "C" size_t cgic_decompress_workspace_bytes(int64_t B, int64_t h, int64_t w)
+{
+    if (B <= 0 || h <= 0 || w <= 0) return 0;
+    const size_t per = (size_t)((h / 4) * (w / 4) + (h / 2) * (w / 2) + h * w);
+    return align16((size_t)B * per * sizeof(int32_t)) + align16((size_t)B * 3 * sizeof(int64_t));
+}
+
+extern "C" int cgic_decompress_streams(const cgic_table *t, const uint8_t *in, int64_t slot, const int32_t *nbytes,
+                                       int64_t B, int64_t h, int64_t w, int mode, int64_t *ind_out,
+                                       int32_t *mask_c_out, int32_t *mask_m_out, int32_t *mask_f_out,
+                                       const float *codebook, int K, int e_dim, float *z_q, int32_t *status,
+                                       void *workspace, cgic_stream_t stream)
+{
+    int rc = check_grid(B, h, w, mode);
+    if (rc) return rc;
+    CGIC_REQUIRE(t && in && nbytes && workspace, CGIC_ERR_INVALID, "decompress_streams: NULL argument");
+    CGIC_REQUIRE(slot % 16 == 0 && slot >= 16, CGIC_ERR_INVALID, "decompress_streams: slot must be a multiple of 16");
+    CGIC_REQUIRE(!z_q || (codebook && e_dim == 4 && K > 0), CGIC_ERR_UNSUPPORTED,
+                 "decompress_streams: fused gather needs a [K,4] codebook");
+    if (B == 0) return CGIC_OK;
+    const size_t per = (size_t)((h / 4) * (w / 4) + (h / 2) * (w / 2) + h * w);
+    DecodeArgs d;
+    rc = table_device_view(t, &d.tab);
+    if (rc) return rc;
+    d.in = in; d.slot = slot; d.nbytes = nbytes; d.h = h; d.w = w; d.stream_mask = kModeStreams[mode];
+    d.dsym = (int32_t *)workspace;
+    d.dcount = (int64_t *)((char *)workspace + align16((size_t)B * per * sizeof(int32_t)));
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(decode_streams_kernel, dim3(3, (unsigned)B), dim3(kWave), 0, s, d);
+    rc = launch_check("decode_streams_kernel");
+    if (rc) return rc;
+    MergeArgs m;
+    m.in = in; m.slot = slot; m.nbytes = nbytes; m.h = h; m.w = w; m.mode = mode;
+    m.dsym = d.dsym; m.dcount = d.dcount; m.ind_out = ind_out;
+    m.mc_out = mask_c_out; m.mm_out = mask_m_out; m.mf_out = mask_f_out;
+    m.codebook = codebook; m.K = K; m.zq = z_q; m.status = status;
+    const size_t wc = (size_t)(((h / 4) * (w / 4) + 31) / 32), wm = (size_t)(((h / 2) * (w / 2) + 31) / 32);
+    const size_t lds = 2 * (wc + wm) * sizeof(uint32_t);
+    CGIC_REQUIRE(lds <= 150 * 1024, CGIC_ERR_UNSUPPORTED, "decompress_streams: grid too large for the mask bitsets");
+    if (lds > 48 * 1024)
+        CGIC_HIP_TRY(hipFuncSetAttribute((const void *)merge_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(merge_kernel, dim3((unsigned)B), dim3(kMergeThreads), lds, s, m);
+    return launch_check("merge_kernel");
+}
+
+extern "C" int cgic_embedding_gather_f32(const int64_t *ind, int64_t B, int64_t hw, const float *codebook, int K,
+                                         int e_dim, float *out, int32_t *status, cgic_stream_t stream)
+{
+    CGIC_REQUIRE(ind && codebook && out, CGIC_ERR_INVALID, "embedding_gather: NULL argument");
+    CGIC_REQUIRE(e_dim == 4 && K > 0, CGIC_ERR_UNSUPPORTED, "embedding_gather: needs a [K,4] codebook");
+    const int64_t n = B * hw;
+    if (n <= 0) return CGIC_OK;
+    int nblk = (int)((n + 255) / 256);
+    if (nblk > 4096) nblk = 4096;
+    hipLaunchKernelGGL(gather_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream, ind, B, hw, codebook, K, out, status);
+    return launch_check("gather_kernel");
+}

@@ -73,7 +73,7 @@ __device__ __forceinline__ T wave_inclusive_scan(T v)
 
 // Block-wide exclusive scan of one value per thread (blockDim.x multiple of 64,
 // <= 1024).  `smem` needs blockDim.x/64 + 1 elements.  Returns the exclusive
-// prefix; *total receives the block total.  Contains two __syncthreads().
+// prefix; *total receives the block total.  Contains three __syncthreads().
 template <typename T>
 __device__ __forceinline__ T block_exclusive_scan(T v, T *smem, T *total)
 {
@@ -92,6 +92,7 @@ __device__ __forceinline__ T block_exclusive_scan(T v, T *smem, T *total)
     __syncthreads();
     T res = smem[wid] + (inc - v);
     *total = smem[nw];
+    __syncthreads();   // smem may be reused by the next call
     return res;
 }
 #endif

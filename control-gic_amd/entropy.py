@@ -1,0 +1,51 @@
+"""Entropy -- drop-in for CGIC/models/model.py:433-483 (the router's input maps).
+
+`entropy_maps(x)` produces the patch-8 and patch-16 maps in ONE pass over the
+image; `Entropy(p)` keeps the reference's per-patch-size module API on top of it.
+"""
+import ctypes
+
+import torch
+from torch import nn
+
+from . import _lib
+
+_BINS = None
+
+
+def _bins():
+    # torch.linspace(-1, 1, 32) evaluated on the CPU, like the CPU reference path (model.py:480)
+    global _BINS
+    if _BINS is None:
+        vals = torch.linspace(-1, 1, 32, dtype=torch.float32).tolist()
+        _BINS = (ctypes.c_float * 32)(*vals)
+    return _BINS
+
+
+def entropy_maps(x, want8=True, want16=True, sigma=0.01):
+    """x [B,3,H,W] fp32 on the device, H and W multiples of 16 -> (e8 [B,H/8,W/8], e16 [B,H/16,W/16])"""
+    _lib.require_device(x)
+    if x.dim() != 4 or x.shape[1] != 3:
+        raise ValueError(f"expected [B,3,H,W], got {tuple(x.shape)}")
+    x = x.contiguous().float()
+    B, _, H, W = x.shape
+    e8 = torch.empty((B, H // 8, W // 8), dtype=torch.float32, device=x.device) if want8 else None
+    e16 = torch.empty((B, H // 16, W // 16), dtype=torch.float32, device=x.device) if want16 else None
+    with torch.cuda.device(x.device):
+        _lib.call("cgic_entropy_maps_f32", _lib.ptr(x), B, H, W, _bins(), 32, float(sigma), _lib.ptr(e8),
+                  _lib.ptr(e16), _lib.current_stream(x.device))
+    return e8, e16
+
+
+class Entropy(nn.Module):
+    def __init__(self, patch_size):
+        super().__init__()
+        if patch_size not in (8, 16):
+            raise NotImplementedError(
+                f"Entropy(patch_size={patch_size}): Control-GIC uses (8, 16) (config_inference.yaml:11-13); "
+                "other sizes are not built")
+        self.psize = patch_size
+
+    def forward(self, inputs):
+        e8, e16 = entropy_maps(inputs, want8=self.psize == 8, want16=self.psize == 16)
+        return e8 if self.psize == 8 else e16

@@ -1,0 +1,166 @@
+"""VectorQuantize2 / VectorQuantizer -- drop-in for the reference's quantizer
+(CGIC/modules/vqvae/quantize.py:9-97; aliased VectorQuantizer at CGIC/models/model.py:14).
+
+Same constructor, attributes, forward signature and state_dict keys; the
+forward body is one fused HIP kernel (csrc/cgic_vq.hip) instead of an N x K
+distance matrix in HBM.
+"""
+from collections.abc import MutableMapping
+
+import torch
+from torch import nn
+
+from . import _lib
+
+
+class _CounterView(MutableMapping):
+    """`embedding_counter` as the reference exposes it (quantize.py:28): a mapping
+    str(i) -> 1-element fp32 tensor (``.item()``, ``+= 1``, ``.data.fill_()`` all work),
+    iterating its keys in nn.ParameterDict order, i.e. SORTED AS STRINGS
+    ('0','1','10','100',...) -- the order HuffmanCoding's heap is filled in
+    (indices_coding.py:46-49).  Backed by one [n_e] tensor instead of n_e Parameters."""
+
+    def __init__(self, owner):
+        self._owner = owner
+        self._keys = sorted(str(i) for i in range(owner.n_e))
+
+    def __getitem__(self, k):
+        i = int(k)
+        if not 0 <= i < self._owner.n_e or str(i) != str(k):
+            raise KeyError(k)
+        return self._owner.usage_counter[i:i + 1]
+
+    def __setitem__(self, k, v):   # `counter[k] += 1` re-assigns the (already updated) view
+        view = self[k]
+        if v is not view:
+            view.copy_(torch.as_tensor(v).reshape(1))
+
+    def __delitem__(self, k):
+        raise TypeError("embedding_counter entries cannot be deleted")
+
+    def __iter__(self):
+        return iter(self._keys)
+
+    def __len__(self):
+        return len(self._keys)
+
+    def as_int_list(self):
+        """[int(counter[str(i)].item()) for i in range(n_e)] with ONE device->host copy"""
+        return [int(v) for v in self._owner.usage_counter.detach().cpu().tolist()]
+
+
+class _VQFunction(torch.autograd.Function):
+    """Forward = the HIP kernel.  Backward restates quantize.py:85-93 analytically:
+    z_q = z + (e - z).detach()  => dz += g_zq;  loss = m1 + beta*m2 (legacy) with
+    m1 = mean((e.detach() - z)^2), m2 = mean((e - z.detach())^2)."""
+
+    @staticmethod
+    def forward(ctx, z, weight, beta, legacy, hist):
+        z_q, loss, idx = _vq_forward(z, weight, beta, legacy, hist)
+        ctx.save_for_backward(z, weight, idx)
+        ctx.beta, ctx.legacy = beta, legacy
+        ctx.mark_non_differentiable(idx)
+        return z_q, loss, idx
+
+    @staticmethod
+    def backward(ctx, g_zq, g_loss, _):
+        z, weight, idx = ctx.saved_tensors
+        B, C, h, w = z.shape
+        zf = z.permute(0, 2, 3, 1).reshape(-1, C)
+        diff = weight.detach()[idx] - zf                      # e - z, [N, C]
+        scale = 2.0 / diff.numel()
+        w_z, w_e = (1.0, ctx.beta) if ctx.legacy else (ctx.beta, 1.0)
+        gz = g_zq + (g_loss * (-scale * w_z) * diff).view(B, h, w, C).permute(0, 3, 1, 2)
+        gw = torch.zeros_like(weight).index_add_(0, idx, g_loss * (scale * w_e) * diff)
+        return gz, gw, None, None, None
+
+
+def _vq_forward(z, weight, beta, legacy, hist, want_zq=True, want_loss=True, kernel="mfma"):
+    _lib.require_device(z, weight)
+    if z.dtype != torch.float32 or weight.dtype != torch.float32:
+        raise TypeError("VectorQuantizer computes in fp32 like the reference; got "
+                        f"{z.dtype}/{weight.dtype}")
+    B, C, h, w = z.shape
+    z = z.contiguous()
+    weight = weight.detach().contiguous()
+    N = B * h * w
+    idx = torch.empty(N, dtype=torch.int64, device=z.device)
+    z_q = torch.empty_like(z) if want_zq else None
+    loss = torch.empty((), dtype=torch.float32, device=z.device) if want_loss else None
+    ws = None
+    if want_loss:
+        ws = torch.empty(_lib.lib().cgic_vq_workspace_bytes(N), dtype=torch.uint8, device=z.device)
+    fn = "cgic_vq_forward_f32" if kernel == "mfma" else "cgic_vq_forward_valu_f32"
+    with torch.cuda.device(z.device):
+        _lib.call(fn, _lib.ptr(z), B, h * w, _lib.ptr(weight), weight.shape[0], C, float(beta), int(bool(legacy)),
+                  _lib.ptr(idx), _lib.ptr(z_q), _lib.ptr(loss), _lib.ptr(hist), _lib.ptr(ws),
+                  _lib.current_stream(z.device))
+    return z_q, loss, idx
+
+
+class VectorQuantize2(nn.Module):
+    def __init__(self, n_e, e_dim, beta, remap=None, unknown_index="random", sane_index_shape=False,
+                 legacy=True):
+        super().__init__()
+        self.n_e = n_e
+        self.e_dim = e_dim
+        self.beta = beta
+        self.legacy = legacy
+        self.embedding = nn.Embedding(n_e, e_dim)
+        self.embedding.weight.data.uniform_(-1.0 / n_e, 1.0 / n_e)          # quantize.py:26
+        # usage counter (quantize.py:28): n_e fp32 counters, saved as embedding_counter.<i>
+        self.register_buffer("usage_counter", torch.zeros(n_e), persistent=False)
+        # exact integer histogram accumulated by the kernel in training mode
+        self.register_buffer("usage_hist", torch.zeros(n_e, dtype=torch.int64), persistent=False)
+        if remap is not None:
+            raise NotImplementedError("remap is unused by Control-GIC (remap=None, model.py:49-50) and not built here")
+        self.remap = None
+        self.re_embed = n_e
+        self.sane_index_shape = sane_index_shape
+        self._register_state_dict_hook(self._save_counter)
+        self._register_load_state_dict_pre_hook(self._load_counter)
+
+    # ---- state_dict compatibility: quantize.embedding_counter.<i>, each of shape [1]
+    @staticmethod
+    def _save_counter(module, state, prefix, local_metadata):
+        c = module.usage_counter.detach()
+        for k in module.embedding_counter:
+            state[f"{prefix}embedding_counter.{k}"] = c[int(k):int(k) + 1].clone()
+
+    def _load_counter(self, state, prefix, local_metadata, strict, missing, unexpected, errors):
+        for k in list(state.keys()):
+            if k.startswith(prefix + "embedding_counter."):
+                i = int(k[len(prefix) + len("embedding_counter."):])
+                if 0 <= i < self.n_e:
+                    with torch.no_grad():
+                        self.usage_counter[i] = state[k].reshape(-1)[0].to(self.usage_counter)
+                del state[k]
+
+    @property
+    def embedding_counter(self):
+        return _CounterView(self)
+
+    def fold_usage_hist(self):
+        """Add the kernel's exact int64 histogram into the fp32 counters and clear it.
+        The reference adds 1.0 per vector in fp32 (quantize.py:79-81), which stops
+        counting at 2**24; below that both give the same integers."""
+        with torch.no_grad():
+            self.usage_counter += self.usage_hist.to(self.usage_counter.dtype)
+            self.usage_hist.zero_()
+
+    def forward(self, z):
+        hist = self.usage_hist if self.training else None
+        if torch.is_grad_enabled() and (z.requires_grad or self.embedding.weight.requires_grad):
+            z_q, loss, idx = _VQFunction.apply(z, self.embedding.weight, self.beta, self.legacy, hist)
+        else:
+            z_q, loss, idx = _vq_forward(z, self.embedding.weight, self.beta, self.legacy, hist)
+        if self.training:
+            self.fold_usage_hist()
+        return z_q, loss, idx
+
+    def indices(self, z, kernel="mfma"):
+        """argmin only (no z_q / loss): what compress() consumes (model.py:216)."""
+        return _vq_forward(z, self.embedding.weight, self.beta, self.legacy, None, False, False, kernel)[2]
+
+
+VectorQuantizer = VectorQuantize2

@@ -152,7 +152,8 @@ int cgic_table_get(const cgic_table *t, int32_t *len, uint32_t *code);
  *   out    device [cap] uint8; framing: 1 byte pad count (1..8), code bits
  *          MSB-first, pad zero bits; n == 0 -> 0 bytes (empty file)
  *   nbytes device [1] int32: bytes produced, or CGIC_ERR_* (<0) if a symbol
- *          is outside the table (KeyError in the reference) / cap too small
+ *          is outside the table (KeyError in the reference) / cap too small;
+ *          `out` must be 4-byte aligned
  * cgic_decode_stream:
  *   in     device [nbytes] uint8 (+ >= 8 readable bytes of slack after it)
  *   syms   device [cap] int64; count device [1] int64: symbols decoded, or -1
@@ -178,7 +179,8 @@ int cgic_decode_stream(const cgic_table *t, const uint8_t *in, int64_t nbytes, i
  *   out     device [B, 5, slot] uint8, slot = cgic_compress_slot_bytes(t, h, w)
  *   nbytes  device [B, 5] int32: length of each stream; -1 = the mode does not
  *           write that stream (model.py:225-260); 0 = written but empty file;
- *           < -1 = CGIC_ERR_* for that stream
+ *           <= -10 = (CGIC_ERR_* - 10) for that stream (a symbol outside the
+ *           table -- KeyError in the reference -- or slot too small)
  *   Streams are produced by: masked select in row-major order of each
  *   granularity's own grid (ind[:, ::4, ::4][mask_c==1] ..., :219-221),
  *   Huffman coding with `t`, 1-bit packing of mask_c / mask_m (:230-231).

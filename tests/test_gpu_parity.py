@@ -1,0 +1,333 @@
+"""GPU: the HIP path (through the C ABI of libcgic_hip.so) against the golden vectors of the real
+reference and against the CPU oracle on seeded inputs.  Integer / byte / index results are
+compared bit-exactly; fp32 tolerances are written next to each assert."""
+import numpy as np
+import pytest
+import torch
+
+import control_gic_amd as cg
+from conftest import unpack_mask
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+class _V:
+    def __init__(self, v): self.v = v
+    def item(self): return self.v
+
+
+def _freq_mapping(freq, order):
+    return {str(int(k)): _V(float(freq[int(k)])) for k in order}
+
+
+def _t(a, dtype=None):
+    t = torch.from_numpy(np.ascontiguousarray(a))
+    if dtype is not None:
+        t = t.to(dtype)
+    return t.to(DEV)
+
+
+# ---------------------------------------------------------------------------- A. VQ
+VQ_CASES = ["normal_b2_32", "normal_n1", "normal_odd", "normal_b1_64", "init_small", "init_mixed", "dup_rows",
+            "codes_as_z", "lattice_ties"]
+
+
+def _make_vq(cb):
+    vq = cg.VectorQuantizer(cb.shape[0], cb.shape[1], beta=0.25).to(DEV).eval()
+    vq.embedding.weight.data.copy_(_t(cb))
+    return vq
+
+
+@pytest.mark.parametrize("kernel", ["mfma", "valu"])
+@pytest.mark.parametrize("case", VQ_CASES)
+def test_vq_golden(golden, case, kernel):
+    from control_gic_amd.quantize import _vq_forward
+    g = golden("vq")
+    vq = _make_vq(g[case + "_cb"])
+    with torch.no_grad():
+        zq, loss, idx = _vq_forward(_t(g[case + "_z"]), vq.embedding.weight, 0.25, True, None, kernel=kernel)
+    assert idx.dtype == torch.int64 and idx.dim() == 1
+    assert np.array_equal(idx.cpu().numpy(), g[case + "_idx"].astype(np.int64).ravel())   # bit-exact
+    assert np.array_equal(zq.cpu().numpy(), g[case + "_zq"])                               # bit-exact
+    ref = float(g[case + "_loss"])
+    assert abs(float(loss) - ref) <= 1e-6 * abs(ref) + 1e-12                               # mean's sum order
+
+
+def test_vq_module_forward_and_counter(golden, orc):
+    g = golden("vq")
+    vq = _make_vq(g["normal_b2_32_cb"])
+    z = _t(g["counter_z"])
+    with torch.no_grad():
+        zq, loss, idx = vq(z)
+        assert vq.usage_counter.sum().item() == 0                 # eval: no counting (quantize.py:79)
+        vq.train()
+        vq(z)
+        vq(z)
+    assert np.array_equal(vq.usage_counter.cpu().numpy(), g["counter_cnt"])
+    assert vq.embedding_counter["3"].item() == float(g["counter_cnt"][3])
+
+
+@pytest.mark.parametrize("shape,scale", [((64, 4, 64, 64), 1.0), ((3, 4, 192, 192), 1.0), ((5, 4, 20, 36), 0.002)])
+def test_vq_vs_oracle_and_cross_kernel(orc, shape, scale):
+    """config 2 size (B=64, 256^2) and a 768^2-tile size: MFMA kernel == VALU kernel everywhere
+    (size-independent property), and == the oracle on a slice the CPU finishes in seconds."""
+    g = torch.Generator().manual_seed(123)
+    z = torch.randn(shape, generator=g) * scale
+    cb = torch.randn(1024, 4, generator=g) * scale if scale == 1.0 else (torch.rand(1024, 4, generator=g) * 2 - 1) / 1024
+    vq = _make_vq(cb.numpy())
+    hist = torch.zeros(1024, dtype=torch.int64, device=DEV)
+    from control_gic_amd.quantize import _vq_forward
+    zq_a, loss_a, idx_a = _vq_forward(z.to(DEV), vq.embedding.weight, 0.25, True, hist, kernel="mfma")
+    zq_b, loss_b, idx_b = _vq_forward(z.to(DEV), vq.embedding.weight, 0.25, True, None, kernel="valu")
+    assert torch.equal(idx_a, idx_b) and torch.equal(zq_a, zq_b)
+    assert abs(float(loss_a) - float(loss_b)) <= 1e-6 * abs(float(loss_b))
+    assert int(hist.sum()) == idx_a.numel()
+    assert torch.equal(hist, torch.bincount(idx_a, minlength=1024))
+    nb = min(2, shape[0])
+    ozq, oloss, oidx = orc.vq(z[:nb].numpy(), cb.numpy())
+    n = oidx.size
+    assert np.array_equal(idx_a[:n].cpu().numpy(), oidx)
+    assert np.array_equal(zq_a[:nb].cpu().numpy(), ozq)
+    # embedding gather is an exact copy of codebook rows (model.py:391-392)
+    e = vq.embedding(idx_a[:n]).cpu().numpy()
+    assert np.array_equal(e, cb.numpy()[oidx])
+
+
+def test_vq_backward_matches_reference_formula():
+    g = torch.Generator().manual_seed(5)
+    z = torch.randn(2, 4, 8, 8, generator=g).to(DEV).requires_grad_(True)
+    vq = cg.VectorQuantizer(1024, 4, beta=0.25).to(DEV).train()
+    vq.embedding.weight.data.copy_(torch.randn(1024, 4, generator=g))
+    zq, loss, idx = vq(z)
+    (zq.square().sum() + 3.0 * loss).backward()
+    # plain-torch restatement of quantize.py:83-93 on the same indices
+    z2 = z.detach().clone().requires_grad_(True)
+    w2 = vq.embedding.weight.detach().clone().requires_grad_(True)
+    zp = z2.permute(0, 2, 3, 1)
+    e = w2[idx].view(zp.shape)
+    l2 = ((e.detach() - zp) ** 2).mean() + 0.25 * ((e - zp.detach()) ** 2).mean()
+    q2 = (zp + (e - zp).detach()).permute(0, 3, 1, 2)
+    (q2.square().sum() + 3.0 * l2).backward()
+    assert torch.allclose(z.grad, z2.grad, rtol=1e-5, atol=1e-7)
+    assert torch.allclose(vq.embedding.weight.grad, w2.grad, rtol=1e-5, atol=1e-7)
+
+
+# ---------------------------------------------------------------------------- C. router
+@pytest.mark.parametrize("shape", ["b1_16x16", "b2_16x16", "b1_4x6", "b3_8x12"])
+def test_router_golden(golden, orc, shape):
+    g = golden("router")
+    e16, e8 = g[shape + "_e16"], g[shape + "_e8"]
+    for ri, (c, m) in enumerate(g["ratios"]):
+        r = cg.TripleGrainFixedEntropyRouter(float(c), float(m))
+        mask, gate, ratios, mode = r(_t(e16), _t(e8))
+        assert mode == int(g[f"{shape}_r{ri}_mode"])
+        for k, t in zip("cmf", mask):
+            assert t.dtype == torch.int32
+            assert np.array_equal(t.cpu().numpy(), unpack_mask(g[f"{shape}_r{ri}_m{k}"], tuple(t.shape))), (c, m, k)
+        omc, omm, omf, ogate, _ = orc.router(e16, e8, float(c), float(m))
+        assert np.array_equal(gate.cpu().numpy(), ogate)
+        assert ratios == [float(c), float(m), 1 - float(c) - float(m)]
+        # per-image routing == B independent B=1 calls
+        pm, _, _, _ = cg.TripleGrainFixedEntropyRouter(float(c), float(m), per_image=True)(_t(e16), _t(e8))
+        pmc, pmm, pmf, _, _ = orc.router(e16, e8, float(c), float(m), per_image=True)
+        for a, b in zip(pm, (pmc, pmm, pmf)):
+            assert np.array_equal(a.cpu().numpy(), b)
+
+
+def test_router_batch64_and_tile_sizes(orc):
+    g = np.random.default_rng(3)
+    for (B, h16, w16) in ((64, 16, 16), (2, 48, 48), (1, 48, 37)):
+        e16 = (g.random((B, h16, w16)) * 2.6).astype(np.float32)
+        e8 = (g.random((B, 2 * h16, 2 * w16)) * 2.6).astype(np.float32)
+        e8.ravel()[g.integers(0, e8.size, e8.size // 5)] = np.float32(1.25)      # heavy ties
+        for c, m in ((0.1, 0.8), (0.25, 0.25), (0.0, 0.5), (0.5, 0.0)):
+            for per_image in (False, True):
+                mask, gate, _, mode = cg.TripleGrainFixedEntropyRouter(c, m, per_image=per_image)(_t(e16), _t(e8))
+                omc, omm, omf, ogate, omode = orc.router(e16, e8, c, m, per_image=per_image)
+                assert mode == omode
+                assert np.array_equal(mask[0].cpu().numpy(), omc) and np.array_equal(mask[1].cpu().numpy(), omm)
+                assert np.array_equal(mask[2].cpu().numpy(), omf) and np.array_equal(gate.cpu().numpy(), ogate)
+
+
+def test_router_constant_map_selects_nothing():
+    e16 = torch.full((1, 16, 16), 3.351e-4, device=DEV)
+    e8 = torch.full((1, 32, 32), 3.351e-4, device=DEV)
+    mask, _, _, mode = cg.TripleGrainFixedEntropyRouter(0.1, 0.8)(e16, e8)
+    assert mode == 0 and int(mask[0].sum()) == 0 and int(mask[1].sum()) == 0 and int(mask[2].sum()) == 64 * 64
+
+
+# ---------------------------------------------------------------------------- C'. entropy
+@pytest.mark.parametrize("name", ["rand_64x96", "u8_48x80", "smooth_64x64", "const_32x32", "signed_32x32"])
+def test_entropy_golden(golden, name):
+    g = golden("entropy")
+    x = _t(g[name + "_x"])
+    e8, e16 = cg.entropy_maps(x)
+    # fp32 with OCML exp/log vs SLEEF + different (fixed) summation order: 2e-5 absolute on values in [0, 3.5]
+    assert np.abs(e8.cpu().numpy() - g[name + "_e8"]).max() < 2e-5
+    assert np.abs(e16.cpu().numpy() - g[name + "_e16"]).max() < 2e-5
+    assert torch.equal(cg.Entropy(8).to(DEV)(x), e8) and torch.equal(cg.Entropy(16).to(DEV)(x), e16)
+
+
+def test_entropy_batch_vs_oracle_and_determinism(orc):
+    g = torch.Generator().manual_seed(2)
+    x = torch.rand(4, 3, 256, 256, generator=g)
+    e8, e16 = cg.entropy_maps(x.to(DEV))
+    e8b, e16b = cg.entropy_maps(x.to(DEV))
+    assert torch.equal(e8, e8b) and torch.equal(e16, e16b)          # fixed summation order: run-to-run identical
+    assert np.abs(e8.cpu().numpy() - orc.entropy(x.numpy(), 8)).max() < 2e-5
+    assert np.abs(e16.cpu().numpy() - orc.entropy(x.numpy(), 16)).max() < 2e-5
+    # images do not interact: batch == per-image
+    e8s, _ = cg.entropy_maps(x[2:3].to(DEV))
+    assert torch.equal(e8s[0], e8[2])
+    # ragged width (W % 64 != 0)
+    x2 = torch.rand(1, 3, 48, 208, generator=g)
+    a8, a16 = cg.entropy_maps(x2.to(DEV))
+    assert np.abs(a8.cpu().numpy() - orc.entropy(x2.numpy(), 8)).max() < 2e-5
+    assert np.abs(a16.cpu().numpy() - orc.entropy(x2.numpy(), 16)).max() < 2e-5
+
+
+# ---------------------------------------------------------------------------- D/E/F. coders
+@pytest.mark.parametrize("name", ["zeros", "zipf", "big", "ties"])
+def test_huffman_streams_golden(golden, name, tmp_path):
+    g = golden("coders")
+    h = cg.HuffmanCoding(_freq_mapping(g[name + "_freq"], g[name + "_order"]))
+    for si in range(6):
+        sym = g[f"{name}_s{si}_sym"].astype(np.int64)
+        data = g[f"{name}_s{si}_bytes"].tobytes()
+        p = h.compress(_t(sym), str(tmp_path / "s.bin"))
+        assert open(p, "rb").read() == data, f"{name} stream {si}"      # byte-identical file
+        dec = h.decompress_string(p)
+        assert (dec is None and len(sym) == 0) or dec == sym.tolist()
+
+
+def test_huffman_long_stream_uses_workspace(orc, golden):
+    g = golden("coders")
+    rng = np.random.default_rng(0)
+    for name in ("zipf", "ties"):
+        h = cg.HuffmanCoding(_freq_mapping(g[name + "_freq"], g[name + "_order"]))
+        t = orc.HuffmanTable(g[name + "_freq"])
+        sym = rng.integers(0, 1024, 36864)
+        data = h.encode_to_bytes(_t(sym))
+        assert data == orc.encode(t, sym)
+        assert h.decode_bytes(data) == sym.tolist()
+
+
+def test_huffman_keyerror_and_truncated_stream(golden):
+    g = golden("coders")
+    h = cg.HuffmanCoding(_freq_mapping(g["zipf_freq"], g["zipf_order"]))
+    with pytest.raises(KeyError):
+        h.encode_to_bytes(torch.tensor([1, 2, 5000], device=DEV))
+    sym = np.arange(100)
+    data = h.encode_to_bytes(_t(sym))
+    dec = h.decode_bytes(data[:-3] + bytes([0]))       # cut: trailing partial code is dropped, no crash
+    assert dec is not None and dec == sym.tolist()[:len(dec)] and len(dec) < 100
+
+
+def test_binary_coding_golden(golden, tmp_path):
+    g = golden("coders")
+    b = cg.BinaryCoding()
+    for n in (0, 1, 7, 8, 256, 1024, 2304):
+        m, data = g[f"binary_{n}_mask"].astype(np.int32), g[f"binary_{n}_bytes"].tobytes()
+        p = b.compress(_t(m), str(tmp_path / "m.bin"))
+        assert open(p, "rb").read() == data
+        dec = b.decompress_string(p)
+        assert (dec is None and n == 0) or dec == m.tolist()
+
+
+# ---------------------------------------------------------------------------- G. compress glue
+def _cfg1_keys(g):
+    return sorted({k[:-5] for k in g if k.endswith("_mode")})
+
+
+def test_compress_config1_bit_identical_bins(golden, tmp_path):
+    """config 1: every .bin the reference wrote for torch.rand(1,3,256,256), all 7 modes, both tables"""
+    g = golden("compress_cfg1")
+    gc = golden("coders")
+    cb = _t(g["codebook"])
+    codecs = {"zipf": cg.GrainCodec(_freq_mapping(gc["zipf_freq"], gc["zipf_order"]), cb),
+              "zeros": cg.GrainCodec(_freq_mapping(np.zeros(1024), gc["zipf_order"]), cb)}
+    vq = _make_vq(g["codebook"])
+    for key in _cfg1_keys(g):
+        tname, ri = key.split("_r")
+        c, m = (float(v) for v in g["ratios"][int(ri)])
+        mode = int(g[key + "_mode"])
+        # the path end to end at the hot path's own inputs: entropies -> masks, latent -> indices -> bytes
+        mask, _, _, rmode = cg.TripleGrainFixedEntropyRouter(c, m)(_t(g["e16"]), _t(g["e8"]))
+        assert rmode == mode
+        ind = vq.indices(_t(g[key + "_z"]))
+        assert np.array_equal(ind.cpu().numpy().reshape(64, 64), g[key + "_ind"].astype(np.int64))
+        comp = codecs[tname].compress(ind, mask, mode)
+        files = comp.to_host()[0]
+        on = cg.mode_streams(mode)
+        assert set(files) == {n for n, o in zip(cg.STREAM_NAMES, on) if o}
+        for n in files:
+            assert files[n] == g[f"{key}_{n}"].tobytes(), f"{key}: {n}.bin differs"
+        assert comp.bpp(256 * 256)[0] == float(g[key + "_bpp"])                  # bpp match
+        paths = comp.write_legacy(str(tmp_path))
+        assert sorted(p.split("/")[-1] for p in paths) == sorted(n + ".bin" for n in files)
+        # decode side
+        rb = cg.CompressedBatch.read_legacy(str(tmp_path), mode, 64, 64, comp.data.shape[2], DEV)
+        dind, dmask, zq, status = codecs[tname].decompress(rb)
+        assert int(status[0]) == 0
+        assert np.array_equal(dind.cpu().numpy()[0], g[key + "_qdec_ind"].astype(np.int64))
+        assert np.array_equal(zq.cpu().numpy()[0], g["codebook"][g[key + "_qdec_ind"].astype(np.int64)].transpose(2, 0, 1))
+        for k, t in zip("cmf", dmask):
+            assert np.array_equal(t.cpu().numpy()[0, 0], unpack_mask(g[f"{key}_m{k}"], tuple(t.shape[-2:])))
+
+
+def _random_case(rng, B, h, w, c, m):
+    e16 = (rng.random((B, h // 4, w // 4)) * 2.6).astype(np.float32)
+    e8 = (rng.random((B, h // 2, w // 2)) * 2.6).astype(np.float32)
+    ind = rng.integers(0, 1024, (B, h, w))
+    # make the index grid consistent with what the encoder merge produces: constant inside a coarse /
+    # medium cell is NOT required by the coder (it reads the top-left element), so keep it fully random
+    return e16, e8, ind
+
+
+@pytest.mark.parametrize("B,h,w", [(64, 64, 64), (2, 192, 192), (3, 192, 148), (1, 4, 4)])
+def test_compress_batch_vs_oracle_and_roundtrip(orc, golden, B, h, w):
+    """configs 2-4: B=64 256^2 and 768^2-tile grids; all modes; bytes == oracle per image (sample) and
+    encode -> decode round trip for every image (size-independent property)."""
+    gc = golden("coders")
+    rng = np.random.default_rng(h * 7 + B)
+    cbk = rng.standard_normal((1024, 4)).astype(np.float32)
+    codec = cg.GrainCodec(_freq_mapping(gc["zipf_freq"], gc["zipf_order"]), _t(cbk))
+    htab = orc.HuffmanTable(gc["zipf_freq"])
+    for c, m in ((0.1, 0.8), (0.0, 0.5), (0.5, 0.0), (0.5, 0.5), (1.0, 0.0), (0.0, 1.0), (0.0, 0.0)):
+        e16, e8, ind = _random_case(rng, B, h, w, c, m)
+        mask, _, _, mode = cg.TripleGrainFixedEntropyRouter(c, m, per_image=True)(_t(e16), _t(e8))
+        comp = codec.compress(_t(ind), mask, mode)
+        host = comp.to_host()
+        mks = [t.cpu().numpy() for t in mask]
+        for b in sorted({0, B // 2, B - 1}):
+            ref = orc.compress_image(ind[b], mks[0][b, 0], mks[1][b, 0], mks[2][b, 0], mode, htab)
+            assert host[b] == ref, f"mode {mode} image {b}"
+        dind, dmask, zq, status = codec.decompress(comp)
+        assert int(status.abs().max()) == 0
+        # expected merged grid: the value each granularity's top-left element carries
+        exp = np.where(mks[2][:, 0] == 1, ind, 0)
+        exp = exp + np.repeat(np.repeat(np.where(mks[1][:, 0] == 1, ind[:, ::2, ::2], 0), 2, 1), 2, 2)
+        exp = exp + np.repeat(np.repeat(np.where(mks[0][:, 0] == 1, ind[:, ::4, ::4], 0), 4, 1), 4, 2)
+        assert np.array_equal(dind.cpu().numpy(), exp)
+        for a, b_ in zip(dmask, mask):
+            assert torch.equal(a, b_)
+        assert np.array_equal(zq.cpu().numpy(), cbk[exp].transpose(0, 3, 1, 2))
+        b0 = 0
+        oind, _, _, _ = orc.decompress_image(host[b0], mode, h, w, htab)
+        assert np.array_equal(oind, exp[b0])
+
+
+def test_decompress_flags_corrupt_streams(golden):
+    gc = golden("coders")
+    rng = np.random.default_rng(1)
+    codec = cg.GrainCodec(_freq_mapping(gc["zipf_freq"], gc["zipf_order"]), _t(rng.standard_normal((1024, 4)).astype(np.float32)))
+    e16, e8, ind = _random_case(rng, 2, 64, 64, 0.1, 0.8)
+    mask, _, _, mode = cg.TripleGrainFixedEntropyRouter(0.1, 0.8, per_image=True)(_t(e16), _t(e8))
+    comp = codec.compress(_t(ind), mask, mode)
+    host = comp.to_host()
+    bad = [dict(host[0]), dict(host[1])]
+    bad[1]["indices_medium"] = bad[1]["indices_medium"][:40]             # symbol count no longer matches its mask
+    rb = cg.CompressedBatch.from_host(bad, mode, 64, 64, comp.data.shape[2], DEV)
+    _, _, _, status = codec.decompress(rb)
+    assert int(status[0]) == 0 and int(status[1]) != 0                   # the reference raises there

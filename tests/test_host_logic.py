@@ -1,0 +1,134 @@
+"""CPU: host-side logic of the product package and the shape of the C ABI (no device compute)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+import control_gic_amd as cg
+from control_gic_amd import _lib
+from conftest import ROOT
+
+
+def test_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "cgic_hip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(cgic_[a-z0-9_]+)\s*\(", hdr))
+    assert len(declared) >= 25
+    l = ctypes.CDLL(cg.LIB_PATH)
+    for name in declared:
+        assert hasattr(l, name), f"{name} declared in cgic_hip.h but not exported"
+    assert declared == set(_lib.PROTOTYPES), "ctypes prototype table out of sync with the header"
+    assert _lib.lib().cgic_abi_version() == 1
+
+
+def test_device_count_does_not_abort_without_gpu():
+    n = _lib.lib().cgic_device_count()
+    assert n == _lib.ERR_HIP or n >= 0
+
+
+class _V:
+    def __init__(self, v): self.v = v
+    def item(self): return self.v
+
+
+@pytest.mark.parametrize("name", ["zeros", "zipf", "big", "ties"])
+def test_native_table_builder_matches_reference_codes(golden, name):
+    """csrc/cgic_table.hip (CPython-heapq restatement) vs the codes the reference built"""
+    g = golden("coders")
+    freq = g[name + "_freq"]
+    order = [str(i) for i in g[name + "_order"]]
+    h = cg.HuffmanCoding({k: _V(float(freq[int(k)])) for k in order})       # mapping iterated in ParameterDict order
+    ln, cd = h.table.arrays()
+    assert np.array_equal(np.array(ln, np.int32), g[name + "_len"])
+    assert np.array_equal(np.array(cd, np.uint32), g[name + "_code"])
+    hn = cg.HuffmanCoding({str(i): _V(float(v)) for i, v in enumerate(freq)})  # plain-dict order
+    assert np.array_equal(np.array(hn.table.arrays()[0], np.int32), g[name + "_natural_len"])
+    codes = h.codes
+    assert len(codes) == 1024 and len(set(codes.values())) == 1024
+    assert h.reverse_mapping[codes[17]] == 17
+    # prefix-free
+    srt = sorted(codes.values())
+    assert all(not b.startswith(a) for a, b in zip(srt, srt[1:]))
+
+
+def test_counter_view_iterates_like_parameter_dict():
+    vq = cg.VectorQuantizer(1024, 4, beta=0.25)
+    ref = torch.nn.ParameterDict({str(i): torch.nn.Parameter(torch.zeros(1)) for i in range(1024)})
+    assert list(vq.embedding_counter.keys()) == list(ref.keys())
+    vq.embedding_counter["7"] += 3
+    vq.embedding_counter["12"].data.fill_(5.0)
+    assert vq.embedding_counter["7"].item() == 3.0 and vq.usage_counter[12].item() == 5.0
+    h = cg.HuffmanCoding(vq.embedding_counter)
+    assert h.table.n == 1024
+
+
+def test_vq_state_dict_keys_match_reference():
+    vq = cg.VectorQuantizer(1024, 4, beta=0.25)
+    vq.usage_counter[5] = 9.0
+    sd = vq.state_dict()
+    assert set(sd) == {"embedding.weight"} | {f"embedding_counter.{i}" for i in range(1024)}
+    assert tuple(sd["embedding_counter.5"].shape) == (1,) and sd["embedding_counter.5"].item() == 9.0
+    vq2 = cg.VectorQuantizer(1024, 4, beta=0.25)
+    missing, unexpected = vq2.load_state_dict(sd, strict=True)
+    assert not missing and not unexpected
+    assert torch.equal(vq2.embedding.weight, vq.embedding.weight) and vq2.usage_counter[5].item() == 9.0
+    # nested prefix, like model.quantize.*
+    wrap = torch.nn.Module()
+    wrap.quantize = cg.VectorQuantizer(1024, 4, beta=0.25)
+    wrap.load_state_dict({"quantize." + k: v for k, v in sd.items()}, strict=True)
+    assert wrap.quantize.usage_counter[5].item() == 9.0
+
+
+def test_router_modes_and_streams():
+    R = cg.TripleGrainFixedEntropyRouter
+    assert R(0.7, 0.3).mode == 0 and R(0.3, 0.7).mode == 3        # float64 quirk, RouterTriple.py:13
+    assert [R(c, m).mode for c, m in ((.1, .8), (0, .4), (.4, 0), (1, 0), (0, 1), (0, 0))] == [0, 1, 2, 4, 5, 6]
+    assert R(0.1, 0.8).fine_grain_ratio == 1 - 0.1 - 0.8
+    want = {0: "11111", 1: "01101", 2: "10110", 3: "11010", 4: "10000", 5: "01000", 6: "00100"}
+    for mode, bits in want.items():
+        assert "".join("1" if b else "0" for b in cg.mode_streams(mode)) == bits
+    with pytest.raises(cg.CgicError):
+        cg.mode_streams(7)
+
+
+def test_product_path_refuses_cpu_tensors():
+    """no CPU fallback: every op raises on CPU tensors instead of computing something else"""
+    vq = cg.VectorQuantizer(1024, 4, beta=0.25)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        vq(torch.zeros(1, 4, 8, 8))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        cg.TripleGrainFixedEntropyRouter(0.1, 0.8)(torch.zeros(1, 4, 4), torch.zeros(1, 8, 8))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        cg.Entropy(8)(torch.zeros(1, 3, 32, 32))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        cg.BinaryCoding().compress(torch.zeros(8, dtype=torch.int32), "/tmp/_never_written.bin")
+    with pytest.raises(NotImplementedError):
+        cg.Entropy(4)
+
+
+def test_argument_validation_happens_before_any_launch():
+    l = _lib.lib()
+    assert l.cgic_vq_forward_f32(None, 1, 16, None, 1024, 4, 0.25, 1, None, None, None, None, None, None) == _lib.ERR_INVALID
+    one = ctypes.c_void_p(16)
+    assert l.cgic_vq_forward_f32(one, 1, 16, one, 1024, 3, 0.25, 1, None, None, None, None, None, None) == _lib.ERR_UNSUPPORTED
+    assert b"embed_dim == 4" in l.cgic_last_error()
+    assert l.cgic_vq_forward_f32(one, 1, 16, one, 1000, 4, 0.25, 1, None, None, None, None, None, None) == _lib.ERR_UNSUPPORTED
+    # router: k > n is an IndexError in the reference
+    assert l.cgic_router_f32(one, one, 1, 4, 4, 1.5, 0.0, 0, one, one, one, None, None, None) == _lib.ERR_INVALID
+    assert b"IndexError" in l.cgic_last_error()
+    bins = (ctypes.c_float * 32)(*np.linspace(-1, 1, 32, dtype=np.float32))
+    assert l.cgic_entropy_maps_f32(one, 1, 24, 32, bins, 32, 0.01, one, one, None) == _lib.ERR_INVALID
+    assert l.cgic_entropy_maps_f32(one, 1, 32, 32, bins, 32, 0.05, one, one, None) == _lib.ERR_UNSUPPORTED
+
+
+def test_slot_and_workspace_sizes():
+    h = cg.HuffmanCoding({str(i): _V(float(1024 - i)) for i in range(1024)})
+    l = _lib.lib()
+    slot = l.cgic_compress_slot_bytes(h.table.handle, 64, 64)
+    assert slot % 16 == 0 and slot >= 4096 * h.table.max_len // 8 + 2
+    assert l.cgic_compress_workspace_bytes(64, 64, 64) == 0                 # 4096 positions fit LDS
+    assert l.cgic_compress_workspace_bytes(1, 192, 192) >= 3 * 36864 * 6    # 768^2 tile: global scratch
+    assert l.cgic_decompress_workspace_bytes(2, 64, 64) >= 2 * (256 + 1024 + 4096) * 4 + 48

@@ -1,0 +1,129 @@
+"""CPU: the oracle (oracle/cgic_oracle.c) against the golden vectors produced by the real
+reference (tests/golden/make_golden.py).  This is what "oracle pinned" means."""
+import numpy as np
+import pytest
+
+from conftest import unpack_mask
+
+VQ_CASES = ["normal_b2_32", "normal_n1", "normal_odd", "normal_b1_64", "init_small", "init_mixed", "dup_rows",
+            "codes_as_z", "lattice_ties"]
+
+
+@pytest.mark.parametrize("case", VQ_CASES)
+def test_vq_matches_reference(orc, golden, case):
+    g = golden("vq")
+    zq, loss, idx = orc.vq(g[case + "_z"], g[case + "_cb"])
+    assert np.array_equal(idx, g[case + "_idx"].astype(np.int64).ravel())        # bit-exact indices
+    assert np.array_equal(zq, g[case + "_zq"])                                   # bit-exact z + (e - z)
+    assert abs(float(loss) - float(g[case + "_loss"])) <= 1e-6 * abs(float(g[case + "_loss"])) + 1e-12
+
+
+def test_vq_usage_counter(orc, golden):
+    g = golden("vq")
+    hist = np.zeros(1024, np.int64)
+    orc.vq(g["counter_z"], g["normal_b2_32_cb"], hist=hist)
+    assert np.array_equal((2 * hist).astype(np.float32), g["counter_cnt"])      # two training forwards
+
+
+@pytest.mark.parametrize("shape", ["b1_16x16", "b2_16x16", "b1_4x6", "b3_8x12"])
+def test_router_matches_reference(orc, golden, shape):
+    g = golden("router")
+    e16, e8 = g[shape + "_e16"], g[shape + "_e8"]
+    B, h16, w16 = e16.shape
+    for ri, (c, m) in enumerate(g["ratios"]):
+        mc, mm, mf, gate, mode = orc.router(e16, e8, float(c), float(m))
+        assert mode == int(g[f"{shape}_r{ri}_mode"])
+        assert np.array_equal(mc, unpack_mask(g[f"{shape}_r{ri}_mc"], mc.shape))
+        assert np.array_equal(mm, unpack_mask(g[f"{shape}_r{ri}_mm"], mm.shape))
+        assert np.array_equal(mf, unpack_mask(g[f"{shape}_r{ri}_mf"], mf.shape))
+        assert np.array_equal(gate[..., :4 * w16], np.repeat(np.repeat(mc, 4, 2), 4, 3).astype(np.float32))
+
+
+def test_router_float64_mode_quirks(orc):
+    # 1 - 0.7 - 0.3 = 5.55e-17 != 0 -> mode 0; 1 - 0.3 - 0.7 == 0.0 -> mode 3
+    assert orc.router_mode(0.7, 0.3) == 0 and orc.router_mode(0.3, 0.7) == 3
+    assert [orc.router_mode(c, m) for c, m in ((0, .4), (.4, 0), (1, 0), (0, 1), (0, 0))] == [1, 2, 4, 5, 6]
+
+
+@pytest.mark.parametrize("name", ["rand_64x96", "u8_48x80", "smooth_64x64", "const_32x32", "signed_32x32"])
+def test_entropy_matches_reference(orc, golden, name):
+    g = golden("entropy")
+    assert np.array_equal(orc.linspace_bins(), g["bins"])
+    for p in (8, 16):
+        e = orc.entropy(g[name + "_x"], p, bins=g["bins"])
+        assert np.abs(e - g[f"{name}_e{p}"]).max() < 2e-5        # exp/log/sum-order: tolerance, not bit-exact
+
+
+@pytest.mark.parametrize("name", ["zeros", "zipf", "big", "ties"])
+def test_huffman_table_and_streams(orc, golden, name):
+    g = golden("coders")
+    assert np.array_equal(g[name + "_order"], orc.param_dict_order(1024))
+    t = orc.HuffmanTable(g[name + "_freq"])                      # ParameterDict (string-sorted) push order
+    assert np.array_equal(t.len, g[name + "_len"]) and np.array_equal(t.code, g[name + "_code"])
+    tn = orc.HuffmanTable(g[name + "_freq"], order="natural")
+    assert np.array_equal(tn.len, g[name + "_natural_len"])
+    for si in range(6):
+        sym = g[f"{name}_s{si}_sym"].astype(np.int64)
+        data = g[f"{name}_s{si}_bytes"].tobytes()
+        assert orc.encode(t, sym) == data
+        dec = orc.decode(t, data)
+        assert (dec is None and len(sym) == 0) or np.array_equal(dec, sym)
+
+
+def test_binary_coder(orc, golden):
+    g = golden("coders")
+    bt = orc.HuffmanTable.binary()
+    for n in (0, 1, 7, 8, 256, 1024, 2304):
+        m, data = g[f"binary_{n}_mask"].astype(np.int32), g[f"binary_{n}_bytes"].tobytes()
+        assert orc.encode(bt, m) == data
+        assert len(data) == (0 if n == 0 else n // 8 + 2)        # header + floor(n/8)+1 payload bytes
+        dec = orc.decode(bt, data)
+        assert (dec is None and n == 0) or np.array_equal(dec, m)
+
+
+def _compress_keys(g):
+    return sorted({k[:-5] for k in g if k.endswith("_mode")})
+
+
+def test_compress_glue_all_modes(orc, golden):
+    """config 1: the reference's CGIC.compress on torch.rand(1,3,256,256) (seed 0), every ratio pair"""
+    g = golden("compress_cfg1")
+    cb = g["codebook"]
+    tabs = {"zipf": orc.HuffmanTable(golden("coders")["zipf_freq"]), "zeros": orc.HuffmanTable(np.zeros(1024, np.int64))}
+    seen_modes = set()
+    for key in _compress_keys(g):
+        tname, ri = key.split("_r")
+        mode = int(g[key + "_mode"])
+        seen_modes.add(mode)
+        c, m = g["ratios"][int(ri)]
+        # router on the captured entropies, VQ on the captured latent
+        mc, mm, mf, _, omode = orc.router(g["e16"], g["e8"], float(c), float(m))
+        assert omode == mode
+        assert np.array_equal(mc[0, 0], unpack_mask(g[key + "_mc"], (16, 16)))
+        assert np.array_equal(mm[0, 0], unpack_mask(g[key + "_mm"], (32, 32)))
+        assert np.array_equal(mf[0, 0], unpack_mask(g[key + "_mf"], (64, 64)))
+        _, _, idx = orc.vq(g[key + "_z"], cb)
+        ind = g[key + "_ind"].astype(np.int64)
+        assert np.array_equal(idx.reshape(64, 64), ind)
+        streams = orc.compress_image(ind, mc[0, 0], mm[0, 0], mf[0, 0], mode, tabs[tname])
+        on = orc.mode_streams(mode)
+        assert set(streams) == {n for n, o in zip(orc.STREAM_NAMES, on) if o}
+        for n in streams:
+            assert streams[n] == g[f"{key}_{n}"].tobytes(), f"{key}: {n}.bin"
+        assert sum(map(len, streams.values())) * 8 / 65536 == float(g[key + "_bpp"])
+        dind, dmc, dmm, dmf = orc.decompress_image(streams, mode, 64, 64, tabs[tname])
+        assert np.array_equal(dind, g[key + "_qdec_ind"].astype(np.int64))
+        assert np.array_equal(orc.gather(dind, cb)[0], cb[dind].transpose(2, 0, 1))
+    assert seen_modes == set(range(7))
+
+
+def test_first_entropy_map_of_config1(orc, golden):
+    """config 1 input is torch.rand under manual_seed(0); regenerate it and check the captured maps"""
+    import torch
+    g = golden("compress_cfg1")
+    torch.manual_seed(0)
+    x = torch.rand(1, 3, 256, 256)
+    if abs(float(x.double().sum()) - float(g["x_seed0_sum"])) > 1e-9:
+        pytest.skip("torch CPU generator differs from the one that made the fixture")
+    assert np.abs(orc.entropy(x.numpy(), 8) - g["e8"]).max() < 2e-5
+    assert np.abs(orc.entropy(x.numpy(), 16) - g["e16"]).max() < 2e-5
