@@ -1,0 +1,277 @@
+#!/usr/bin/env python3
+"""bench.py -- encode+decode MPixels/s of the Control-GIC hot path on MI355X.
+
+One "step" = one pass of the hot path over one batch of synthetic input already resident in HBM:
+  encode: entropy maps (p8+p16) -> per-image router -> VQ argmin (+z_q, usage histogram)
+          -> masked select + Huffman + mask packing  (the five .bin streams per image)
+  decode: prefix decode -> mask/index scatter + x2/x4 merge -> embedding gather
+Workload = BASELINE.json configs[1]: batch 64 of 256x256, codebook 1024x4, ratio (0.1, 0.8, 0.1).
+The conv encoder/decoder of the codec are out of scope: `z` is a
+synthetic N(0,1) latent standing in for the encoder output.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W]
+For N > 1 launch under torch.distributed.run (one rank per GPU); images shard across ranks with
+no data-path collective, plus ONE RCCL all-reduce of the int64[1024] usage histogram per run.
+Rank 0 prints one JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_F32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: fp32-input MFMA == fp32 vector peak
+PEAK_HBM_GBS = 8000.0
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+def zipf_freq():
+    return np.floor(2.0e6 / (1 + np.arange(1024)) ** 1.1).astype(np.int64)
+
+
+def make_inputs(B, H, W, seed):
+    rng = np.random.default_rng(seed)
+    x = rng.random((B, 3, H, W), dtype=np.float32)
+    z = rng.standard_normal((B, 4, H // 4, W // 4), dtype=np.float32)
+    cb = np.random.default_rng(12345).standard_normal((1024, 4), dtype=np.float32)   # same codebook on every rank
+    return x, z, cb
+
+
+class HotPath:
+    """pre-built modules + one step() that only enqueues work (graph-capturable)"""
+
+    def __init__(self, dev, x, z, cb, ratio):
+        import control_gic_amd as cg
+        self.cg = cg
+        self.x = torch.from_numpy(x).to(dev)
+        self.z = torch.from_numpy(z).to(dev)
+        self.vq = cg.VectorQuantizer(1024, 4, beta=0.25).to(dev).eval()
+        self.vq.embedding.weight.data.copy_(torch.from_numpy(cb))
+        self.vq.usage_counter.copy_(torch.from_numpy(zipf_freq().astype(np.float32)))
+        self.codec = cg.GrainCodec(self.vq.embedding_counter, self.vq.embedding.weight)
+        self.router = cg.TripleGrainFixedEntropyRouter(ratio[0], ratio[1], per_image=True)
+        self.hist = torch.zeros(1024, dtype=torch.int64, device=dev)
+        self.out = None
+
+    def encode(self):
+        from control_gic_amd.quantize import _vq_forward
+        e8, e16 = self.cg.entropy_maps(self.x)
+        mask, _, _, mode = self.router(e16, e8, want_gate=False)
+        zq, loss, ind = _vq_forward(self.z, self.vq.embedding.weight, 0.25, True, self.hist)
+        comp = self.codec.compress(ind, mask, mode)
+        return e8, e16, mask, mode, zq, ind, comp
+
+    def decode(self, comp):
+        return self.codec.decompress(comp)
+
+    def step(self):
+        e8, e16, mask, mode, zq, ind, comp = self.encode()
+        dind, dmask, dq, status = self.decode(comp)
+        self.out = (e8, e16, mask, mode, zq, ind, comp, dind, dmask, dq, status)
+
+
+def time_events(fn, iters):
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(iters):
+        fn()
+    e.record()
+    e.synchronize()
+    return s.elapsed_time(e) * 1e3 / iters      # microseconds per call
+
+
+def stage_breakdown(hp, iters=30):
+    """per-stage device time with HIP events on the launch stream (torch's current stream)"""
+    from control_gic_amd.quantize import _vq_forward
+    cg = hp.cg
+    e8, e16 = cg.entropy_maps(hp.x)
+    mask, _, _, mode = hp.router(e16, e8, want_gate=False)
+    _, _, ind = _vq_forward(hp.z, hp.vq.embedding.weight, 0.25, True, hp.hist)
+    comp = hp.codec.compress(ind, mask, mode)
+    st = {}
+    st["entropy_maps"] = time_events(lambda: cg.entropy_maps(hp.x), iters)
+    st["router"] = time_events(lambda: hp.router(e16, e8, want_gate=False), iters)
+    st["vq_argmin"] = time_events(lambda: _vq_forward(hp.z, hp.vq.embedding.weight, 0.25, True, hp.hist), iters)
+    st["vq_argmin_indices_only"] = time_events(lambda: hp.vq.indices(hp.z), iters)
+    st["compress_streams"] = time_events(lambda: hp.codec.compress(ind, mask, mode), iters)
+    st["decompress_streams"] = time_events(lambda: hp.codec.decompress(comp), iters)
+    return {k: round(v, 2) for k, v in st.items()}
+
+
+def cpu_baseline(x, z, cb, ratio, budget_s=12.0):
+    """the oracle (a scalar C port of the reference algorithm) on ONE host core, same workload,
+    bounded sample of the batch"""
+    from oracle import cgic_oracle as orc
+    htab = orc.HuffmanTable(zipf_freq())
+    H, W = x.shape[2], x.shape[3]
+
+    def one(b):
+        e8 = orc.entropy(x[b:b + 1], 8)
+        e16 = orc.entropy(x[b:b + 1], 16)
+        mc, mm, mf, _, mode = orc.router(e16, e8, ratio[0], ratio[1], per_image=True, want_gate=False)
+        _, _, idx = orc.vq(z[b:b + 1], cb)
+        ind = idx.reshape(H // 4, W // 4)
+        streams = orc.compress_image(ind, mc[0, 0], mm[0, 0], mf[0, 0], mode, htab)
+        dind, _, _, _ = orc.decompress_image(streams, mode, H // 4, W // 4, htab)
+        orc.gather(dind, cb)
+        return streams
+
+    t0 = time.perf_counter()
+    one(0)
+    t1 = time.perf_counter() - t0
+    n = int(max(2, min(x.shape[0], budget_s / max(t1, 1e-3))))
+    t0 = time.perf_counter()
+    for b in range(n):
+        one(b)
+    dt = time.perf_counter() - t0
+    return {"value": round(n * H * W / dt / 1e6, 4), "unit": "MPixels/s", "cores": 1, "kind": "port",
+            "sample": f"{n} of the batch's images (256x256 each), encode+decode hot path, oracle/cgic_oracle.c "
+                      f"single thread, {dt:.1f} s; host has {os.cpu_count()} logical cores"}
+
+
+def check_against_oracle(hp, x, z, cb, ratio):
+    """bpp / bitstream match on one image of the timed workload (outside the timed region)"""
+    from oracle import cgic_oracle as orc
+    e8, e16, mask, mode, zq, ind, comp, dind, dmask, dq, status = hp.out
+    torch.cuda.synchronize()
+    b = 0
+    H, W = x.shape[2], x.shape[3]
+    h, w = H // 4, W // 4
+    _, _, oidx = orc.vq(z[b:b + 1], cb)
+    ok = bool(np.array_equal(ind.view(-1, h, w)[b].cpu().numpy(), oidx.reshape(h, w)))
+    mk = [m[b, 0].cpu().numpy() for m in mask]
+    ref = orc.compress_image(oidx.reshape(h, w), mk[0], mk[1], mk[2], mode, orc.HuffmanTable(zipf_freq()))
+    host = comp.to_host()[b]
+    ok = ok and host == ref and int(status.abs().max()) == 0
+    omc, omm, omf, _, _ = orc.router(e16[b:b + 1].cpu().numpy(), e8[b:b + 1].cpu().numpy(), ratio[0], ratio[1])
+    ok = ok and np.array_equal(mk[0], omc[0, 0]) and np.array_equal(mk[1], omm[0, 0]) and np.array_equal(mk[2], omf[0, 0])
+    bpp = sum(len(v) for v in host.values()) * 8 / (H * W)
+    return ok, bpp
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--batch", type=int, default=64)
+    ap.add_argument("--size", type=int, default=256)
+    ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a hipGraph")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    a = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:
+        log(f"warning: WORLD_SIZE={world} but --gpus {a.gpus}; using WORLD_SIZE")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)      # "nccl" is RCCL on ROCm
+
+    B, H, W = a.batch, a.size, a.size
+    ratio = (0.1, 0.8)
+    x, z, cb = make_inputs(B, H, W, seed=1000 + rank)       # each rank owns its own shard of images
+    hp = HotPath(dev, x, z, cb, ratio)
+
+    # warm-up (also uploads tables / sets function attributes -- nothing synchronous is left for capture)
+    for _ in range(max(2, min(a.warmup, 5))):
+        hp.step()
+    torch.cuda.synchronize()
+    graph = None
+    if not a.no_graph:
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            hp.step()
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph, stream=side):
+                hp.step()
+        torch.cuda.current_stream().wait_stream(side)
+    run = graph.replay if graph is not None else hp.step
+    for _ in range(a.warmup):
+        run()
+    hp.hist.zero_()
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        run()
+    if dist is not None:
+        # the path's only exchange: global usage histogram (int64, exact) -- once per stream of batches
+        dist.all_reduce(hp.hist, op=dist.ReduceOp.SUM)
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+    hist_total = int(hp.hist.sum().item())
+    assert hist_total == world * a.steps * B * (H // 4) * (W // 4), "usage histogram lost counts"
+
+    if rank == 0:
+        ok, bpp = check_against_oracle(hp, x, z, cb, ratio)
+        stages = stage_breakdown(hp)
+        dom = "vq_argmin"
+        t_dom = stages[dom] * 1e-6
+        N = B * (H // 4) * (W // 4)
+        flops = 2.0 * N * 1024 * 4                        # 2*N*K*D per launch (0.512 kFLOP/pixel)
+        achieved = flops / t_dom / 1e12
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "pmc_vq.json")
+        if os.path.exists(pmc):
+            try:
+                traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        res = {
+            "metric": "encode+decode MPixels/s at fixed granularity ratio; bpp match vs reference",
+            "value": round(world * a.steps * B * H * W / dt / 1e6, 2),
+            "unit": "MPixels/s",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": round(dt / a.steps * 1e3, 5),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"batch {B} of {H}x{W} per GPU, codebook 1024x4, ratio (0.1,0.8,0.1), "
+                                   "hot path only (entropy maps + router + VQ + Huffman/mask coder, encode+decode); "
+                                   "conv encoder/decoder out of scope, latent synthetic",
+                       "launch": "eager" if graph is None else "hipGraph replay",
+                       "sharding": "images round-robin over ranks; one RCCL all-reduce of the int64[1024] histogram per run"},
+            "bpp": round(bpp, 6), "bpp_match": bool(ok),
+            "stages_us": stages,
+            "roofline": {"kernel": "vq_mfma_kernel<8>", "bound": "mfma", "achieved": round(achieved, 3),
+                         "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4),
+                         "traffic": traffic,
+                         "note": "algorithmic flops = 2*N*K*D of the distance contraction per launch / HIP-event "
+                                 "average launch duration; the add/fma/compare epilogue is not counted"},
+        }
+        if not a.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline(x, z, cb, ratio)
+        if not ok:
+            log("ERROR: bitstream / masks / indices differ from the oracle")
+        print(json.dumps(res), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -261,114 +261,121 @@ __global__ __launch_bounds__(kEncThreads) void encode_stream_kernel(EncodeOneArg
 // -------------------------------------------------------------------------------------------
 // decode
 // -------------------------------------------------------------------------------------------
-// 32 payload bits starting at payload bit p (MSB first).  `in` points at the header byte.
-__device__ __forceinline__ uint32_t fetch32(const uint8_t *in, int64_t p)
-{
-    const uintptr_t addr = reinterpret_cast<uintptr_t>(in) + 1 + (uintptr_t)(p >> 3);
-    const uint32_t *al = reinterpret_cast<const uint32_t *>(addr & ~(uintptr_t)3);
-    const uint32_t o = (uint32_t)(addr & 3);
-    const uint64_t w = ((uint64_t)__builtin_bswap32(al[0]) << 32) | __builtin_bswap32(al[1]);
-    return (uint32_t)((w << (8 * o + (uint32_t)(p & 7))) >> 32);
-}
+constexpr int kWinBytes = 8192;          // LDS window of stream bytes per decoding wave
+constexpr int kWinWords = kWinBytes / 4 + 4;
 
-// One wave decodes one stream.  lut: LDS copy of the table's LUT.  put(k, sym) stores the
-// k-th symbol.  Returns the symbol count, -1 for an empty input (None in the reference).
-template <typename Put>
-__device__ int64_t decode_stream_wave(const TableDev &t, const uint32_t *lut, const uint8_t *in,
-                                      int64_t nbytes, int64_t cap, Put put, int *overflow)
-{
-    if (nbytes <= 0) return -1;                                  // :158-159
-    const int lane = lane_id();
-    const int pad = in[0];                                       // remove_padding :131-138
-    const int64_t total = (nbytes - 1) * 8;
-    int64_t nbits = pad == 0 ? 0 : total - pad;                  // text[:-0] is empty in Python
-    if (nbits < 0) nbits = 0;
-    const int LB = t.lut_bits;
-    int64_t pos = 0, count = 0;
-    bool done = false;
-    for (int64_t base = 0; base < nbits && !done; base += kWave) {
-        const int64_t p = base + lane;
-        uint32_t e = 0xFFFFFF00u;
-        if (p < nbits) e = lut[fetch32(in, p) >> (32 - LB)];
-        int L = (int)(e & 0xFF);
-        int S = (int)(e >> 8);
-        unsigned long long starts = 0;
-        while (pos < base + kWave) {
-            const int i = (int)(pos - base);
-            int Li = __builtin_amdgcn_readlane(L, i);
-            const int Si = __builtin_amdgcn_readlane(S, i);
-            if (Li == 0) {
-                // code longer than the LUT window: continue in the trie from node Si
-                if (Si == 0xFFFFFF) { done = true; break; }
-                int node = Si, sym = -1;
-                int64_t q = pos + LB;
-                while (q < nbits) {
-                    const int bit = (in[1 + (q >> 3)] >> (7 - (int)(q & 7))) & 1;
-                    const int c = t.child[2 * node + bit];
-                    ++q;
-                    if (c == INT32_MIN) break;
-                    if (c < 0) { sym = ~c; break; }
-                    node = c;
-                }
-                if (sym < 0) { done = true; break; }             // ran out of bits: trailing partial code is dropped
-                Li = (int)(q - pos);
-                S = lane == i ? sym : S;
-            }
-            if (pos + Li > nbits) { done = true; break; }
-            starts |= 1ull << i;
-            pos += Li;
-        }
-        if (starts) {
-            const int rank = __popcll(starts & ((1ull << lane) - 1ull));
-            if ((starts >> lane) & 1ull) {
-                if (count + rank < cap) put(count + rank, S);
-                else *overflow = 1;
-            }
-            count += __popcll(starts);
-        }
+// One wave decodes one stream.  The stream is staged through an LDS window (coalesced 16-byte
+// loads), every lane looks up "the codeword starting at bit base+lane" in the LDS LUT one chunk
+// AHEAD of the scalar chain that walks the true boundaries, so the chain (v_readlane + SALU,
+// wave-uniform) is the only serial part.  put(k, sym) stores the k-th symbol.
+// Returns the symbol count, -1 for an empty input (None in the reference, :158-159).
+struct WaveDecoder {
+    const TableDev &t;
+    const uint32_t *lut;     // LDS
+    uint32_t *win;           // LDS, kWinWords
+    const uint8_t *in;       // global; in[0] is the pad-count byte
+    int nbytes;
+    int wb;                  // first stream byte held in the window (multiple of 4)
+
+    __device__ __forceinline__ void fill(int first_byte)
+    {
+        // window = stream bytes [wb, wb + kWinBytes + 16), wb 4-aligned relative to the (16-byte
+        // aligned or not) base pointer: use aligned dword loads of the global buffer
+        const int lane = lane_id();
+        wb = first_byte & ~3;
+        const uintptr_t g = reinterpret_cast<uintptr_t>(in) + (uintptr_t)wb;
+        const uint32_t *ga = reinterpret_cast<const uint32_t *>(g & ~(uintptr_t)3);
+        wsh = (int)(g & 3);          // the window is shifted by this many bytes w.r.t. wb
+        const int limit = (nbytes - wb + wsh + 3) / 4 + 2;   // dwords that may be touched (slack in the buffer contract)
+        for (int k = lane; k < kWinWords; k += kWave) win[k] = k < limit ? ga[k] : 0u;
+        __builtin_amdgcn_wave_barrier();
     }
-    return count;
-}
+    int wsh;
+
+    // 32 payload bits starting at payload bit p (MSB first); caller guarantees the window covers them
+    __device__ __forceinline__ uint32_t fetch32(int p) const
+    {
+        const int o = 1 + (p >> 3) - wb + wsh;       // byte offset inside the window
+        const uint32_t a = win[o >> 2], b = win[(o >> 2) + 1];
+        const uint64_t w = ((uint64_t)__builtin_bswap32(a) << 32) | __builtin_bswap32(b);
+        return (uint32_t)((w << (8 * (o & 3) + (p & 7))) >> 32);
+    }
+    __device__ __forceinline__ bool covers(int p_last) const
+    {   // bytes needed: up to stream byte 1 + (p_last >> 3) + 4 (+ shift)
+        return 1 + (p_last >> 3) + 8 + wsh < wb + kWinBytes;
+    }
+
+    template <typename Put>
+    __device__ int run(int cap, Put put, int *overflow)
+    {
+        if (nbytes <= 0) return -1;
+        const int lane = lane_id();
+        fill(0);
+        const int pad = (int)(__builtin_bswap32(win[wsh >> 2]) >> (24 - 8 * (wsh & 3))) & 0xFF;   // remove_padding :131-138
+        const int total = (nbytes - 1) * 8;
+        int nbits = pad == 0 ? 0 : total - pad;                  // text[:-0] is empty in Python
+        if (nbits < 0) nbits = 0;
+        const int LB = t.lut_bits;
+        int pos = 0, count = 0;
+        bool done = false;
+        // prologue: lookups for chunk 0
+        uint32_t e_cur = 0xFFFFFF00u;
+        if (lane < nbits) e_cur = lut[fetch32(lane) >> (32 - LB)];
+        for (int base = 0; base < nbits && !done; base += kWave) {
+            // lookups for the NEXT chunk, issued before this chunk's chain
+            const int nbase = base + kWave;
+            uint32_t e_next = 0xFFFFFF00u;
+            if (nbase < nbits) {
+                if (!covers(nbase + kWave)) fill(1 + (nbase >> 3));
+                const int p = nbase + lane;
+                if (p < nbits) e_next = lut[fetch32(p) >> (32 - LB)];
+            }
+            const int L = (int)(e_cur & 0xFF);
+            int S = (int)(e_cur >> 8);
+            unsigned long long starts = 0;
+            while (pos < base + kWave) {
+                const int i = pos - base;
+                int Li = __builtin_amdgcn_readlane(L, i);
+                const int Si = __builtin_amdgcn_readlane(S, i);
+                if (Li == 0) {
+                    // code longer than the LUT window: continue in the trie from node Si
+                    if (Si == 0xFFFFFF) { done = true; break; }
+                    int node = Si, sym = -1;
+                    int q = pos + LB;
+                    while (q < nbits) {
+                        const int bit = (in[1 + (q >> 3)] >> (7 - (q & 7))) & 1;
+                        const int c = t.child[2 * node + bit];
+                        ++q;
+                        if (c == INT32_MIN) break;
+                        if (c < 0) { sym = ~c; break; }
+                        node = c;
+                    }
+                    if (sym < 0) { done = true; break; }         // out of bits: trailing partial code is dropped
+                    Li = q - pos;
+                    S = lane == i ? sym : S;
+                }
+                if (pos + Li > nbits) { done = true; break; }
+                starts |= 1ull << i;
+                pos += Li;
+            }
+            if (starts) {
+                const int rank = __popcll(starts & ((1ull << lane) - 1ull));
+                if ((starts >> lane) & 1ull) {
+                    if (count + rank < cap) put(count + rank, S);
+                    else *overflow = 1;
+                }
+                count += __popcll(starts);
+            }
+            e_cur = e_next;
+        }
+        return count;
+    }
+};
 
 __device__ __forceinline__ void load_lut(const TableDev &t, uint32_t *lut)
 {
     const int n = 1 << t.lut_bits;
     for (int i = threadIdx.x; i < n; i += blockDim.x) lut[i] = t.lut[i];
-    __syncthreads();
-}
-
-struct DecodeArgs {
-    TableDev tab;
-    const uint8_t *in;
-    int64_t slot;
-    const int32_t *nbytes;   // [B, 5]
-    int64_t h, w;
-    int stream_mask;
-    int32_t *dsym;           // [B, n_c + n_m + n_f] decoded symbols
-    int64_t *dcount;         // [B, 3]: count, -1 = empty file, -2 = not sent, -3 = overflow
-};
-
-__global__ __launch_bounds__(kWave) void decode_streams_kernel(DecodeArgs a)
-{
-    __shared__ uint32_t lut[kDecLutMax];
-    const int s = blockIdx.x;
-    const int64_t b = blockIdx.y;
-    int64_t *dc = a.dcount + b * 3 + s;
-    if (!((a.stream_mask >> s) & 1)) {
-        if (threadIdx.x == 0) *dc = -2;
-        return;
-    }
-    load_lut(a.tab, lut);
-    const int64_t n_c = (a.h >> 2) * (a.w >> 2), n_m = (a.h >> 1) * (a.w >> 1), n_f = a.h * a.w;
-    const int64_t off = s == 0 ? 0 : (s == 1 ? n_c : n_c + n_m);
-    const int64_t cap = s == 0 ? n_c : (s == 1 ? n_m : n_f);
-    int32_t *dst = a.dsym + b * (n_c + n_m + n_f) + off;
-    const int32_t nb = a.nbytes[b * CGIC_NUM_STREAMS + s];
-    int overflow = 0;
-    int64_t cnt = decode_stream_wave(a.tab, lut, a.in + (b * CGIC_NUM_STREAMS + s) * a.slot, nb, cap,
-                                     [&](int64_t k, int sym) { dst[k] = sym; }, &overflow);
-    overflow = __any(overflow);
-    if (threadIdx.x == 0) *dc = overflow ? -3 : cnt;
 }
 
 struct DecodeOneArgs {
@@ -383,29 +390,37 @@ struct DecodeOneArgs {
 __global__ __launch_bounds__(kWave) void decode_stream_kernel(DecodeOneArgs a)
 {
     __shared__ uint32_t lut[kDecLutMax];
+    __shared__ uint32_t win[kWinWords];
     load_lut(a.tab, lut);
+    __syncthreads();
     int overflow = 0;
     int64_t *dst = a.syms;
-    int64_t cnt = decode_stream_wave(a.tab, lut, a.in, a.nbytes, a.cap,
-                                     [&](int64_t k, int sym) { dst[k] = sym; }, &overflow);
+    WaveDecoder d{a.tab, lut, win, a.in, (int)a.nbytes, 0, 0};
+    const int cap = a.cap > 0x7FFFFFFF ? 0x7FFFFFFF : (int)a.cap;
+    int cnt = d.run(cap, [&](int k, int sym) { dst[k] = sym; }, &overflow);
     overflow = __any(overflow);
-    if (threadIdx.x == 0) *a.count = overflow ? (int64_t)CGIC_ERR_CAPACITY : cnt;
+    if (threadIdx.x == 0) *a.count = overflow ? (int64_t)CGIC_ERR_CAPACITY : (int64_t)cnt;
 }
 
 // -------------------------------------------------------------------------------------------
-// merge: masks + symbol lists -> index grid (+ masks, + z_q)         model.py:269-397
+// decompress: one 256-thread workgroup per image.  Waves 0..2 decode the coarse / medium / fine
+// index streams into LDS while wave 3 unpacks the two mask streams into bitsets and their
+// popcount prefixes; after one barrier all four waves scatter + merge + gather.
+//                                                                    model.py:269-397
 // -------------------------------------------------------------------------------------------
 constexpr int kMergeThreads = 256;
 constexpr int kMergeItems = 4;
 
-struct MergeArgs {
+struct DecompressArgs {
+    TableDev tab;
     const uint8_t *in;
     int64_t slot;
     const int32_t *nbytes;
     int64_t h, w;
     int mode;
-    const int32_t *dsym;
-    const int64_t *dcount;
+    int stream_mask;
+    int dsym_in_lds;         // 1: decoded symbols live in LDS (u16); 0: in the global workspace (i32)
+    int32_t *ws_dsym;        // [B, n_c + n_m + n_f] when !dsym_in_lds
     int64_t *ind_out;
     int32_t *mc_out, *mm_out, *mf_out;
     const float *codebook;
@@ -428,96 +443,129 @@ __device__ __forceinline__ uint32_t mask_stream_word(const uint8_t *in, int64_t 
     return v;
 }
 
-__global__ __launch_bounds__(kMergeThreads) void merge_kernel(MergeArgs a)
+// exclusive popcount prefix of a bit array by ONE wave; returns the total
+__device__ __forceinline__ uint32_t wave_popc_prefix(const uint32_t *bits, uint32_t *prefix, int64_t nwords)
+{
+    const int lane = lane_id();
+    uint32_t carry = 0;
+    for (int64_t base = 0; base < nwords; base += kWave) {
+        const int64_t i = base + lane;
+        const uint32_t c = i < nwords ? (uint32_t)__popc(bits[i]) : 0u;
+        const uint32_t inc = wave_inclusive_scan(c);
+        if (i < nwords) prefix[i] = carry + inc - c;
+        carry += __shfl(inc, kWave - 1, kWave);
+    }
+    return carry;
+}
+
+__global__ __launch_bounds__(kMergeThreads) void decompress_kernel(DecompressArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t sm[];
     __shared__ uint32_t scan_smem[kMergeThreads / kWave + 1];
+    __shared__ int s_cnt[3];         // decoded counts: >=0, -1 empty file, -2 not sent, -3 overflow
+    __shared__ uint32_t s_mcnt[2];   // ones in the coarse / medium masks
     __shared__ int s_status;
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, lane = lane_id(), wave = tid >> 6;
     const int64_t b = blockIdx.x;
     const int64_t h = a.h, w = a.w, h2 = h >> 1, w2 = w >> 1, h4 = h >> 2, w4 = w >> 2;
     const int64_t n_c = h4 * w4, n_m = h2 * w2, n_f = h * w;
     const int64_t wc = (n_c + 31) >> 5, wm = (n_m + 31) >> 5;
-    uint32_t *mcb = sm;                 // [wc] coarse mask bits, LSB first
-    uint32_t *mmb = mcb + wc;           // [wm]
-    uint32_t *pcb = mmb + wm;           // [wc] exclusive popcount prefix
-    uint32_t *pmb = pcb + wc;           // [wm]
+    // LDS carve-up
+    uint32_t *lut = sm;                                 // [4096]
+    uint32_t *win = lut + kDecLutMax;                   // [3][kWinWords]
+    uint32_t *mcb = win + 3 * kWinWords;                // [wc] coarse mask bits, LSB first
+    uint32_t *mmb = mcb + wc;                           // [wm]
+    uint32_t *pcb = mmb + wm;                           // [wc] exclusive popcount prefix
+    uint32_t *pmb = pcb + wc;                           // [wm]
+    uint16_t *lsym = reinterpret_cast<uint16_t *>(pmb + wm);   // [n_c + n_m + n_f] if dsym_in_lds
     const int mode = a.mode;
     if (tid == 0) s_status = 0;
+    load_lut(a.tab, lut);
     __syncthreads();
 
     const bool send_mc = mode == 0 || mode == 2 || mode == 3;
     const bool send_mm = mode == 0 || mode == 1;
-    const uint8_t *in_mc = a.in + (b * CGIC_NUM_STREAMS + 3) * a.slot;
-    const uint8_t *in_mm = a.in + (b * CGIC_NUM_STREAMS + 4) * a.slot;
-    // a mask stream must be exactly 1 + n/8 + 1 bytes with pad = 8 - n%8 (mask_coding.py:19-26)
-    if (tid == 0) {
-        if (send_mc) {
-            const int32_t nb = a.nbytes[b * CGIC_NUM_STREAMS + 3];
-            if (nb != 2 + (n_c >> 3) || in_mc[0] != 8 - (n_c & 7)) s_status = CGIC_ERR_INVALID;
+    int32_t *gsym = a.dsym_in_lds ? nullptr : a.ws_dsym + b * (n_c + n_m + n_f);
+
+    if (wave < 3) {
+        // ---- phase 1a: decode stream `wave`
+        const int s = wave;
+        const int64_t off = s == 0 ? 0 : (s == 1 ? n_c : n_c + n_m);
+        const int64_t cap = s == 0 ? n_c : (s == 1 ? n_m : n_f);
+        int cnt = -2;
+        if ((a.stream_mask >> s) & 1) {
+            int overflow = 0;
+            WaveDecoder d{a.tab, lut, win + s * kWinWords, a.in + (b * CGIC_NUM_STREAMS + s) * a.slot,
+                          a.nbytes[b * CGIC_NUM_STREAMS + s], 0, 0};
+            if (a.dsym_in_lds) {
+                uint16_t *dst = lsym + off;
+                cnt = d.run((int)cap, [&](int k, int sym) { dst[k] = (uint16_t)sym; }, &overflow);
+            } else {
+                int32_t *dst = gsym + off;
+                cnt = d.run((int)cap, [&](int k, int sym) { dst[k] = sym; }, &overflow);
+            }
+            if (__any(overflow)) cnt = -3;
         }
-        if (send_mm) {
-            const int32_t nb = a.nbytes[b * CGIC_NUM_STREAMS + 4];
-            if (nb != 2 + (n_m >> 3) || in_mm[0] != 8 - (n_m & 7)) s_status = CGIC_ERR_INVALID;
+        if (lane == 0) s_cnt[s] = cnt;
+    } else {
+        // ---- phase 1b (wave 3): mask streams -> bitsets + popcount prefixes
+        const uint8_t *in_mc = a.in + (b * CGIC_NUM_STREAMS + 3) * a.slot;
+        const uint8_t *in_mm = a.in + (b * CGIC_NUM_STREAMS + 4) * a.slot;
+        // a mask stream must be exactly 1 + n/8 + 1 bytes with pad = 8 - n%8 (mask_coding.py:19-26)
+        if (lane == 0) {
+            if (send_mc) {
+                const int32_t nb = a.nbytes[b * CGIC_NUM_STREAMS + 3];
+                if (nb != 2 + (n_c >> 3) || in_mc[0] != 8 - (n_c & 7)) s_status = CGIC_ERR_INVALID;
+            }
+            if (send_mm) {
+                const int32_t nb = a.nbytes[b * CGIC_NUM_STREAMS + 4];
+                if (nb != 2 + (n_m >> 3) || in_mm[0] != 8 - (n_m & 7)) s_status = CGIC_ERR_INVALID;
+            }
         }
+        __builtin_amdgcn_wave_barrier();
+        const bool bad = __shfl(s_status, 0, kWave) != 0;
+        for (int64_t i = lane; i < wc; i += kWave) {
+            uint32_t v = 0;
+            if (send_mc && !bad) v = mask_stream_word(in_mc, i, n_c);
+            else if (mode == 4) {                                               // ones (:355)
+                v = 0xFFFFFFFFu;
+                const int64_t rem = n_c - i * 32;
+                if (rem < 32) v &= (1u << rem) - 1u;
+            }
+            mcb[i] = v;
+        }
+        __builtin_amdgcn_wave_barrier();
+        for (int64_t i = lane; i < wm; i += kWave) {
+            uint32_t v = 0;
+            if (send_mm && !bad) v = mask_stream_word(in_mm, i, n_m);
+            else if (mode == 3 || mode == 5) {
+                for (int k = 0; k < 32; ++k) {
+                    const int64_t j = i * 32 + k;
+                    if (j >= n_m) break;
+                    bool bit = true;                                            // mode 5: ones (:368)
+                    if (mode == 3) {                                            // 1 - up2(mask_coarse) (:332)
+                        const int64_t y = j / w2, x = j - y * w2, c = (y >> 1) * w4 + (x >> 1);
+                        bit = !((mcb[c >> 5] >> (c & 31)) & 1u);
+                    }
+                    v |= (uint32_t)bit << k;
+                }
+            }
+            mmb[i] = v;
+        }
+        __builtin_amdgcn_wave_barrier();
+        const uint32_t cc = wave_popc_prefix(mcb, pcb, wc);
+        const uint32_t cm = wave_popc_prefix(mmb, pmb, wm);
+        if (lane == 0) { s_mcnt[0] = cc; s_mcnt[1] = cm; }
     }
     __syncthreads();
     if (s_status) {
         if (tid == 0 && a.status) a.status[b] = s_status;
         return;
     }
-    for (int64_t i = tid; i < wc; i += kMergeThreads) {
-        uint32_t v;
-        if (send_mc) v = mask_stream_word(in_mc, i, n_c);
-        else {
-            v = mode == 4 ? 0xFFFFFFFFu : 0u;                                   // :355 / zeros
-            const int64_t rem = n_c - i * 32;
-            if (rem < 32) v &= (1u << rem) - 1u;
-        }
-        mcb[i] = v;
-    }
-    __syncthreads();
-    for (int64_t i = tid; i < wm; i += kMergeThreads) {
-        uint32_t v = 0;
-        if (send_mm) v = mask_stream_word(in_mm, i, n_m);
-        else if (mode == 3 || mode == 5) {
-            for (int k = 0; k < 32; ++k) {
-                const int64_t j = i * 32 + k;
-                if (j >= n_m) break;
-                bool bit = true;                                                // mode 5: ones (:368)
-                if (mode == 3) {                                                // 1 - up2(mask_coarse) (:332)
-                    const int64_t y = j / w2, x = j - y * w2, c = (y >> 1) * w4 + (x >> 1);
-                    bit = !((mcb[c >> 5] >> (c & 31)) & 1u);
-                }
-                v |= (uint32_t)bit << k;
-            }
-        }
-        mmb[i] = v;
-    }
-    __syncthreads();
-    // exclusive popcount prefixes of both bit arrays
-    uint32_t carry = 0, total;
-    for (int64_t base = 0; base < wc; base += kMergeThreads) {
-        const int64_t i = base + tid;
-        const uint32_t c = i < wc ? __popc(mcb[i]) : 0u;
-        const uint32_t ex = block_exclusive_scan(c, scan_smem, &total);
-        if (i < wc) pcb[i] = carry + ex;
-        carry += total;
-    }
-    const uint32_t cnt_c = carry;
-    carry = 0;
-    for (int64_t base = 0; base < wm; base += kMergeThreads) {
-        const int64_t i = base + tid;
-        const uint32_t c = i < wm ? __popc(mmb[i]) : 0u;
-        const uint32_t ex = block_exclusive_scan(c, scan_smem, &total);
-        if (i < wm) pmb[i] = carry + ex;
-        carry += total;
-    }
-    const uint32_t cnt_m = carry;
-    __syncthreads();
 
-    const int32_t *ds_c = a.dsym + b * (n_c + n_m + n_f), *ds_m = ds_c + n_c, *ds_f = ds_m + n_m;
-    const int64_t dc_c = a.dcount[b * 3 + 0], dc_m = a.dcount[b * 3 + 1], dc_f = a.dcount[b * 3 + 2];
+    // ---- phase 2: scatter + merge + gather
+    const uint32_t cnt_c = s_mcnt[0], cnt_m = s_mcnt[1];
+    const int64_t dc_c = s_cnt[0], dc_m = s_cnt[1], dc_f = s_cnt[2];
     const bool has_c = mode == 0 || mode == 2 || mode == 3 || mode == 4;
     const bool has_m = mode == 0 || mode == 1 || mode == 3 || mode == 5;
     const bool has_f = mode == 0 || mode == 1 || mode == 2 || mode == 6;
@@ -528,6 +576,7 @@ __global__ __launch_bounds__(kMergeThreads) void merge_kernel(MergeArgs a)
     if (has_c && dc_c >= 0 && dc_c != cnt_c) st = CGIC_ERR_INVALID;
     if (has_m && dc_m >= 0 && dc_m != cnt_m) st = CGIC_ERR_INVALID;
     const bool use_c = has_c && dc_c >= 0, use_m = has_m && dc_m >= 0, use_f = has_f && dc_f >= 0;
+    auto sym_at = [&](int64_t k) -> int64_t { return a.dsym_in_lds ? (int64_t)lsym[k] : (int64_t)gsym[k]; };
 
     int64_t *ind_out = a.ind_out ? a.ind_out + b * n_f : nullptr;
     float *zq = a.zq ? a.zq + b * 4 * n_f : nullptr;
@@ -535,7 +584,7 @@ __global__ __launch_bounds__(kMergeThreads) void merge_kernel(MergeArgs a)
     int bad_index = 0;
     for (int64_t base = 0; base < n_f; base += (int64_t)kMergeThreads * kMergeItems) {
         uint32_t fl = 0;       // fine flags of my items
-        int64_t i0 = base + (int64_t)tid * kMergeItems;
+        const int64_t i0 = base + (int64_t)tid * kMergeItems;
         int64_t vals[kMergeItems];
 #pragma unroll
         for (int k = 0; k < kMergeItems; ++k) {
@@ -556,8 +605,8 @@ __global__ __launch_bounds__(kMergeThreads) void merge_kernel(MergeArgs a)
             }
             fl |= (uint32_t)bf << k;
             int64_t v = 0;
-            if (bc && use_c) v += ds_c[pcb[j4 >> 5] + __popc(mcb[j4 >> 5] & ((1u << (j4 & 31)) - 1u))];
-            if (bm && use_m) v += ds_m[pmb[j2 >> 5] + __popc(mmb[j2 >> 5] & ((1u << (j2 & 31)) - 1u))];
+            if (bc && use_c) v += sym_at(pcb[j4 >> 5] + __popc(mcb[j4 >> 5] & ((1u << (j4 & 31)) - 1u)));
+            if (bm && use_m) v += sym_at(n_c + pmb[j2 >> 5] + __popc(mmb[j2 >> 5] & ((1u << (j2 & 31)) - 1u)));
             vals[k] = v;
             if (a.mc_out && (y & 3) == 0 && (x & 3) == 0) a.mc_out[b * n_c + j4] = bc;
             if (a.mm_out && (y & 1) == 0 && (x & 1) == 0) a.mm_out[b * n_m + j2] = bm;
@@ -571,7 +620,7 @@ __global__ __launch_bounds__(kMergeThreads) void merge_kernel(MergeArgs a)
             if (i >= n_f) continue;
             int64_t v = vals[k];
             if ((fl >> k) & 1u) {
-                if (use_f && (int64_t)frank < dc_f) v += ds_f[frank];           // t[t==1] = decoded (:292)
+                if (use_f && (int64_t)frank < dc_f) v += sym_at(n_c + n_m + frank);   // t[t==1] = decoded (:292)
                 ++frank;
             }
             if (ind_out) ind_out[i] = v;                                        // sum of the three grids (:293)
@@ -710,7 +759,7 @@ extern "C" int cgic_decode_stream(const cgic_table *t, const uint8_t *in, int64_
                                   int64_t cap, int64_t *count, cgic_stream_t stream)
 {
     CGIC_REQUIRE(t && count && (in || nbytes == 0) && (syms || cap == 0), CGIC_ERR_INVALID, "decode_stream: NULL argument");
-    CGIC_REQUIRE(nbytes >= 0 && cap >= 0, CGIC_ERR_INVALID, "decode_stream: negative size");
+    CGIC_REQUIRE(nbytes >= 0 && cap >= 0 && nbytes < ((int64_t)1 << 28), CGIC_ERR_INVALID, "decode_stream: size out of range");
     DecodeOneArgs a;
     int rc = table_device_view(t, &a.tab);
     if (rc) return rc;
@@ -719,11 +768,21 @@ extern "C" int cgic_decode_stream(const cgic_table *t, const uint8_t *in, int64_
     return launch_check("decode_stream_kernel");
 }
 
+static size_t decompress_lds_bytes(int64_t h, int64_t w, bool sym_in_lds)
+{
+    const size_t wc = (size_t)(((h / 4) * (w / 4) + 31) / 32), wm = (size_t)(((h / 2) * (w / 2) + 31) / 32);
+    size_t b = sizeof(uint32_t) * (kDecLutMax + 3 * kWinWords + 2 * (wc + wm));
+    if (sym_in_lds) b += sizeof(uint16_t) * (size_t)((h / 4) * (w / 4) + (h / 2) * (w / 2) + h * w) + 16;
+    return b;
+}
+static const size_t kLdsBudget = 150 * 1024;
+
 extern "C" size_t cgic_decompress_workspace_bytes(int64_t B, int64_t h, int64_t w)
 {
     if (B <= 0 || h <= 0 || w <= 0) return 0;
+    if (decompress_lds_bytes(h, w, true) <= kLdsBudget) return 0;      // decoded symbols stay in LDS
     const size_t per = (size_t)((h / 4) * (w / 4) + (h / 2) * (w / 2) + h * w);
-    return align16((size_t)B * per * sizeof(int32_t)) + align16((size_t)B * 3 * sizeof(int64_t));
+    return align16((size_t)B * per * sizeof(int32_t));
 }
 
 extern "C" int cgic_decompress_streams(const cgic_table *t, const uint8_t *in, int64_t slot, const int32_t *nbytes,
@@ -734,34 +793,31 @@ extern "C" int cgic_decompress_streams(const cgic_table *t, const uint8_t *in, i
 {
     int rc = check_grid(B, h, w, mode);
     if (rc) return rc;
-    CGIC_REQUIRE(t && in && nbytes && workspace, CGIC_ERR_INVALID, "decompress_streams: NULL argument");
-    CGIC_REQUIRE(slot % 16 == 0 && slot >= 16, CGIC_ERR_INVALID, "decompress_streams: slot must be a multiple of 16");
+    CGIC_REQUIRE(t && in && nbytes, CGIC_ERR_INVALID, "decompress_streams: NULL argument");
+    CGIC_REQUIRE(slot % 16 == 0 && slot >= 16 && slot < ((int64_t)1 << 28), CGIC_ERR_INVALID,
+                 "decompress_streams: slot must be a multiple of 16 below 2^28");
     CGIC_REQUIRE(!z_q || (codebook && e_dim == 4 && K > 0), CGIC_ERR_UNSUPPORTED,
                  "decompress_streams: fused gather needs a [K,4] codebook");
+    CGIC_REQUIRE(cgic_table_num_symbols(t) <= 65536, CGIC_ERR_UNSUPPORTED, "table too large");
+    const bool in_lds = decompress_lds_bytes(h, w, true) <= kLdsBudget;
+    CGIC_REQUIRE(in_lds || workspace, CGIC_ERR_INVALID, "decompress_streams: workspace required for %lldx%lld grids",
+                 (long long)h, (long long)w);
+    const size_t lds = decompress_lds_bytes(h, w, in_lds);
+    CGIC_REQUIRE(lds <= kLdsBudget, CGIC_ERR_UNSUPPORTED, "decompress_streams: grid too large for the mask bitsets");
     if (B == 0) return CGIC_OK;
-    const size_t per = (size_t)((h / 4) * (w / 4) + (h / 2) * (w / 2) + h * w);
-    DecodeArgs d;
+    DecompressArgs d;
     rc = table_device_view(t, &d.tab);
     if (rc) return rc;
-    d.in = in; d.slot = slot; d.nbytes = nbytes; d.h = h; d.w = w; d.stream_mask = kModeStreams[mode];
-    d.dsym = (int32_t *)workspace;
-    d.dcount = (int64_t *)((char *)workspace + align16((size_t)B * per * sizeof(int32_t)));
-    hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(decode_streams_kernel, dim3(3, (unsigned)B), dim3(kWave), 0, s, d);
-    rc = launch_check("decode_streams_kernel");
-    if (rc) return rc;
-    MergeArgs m;
-    m.in = in; m.slot = slot; m.nbytes = nbytes; m.h = h; m.w = w; m.mode = mode;
-    m.dsym = d.dsym; m.dcount = d.dcount; m.ind_out = ind_out;
-    m.mc_out = mask_c_out; m.mm_out = mask_m_out; m.mf_out = mask_f_out;
-    m.codebook = codebook; m.K = K; m.zq = z_q; m.status = status;
-    const size_t wc = (size_t)(((h / 4) * (w / 4) + 31) / 32), wm = (size_t)(((h / 2) * (w / 2) + 31) / 32);
-    const size_t lds = 2 * (wc + wm) * sizeof(uint32_t);
-    CGIC_REQUIRE(lds <= 150 * 1024, CGIC_ERR_UNSUPPORTED, "decompress_streams: grid too large for the mask bitsets");
+    d.in = in; d.slot = slot; d.nbytes = nbytes; d.h = h; d.w = w; d.mode = mode;
+    d.stream_mask = kModeStreams[mode];
+    d.dsym_in_lds = in_lds ? 1 : 0;
+    d.ws_dsym = (int32_t *)workspace;
+    d.ind_out = ind_out; d.mc_out = mask_c_out; d.mm_out = mask_m_out; d.mf_out = mask_f_out;
+    d.codebook = codebook; d.K = K; d.zq = z_q; d.status = status;
     if (lds > 48 * 1024)
-        CGIC_HIP_TRY(hipFuncSetAttribute((const void *)merge_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(merge_kernel, dim3((unsigned)B), dim3(kMergeThreads), lds, s, m);
-    return launch_check("merge_kernel");
+        CGIC_HIP_TRY(hipFuncSetAttribute((const void *)decompress_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(decompress_kernel, dim3((unsigned)B), dim3(kMergeThreads), lds, (hipStream_t)stream, d);
+    return launch_check("decompress_kernel");
 }
 
 extern "C" int cgic_embedding_gather_f32(const int64_t *ind, int64_t B, int64_t hw, const float *codebook, int K,

@@ -46,12 +46,67 @@ __device__ __forceinline__ void stage_codebook(const float *__restrict__ cb, int
     }
 }
 
-// ZT = latent tiles (of 16 vectors) per wave; a wave owns 16*ZT vectors and
-// scans all K codes; a block owns 4 * 16 * ZT vectors.
+// distance of latent (z0..z3, zz) to code `c`, the reference's rounding sequence, on the VALU
+__device__ __forceinline__ float dist_valu(float z0, float z1, float z2, float z3, float zz,
+                                           const float *cbT, const float *ee, int K, int c)
+{
+    float mm = z0 * cbT[c];
+    mm = __builtin_fmaf(z1, cbT[K + c], mm);
+    mm = __builtin_fmaf(z2, cbT[2 * K + c], mm);
+    mm = __builtin_fmaf(z3, cbT[3 * K + c], mm);
+    return __builtin_fmaf(-2.0f, mm, zz + ee[c]);
+}
+
+// Last-arriving block sums the per-block partials in a fixed order (deterministic whichever
+// block is last) and writes loss = m + beta*m (quantize.py:85-90).  Hand-off per
+// cdna_hip_programming.md G16: plain stores -> barrier -> agent release -> ticket; the last
+// block does one agent acquire before reading.  `ticket` is zeroed by a memset node per call.
+__device__ __forceinline__ void finish_loss(double block_sum, double *sq_partial, unsigned int *ticket,
+                                            double count, float beta, int legacy, float *loss)
+{
+    __shared__ double red[kVqThreads];
+    __shared__ unsigned int s_last;
+    const int tid = threadIdx.x;
+    if (tid == 0) {
+        sq_partial[blockIdx.x] = block_sum;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        s_last = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1;
+    }
+    __syncthreads();
+    if (!s_last) return;
+    if (tid == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    __syncthreads();
+    double a = 0.0;
+    for (unsigned int i = tid; i < gridDim.x; i += kVqThreads)
+        a += __hip_atomic_load(&sq_partial[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    red[tid] = a;
+    __syncthreads();
+    for (int off = kVqThreads / 2; off > 0; off >>= 1) {
+        if (tid < off) red[tid] += red[tid + off];
+        __syncthreads();
+    }
+    if (tid == 0) {
+        const float m = (float)(red[0] / count);
+        *loss = legacy ? (m + beta * m) : (beta * m + m);
+    }
+}
+
+// ZT = latent tiles (of 16 vectors) per wave; a wave owns 16*ZT vectors and scans all K codes;
+// a block owns 4 * 16 * ZT vectors.  __launch_bounds__(256, 2): a <=256-VGPR budget makes hipcc
+// pick the VGPR-destination MFMA form (no v_accvgpr_read per output).
+//
+// Epilogue per MFMA (4 outputs per lane): 4 add + 4 fma + 2 v_min3 + 1 cmp + 1 cndmask.  Only the
+// running minimum VALUE and the index of the 16-code TILE where it last strictly decreased are
+// tracked; which of the lane's 4 rows achieved it is resolved once at the end by recomputing that
+// one tile on the VALU (bit-identical to the MFMA: same fmaf chain) and taking the first row equal
+// to the minimum.  Strict '<' on tiles + first-equal on rows + (value, index) lexicographic merge
+// across the 4 row groups == lowest index among exact minima, like torch.argmin.
 template <int ZT>
-__global__ __launch_bounds__(kVqThreads) void vq_mfma_kernel(
+__global__ __launch_bounds__(kVqThreads, 2) void vq_mfma_kernel(
     const float *__restrict__ z, int64_t hw, int64_t N, const float *__restrict__ cb, int K,
     int64_t *__restrict__ idx_out, float *__restrict__ zq_out, double *__restrict__ sq_partial,
+    unsigned int *__restrict__ ticket, float beta, int legacy, float *__restrict__ loss,
     unsigned long long *__restrict__ hist)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -72,7 +127,7 @@ __global__ __launch_bounds__(kVqThreads) void vq_mfma_kernel(
 
     // B operand: lane holds z[n_j][k=g] for each tile; zz per column.
     float zv[ZT], zz[ZT], best[ZT];
-    int bi[ZT];
+    int bt[ZT];
 #pragma unroll
     for (int t = 0; t < ZT; ++t) {
         int64_t n = wave_base + 16 * t + j;
@@ -85,49 +140,54 @@ __global__ __launch_bounds__(kVqThreads) void vq_mfma_kernel(
         float z0 = __shfl(v, j, kWave), z1 = __shfl(v, 16 + j, kWave);
         float z2 = __shfl(v, 32 + j, kWave), z3 = __shfl(v, 48 + j, kWave);
         zz[t] = sumsq4(z0, z1, z2, z3);
-        best[t] = 0.f;
-        bi[t] = 0;
+        best[t] = __builtin_inff();
+        bt[t] = 0;
     }
 
     const int ntile = K >> 4;
     for (int ct = 0; ct < ntile; ++ct) {
         // A operand: A[i = lane&15][k = lane>>4] = e[16*ct + i][k]
-        float a = cbT[g * K + 16 * ct + j];
+        const float a = cbT[g * K + 16 * ct + j];
         // C rows held by this lane: codes 16*ct + 4*g + r, r = 0..3
-        f32x4 e4 = *reinterpret_cast<const f32x4 *>(&ee[16 * ct + 4 * g]);
-        const int code0 = 16 * ct;  // + 4*g + r added at the end
+        const f32x4 e4 = *reinterpret_cast<const f32x4 *>(&ee[16 * ct + 4 * g]);
 #pragma unroll
         for (int t = 0; t < ZT; ++t) {
             f32x4 acc = {0.f, 0.f, 0.f, 0.f};
             acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, zv[t], acc, 0, 0, 0);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                float s = zz[t] + e4[r];
-                float d = __builtin_fmaf(-2.0f, acc[r], s);   // fl(s - 2*mm), 2*mm exact
-                // first code of the scan initialises; NaN never replaces (d < best false)
-                bool take = (ct == 0 && r == 0) || d < best[t];
-                best[t] = take ? d : best[t];
-                bi[t] = take ? (code0 + r) : bi[t];
-            }
+            const float d0 = __builtin_fmaf(-2.0f, acc[0], zz[t] + e4[0]);   // fl(fl(zz+ee) - 2*mm)
+            const float d1 = __builtin_fmaf(-2.0f, acc[1], zz[t] + e4[1]);
+            const float d2 = __builtin_fmaf(-2.0f, acc[2], zz[t] + e4[2]);
+            const float d3 = __builtin_fmaf(-2.0f, acc[3], zz[t] + e4[3]);
+            const float m1 = __builtin_fminf(__builtin_fminf(best[t], d0), d1);   // v_min3_f32
+            const float m2 = __builtin_fminf(__builtin_fminf(m1, d2), d3);
+            bt[t] = m2 < best[t] ? ct : bt[t];
+            best[t] = m2;
         }
     }
 
-    // Combine the 4 row groups (lanes j, j+16, j+32, j+48): lexicographic (d, index).
+    // Resolve the row inside the winning tile, then combine the 4 row groups
+    // (lanes j, j+16, j+32, j+48): lexicographic (d, index).
     double sq = 0.0;
 #pragma unroll
     for (int t = 0; t < ZT; ++t) {
+        const float v = zv[t];
+        const float z0 = __shfl(v, j, kWave), z1 = __shfl(v, 16 + j, kWave);
+        const float z2 = __shfl(v, 32 + j, kWave), z3 = __shfl(v, 48 + j, kWave);
+        const int c0 = 16 * bt[t] + 4 * g;
         float d = best[t];
-        int i = bi[t] + 4 * g;
+        int i = c0;
+#pragma unroll
+        for (int r = 3; r >= 0; --r)      // descending: the lowest matching row wins
+            i = dist_valu(z0, z1, z2, z3, zz[t], cbT, ee, K, c0 + r) == d ? c0 + r : i;
 #pragma unroll
         for (int off = 16; off < 64; off <<= 1) {
             float od = __shfl_xor(d, off, kWave);
             int oi = __shfl_xor(i, off, kWave);
-            // NaN handling mirrors torch.argmin only for non-NaN inputs
+            // non-finite distances are outside the contract
             bool take = od < d || (od == d && oi < i);
             d = take ? od : d;
             i = take ? oi : i;
         }
-        bi[t] = i;
         int64_t n = wave_base + 16 * t + j;
         if (n < N) {
             if (zq_out || sq_partial) {
@@ -147,6 +207,13 @@ __global__ __launch_bounds__(kVqThreads) void vq_mfma_kernel(
         }
     }
 
+    if (hist) {
+        __syncthreads();
+        for (int k = threadIdx.x; k < K; k += blockDim.x) {
+            unsigned int c = lhist[k];
+            if (c) atomicAdd(&hist[k], (unsigned long long)c);
+        }
+    }
     if (sq_partial) {
         // deterministic block reduction: fixed shuffle tree, then waves in order
         __shared__ double wsum[4];
@@ -154,14 +221,7 @@ __global__ __launch_bounds__(kVqThreads) void vq_mfma_kernel(
         for (int off = 32; off > 0; off >>= 1) sq += __shfl_down(sq, off, kWave);
         if (lane == 0) wsum[wave] = sq;
         __syncthreads();
-        if (threadIdx.x == 0) sq_partial[blockIdx.x] = ((wsum[0] + wsum[1]) + wsum[2]) + wsum[3];
-    }
-    if (hist) {
-        __syncthreads();
-        for (int k = threadIdx.x; k < K; k += blockDim.x) {
-            unsigned int c = lhist[k];
-            if (c) atomicAdd(&hist[k], (unsigned long long)c);
-        }
+        finish_loss(((wsum[0] + wsum[1]) + wsum[2]) + wsum[3], sq_partial, ticket, (double)N * 4.0, beta, legacy, loss);
     }
 }
 
@@ -170,6 +230,7 @@ __global__ __launch_bounds__(kVqThreads) void vq_mfma_kernel(
 __global__ __launch_bounds__(kVqThreads) void vq_valu_kernel(
     const float *__restrict__ z, int64_t hw, int64_t N, const float *__restrict__ cb, int K,
     int64_t *__restrict__ idx_out, float *__restrict__ zq_out, double *__restrict__ sq_partial,
+    unsigned int *__restrict__ ticket, float beta, int legacy, float *__restrict__ loss,
     unsigned long long *__restrict__ hist)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -221,27 +282,7 @@ __global__ __launch_bounds__(kVqThreads) void vq_valu_kernel(
         for (int off = 32; off > 0; off >>= 1) sq += __shfl_down(sq, off, kWave);
         if (lane == 0) wsum[wave] = sq;
         __syncthreads();
-        if (threadIdx.x == 0) sq_partial[blockIdx.x] = ((wsum[0] + wsum[1]) + wsum[2]) + wsum[3];
-    }
-}
-
-// loss = m + beta*m (legacy) with m = fp32(mean) -- quantize.py:85-90.  One
-// block, fixed summation order => deterministic.
-__global__ void vq_loss_kernel(const double *__restrict__ partial, int nblk, double count, float beta,
-                               int legacy, float *__restrict__ loss)
-{
-    __shared__ double s[256];
-    double a = 0.0;
-    for (int i = threadIdx.x; i < nblk; i += 256) a += partial[i];
-    s[threadIdx.x] = a;
-    __syncthreads();
-    for (int off = 128; off > 0; off >>= 1) {
-        if ((int)threadIdx.x < off) s[threadIdx.x] += s[threadIdx.x + off];
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) {
-        float m = (float)(s[0] / count);
-        *loss = legacy ? (m + beta * m) : (beta * m + m);
+        finish_loss(((wsum[0] + wsum[1]) + wsum[2]) + wsum[3], sq_partial, ticket, (double)N * 4.0, beta, legacy, loss);
     }
 }
 
@@ -273,15 +314,28 @@ static int vq_check(const float *z, int64_t B, int64_t hw, const float *cb, int 
     return CGIC_OK;
 }
 
+struct VqWs {      // workspace layout: [ticket (16 B)] [double partial[nblk]]
+    unsigned int *ticket;
+    double *partial;
+};
+static VqWs vq_ws(void *workspace)
+{
+    VqWs w;
+    w.ticket = (unsigned int *)workspace;
+    w.partial = workspace ? (double *)((char *)workspace + 16) : nullptr;
+    return w;
+}
+
 template <int ZT>
 static int launch_mfma(const float *z, int64_t hw, int64_t N, const float *cb, int K, int64_t *idx,
-                       float *zq, double *part, unsigned long long *hist, hipStream_t s, int *nblk)
+                       float *zq, VqWs ws, float beta, int legacy, float *loss, unsigned long long *hist,
+                       hipStream_t s)
 {
     const int64_t per_block = 4 * 16 * ZT;
-    *nblk = (int)((N + per_block - 1) / per_block);
+    const int nblk = (int)((N + per_block - 1) / per_block);
     size_t lds = sizeof(float) * (size_t)K * (hist ? 6 : 5);
-    hipLaunchKernelGGL(vq_mfma_kernel<ZT>, dim3(*nblk), dim3(kVqThreads), lds, s, z, hw, N, cb, K, idx, zq,
-                       part, hist);
+    hipLaunchKernelGGL(vq_mfma_kernel<ZT>, dim3(nblk), dim3(kVqThreads), lds, s, z, hw, N, cb, K, idx, zq,
+                       loss ? ws.partial : nullptr, ws.ticket, beta, legacy, loss, hist);
     return launch_check("vq_mfma_kernel");
 }
 
@@ -291,8 +345,8 @@ using namespace cgic;
 
 extern "C" size_t cgic_vq_workspace_bytes(int64_t n_vectors)
 {
-    // one double per block of the smallest tiling (64 vectors per block)
-    return sizeof(double) * (size_t)((n_vectors + 63) / 64 + 1);
+    // ticket + one double per block of the smallest tiling (64 vectors per block)
+    return 16 + sizeof(double) * (size_t)((n_vectors + 63) / 64 + 1);
 }
 
 extern "C" int cgic_vq_forward_f32(const float *z, int64_t B, int64_t hw, const float *codebook, int K,
@@ -304,20 +358,14 @@ extern "C" int cgic_vq_forward_f32(const float *z, int64_t B, int64_t hw, const 
     const int64_t N = B * hw;
     if (N == 0) return CGIC_OK;
     hipStream_t s = (hipStream_t)stream;
-    double *part = loss ? (double *)workspace : nullptr;
+    VqWs ws = vq_ws(loss ? workspace : nullptr);
+    if (loss) CGIC_HIP_TRY(hipMemsetAsync(ws.ticket, 0, 16, s));
     unsigned long long *h = (unsigned long long *)hist;
-    int nblk = 0;
-    // pick the largest per-wave tile that still leaves >= ~2 waves per SIMD busy
-    if (N >= (int64_t)512 * 2048) rc = launch_mfma<8>(z, hw, N, codebook, K, indices, z_q, part, h, s, &nblk);
-    else if (N >= (int64_t)256 * 1024) rc = launch_mfma<4>(z, hw, N, codebook, K, indices, z_q, part, h, s, &nblk);
-    else if (N >= (int64_t)128 * 512) rc = launch_mfma<2>(z, hw, N, codebook, K, indices, z_q, part, h, s, &nblk);
-    else rc = launch_mfma<1>(z, hw, N, codebook, K, indices, z_q, part, h, s, &nblk);
-    if (rc) return rc;
-    if (loss) {
-        hipLaunchKernelGGL(vq_loss_kernel, dim3(1), dim3(256), 0, s, part, nblk, (double)N * 4.0, beta, legacy,
-                           loss);
-        rc = launch_check("vq_loss_kernel");
-    }
+    // largest per-wave tile that still gives every SIMD >= 2 waves (1024 SIMDs, 4 waves per block)
+    if (N >= (int64_t)512 * 512) rc = launch_mfma<8>(z, hw, N, codebook, K, indices, z_q, ws, beta, legacy, loss, h, s);
+    else if (N >= (int64_t)256 * 512) rc = launch_mfma<4>(z, hw, N, codebook, K, indices, z_q, ws, beta, legacy, loss, h, s);
+    else if (N >= (int64_t)128 * 512) rc = launch_mfma<2>(z, hw, N, codebook, K, indices, z_q, ws, beta, legacy, loss, h, s);
+    else rc = launch_mfma<1>(z, hw, N, codebook, K, indices, z_q, ws, beta, legacy, loss, h, s);
     return rc;
 }
 
@@ -330,19 +378,13 @@ extern "C" int cgic_vq_forward_valu_f32(const float *z, int64_t B, int64_t hw, c
     const int64_t N = B * hw;
     if (N == 0) return CGIC_OK;
     hipStream_t s = (hipStream_t)stream;
-    double *part = loss ? (double *)workspace : nullptr;
+    VqWs ws = vq_ws(loss ? workspace : nullptr);
+    if (loss) CGIC_HIP_TRY(hipMemsetAsync(ws.ticket, 0, 16, s));
     int nblk = (int)((N + kVqThreads - 1) / kVqThreads);
     size_t lds = sizeof(float) * (size_t)K * 5;
     hipLaunchKernelGGL(vq_valu_kernel, dim3(nblk), dim3(kVqThreads), lds, s, z, hw, N, codebook, K, indices, z_q,
-                       part, (unsigned long long *)hist);
-    rc = launch_check("vq_valu_kernel");
-    if (rc) return rc;
-    if (loss) {
-        hipLaunchKernelGGL(vq_loss_kernel, dim3(1), dim3(256), 0, s, part, nblk, (double)N * 4.0, beta, legacy,
-                           loss);
-        rc = launch_check("vq_loss_kernel");
-    }
-    return rc;
+                       loss ? ws.partial : nullptr, ws.ticket, beta, legacy, loss, (unsigned long long *)hist);
+    return launch_check("vq_valu_kernel");
 }
 
 extern "C" int cgic_index_histogram(const int64_t *indices, int64_t n, int K, int64_t *hist, cgic_stream_t stream)

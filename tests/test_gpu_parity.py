@@ -90,7 +90,7 @@ def test_vq_vs_oracle_and_cross_kernel(orc, shape, scale):
     assert np.array_equal(idx_a[:n].cpu().numpy(), oidx)
     assert np.array_equal(zq_a[:nb].cpu().numpy(), ozq)
     # embedding gather is an exact copy of codebook rows (model.py:391-392)
-    e = vq.embedding(idx_a[:n]).cpu().numpy()
+    e = vq.embedding(idx_a[:n]).detach().cpu().numpy()
     assert np.array_equal(e, cb.numpy()[oidx])
 
 
