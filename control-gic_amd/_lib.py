@@ -8,7 +8,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libcgic_hip.so")
+# CGIC_LIB lets dev tools load an instrumented build of the SAME sources (make -C csrc dbg)
+LIB_PATH = os.environ.get("CGIC_LIB") or os.path.join(_HERE, "libcgic_hip.so")
 
 OK, ERR_INVALID, ERR_UNSUPPORTED, ERR_HIP, ERR_NOMEM, ERR_CAPACITY = 0, -1, -2, -3, -4, -5
 NUM_STREAMS = 5

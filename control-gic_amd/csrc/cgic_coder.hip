@@ -30,6 +30,16 @@
 
 namespace cgic {
 
+// Debug-only phase stamps (make dbg -> libcgic_hip_dbg.so): block 0 / thread 0 records the shader
+// clock at phase boundaries of decompress_kernel.  Compiled out of the product library.
+#ifdef CGIC_PHASE_CLOCKS
+__device__ long long g_phase_clk[16];
+#define CGIC_STAMP(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_phase_clk[i] = clock64(); \
+        if (blockIdx.x == 0 && threadIdx.x == 192 && (i) >= 2 && (i) <= 7) g_phase_clk[8 + (i)] = clock64(); } while (0)
+#else
+#define CGIC_STAMP(i) do {} while (0)
+#endif
+
 constexpr int kEncThreads = 256;
 constexpr int kEncItems = 4;            // consecutive positions per thread per scan round
 constexpr int kLdsPos = 8192;           // streams up to this many positions keep phase-A results in LDS
@@ -403,14 +413,214 @@ __global__ __launch_bounds__(kWave) void decode_stream_kernel(DecodeOneArgs a)
 }
 
 // -------------------------------------------------------------------------------------------
-// decompress: one 256-thread workgroup per image.  Waves 0..2 decode the coarse / medium / fine
-// index streams into LDS while wave 3 unpacks the two mask streams into bitsets and their
-// popcount prefixes; after one barrier all four waves scatter + merge + gather.
-//                                                                    model.py:269-397
+// Parallel prefix-code decoding inside ONE stream (fast mode, max code length <= 64 bits).
+//
+// A stream is cut into 64-bit chunks; a wave owns a contiguous range of chunks.  Where the
+// first codeword of a chunk starts depends on everything before it, so each wave first builds
+// the FUNCTION  entry offset e in [0,64)  ->  (exit offset into the chunk after its range,
+// number of symbols decoded)  without knowing e:
+//   lane i looks up the codeword starting at bit i of the chunk (LUT in LDS, long codes by a
+//   per-lane trie walk) -> next[i] = i + len, cnt[i] = 1;  six rounds of pointer doubling with
+//   ds_bpermute turn next/cnt into "first position >= 64 reached from i / symbols on the way";
+//   the chunk function is folded into the wave's running function with two more bpermutes.
+// Functions of consecutive waves are composed through LDS (<= 16 scalar steps), which gives
+// every wave its true entry offset and output index; then all waves decode their ranges
+// concurrently with the scalar chain of WaveDecoder::run.  Exact for every table with
+// max_len <= 64; longer tables (all-zero frequency counters give 224-bit codes) take the
+// single-wave path.  A codeword never spans more than two chunks in fast mode, so every
+// entry offset is < 64.
 // -------------------------------------------------------------------------------------------
-constexpr int kMergeThreads = 256;
+constexpr int kDecThreads = 1024;
+constexpr int kDecWaves = kDecThreads / kWave;
+constexpr int kSegWin = 1024;                      // LDS window of stream bytes per wave
+constexpr int kSegWinWords = kSegWin / 4 + 4;           // 65 x 16 B: one uint4 per lane + one tail
+constexpr int kBig = 1 << 28;                      // "past the end of the stream"
+constexpr int kU = 4;                              // chunks in flight per wave
 constexpr int kMergeItems = 4;
 
+struct BitWindow {
+    uint32_t *win;           // LDS, kSegWinWords
+    const uint8_t *in;       // global; in[0] is the pad-count byte
+    int nbytes;
+    int wb, wsh;
+
+    __device__ __forceinline__ void fill(int first_byte)
+    {
+        // one 16-byte load per lane (+1 tail) -> a single global round trip per refill
+        const int lane = lane_id();
+        wb = first_byte & ~3;
+        const uintptr_t g = reinterpret_cast<uintptr_t>(in) + (uintptr_t)wb;
+        const uint4 *ga = reinterpret_cast<const uint4 *>(g & ~(uintptr_t)15);
+        wsh = (int)(g & 15);         // the window starts this many bytes before stream byte wb
+        const int limit = (nbytes - wb + wsh + 15) / 16 + 1;      // 16-byte words that may be touched
+        uint4 v0 = {0u, 0u, 0u, 0u}, v1 = {0u, 0u, 0u, 0u};
+        if (lane < limit) v0 = ga[lane];
+        if (lane == 0 && kWave < limit) v1 = ga[kWave];
+        reinterpret_cast<uint4 *>(win)[lane] = v0;
+        if (lane == 0) reinterpret_cast<uint4 *>(win)[kWave] = v1;
+        __builtin_amdgcn_wave_barrier();
+    }
+    __device__ __forceinline__ bool covers(int p_last) const { return 1 + (p_last >> 3) + 8 + wsh < wb + kSegWin - 16; }
+    __device__ __forceinline__ uint32_t fetch32(int p) const
+    {
+        const int o = 1 + (p >> 3) - wb + wsh;
+        const uint32_t a = win[o >> 2], b = win[(o >> 2) + 1];
+        const uint64_t w = ((uint64_t)__builtin_bswap32(a) << 32) | __builtin_bswap32(b);
+        return (uint32_t)((w << (8 * (o & 3) + (p & 7))) >> 32);
+    }
+    __device__ __forceinline__ int bit(int p) const
+    {
+        const int o = 1 + (p >> 3) - wb + wsh;
+        return (int)((win[o >> 2] >> (8 * (o & 3) + 7 - (p & 7))) & 1u);
+    }
+};
+
+// codeword starting at payload bit p: returns its length (0 = no complete codeword before
+// nbits) and symbol.  Per-lane; long codes walk the trie (window must cover p + 64 + 32 bits).
+__device__ __forceinline__ int codeword_at(const TableDev &t, const uint32_t *lut, const BitWindow &bw,
+                                           int p, int nbits, int *sym)
+{
+    if (p >= nbits) return 0;
+    const uint32_t e = lut[bw.fetch32(p) >> (32 - t.lut_bits)];
+    int L = (int)(e & 0xFF);
+    int S = (int)(e >> 8);
+    if (L == 0) {
+        if (S == 0xFFFFFF) return 0;
+        int node = S, q = p + t.lut_bits;
+        S = -1;
+        while (q < nbits) {
+            const int c = t.child[2 * node + bw.bit(q)];
+            ++q;
+            if (c == INT32_MIN) break;
+            if (c < 0) { S = ~c; break; }
+            node = c;
+        }
+        if (S < 0) return 0;
+        L = q - p;
+    }
+    if (p + L > nbits) return 0;       // trailing partial codeword: dropped by the reference
+    *sym = S;
+    return L;
+}
+
+struct SegShared {
+    int F[kDecWaves][kWave];          // exit offset of wave's range as a function of entry offset
+    int C[kDecWaves][kWave];          // symbols decoded as a function of entry offset
+};
+
+// Decode stream bytes `in` with waves [w0, w0+nw) of the block; each participating wave calls
+// this with k = its index inside the stream.  Two block-wide barriers inside (ALL waves of the
+// block must reach them, also waves with nw == 0 work: pass nw=0 and they just sync).
+template <typename Put>
+__device__ __forceinline__ void decode_segmented(const TableDev &t, const uint32_t *lut, uint32_t *win,
+                                                 SegShared *sh, const uint8_t *in, int nbytes, int w0, int nw,
+                                                 int k, int cap, Put put, int *count_out)
+{
+    const int lane = lane_id();
+    const int wave = threadIdx.x >> 6;
+    int nbits = 0, nchunks = 0, c0 = 0, c1 = 0;
+    BitWindow bw{win, in, nbytes, 0, 0};
+    const bool active = nw > 0 && nbytes > 0;
+    if (active) {
+        const int pad = in[0];                                   // remove_padding :131-138
+        nbits = pad == 0 ? 0 : (nbytes - 1) * 8 - pad;
+        if (nbits < 0) nbits = 0;
+        nchunks = (nbits + kWave - 1) / kWave;
+        c0 = (int)((int64_t)k * nchunks / nw);
+        c1 = (int)((int64_t)(k + 1) * nchunks / nw);
+    }
+    // ---- pass A: range function (F, C) by pointer doubling; kU chunks in flight per wave so that
+    // the LDS round trips of independent chunks overlap (one wave per SIMD has no other cover)
+    CGIC_STAMP(2);
+    int F = lane, C = 0;
+    if (active && c1 > c0) {
+        bw.fill(1 + ((c0 * kWave) >> 3));
+        for (int c = c0; c < c1; c += kU) {
+            if (!bw.covers((c + kU + 2) * kWave)) bw.fill(1 + ((c * kWave) >> 3));
+            int nxt[kU], cnt[kU];
+#pragma unroll
+            for (int u = 0; u < kU; ++u) {
+                int sym;
+                const int L = c + u < c1 ? codeword_at(t, lut, bw, (c + u) * kWave + lane, nbits, &sym) : 0;
+                nxt[u] = L ? lane + L : kBig;
+                cnt[u] = L ? 1 : 0;
+            }
+            for (int r = 0; r < t.dbl_rounds; ++r) {
+#pragma unroll
+                for (int u = 0; u < kU; ++u) {
+                    const int jn = __shfl(nxt[u], nxt[u] & 63, kWave);
+                    const int cn = __shfl(cnt[u], nxt[u] & 63, kWave);
+                    if (nxt[u] < kWave) { cnt[u] += cn; nxt[u] = jn; }
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < kU; ++u) {
+                if (c + u < c1) {
+                    const int jx = __shfl(nxt[u], F & 63, kWave);
+                    const int cx = __shfl(cnt[u], F & 63, kWave);
+                    if (F < kWave) { C += cx; F = jx; }
+                    F = F >= kBig / 2 ? kBig : F - kWave;
+                }
+            }
+        }
+    }
+    sh->F[wave][lane] = F;
+    sh->C[wave][lane] = C;
+    CGIC_STAMP(3);
+    __syncthreads();
+    CGIC_STAMP(4);
+    // ---- pass B: true entry offset + output index of this wave's range
+    int e = 0, n = 0;
+    if (active) {
+        for (int v = w0; v < w0 + k; ++v) {
+            if (e >= kWave) break;
+            n += sh->C[v][e];
+            e = sh->F[v][e];
+        }
+        if (k == nw - 1 && lane == 0) *count_out = e < kWave ? n + sh->C[wave][e] : n;
+    }
+    // ---- pass C: decode the range from its true entry offset (lookups for kU chunks issued
+    // together, then the scalar chains one after the other)
+    CGIC_STAMP(5);
+    if (active && c1 > c0 && e < kWave) {
+        if (!bw.covers((c0 + kU + 2) * kWave) || 1 + ((c0 * kWave) >> 3) < bw.wb) bw.fill(1 + ((c0 * kWave) >> 3));
+        for (int c = c0; c < c1 && e < kWave; c += kU) {
+            if (!bw.covers((c + kU + 2) * kWave)) bw.fill(1 + ((c * kWave) >> 3));
+            int Ls[kU], syms[kU];
+#pragma unroll
+            for (int u = 0; u < kU; ++u) {
+                syms[u] = 0;
+                Ls[u] = c + u < c1 ? codeword_at(t, lut, bw, (c + u) * kWave + lane, nbits, &syms[u]) : 0;
+            }
+#pragma unroll
+            for (int u = 0; u < kU; ++u) {
+                if (c + u < c1 && e < kWave) {
+                    unsigned long long starts = 0;
+                    int i = e;
+                    while (i < kWave) {
+                        const int Li = __builtin_amdgcn_readlane(Ls[u], i);
+                        starts |= (unsigned long long)(Li != 0) << i;
+                        i = Li ? i + Li : kBig;
+                    }
+                    e = i >= kBig / 2 ? kBig : i - kWave;
+                    const int rank = __popcll(starts & ((1ull << lane) - 1ull));
+                    if (((starts >> lane) & 1ull) && n + rank < cap) put(n + rank, syms[u]);
+                    n += __popcll(starts);
+                }
+            }
+        }
+    }
+    CGIC_STAMP(6);
+    __syncthreads();
+    CGIC_STAMP(7);
+}
+
+// -------------------------------------------------------------------------------------------
+// decompress: one 1024-thread workgroup per image.  The 16 waves are shared out over the three
+// index streams in proportion to their length and decode them concurrently (above); then the
+// whole block unpacks the two mask streams into bitsets + popcount prefixes and scatters,
+// merges (x1 + x2 + x4 grids) and gathers codebook rows.                 model.py:269-397
+// -------------------------------------------------------------------------------------------
 struct DecompressArgs {
     TableDev tab;
     const uint8_t *in;
@@ -443,27 +653,11 @@ __device__ __forceinline__ uint32_t mask_stream_word(const uint8_t *in, int64_t 
     return v;
 }
 
-// exclusive popcount prefix of a bit array by ONE wave; returns the total
-__device__ __forceinline__ uint32_t wave_popc_prefix(const uint32_t *bits, uint32_t *prefix, int64_t nwords)
-{
-    const int lane = lane_id();
-    uint32_t carry = 0;
-    for (int64_t base = 0; base < nwords; base += kWave) {
-        const int64_t i = base + lane;
-        const uint32_t c = i < nwords ? (uint32_t)__popc(bits[i]) : 0u;
-        const uint32_t inc = wave_inclusive_scan(c);
-        if (i < nwords) prefix[i] = carry + inc - c;
-        carry += __shfl(inc, kWave - 1, kWave);
-    }
-    return carry;
-}
-
-__global__ __launch_bounds__(kMergeThreads) void decompress_kernel(DecompressArgs a)
+__global__ __launch_bounds__(kDecThreads) void decompress_kernel(DecompressArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t sm[];
-    __shared__ uint32_t scan_smem[kMergeThreads / kWave + 1];
+    __shared__ uint32_t scan_smem[kDecWaves + 1];
     __shared__ int s_cnt[3];         // decoded counts: >=0, -1 empty file, -2 not sent, -3 overflow
-    __shared__ uint32_t s_mcnt[2];   // ones in the coarse / medium masks
     __shared__ int s_status;
     const int tid = threadIdx.x, lane = lane_id(), wave = tid >> 6;
     const int64_t b = blockIdx.x;
@@ -472,99 +666,171 @@ __global__ __launch_bounds__(kMergeThreads) void decompress_kernel(DecompressArg
     const int64_t wc = (n_c + 31) >> 5, wm = (n_m + 31) >> 5;
     // LDS carve-up
     uint32_t *lut = sm;                                 // [4096]
-    uint32_t *win = lut + kDecLutMax;                   // [3][kWinWords]
-    uint32_t *mcb = win + 3 * kWinWords;                // [wc] coarse mask bits, LSB first
+    uint32_t *win = lut + kDecLutMax;                   // [16][kSegWinWords]
+    SegShared *seg = reinterpret_cast<SegShared *>(win + kDecWaves * kSegWinWords);
+    uint32_t *mcb = reinterpret_cast<uint32_t *>(seg + 1);   // [wc] coarse mask bits, LSB first
     uint32_t *mmb = mcb + wc;                           // [wm]
     uint32_t *pcb = mmb + wm;                           // [wc] exclusive popcount prefix
     uint32_t *pmb = pcb + wc;                           // [wm]
     uint16_t *lsym = reinterpret_cast<uint16_t *>(pmb + wm);   // [n_c + n_m + n_f] if dsym_in_lds
     const int mode = a.mode;
+    CGIC_STAMP(0);
     if (tid == 0) s_status = 0;
+    if (tid < 3) s_cnt[tid] = -2;
     load_lut(a.tab, lut);
     __syncthreads();
+    CGIC_STAMP(1);
 
-    const bool send_mc = mode == 0 || mode == 2 || mode == 3;
-    const bool send_mm = mode == 0 || mode == 1;
     int32_t *gsym = a.dsym_in_lds ? nullptr : a.ws_dsym + b * (n_c + n_m + n_f);
+    const int64_t offs[3] = {0, n_c, n_c + n_m};
+    const int64_t caps[3] = {n_c, n_m, n_f};
+    int nb[3];
+#pragma unroll
+    for (int s = 0; s < 3; ++s) nb[s] = ((a.stream_mask >> s) & 1) ? a.nbytes[b * CGIC_NUM_STREAMS + s] : -1;
 
-    if (wave < 3) {
-        // ---- phase 1a: decode stream `wave`
+    if (a.tab.max_len <= 64) {
+        // ---- share the 16 waves out over the streams that carry data, proportional to bytes
+        // (integer arithmetic only: this runs on every wave before any decoding starts)
+        int nw[3] = {0, 0, 0};
+        const int tot = (nb[0] > 0 ? nb[0] : 0) + (nb[1] > 0 ? nb[1] : 0) + (nb[2] > 0 ? nb[2] : 0);
+        int used = 0;
+#pragma unroll
+        for (int s = 0; s < 3; ++s) {
+            if (nb[s] > 0) {
+                int q = (int)((int64_t)nb[s] * kDecWaves / tot);          // floor share
+                const int need = (nb[s] + 15) >> 4;                         // no wave below ~2 chunks
+                q = q < 1 ? 1 : q;
+                nw[s] = q < need ? q : need;
+                used += nw[s];
+            }
+        }
+        // floor shares sum to <= 16 except when the "at least one" bumps pushed it over
+        for (int s = 2; s >= 0 && used > kDecWaves; --s)
+            while (nw[s] > 1 && used > kDecWaves) { --nw[s]; --used; }
+        // hand the spare waves to the longest stream
+        {
+            int big = 0;
+            if (nb[1] > nb[big]) big = 1;
+            if (nb[2] > nb[big]) big = 2;
+            if (nb[big] > 0) {
+                const int need = (nb[big] + 15) >> 4;
+                const int extra = kDecWaves - used;
+                const int room = need - nw[big];
+                nw[big] += extra < room ? extra : (room > 0 ? room : 0);
+            }
+        }
+        const int w0[3] = {0, nw[0], nw[0] + nw[1]};
+        int s_mine = -1;
+#pragma unroll
+        for (int s = 0; s < 3; ++s) if (wave >= w0[s] && wave < w0[s] + nw[s]) s_mine = s;
+        const int s = s_mine < 0 ? 0 : s_mine;
+        const uint8_t *in = a.in + (b * CGIC_NUM_STREAMS + s) * a.slot;
+        const int my_nw = s_mine < 0 ? 0 : nw[s];
+        if (a.dsym_in_lds) {
+            uint16_t *dst = lsym + offs[s];
+            decode_segmented(a.tab, lut, win + wave * kSegWinWords, seg, in, nb[s], w0[s], my_nw, wave - w0[s],
+                             (int)caps[s], [&](int k, int sym) { dst[k] = (uint16_t)sym; }, &s_cnt[s]);
+        } else {
+            int32_t *dst = gsym + offs[s];
+            decode_segmented(a.tab, lut, win + wave * kSegWinWords, seg, in, nb[s], w0[s], my_nw, wave - w0[s],
+                             (int)caps[s], [&](int k, int sym) { dst[k] = sym; }, &s_cnt[s]);
+        }
+        if (tid < 3 && nb[tid] == 0) s_cnt[tid] = -1;     // empty file -> None
+    } else if (wave < 3) {
+        // ---- tables with codes longer than 64 bits: one wave per stream, serial chain
         const int s = wave;
-        const int64_t off = s == 0 ? 0 : (s == 1 ? n_c : n_c + n_m);
-        const int64_t cap = s == 0 ? n_c : (s == 1 ? n_m : n_f);
         int cnt = -2;
-        if ((a.stream_mask >> s) & 1) {
+        if (nb[s] >= 0) {
             int overflow = 0;
-            WaveDecoder d{a.tab, lut, win + s * kWinWords, a.in + (b * CGIC_NUM_STREAMS + s) * a.slot,
-                          a.nbytes[b * CGIC_NUM_STREAMS + s], 0, 0};
+            WaveDecoder d{a.tab, lut, win + s * kWinWords, a.in + (b * CGIC_NUM_STREAMS + s) * a.slot, nb[s], 0, 0};
             if (a.dsym_in_lds) {
-                uint16_t *dst = lsym + off;
-                cnt = d.run((int)cap, [&](int k, int sym) { dst[k] = (uint16_t)sym; }, &overflow);
+                uint16_t *dst = lsym + offs[s];
+                cnt = d.run((int)caps[s], [&](int k, int sym) { dst[k] = (uint16_t)sym; }, &overflow);
             } else {
-                int32_t *dst = gsym + off;
-                cnt = d.run((int)cap, [&](int k, int sym) { dst[k] = sym; }, &overflow);
+                int32_t *dst = gsym + offs[s];
+                cnt = d.run((int)caps[s], [&](int k, int sym) { dst[k] = sym; }, &overflow);
             }
             if (__any(overflow)) cnt = -3;
         }
         if (lane == 0) s_cnt[s] = cnt;
-    } else {
-        // ---- phase 1b (wave 3): mask streams -> bitsets + popcount prefixes
-        const uint8_t *in_mc = a.in + (b * CGIC_NUM_STREAMS + 3) * a.slot;
-        const uint8_t *in_mm = a.in + (b * CGIC_NUM_STREAMS + 4) * a.slot;
-        // a mask stream must be exactly 1 + n/8 + 1 bytes with pad = 8 - n%8 (mask_coding.py:19-26)
-        if (lane == 0) {
-            if (send_mc) {
-                const int32_t nb = a.nbytes[b * CGIC_NUM_STREAMS + 3];
-                if (nb != 2 + (n_c >> 3) || in_mc[0] != 8 - (n_c & 7)) s_status = CGIC_ERR_INVALID;
-            }
-            if (send_mm) {
-                const int32_t nb = a.nbytes[b * CGIC_NUM_STREAMS + 4];
-                if (nb != 2 + (n_m >> 3) || in_mm[0] != 8 - (n_m & 7)) s_status = CGIC_ERR_INVALID;
-            }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int s = 0; s < 3; ++s) if (s_cnt[s] > caps[s]) { __syncthreads(); if (tid == 0) s_cnt[s] = -3; }
+    __syncthreads();
+
+    // ---- mask streams -> bitsets + popcount prefixes
+    const bool send_mc = mode == 0 || mode == 2 || mode == 3;
+    const bool send_mm = mode == 0 || mode == 1;
+    const uint8_t *in_mc = a.in + (b * CGIC_NUM_STREAMS + 3) * a.slot;
+    const uint8_t *in_mm = a.in + (b * CGIC_NUM_STREAMS + 4) * a.slot;
+    // a mask stream must be exactly 1 + n/8 + 1 bytes with pad = 8 - n%8 (mask_coding.py:19-26)
+    if (tid == 0) {
+        if (send_mc) {
+            const int32_t nbm = a.nbytes[b * CGIC_NUM_STREAMS + 3];
+            if (nbm != 2 + (n_c >> 3) || in_mc[0] != 8 - (n_c & 7)) s_status = CGIC_ERR_INVALID;
         }
-        __builtin_amdgcn_wave_barrier();
-        const bool bad = __shfl(s_status, 0, kWave) != 0;
-        for (int64_t i = lane; i < wc; i += kWave) {
-            uint32_t v = 0;
-            if (send_mc && !bad) v = mask_stream_word(in_mc, i, n_c);
-            else if (mode == 4) {                                               // ones (:355)
-                v = 0xFFFFFFFFu;
-                const int64_t rem = n_c - i * 32;
-                if (rem < 32) v &= (1u << rem) - 1u;
-            }
-            mcb[i] = v;
+        if (send_mm) {
+            const int32_t nbm = a.nbytes[b * CGIC_NUM_STREAMS + 4];
+            if (nbm != 2 + (n_m >> 3) || in_mm[0] != 8 - (n_m & 7)) s_status = CGIC_ERR_INVALID;
         }
-        __builtin_amdgcn_wave_barrier();
-        for (int64_t i = lane; i < wm; i += kWave) {
-            uint32_t v = 0;
-            if (send_mm && !bad) v = mask_stream_word(in_mm, i, n_m);
-            else if (mode == 3 || mode == 5) {
-                for (int k = 0; k < 32; ++k) {
-                    const int64_t j = i * 32 + k;
-                    if (j >= n_m) break;
-                    bool bit = true;                                            // mode 5: ones (:368)
-                    if (mode == 3) {                                            // 1 - up2(mask_coarse) (:332)
-                        const int64_t y = j / w2, x = j - y * w2, c = (y >> 1) * w4 + (x >> 1);
-                        bit = !((mcb[c >> 5] >> (c & 31)) & 1u);
-                    }
-                    v |= (uint32_t)bit << k;
-                }
-            }
-            mmb[i] = v;
-        }
-        __builtin_amdgcn_wave_barrier();
-        const uint32_t cc = wave_popc_prefix(mcb, pcb, wc);
-        const uint32_t cm = wave_popc_prefix(mmb, pmb, wm);
-        if (lane == 0) { s_mcnt[0] = cc; s_mcnt[1] = cm; }
     }
     __syncthreads();
     if (s_status) {
         if (tid == 0 && a.status) a.status[b] = s_status;
         return;
     }
+    for (int64_t i = tid; i < wc; i += kDecThreads) {
+        uint32_t v = 0;
+        if (send_mc) v = mask_stream_word(in_mc, i, n_c);
+        else if (mode == 4) {                                                   // ones (:355)
+            v = 0xFFFFFFFFu;
+            const int64_t rem = n_c - i * 32;
+            if (rem < 32) v &= (1u << rem) - 1u;
+        }
+        mcb[i] = v;
+    }
+    __syncthreads();
+    for (int64_t i = tid; i < wm; i += kDecThreads) {
+        uint32_t v = 0;
+        if (send_mm) v = mask_stream_word(in_mm, i, n_m);
+        else if (mode == 3 || mode == 5) {
+            for (int k = 0; k < 32; ++k) {
+                const int64_t j = i * 32 + k;
+                if (j >= n_m) break;
+                bool bit = true;                                                // mode 5: ones (:368)
+                if (mode == 3) {                                                // 1 - up2(mask_coarse) (:332)
+                    const int64_t y = j / w2, x = j - y * w2, c = (y >> 1) * w4 + (x >> 1);
+                    bit = !((mcb[c >> 5] >> (c & 31)) & 1u);
+                }
+                v |= (uint32_t)bit << k;
+            }
+        }
+        mmb[i] = v;
+    }
+    __syncthreads();
+    uint32_t carry = 0, total;
+    for (int64_t base = 0; base < wc; base += kDecThreads) {
+        const int64_t i = base + tid;
+        const uint32_t c = i < wc ? (uint32_t)__popc(mcb[i]) : 0u;
+        const uint32_t ex = block_exclusive_scan(c, scan_smem, &total);
+        if (i < wc) pcb[i] = carry + ex;
+        carry += total;
+    }
+    const uint32_t cnt_c = carry;
+    carry = 0;
+    for (int64_t base = 0; base < wm; base += kDecThreads) {
+        const int64_t i = base + tid;
+        const uint32_t c = i < wm ? (uint32_t)__popc(mmb[i]) : 0u;
+        const uint32_t ex = block_exclusive_scan(c, scan_smem, &total);
+        if (i < wm) pmb[i] = carry + ex;
+        carry += total;
+    }
+    const uint32_t cnt_m = carry;
+    __syncthreads();
+    CGIC_STAMP(8);
 
-    // ---- phase 2: scatter + merge + gather
-    const uint32_t cnt_c = s_mcnt[0], cnt_m = s_mcnt[1];
+    // ---- scatter + merge + gather
     const int64_t dc_c = s_cnt[0], dc_m = s_cnt[1], dc_f = s_cnt[2];
     const bool has_c = mode == 0 || mode == 2 || mode == 3 || mode == 4;
     const bool has_m = mode == 0 || mode == 1 || mode == 3 || mode == 5;
@@ -582,7 +848,7 @@ __global__ __launch_bounds__(kMergeThreads) void decompress_kernel(DecompressArg
     float *zq = a.zq ? a.zq + b * 4 * n_f : nullptr;
     uint32_t fcarry = 0;
     int bad_index = 0;
-    for (int64_t base = 0; base < n_f; base += (int64_t)kMergeThreads * kMergeItems) {
+    for (int64_t base = 0; base < n_f; base += (int64_t)kDecThreads * kMergeItems) {
         uint32_t fl = 0;       // fine flags of my items
         const int64_t i0 = base + (int64_t)tid * kMergeItems;
         int64_t vals[kMergeItems];
@@ -635,6 +901,7 @@ __global__ __launch_bounds__(kMergeThreads) void decompress_kernel(DecompressArg
     if (has_f && (dc_f >= 0 ? dc_f != (int64_t)fcarry : fcarry != 0)) st = CGIC_ERR_INVALID;
     if (bad_index) s_status = CGIC_ERR_INVALID;
     __syncthreads();
+    CGIC_STAMP(9);
     if (tid == 0 && a.status) a.status[b] = st ? st : s_status;
 }
 
@@ -660,6 +927,14 @@ static size_t align16(size_t v) { return (v + 15) & ~(size_t)15; }
 }  // namespace cgic
 
 using namespace cgic;
+
+#ifdef CGIC_PHASE_CLOCKS
+extern "C" int cgic_debug_phase_clocks(long long *out16)
+{
+    CGIC_HIP_TRY(hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_phase_clk), sizeof(long long) * 16));
+    return CGIC_OK;
+}
+#endif
 
 extern "C" int cgic_mode_streams(int mode)
 {
@@ -771,7 +1046,8 @@ extern "C" int cgic_decode_stream(const cgic_table *t, const uint8_t *in, int64_
 static size_t decompress_lds_bytes(int64_t h, int64_t w, bool sym_in_lds)
 {
     const size_t wc = (size_t)(((h / 4) * (w / 4) + 31) / 32), wm = (size_t)(((h / 2) * (w / 2) + 31) / 32);
-    size_t b = sizeof(uint32_t) * (kDecLutMax + 3 * kWinWords + 2 * (wc + wm));
+    size_t b = sizeof(uint32_t) * (kDecLutMax + kDecWaves * kSegWinWords + 2 * (wc + wm)) + sizeof(SegShared);
+    if (b < sizeof(uint32_t) * (kDecLutMax + 3 * kWinWords)) b = sizeof(uint32_t) * (kDecLutMax + 3 * kWinWords);
     if (sym_in_lds) b += sizeof(uint16_t) * (size_t)((h / 4) * (w / 4) + (h / 2) * (w / 2) + h * w) + 16;
     return b;
 }
@@ -816,7 +1092,7 @@ extern "C" int cgic_decompress_streams(const cgic_table *t, const uint8_t *in, i
     d.codebook = codebook; d.K = K; d.zq = z_q; d.status = status;
     if (lds > 48 * 1024)
         CGIC_HIP_TRY(hipFuncSetAttribute((const void *)decompress_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(decompress_kernel, dim3((unsigned)B), dim3(kMergeThreads), lds, (hipStream_t)stream, d);
+    hipLaunchKernelGGL(decompress_kernel, dim3((unsigned)B), dim3(kDecThreads), lds, (hipStream_t)stream, d);
     return launch_check("decompress_kernel");
 }
 

@@ -49,6 +49,7 @@ struct TableDev {
     int words;
     int max_len;
     int lut_bits;
+    int dbl_rounds;   // pointer-doubling rounds that cover a 64-bit chunk: ceil(log2(ceil(64 / min_len)))
 };
 
 struct Table;  // host object behind cgic_table

@@ -182,6 +182,13 @@ int table_device_view(const cgic_table *ct, TableDev *out)
     out->words = t->words;
     out->max_len = t->max_len;
     out->lut_bits = t->lut_bits;
+    int min_len = t->max_len;
+    for (int v : t->len) if (v > 0 && v < min_len) min_len = v;
+    if (min_len < 1) min_len = 1;
+    const int hops = (kWave + min_len - 1) / min_len;     // codewords that can start inside one chunk
+    int r = 0;
+    while ((1 << r) < hops) ++r;
+    out->dbl_rounds = r;
     return CGIC_OK;
 }
 

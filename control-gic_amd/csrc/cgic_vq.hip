@@ -103,20 +103,16 @@ __device__ __forceinline__ void finish_loss(double block_sum, double *sq_partial
 // to the minimum.  Strict '<' on tiles + first-equal on rows + (value, index) lexicographic merge
 // across the 4 row groups == lowest index among exact minima, like torch.argmin.
 template <int ZT>
-__global__ __launch_bounds__(kVqThreads, 2) void vq_mfma_kernel(
+__global__ __launch_bounds__(kVqThreads, ZT <= 4 ? 4 : 2) void vq_mfma_kernel(
     const float *__restrict__ z, int64_t hw, int64_t N, const float *__restrict__ cb, int K,
     int64_t *__restrict__ idx_out, float *__restrict__ zq_out, double *__restrict__ sq_partial,
-    unsigned int *__restrict__ ticket, float beta, int legacy, float *__restrict__ loss,
-    unsigned long long *__restrict__ hist)
+    unsigned int *__restrict__ ticket, float beta, int legacy, float *__restrict__ loss)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float *cbT = smem;                // [4][K]
     float *ee = smem + 4 * K;         // [K]
-    unsigned int *lhist = reinterpret_cast<unsigned int *>(smem + 5 * K);  // [K] (only if hist)
 
     stage_codebook(cb, K, cbT, ee);
-    if (hist)
-        for (int k = threadIdx.x; k < K; k += blockDim.x) lhist[k] = 0;
     __syncthreads();
 
     const int lane = lane_id();
@@ -200,20 +196,10 @@ __global__ __launch_bounds__(kVqThreads, 2) void vq_mfma_kernel(
                 }
                 sq += (double)diff * (double)diff;
             }
-            if (g == 0) {
-                if (idx_out) idx_out[n] = (int64_t)i;
-                if (hist) atomicAdd(&lhist[i], 1u);
-            }
+            if (g == 0 && idx_out) idx_out[n] = (int64_t)i;
         }
     }
 
-    if (hist) {
-        __syncthreads();
-        for (int k = threadIdx.x; k < K; k += blockDim.x) {
-            unsigned int c = lhist[k];
-            if (c) atomicAdd(&hist[k], (unsigned long long)c);
-        }
-    }
     if (sq_partial) {
         // deterministic block reduction: fixed shuffle tree, then waves in order
         __shared__ double wsum[4];
@@ -230,8 +216,7 @@ __global__ __launch_bounds__(kVqThreads, 2) void vq_mfma_kernel(
 __global__ __launch_bounds__(kVqThreads) void vq_valu_kernel(
     const float *__restrict__ z, int64_t hw, int64_t N, const float *__restrict__ cb, int K,
     int64_t *__restrict__ idx_out, float *__restrict__ zq_out, double *__restrict__ sq_partial,
-    unsigned int *__restrict__ ticket, float beta, int legacy, float *__restrict__ loss,
-    unsigned long long *__restrict__ hist)
+    unsigned int *__restrict__ ticket, float beta, int legacy, float *__restrict__ loss)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float4 *cbs = reinterpret_cast<float4 *>(smem);  // [K]
@@ -264,7 +249,6 @@ __global__ __launch_bounds__(kVqThreads) void vq_valu_kernel(
             bi = take ? k : bi;
         }
         if (idx_out) idx_out[n] = bi;
-        if (hist) atomicAdd(&hist[bi], 1ull);
         if (zq_out || sq_partial) {
             float4 e = cbs[bi];
             float d0 = e.x - z0, d1 = e.y - z1, d2 = e.z - z2, d3 = e.w - z3;
@@ -286,13 +270,18 @@ __global__ __launch_bounds__(kVqThreads) void vq_valu_kernel(
     }
 }
 
-__global__ void index_hist_kernel(const int64_t *__restrict__ idx, int64_t n, int K,
-                                  unsigned long long *__restrict__ hist)
+// Usage histogram of an index tensor (quantize.py:79-81).  A small number of fat blocks, each with a
+// private LDS histogram, so a hot bin receives at most gridDim.x global atomics (not one per
+// 256 vectors): same-address atomics serialise in L2.
+__global__ __launch_bounds__(1024) void index_hist_kernel(const int64_t *__restrict__ idx, int64_t n, int K,
+                                                          unsigned long long *__restrict__ hist)
 {
     extern __shared__ unsigned int lh[];
     for (int k = threadIdx.x; k < K; k += blockDim.x) lh[k] = 0;
     __syncthreads();
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t per = (n + gridDim.x - 1) / gridDim.x;
+    const int64_t lo = per * blockIdx.x, hi = lo + per < n ? lo + per : n;
+    for (int64_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
         int64_t v = idx[i];
         if (v >= 0 && v < K) atomicAdd(&lh[v], 1u);
     }
@@ -301,8 +290,18 @@ __global__ void index_hist_kernel(const int64_t *__restrict__ idx, int64_t n, in
         if (lh[k]) atomicAdd(&hist[k], (unsigned long long)lh[k]);
 }
 
+static int launch_hist(const int64_t *idx, int64_t n, int K, int64_t *hist, hipStream_t s)
+{
+    int nblk = (int)((n + 4095) / 4096);
+    if (nblk > 64) nblk = 64;
+    if (nblk < 1) nblk = 1;
+    hipLaunchKernelGGL(index_hist_kernel, dim3(nblk), dim3(1024), sizeof(unsigned int) * (size_t)K, s, idx, n, K,
+                       (unsigned long long *)hist);
+    return launch_check("index_hist_kernel");
+}
+
 static int vq_check(const float *z, int64_t B, int64_t hw, const float *cb, int K, int e_dim,
-                    const float *loss, const void *ws)
+                    const float *loss, const void *ws, bool hist_needs_idx)
 {
     CGIC_REQUIRE(z && cb, CGIC_ERR_INVALID, "vq: z and codebook must not be NULL");
     CGIC_REQUIRE(B >= 0 && hw >= 0, CGIC_ERR_INVALID, "vq: negative shape");
@@ -311,6 +310,7 @@ static int vq_check(const float *z, int64_t B, int64_t hw, const float *cb, int 
     CGIC_REQUIRE(K > 0 && K % 16 == 0 && K <= kVqMaxK, CGIC_ERR_UNSUPPORTED,
                  "vq: K=%d; need K %% 16 == 0 and K <= %d", K, kVqMaxK);
     CGIC_REQUIRE(!loss || ws, CGIC_ERR_INVALID, "vq: loss requested without workspace");
+    CGIC_REQUIRE(!hist_needs_idx, CGIC_ERR_INVALID, "vq: hist requires indices (the histogram is taken from them)");
     return CGIC_OK;
 }
 
@@ -328,14 +328,13 @@ static VqWs vq_ws(void *workspace)
 
 template <int ZT>
 static int launch_mfma(const float *z, int64_t hw, int64_t N, const float *cb, int K, int64_t *idx,
-                       float *zq, VqWs ws, float beta, int legacy, float *loss, unsigned long long *hist,
-                       hipStream_t s)
+                       float *zq, VqWs ws, float beta, int legacy, float *loss, hipStream_t s)
 {
     const int64_t per_block = 4 * 16 * ZT;
     const int nblk = (int)((N + per_block - 1) / per_block);
-    size_t lds = sizeof(float) * (size_t)K * (hist ? 6 : 5);
+    size_t lds = sizeof(float) * (size_t)K * 5;
     hipLaunchKernelGGL(vq_mfma_kernel<ZT>, dim3(nblk), dim3(kVqThreads), lds, s, z, hw, N, cb, K, idx, zq,
-                       loss ? ws.partial : nullptr, ws.ticket, beta, legacy, loss, hist);
+                       loss ? ws.partial : nullptr, ws.ticket, beta, legacy, loss);
     return launch_check("vq_mfma_kernel");
 }
 
@@ -353,19 +352,20 @@ extern "C" int cgic_vq_forward_f32(const float *z, int64_t B, int64_t hw, const 
                                    int e_dim, float beta, int legacy, int64_t *indices, float *z_q,
                                    float *loss, int64_t *hist, void *workspace, cgic_stream_t stream)
 {
-    int rc = vq_check(z, B, hw, codebook, K, e_dim, loss, workspace);
+    int rc = vq_check(z, B, hw, codebook, K, e_dim, loss, workspace, hist && !indices);
     if (rc) return rc;
     const int64_t N = B * hw;
     if (N == 0) return CGIC_OK;
     hipStream_t s = (hipStream_t)stream;
     VqWs ws = vq_ws(loss ? workspace : nullptr);
     if (loss) CGIC_HIP_TRY(hipMemsetAsync(ws.ticket, 0, 16, s));
-    unsigned long long *h = (unsigned long long *)hist;
-    // largest per-wave tile that still gives every SIMD >= 2 waves (1024 SIMDs, 4 waves per block)
-    if (N >= (int64_t)512 * 512) rc = launch_mfma<8>(z, hw, N, codebook, K, indices, z_q, ws, beta, legacy, loss, h, s);
-    else if (N >= (int64_t)256 * 512) rc = launch_mfma<4>(z, hw, N, codebook, K, indices, z_q, ws, beta, legacy, loss, h, s);
-    else if (N >= (int64_t)128 * 512) rc = launch_mfma<2>(z, hw, N, codebook, K, indices, z_q, ws, beta, legacy, loss, h, s);
-    else rc = launch_mfma<1>(z, hw, N, codebook, K, indices, z_q, ws, beta, legacy, loss, h, s);
+    // per-wave tile: measured on MI355X (tools/probe_vq.hip) ZT=4 at 4 waves/SIMD is the fastest
+    // for large N; smaller N shrinks the tile so that all 256 CUs get work
+    if (N >= (int64_t)1 << 22) rc = launch_mfma<8>(z, hw, N, codebook, K, indices, z_q, ws, beta, legacy, loss, s);
+    else if (N >= (int64_t)256 * 512) rc = launch_mfma<4>(z, hw, N, codebook, K, indices, z_q, ws, beta, legacy, loss, s);
+    else if (N >= (int64_t)128 * 512) rc = launch_mfma<2>(z, hw, N, codebook, K, indices, z_q, ws, beta, legacy, loss, s);
+    else rc = launch_mfma<1>(z, hw, N, codebook, K, indices, z_q, ws, beta, legacy, loss, s);
+    if (rc == CGIC_OK && hist) rc = launch_hist(indices, N, K, hist, s);
     return rc;
 }
 
@@ -373,7 +373,7 @@ extern "C" int cgic_vq_forward_valu_f32(const float *z, int64_t B, int64_t hw, c
                                         int e_dim, float beta, int legacy, int64_t *indices, float *z_q,
                                         float *loss, int64_t *hist, void *workspace, cgic_stream_t stream)
 {
-    int rc = vq_check(z, B, hw, codebook, K, e_dim, loss, workspace);
+    int rc = vq_check(z, B, hw, codebook, K, e_dim, loss, workspace, hist && !indices);
     if (rc) return rc;
     const int64_t N = B * hw;
     if (N == 0) return CGIC_OK;
@@ -383,17 +383,15 @@ extern "C" int cgic_vq_forward_valu_f32(const float *z, int64_t B, int64_t hw, c
     int nblk = (int)((N + kVqThreads - 1) / kVqThreads);
     size_t lds = sizeof(float) * (size_t)K * 5;
     hipLaunchKernelGGL(vq_valu_kernel, dim3(nblk), dim3(kVqThreads), lds, s, z, hw, N, codebook, K, indices, z_q,
-                       loss ? ws.partial : nullptr, ws.ticket, beta, legacy, loss, (unsigned long long *)hist);
-    return launch_check("vq_valu_kernel");
+                       loss ? ws.partial : nullptr, ws.ticket, beta, legacy, loss);
+    rc = launch_check("vq_valu_kernel");
+    if (rc == CGIC_OK && hist) rc = launch_hist(indices, N, K, hist, s);
+    return rc;
 }
 
 extern "C" int cgic_index_histogram(const int64_t *indices, int64_t n, int K, int64_t *hist, cgic_stream_t stream)
 {
     CGIC_REQUIRE(indices && hist && K > 0 && K <= 16384 && n >= 0, CGIC_ERR_INVALID, "index_histogram: bad args");
     if (n == 0) return CGIC_OK;
-    int nblk = (int)((n + 1023) / 1024);
-    if (nblk > 1024) nblk = 1024;
-    hipLaunchKernelGGL(index_hist_kernel, dim3(nblk), dim3(256), sizeof(unsigned int) * (size_t)K,
-                       (hipStream_t)stream, indices, n, K, (unsigned long long *)hist);
-    return launch_check("index_hist_kernel");
+    return launch_hist(indices, n, K, hist, (hipStream_t)stream);
 }

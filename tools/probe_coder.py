@@ -29,3 +29,23 @@ for n in (64, 256, 1024, 4096, 8192, 36864):
     assert int(cnt.item()) == n and torch.equal(dsym[:n], sym)
     te, td = time_events(enc, 50), time_events(dec, 50)
     print(f"n={n:6d} bytes={nbytes:6d} encode {te:8.1f} us  decode {td:8.1f} us  ({td*1e3/n:7.1f} ns/sym)")
+
+# ---- decompress phase clocks (needs CGIC_LIB=.../libcgic_hip_dbg.so)
+if os.environ.get("CGIC_LIB"):
+    import ctypes
+    from bench import HotPath, make_inputs
+    x, z, cb = make_inputs(64, 256, 256, 1000)
+    hp = HotPath(dev, x, z, cb, (0.1, 0.8))
+    e8, e16, mask, mode, zq, ind, comp = hp.encode()
+    for _ in range(3):
+        hp.decode(comp)
+    torch.cuda.synchronize()
+    clk = (ctypes.c_longlong * 16)()
+    l.cgic_debug_phase_clocks.argtypes = [ctypes.c_void_p]
+    l.cgic_debug_phase_clocks(clk)
+    c = list(clk)
+    names = ["start", "lut loaded", "passA begin", "passA end", "sync", "passB end", "passC end", "sync", "masks+prefix", "merge end"]
+    for i in range(1, 10):
+        print(f"  {names[i]:14s} +{(c[i]-c[i-1])/2.29e3:7.2f} us   (t={(c[i]-c[0])/2.29e3:7.2f})")
+    print("  wave 3 (first medium-stream wave):", " ".join(f"{n}+{(c[8+i]-c[8+i-1])/2.29e3:.2f}" for i, n in zip(range(3, 8), ["passA", "sync", "passB", "passC", "sync"])), "us")
+    print("decompress total (events):", time_events(lambda: hp.decode(comp), 50), "us; nbytes[0] =", comp.nbytes[0].tolist())
