@@ -16,6 +16,9 @@
 // Compiled with -ffp-contract=off; every fused op is an explicit fmaf / MFMA.
 #include "cgic_common.h"
 
+#include <map>
+#include <mutex>
+
 namespace cgic {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -60,7 +63,8 @@ __device__ __forceinline__ float dist_valu(float z0, float z1, float z2, float z
 // Last-arriving block sums the per-block partials in a fixed order (deterministic whichever
 // block is last) and writes loss = m + beta*m (quantize.py:85-90).  Hand-off per
 // cdna_hip_programming.md G16: plain stores -> barrier -> agent release -> ticket; the last
-// block does one agent acquire before reading.  `ticket` is zeroed by a memset node per call.
+// block does one agent acquire before reading.  `ticket` lives in library-owned device memory,
+// zeroed once at allocation; the last block resets it, so no per-call memset node is needed.
 __device__ __forceinline__ void finish_loss(double block_sum, double *sq_partial, unsigned int *ticket,
                                             double count, float beta, int legacy, float *loss)
 {
@@ -89,6 +93,7 @@ __device__ __forceinline__ void finish_loss(double block_sum, double *sq_partial
     if (tid == 0) {
         const float m = (float)(red[0] / count);
         *loss = legacy ? (m + beta * m) : (beta * m + m);
+        __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
     }
 }
 
@@ -314,16 +319,35 @@ static int vq_check(const float *z, int64_t B, int64_t hw, const float *cb, int 
     return CGIC_OK;
 }
 
-struct VqWs {      // workspace layout: [ticket (16 B)] [double partial[nblk]]
-    unsigned int *ticket;
-    double *partial;
+struct VqWs {
+    unsigned int *ticket;   // library-owned, self-resetting
+    double *partial;        // caller's workspace: double partial[nblk]
 };
-static VqWs vq_ws(void *workspace)
+
+// One ticket word per (device, stream-hash) slot, zeroed when first allocated.  Launches that
+// share a slot must be stream-ordered (same stream) -- two different streams land on different
+// slots unless their handles collide modulo kTicketSlots.
+constexpr int kTicketSlots = 64;
+static int vq_ws(void *workspace, hipStream_t s, VqWs *out)
 {
-    VqWs w;
-    w.ticket = (unsigned int *)workspace;
-    w.partial = workspace ? (double *)((char *)workspace + 16) : nullptr;
-    return w;
+    static std::mutex mu;
+    static std::map<int, unsigned int *> pool;
+    out->partial = (double *)workspace;
+    out->ticket = nullptr;
+    if (!workspace) return CGIC_OK;
+    int dev = 0;
+    CGIC_HIP_TRY(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lock(mu);
+    auto it = pool.find(dev);
+    if (it == pool.end()) {
+        unsigned int *p = nullptr;
+        CGIC_HIP_TRY(hipMalloc((void **)&p, sizeof(unsigned int) * kTicketSlots * 16));
+        CGIC_HIP_TRY(hipMemset(p, 0, sizeof(unsigned int) * kTicketSlots * 16));    // once per device
+        it = pool.emplace(dev, p).first;
+    }
+    const size_t slot = ((uintptr_t)s >> 6) % kTicketSlots;
+    out->ticket = it->second + slot * 16;       // 64-byte spacing
+    return CGIC_OK;
 }
 
 template <int ZT>
@@ -344,8 +368,8 @@ using namespace cgic;
 
 extern "C" size_t cgic_vq_workspace_bytes(int64_t n_vectors)
 {
-    // ticket + one double per block of the smallest tiling (64 vectors per block)
-    return 16 + sizeof(double) * (size_t)((n_vectors + 63) / 64 + 1);
+    // one double per block of the smallest tiling (64 vectors per block)
+    return sizeof(double) * (size_t)((n_vectors + 63) / 64 + 1);
 }
 
 extern "C" int cgic_vq_forward_f32(const float *z, int64_t B, int64_t hw, const float *codebook, int K,
@@ -357,8 +381,9 @@ extern "C" int cgic_vq_forward_f32(const float *z, int64_t B, int64_t hw, const 
     const int64_t N = B * hw;
     if (N == 0) return CGIC_OK;
     hipStream_t s = (hipStream_t)stream;
-    VqWs ws = vq_ws(loss ? workspace : nullptr);
-    if (loss) CGIC_HIP_TRY(hipMemsetAsync(ws.ticket, 0, 16, s));
+    VqWs ws;
+    rc = vq_ws(loss ? workspace : nullptr, s, &ws);
+    if (rc) return rc;
     // per-wave tile: measured on MI355X (tools/probe_vq.hip) ZT=4 at 4 waves/SIMD is the fastest
     // for large N; smaller N shrinks the tile so that all 256 CUs get work
     if (N >= (int64_t)1 << 22) rc = launch_mfma<8>(z, hw, N, codebook, K, indices, z_q, ws, beta, legacy, loss, s);
@@ -378,8 +403,9 @@ extern "C" int cgic_vq_forward_valu_f32(const float *z, int64_t B, int64_t hw, c
     const int64_t N = B * hw;
     if (N == 0) return CGIC_OK;
     hipStream_t s = (hipStream_t)stream;
-    VqWs ws = vq_ws(loss ? workspace : nullptr);
-    if (loss) CGIC_HIP_TRY(hipMemsetAsync(ws.ticket, 0, 16, s));
+    VqWs ws;
+    rc = vq_ws(loss ? workspace : nullptr, s, &ws);
+    if (rc) return rc;
     int nblk = (int)((N + kVqThreads - 1) / kVqThreads);
     size_t lds = sizeof(float) * (size_t)K * 5;
     hipLaunchKernelGGL(vq_valu_kernel, dim3(nblk), dim3(kVqThreads), lds, s, z, hw, N, codebook, K, indices, z_q,
