@@ -49,7 +49,7 @@ def make_inputs(B, H, W, seed):
 class HotPath:
     """pre-built modules + one step() that only enqueues work (graph-capturable)"""
 
-    def __init__(self, dev, x, z, cb, ratio):
+    def __init__(self, dev, x, z, cb, ratio, chunks=1, fork_vq=False):
         import control_gic_amd as cg
         self.cg = cg
         self.x = torch.from_numpy(x).to(dev)
@@ -61,22 +61,24 @@ class HotPath:
         self.router = cg.TripleGrainFixedEntropyRouter(ratio[0], ratio[1], per_image=True)
         self.hist = torch.zeros(1024, dtype=torch.int64, device=dev)
         self.out = None
+        self.pipe = cg.pipeline.HotPathPipeline(self.vq, ratio[0], ratio[1], chunks=chunks, frequency=self.codec.huffman, fork_vq=fork_vq)
 
     def encode(self):
         from control_gic_amd.quantize import _vq_forward
         e8, e16 = self.cg.entropy_maps(self.x)
         mask, _, _, mode = self.router(e16, e8, want_gate=False)
-        zq, loss, ind = _vq_forward(self.z, self.vq.embedding.weight, 0.25, True, self.hist)
-        comp = self.codec.compress(ind, mask, mode)
+        zq, loss, ind = _vq_forward(self.z, self.vq.embedding.weight, 0.25, True, None)
+        comp = self.codec.compress(ind, mask, mode, hist=self.hist)
         return e8, e16, mask, mode, zq, ind, comp
 
     def decode(self, comp):
         return self.codec.decompress(comp)
 
     def step(self):
-        e8, e16, mask, mode, zq, ind, comp = self.encode()
-        dind, dmask, dq, status = self.decode(comp)
-        self.out = (e8, e16, mask, mode, zq, ind, comp, dind, dmask, dq, status)
+        # the batch as `chunks` concurrent chains (entropy -> router -> VQ(+hist) -> compress -> decompress)
+        self.res = self.pipe.run(self.x, self.z, self.hist, decode=True)
+        r = self.res[0]
+        self.out = (r["e8"], r["e16"], r["mask"], r["mode"], r["z_q"], r["ind"], r["comp"], *r["dec"])
 
 
 def time_events(fn, iters):
@@ -100,11 +102,10 @@ def stage_breakdown(hp, iters=30):
     st = {}
     st["entropy_maps"] = time_events(lambda: cg.entropy_maps(hp.x), iters)
     st["router"] = time_events(lambda: hp.router(e16, e8, want_gate=False), iters)
-    st["vq_forward+hist"] = time_events(lambda: _vq_forward(hp.z, hp.vq.embedding.weight, 0.25, True, hp.hist), iters)
     # the dominant kernel on its own (one launch per call: indices + z_q + loss, no histogram pass)
     st["vq_kernel"] = time_events(lambda: _vq_forward(hp.z, hp.vq.embedding.weight, 0.25, True, None), max(iters, 100))
     st["vq_kernel_indices_only"] = time_events(lambda: hp.vq.indices(hp.z), iters)
-    st["compress_streams"] = time_events(lambda: hp.codec.compress(ind, mask, mode), iters)
+    st["compress_streams+hist"] = time_events(lambda: hp.codec.compress(ind, mask, mode, hist=hp.hist), iters)
     st["decompress_streams"] = time_events(lambda: hp.codec.decompress(comp), iters)
     return {k: round(v, 2) for k, v in st.items()}
 
@@ -168,6 +169,8 @@ def main():
     ap.add_argument("--size", type=int, default=256)
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a hipGraph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--chunks", type=int, default=1, help="process the batch as this many concurrent stream chains")
+    ap.add_argument("--fork-vq", action="store_true", help="run VQ on a side stream next to entropy -> router")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -186,7 +189,7 @@ def main():
     B, H, W = a.batch, a.size, a.size
     ratio = (0.1, 0.8)
     x, z, cb = make_inputs(B, H, W, seed=1000 + rank)       # each rank owns its own shard of images
-    hp = HotPath(dev, x, z, cb, ratio)
+    hp = HotPath(dev, x, z, cb, ratio, chunks=a.chunks, fork_vq=a.fork_vq)
 
     # warm-up (also uploads tables / sets function attributes -- nothing synchronous is left for capture)
     for _ in range(max(2, min(a.warmup, 5))):
@@ -254,7 +257,7 @@ def main():
             "config": {"workload": f"batch {B} of {H}x{W} per GPU, codebook 1024x4, ratio (0.1,0.8,0.1), "
                                    "hot path only (entropy maps + router + VQ + Huffman/mask coder, encode+decode); "
                                    "conv encoder/decoder out of scope, latent synthetic",
-                       "launch": "eager" if graph is None else "hipGraph replay",
+                       "launch": ("eager" if graph is None else "hipGraph replay") + f", {a.chunks} concurrent chunk streams",
                        "sharding": "images round-robin over ranks; one RCCL all-reduce of the int64[1024] histogram per run"},
             "bpp": round(bpp, 6), "bpp_match": bool(ok),
             "stages_us": stages,

@@ -13,7 +13,9 @@ from .entropy import Entropy, entropy_maps
 from .indices_coding import HuffmanCoding
 from .mask_coding import BinaryCoding
 from .codec import GrainCodec, CompressedBatch, mode_streams, STREAM_NAMES
+from . import pipeline
+from .pipeline import HotPathPipeline
 
 __all__ = ["VectorQuantize2", "VectorQuantizer", "TripleGrainFixedEntropyRouter", "Entropy", "entropy_maps",
            "HuffmanCoding", "BinaryCoding", "GrainCodec", "CompressedBatch", "mode_streams", "STREAM_NAMES",
-           "CgicError", "LIB_PATH"]
+           "HotPathPipeline", "CgicError", "LIB_PATH"]

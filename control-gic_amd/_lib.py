@@ -50,7 +50,7 @@ PROTOTYPES = {
     "cgic_compress_slot_bytes": (_sz, [_vp, _i64, _i64]),
     "cgic_compress_workspace_bytes": (_sz, [_i64, _i64, _i64]),
     "cgic_mode_streams": (_int, [_int]),
-    "cgic_compress_streams": (_int, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _int, _vp, _i64, _vp, _vp, _vp]),
+    "cgic_compress_streams": (_int, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _int, _vp, _i64, _vp, _vp, _vp, _vp]),
     "cgic_decompress_workspace_bytes": (_sz, [_i64, _i64, _i64]),
     "cgic_decompress_streams": (_int, [_vp, _vp, _i64, _vp, _i64, _i64, _i64, _int, _vp, _vp, _vp, _vp, _vp, _int,
                                        _int, _vp, _vp, _vp, _vp]),

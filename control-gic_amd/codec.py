@@ -109,8 +109,9 @@ class GrainCodec:
     def slot_bytes(self, h, w):
         return int(_lib.lib().cgic_compress_slot_bytes(self.huffman.table.handle, h, w))
 
-    def compress(self, ind, masks, mode):
-        """ind [B,h,w] (or flat [B*h*w]) int64; masks = [mask_c, mask_m, mask_f] int32 -> CompressedBatch"""
+    def compress(self, ind, masks, mode, hist=None):
+        """ind [B,h,w] (or flat [B*h*w]) int64; masks = [mask_c, mask_m, mask_f] int32 -> CompressedBatch.
+        hist (int64 [n_e], optional) accumulates the usage histogram of `ind` in the same launch."""
         mc, mm, mf = (m.contiguous() for m in masks)
         _lib.require_device(ind, mc, mm, mf)
         B, h, w = mf.shape[0], mf.shape[-2], mf.shape[-1]
@@ -129,8 +130,8 @@ class GrainCodec:
         ws = torch.empty(wsb, dtype=torch.uint8, device=dev) if wsb else None
         with torch.cuda.device(dev):
             _lib.call("cgic_compress_streams", self.huffman.table.handle, _lib.ptr(ind), _lib.ptr(mc), _lib.ptr(mm),
-                      _lib.ptr(mf), B, h, w, int(mode), _lib.ptr(data), slot, _lib.ptr(nbytes), _lib.ptr(ws),
-                      _lib.current_stream(dev))
+                      _lib.ptr(mf), B, h, w, int(mode), _lib.ptr(data), slot, _lib.ptr(nbytes), _lib.ptr(hist),
+                      _lib.ptr(ws), _lib.current_stream(dev))
         return CompressedBatch(data, nbytes, mode, h, w)
 
     def decompress(self, cb, want_masks=True, want_zq=True):

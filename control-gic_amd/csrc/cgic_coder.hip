@@ -30,17 +30,11 @@
 
 namespace cgic {
 
-// Debug-only phase stamps (make dbg -> libcgic_hip_dbg.so): block 0 / thread 0 records the shader
-// clock at phase boundaries of decompress_kernel.  Compiled out of the product library.
 #ifdef CGIC_PHASE_CLOCKS
-__device__ long long g_phase_clk[16];
-#define CGIC_STAMP(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_phase_clk[i] = clock64(); \
-        if (blockIdx.x == 0 && threadIdx.x == 192 && (i) >= 2 && (i) <= 7) g_phase_clk[8 + (i)] = clock64(); } while (0)
-#else
-#define CGIC_STAMP(i) do {} while (0)
+__device__ long long g_phase_clk[32];
 #endif
 
-constexpr int kEncThreads = 256;
+constexpr int kEncThreads = 1024;         // x kEncItems = 4096 positions per scan round: one round per 256x256 stream
 constexpr int kEncItems = 4;            // consecutive positions per thread per scan round
 constexpr int kLdsPos = 8192;           // streams up to this many positions keep phase-A results in LDS
 constexpr int kDecLutMax = 4096;        // 12-bit LUT
@@ -74,6 +68,7 @@ __device__ int encode_huffman_stream(const TableDev &t, int64_t npos, SymAt sym_
     const int tid = threadIdx.x;
     if (tid == 0) s_err = 0;
     __syncthreads();
+    CGIC_STAMP2(1);
 
     unsigned long long carry = 0;   // (count << 32) | bits, uniform
     for (int64_t base = 0; base < npos; base += (int64_t)kEncThreads * kEncItems) {
@@ -109,6 +104,7 @@ __device__ int encode_huffman_stream(const TableDev &t, int64_t npos, SymAt sym_
         carry += total;
     }
     __syncthreads();   // phase-A stores (LDS or global, same workgroup) visible to phase B
+    CGIC_STAMP2(2);
     if (s_err) return s_err;
 
     const uint32_t count = (uint32_t)(carry >> 32);
@@ -145,6 +141,7 @@ __device__ int encode_huffman_stream(const TableDev &t, int64_t npos, SymAt sym_
         }
         out32[q] = __builtin_bswap32(acc);                       // MSB-first bytes (:108)
     }
+    CGIC_STAMP2(3);
     return (int)nbytes;
 }
 
@@ -190,14 +187,39 @@ struct CompressArgs {
     uint32_t *ws_end;       // global phase-A storage for streams > kLdsPos positions
     uint16_t *ws_sym;
     int64_t ws_stride;      // positions reserved per (image, stream) in the workspace
+    unsigned long long *hist;   // optional [tab.n]: usage histogram of ALL h*w indices (job 5 of each image)
 };
+
+constexpr int kLdsTable = 1024;          // tables up to this many single-word codes are staged in LDS
 
 __global__ __launch_bounds__(kEncThreads) void compress_streams_kernel(CompressArgs a)
 {
     __shared__ __attribute__((aligned(16))) uint32_t lds_end[kLdsPos];
     __shared__ uint16_t lds_sym[kLdsPos];
+    __shared__ int32_t lds_len[kLdsTable];
+    __shared__ uint32_t lds_code[kLdsTable];
     const int s = blockIdx.x;
     const int64_t b = blockIdx.y;
+    CGIC_STAMP2(0);
+    CGIC_SPAN_BEGIN();
+    if (s == CGIC_NUM_STREAMS) {
+        // job 5: usage histogram of this image's indices (quantize.py:79-81) -- LDS histogram, then
+        // at most one global atomic per non-empty bin per image
+        unsigned int *lh = lds_end;
+        const int K = a.tab.n;
+        for (int k = threadIdx.x; k < K; k += kEncThreads) lh[k] = 0;
+        __syncthreads();
+        const int64_t n = a.h * a.w;
+        const int64_t *ind = a.ind + b * n;
+        for (int64_t i = threadIdx.x; i < n; i += kEncThreads) {
+            const int64_t v = ind[i];
+            if (v >= 0 && v < K) atomicAdd(&lh[v], 1u);
+        }
+        __syncthreads();
+        for (int k = threadIdx.x; k < K; k += kEncThreads)
+            if (lh[k]) atomicAdd(&a.hist[k], (unsigned long long)lh[k]);
+        return;
+    }
     int32_t *nb = a.nbytes + b * CGIC_NUM_STREAMS + s;
     if (!((a.stream_mask >> s) & 1)) {
         if (threadIdx.x == 0) *nb = -1;
@@ -207,6 +229,13 @@ __global__ __launch_bounds__(kEncThreads) void compress_streams_kernel(CompressA
     const int64_t h = a.h, w = a.w;
     int rc;
     if (s < 3) {
+        // code table -> LDS (length + code lookups then cost an LDS access, not an L2 round trip each)
+        if (a.tab.n <= kLdsTable && a.tab.words == 1) {
+            for (int i = threadIdx.x; i < a.tab.n; i += kEncThreads) { lds_len[i] = a.tab.len[i]; lds_code[i] = a.tab.code[i]; }
+            a.tab.len = lds_len;
+            a.tab.code = lds_code;
+            __syncthreads();
+        }
         const int sh = 2 - s;                                   // stride 4, 2, 1
         const int64_t gh = h >> sh, gw = w >> sh, npos = gh * gw;
         const int32_t *mask = (s == 0 ? a.mc : s == 1 ? a.mm : a.mf) + b * npos;
@@ -219,10 +248,11 @@ __global__ __launch_bounds__(kEncThreads) void compress_streams_kernel(CompressA
         }
         // ind[:, ::4, ::4][mask_c == 1] etc.: row-major over the granularity's own grid (:219-221)
         auto sym_at = [&](int64_t i, bool *flag) -> int64_t {
-            *flag = mask[i] == 1;
-            if (!*flag) return 0;
+            // both loads are issued unconditionally so that they share one memory round trip
             const int64_t y = i / gw, x = i - y * gw;
-            return ind[((y << sh) * w) + (x << sh)];
+            const int64_t v = ind[((y << sh) * w) + (x << sh)];
+            *flag = mask[i] == 1;
+            return v;
         };
         rc = encode_huffman_stream(a.tab, npos, sym_at, st, out, a.slot);
     } else {
@@ -232,6 +262,7 @@ __global__ __launch_bounds__(kEncThreads) void compress_streams_kernel(CompressA
         rc = encode_binary_stream(npos, [&](int64_t i) { return (int)mask[i]; }, out, a.slot);
     }
     if (threadIdx.x == 0) *nb = rc < 0 ? rc - 10 : rc;     // errors are CGIC_ERR_* - 10 (-1 means "not written")
+    CGIC_SPAN_END();
 }
 
 struct EncodeOneArgs {
@@ -513,7 +544,7 @@ struct SegShared {
 // block must reach them, also waves with nw == 0 work: pass nw=0 and they just sync).
 template <typename Put>
 __device__ __forceinline__ void decode_segmented(const TableDev &t, const uint32_t *lut, uint32_t *win,
-                                                 SegShared *sh, const uint8_t *in, int nbytes, int w0, int nw,
+                                                 SegShared *sh, const uint8_t *in, int nbytes, int pad, int w0, int nw,
                                                  int k, int cap, Put put, int *count_out)
 {
     const int lane = lane_id();
@@ -522,8 +553,7 @@ __device__ __forceinline__ void decode_segmented(const TableDev &t, const uint32
     BitWindow bw{win, in, nbytes, 0, 0};
     const bool active = nw > 0 && nbytes > 0;
     if (active) {
-        const int pad = in[0];                                   // remove_padding :131-138
-        nbits = pad == 0 ? 0 : (nbytes - 1) * 8 - pad;
+        nbits = pad == 0 ? 0 : (nbytes - 1) * 8 - pad;           // remove_padding :131-138
         if (nbits < 0) nbits = 0;
         nchunks = (nbits + kWave - 1) / kWave;
         c0 = (int)((int64_t)k * nchunks / nw);
@@ -616,27 +646,97 @@ __device__ __forceinline__ void decode_segmented(const TableDev &t, const uint32
 }
 
 // -------------------------------------------------------------------------------------------
-// decompress: one 1024-thread workgroup per image.  The 16 waves are shared out over the three
-// index streams in proportion to their length and decode them concurrently (above); then the
-// whole block unpacks the two mask streams into bitsets + popcount prefixes and scatters,
-// merges (x1 + x2 + x4 grids) and gathers codebook rows.                 model.py:269-397
+// decompress = two launches                                               model.py:269-397
+//   decode_streams_kernel  grid (3 streams, B), 1024 threads: every (stream, image) gets a whole
+//       CU -- measured on MI355X the segmented decoder is bound by ONE CU's LDS-crossbar
+//       (ds_bpermute) and scalar-issue throughput, so spreading an image over three CUs beats
+//       sharing 16 waves between its streams.  Symbols go to a u16 workspace.
+//   merge_kernel           grid (4 row bands, B), 256 threads: mask streams -> bitsets + popcount
+//       prefixes (recomputed per band, they are tiny), then scatter + x1/x2/x4 merge + gather for
+//       the band's rows.
 // -------------------------------------------------------------------------------------------
-struct DecompressArgs {
+struct DecodeArgs {
     TableDev tab;
     const uint8_t *in;
     int64_t slot;
     const int32_t *nbytes;
     int64_t h, w;
-    int mode;
     int stream_mask;
-    int dsym_in_lds;         // 1: decoded symbols live in LDS (u16); 0: in the global workspace (i32)
-    int32_t *ws_dsym;        // [B, n_c + n_m + n_f] when !dsym_in_lds
+    uint16_t *dsym;          // [B, n_c + n_m + n_f]
+    int32_t *dcount;         // [B, 3]: >=0 count, -1 empty file (None), -2 not sent, -3 overflow
+    int32_t *status;         // [B] zeroed here for the merge kernel's atomicMin
+};
+
+__global__ __launch_bounds__(kDecThreads) void decode_streams_kernel(DecodeArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t sm[];
+    __shared__ int s_count;
+    uint32_t *lut = sm;                                 // [4096]
+    uint32_t *win = lut + kDecLutMax;                   // [16][kSegWinWords] (slow mode: 1 x kWinWords)
+    SegShared *seg = reinterpret_cast<SegShared *>(win + kDecWaves * kSegWinWords);
+    const int tid = threadIdx.x, lane = lane_id(), wave = tid >> 6;
+    const int s = blockIdx.x;
+    const int64_t b = blockIdx.y;
+    const int64_t n_c = (a.h >> 2) * (a.w >> 2), n_m = (a.h >> 1) * (a.w >> 1), n_f = a.h * a.w;
+    const int64_t off = s == 0 ? 0 : (s == 1 ? n_c : n_c + n_m);
+    const int cap = (int)(s == 0 ? n_c : (s == 1 ? n_m : n_f));
+    if (s == 0 && tid == 0 && a.status) a.status[b] = 0;
+    int32_t *dc = a.dcount + b * 3 + s;
+    const uint8_t *in = a.in + (b * CGIC_NUM_STREAMS + s) * a.slot;
+    // one wave of independent loads: stream length, header byte (slot memory is always readable),
+    // and the decode LUT
+    __shared__ int s_nb, s_pad;
+    if (tid == 0) {
+        s_nb = ((a.stream_mask >> s) & 1) ? a.nbytes[b * CGIC_NUM_STREAMS + s] : -2;
+        s_pad = in[0];
+        s_count = 0;
+    }
+    CGIC_STAMP(0);
+    load_lut(a.tab, lut);
+    __syncthreads();
+    CGIC_STAMP(1);
+    const int nb = s_nb;
+    if (nb <= 0) {
+        if (tid == 0) *dc = nb == 0 ? -1 : -2;
+        return;
+    }
+    uint16_t *dst = a.dsym + b * (n_c + n_m + n_f) + off;
+    auto put = [&](int k, int sym) { dst[k] = (uint16_t)sym; };
+    if (a.tab.max_len <= 64) {
+        int nw = (nb + 15) >> 4;                         // no wave below ~2 chunks
+        nw = nw < 1 ? 1 : (nw > kDecWaves ? kDecWaves : nw);
+        decode_segmented(a.tab, lut, win + wave * kSegWinWords, seg, in, nb, s_pad, 0, wave < nw ? nw : 0, wave, cap, put,
+                         &s_count);
+    } else if (wave == 0) {
+        // tables with codes longer than 64 bits: one wave, serial chain
+        int overflow = 0;
+        WaveDecoder d{a.tab, lut, win, in, nb, 0, 0};
+        int cnt = d.run(cap, put, &overflow);
+        if (__any(overflow)) cnt = cap + 1;
+        if (lane == 0) s_count = cnt;
+    }
+    __syncthreads();
+    if (tid == 0) *dc = s_count > cap ? -3 : s_count;
+}
+
+constexpr int kMergeThreads = 256;
+constexpr int kMergeBands = 4;
+
+struct MergeArgs {
+    const uint8_t *in;
+    int64_t slot;
+    const int32_t *nbytes;
+    int64_t h, w;
+    int mode;
+    const uint16_t *dsym;
+    const int32_t *dcount;
     int64_t *ind_out;
     int32_t *mc_out, *mm_out, *mf_out;
     const float *codebook;
     int K;
     float *zq;
     int32_t *status;
+    int stage_sym, stage_cb;   // keep the image's decoded symbols / the codebook in LDS
 };
 
 // LSB-first bit array word `wi` (bits 32wi..32wi+31) of an MSB-first mask stream
@@ -653,136 +753,82 @@ __device__ __forceinline__ uint32_t mask_stream_word(const uint8_t *in, int64_t 
     return v;
 }
 
-__global__ __launch_bounds__(kDecThreads) void decompress_kernel(DecompressArgs a)
+__global__ __launch_bounds__(kMergeThreads) void merge_kernel(MergeArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t sm[];
-    __shared__ uint32_t scan_smem[kDecWaves + 1];
-    __shared__ int s_cnt[3];         // decoded counts: >=0, -1 empty file, -2 not sent, -3 overflow
+    __shared__ uint32_t scan_smem[kMergeThreads / kWave + 1];
     __shared__ int s_status;
-    const int tid = threadIdx.x, lane = lane_id(), wave = tid >> 6;
-    const int64_t b = blockIdx.x;
+    __shared__ int s_hdr[8];            // nbytes[3], nbytes[4], dcount[0..2]
+    const int tid = threadIdx.x;
+    const int band = blockIdx.x;
+    const int64_t b = blockIdx.y;
     const int64_t h = a.h, w = a.w, h2 = h >> 1, w2 = w >> 1, h4 = h >> 2, w4 = w >> 2;
     const int64_t n_c = h4 * w4, n_m = h2 * w2, n_f = h * w;
     const int64_t wc = (n_c + 31) >> 5, wm = (n_m + 31) >> 5;
-    // LDS carve-up
-    uint32_t *lut = sm;                                 // [4096]
-    uint32_t *win = lut + kDecLutMax;                   // [16][kSegWinWords]
-    SegShared *seg = reinterpret_cast<SegShared *>(win + kDecWaves * kSegWinWords);
-    uint32_t *mcb = reinterpret_cast<uint32_t *>(seg + 1);   // [wc] coarse mask bits, LSB first
-    uint32_t *mmb = mcb + wc;                           // [wm]
-    uint32_t *pcb = mmb + wm;                           // [wc] exclusive popcount prefix
-    uint32_t *pmb = pcb + wc;                           // [wm]
-    uint16_t *lsym = reinterpret_cast<uint16_t *>(pmb + wm);   // [n_c + n_m + n_f] if dsym_in_lds
+    const int64_t nsym = n_c + n_m + n_f;
+    // LDS: [codebook rows (16-B aligned)][symbols u16][raw mask-stream words][bitsets][prefixes]
+    float4 *cbk = reinterpret_cast<float4 *>(sm);                                   // [K] if a.stage_cb
+    uint16_t *lsym = reinterpret_cast<uint16_t *>(cbk + (a.stage_cb ? a.K : 0));   // [nsym] if a.stage_sym
+    uint32_t *rawc = reinterpret_cast<uint32_t *>(lsym) + (a.stage_sym ? (nsym + 1) / 2 : 0);   // [wc + 2]
+    uint32_t *rawm = rawc + wc + 2;     // [wm + 2] stream bytes incl. header, as loaded
+    uint32_t *mcb = rawm + wm + 2;      // [wc] coarse mask bits, LSB first
+    uint32_t *mmb = mcb + wc;           // [wm]
+    uint32_t *pcb = mmb + wm;           // [wc] exclusive popcount prefix
+    uint32_t *pmb = pcb + wc;           // [wm]
     const int mode = a.mode;
-    CGIC_STAMP(0);
-    if (tid == 0) s_status = 0;
-    if (tid < 3) s_cnt[tid] = -2;
-    load_lut(a.tab, lut);
-    __syncthreads();
-    CGIC_STAMP(1);
-
-    int32_t *gsym = a.dsym_in_lds ? nullptr : a.ws_dsym + b * (n_c + n_m + n_f);
-    const int64_t offs[3] = {0, n_c, n_c + n_m};
-    const int64_t caps[3] = {n_c, n_m, n_f};
-    int nb[3];
-#pragma unroll
-    for (int s = 0; s < 3; ++s) nb[s] = ((a.stream_mask >> s) & 1) ? a.nbytes[b * CGIC_NUM_STREAMS + s] : -1;
-
-    if (a.tab.max_len <= 64) {
-        // ---- share the 16 waves out over the streams that carry data, proportional to bytes
-        // (integer arithmetic only: this runs on every wave before any decoding starts)
-        int nw[3] = {0, 0, 0};
-        const int tot = (nb[0] > 0 ? nb[0] : 0) + (nb[1] > 0 ? nb[1] : 0) + (nb[2] > 0 ? nb[2] : 0);
-        int used = 0;
-#pragma unroll
-        for (int s = 0; s < 3; ++s) {
-            if (nb[s] > 0) {
-                int q = (int)((int64_t)nb[s] * kDecWaves / tot);          // floor share
-                const int need = (nb[s] + 15) >> 4;                         // no wave below ~2 chunks
-                q = q < 1 ? 1 : q;
-                nw[s] = q < need ? q : need;
-                used += nw[s];
-            }
-        }
-        // floor shares sum to <= 16 except when the "at least one" bumps pushed it over
-        for (int s = 2; s >= 0 && used > kDecWaves; --s)
-            while (nw[s] > 1 && used > kDecWaves) { --nw[s]; --used; }
-        // hand the spare waves to the longest stream
-        {
-            int big = 0;
-            if (nb[1] > nb[big]) big = 1;
-            if (nb[2] > nb[big]) big = 2;
-            if (nb[big] > 0) {
-                const int need = (nb[big] + 15) >> 4;
-                const int extra = kDecWaves - used;
-                const int room = need - nw[big];
-                nw[big] += extra < room ? extra : (room > 0 ? room : 0);
-            }
-        }
-        const int w0[3] = {0, nw[0], nw[0] + nw[1]};
-        int s_mine = -1;
-#pragma unroll
-        for (int s = 0; s < 3; ++s) if (wave >= w0[s] && wave < w0[s] + nw[s]) s_mine = s;
-        const int s = s_mine < 0 ? 0 : s_mine;
-        const uint8_t *in = a.in + (b * CGIC_NUM_STREAMS + s) * a.slot;
-        const int my_nw = s_mine < 0 ? 0 : nw[s];
-        if (a.dsym_in_lds) {
-            uint16_t *dst = lsym + offs[s];
-            decode_segmented(a.tab, lut, win + wave * kSegWinWords, seg, in, nb[s], w0[s], my_nw, wave - w0[s],
-                             (int)caps[s], [&](int k, int sym) { dst[k] = (uint16_t)sym; }, &s_cnt[s]);
-        } else {
-            int32_t *dst = gsym + offs[s];
-            decode_segmented(a.tab, lut, win + wave * kSegWinWords, seg, in, nb[s], w0[s], my_nw, wave - w0[s],
-                             (int)caps[s], [&](int k, int sym) { dst[k] = sym; }, &s_cnt[s]);
-        }
-        if (tid < 3 && nb[tid] == 0) s_cnt[tid] = -1;     // empty file -> None
-    } else if (wave < 3) {
-        // ---- tables with codes longer than 64 bits: one wave per stream, serial chain
-        const int s = wave;
-        int cnt = -2;
-        if (nb[s] >= 0) {
-            int overflow = 0;
-            WaveDecoder d{a.tab, lut, win + s * kWinWords, a.in + (b * CGIC_NUM_STREAMS + s) * a.slot, nb[s], 0, 0};
-            if (a.dsym_in_lds) {
-                uint16_t *dst = lsym + offs[s];
-                cnt = d.run((int)caps[s], [&](int k, int sym) { dst[k] = (uint16_t)sym; }, &overflow);
-            } else {
-                int32_t *dst = gsym + offs[s];
-                cnt = d.run((int)caps[s], [&](int k, int sym) { dst[k] = sym; }, &overflow);
-            }
-            if (__any(overflow)) cnt = -3;
-        }
-        if (lane == 0) s_cnt[s] = cnt;
-    }
-    __syncthreads();
-#pragma unroll
-    for (int s = 0; s < 3; ++s) if (s_cnt[s] > caps[s]) { __syncthreads(); if (tid == 0) s_cnt[s] = -3; }
-    __syncthreads();
-
-    // ---- mask streams -> bitsets + popcount prefixes
+    // this block's rows: bands of whole coarse rows (multiples of 4 fine rows)
+    const int64_t rows_per = ((h4 + kMergeBands - 1) / kMergeBands) * 4;
+    const int64_t r0 = band * rows_per, r1 = r0 + rows_per < h ? r0 + rows_per : h;
+    if (r0 >= h) return;
+    CGIC_STAMP(10);
     const bool send_mc = mode == 0 || mode == 2 || mode == 3;
     const bool send_mm = mode == 0 || mode == 1;
     const uint8_t *in_mc = a.in + (b * CGIC_NUM_STREAMS + 3) * a.slot;
     const uint8_t *in_mm = a.in + (b * CGIC_NUM_STREAMS + 4) * a.slot;
+
+    // ---- ONE wave of independent global loads: headers, both mask streams (slots are 16-byte
+    // aligned and at least wc*4+8 / wm*4+8 bytes long), all decoded symbols, the codebook
+    if (tid == 0) s_status = 0;
+    if (tid < 2) s_hdr[tid] = a.nbytes[b * CGIC_NUM_STREAMS + 3 + tid];
+    else if (tid < 5) s_hdr[tid] = a.dcount[b * 3 + (tid - 2)];
+    if (send_mc) for (int64_t i = tid; i < wc + 2; i += kMergeThreads) rawc[i] = reinterpret_cast<const uint32_t *>(in_mc)[i];
+    if (send_mm) for (int64_t i = tid; i < wm + 2; i += kMergeThreads) rawm[i] = reinterpret_cast<const uint32_t *>(in_mm)[i];
+    const uint16_t *gsym = a.dsym + b * nsym;
+    if (a.stage_sym) {
+        // nsym = 21 * n_c is even; the per-image base is 4-byte aligned when nsym is even
+        const uint32_t *g32 = reinterpret_cast<const uint32_t *>(gsym);
+        uint32_t *l32 = reinterpret_cast<uint32_t *>(lsym);
+        for (int64_t i = tid; i < (nsym + 1) / 2; i += kMergeThreads) l32[i] = g32[i];
+    }
+    if (a.stage_cb && a.zq)
+        for (int i = tid; i < a.K; i += kMergeThreads) cbk[i] = reinterpret_cast<const float4 *>(a.codebook)[i];
+    __syncthreads();
+    CGIC_STAMP(11);
+
     // a mask stream must be exactly 1 + n/8 + 1 bytes with pad = 8 - n%8 (mask_coding.py:19-26)
     if (tid == 0) {
-        if (send_mc) {
-            const int32_t nbm = a.nbytes[b * CGIC_NUM_STREAMS + 3];
-            if (nbm != 2 + (n_c >> 3) || in_mc[0] != 8 - (n_c & 7)) s_status = CGIC_ERR_INVALID;
-        }
-        if (send_mm) {
-            const int32_t nbm = a.nbytes[b * CGIC_NUM_STREAMS + 4];
-            if (nbm != 2 + (n_m >> 3) || in_mm[0] != 8 - (n_m & 7)) s_status = CGIC_ERR_INVALID;
-        }
+        if (send_mc && (s_hdr[0] != 2 + (n_c >> 3) || (int)(rawc[0] & 0xFF) != 8 - (int)(n_c & 7))) s_status = CGIC_ERR_INVALID;
+        if (send_mm && (s_hdr[1] != 2 + (n_m >> 3) || (int)(rawm[0] & 0xFF) != 8 - (int)(n_m & 7))) s_status = CGIC_ERR_INVALID;
     }
     __syncthreads();
     if (s_status) {
-        if (tid == 0 && a.status) a.status[b] = s_status;
+        if (tid == 0 && a.status) atomicMin(&a.status[b], s_status);
         return;
     }
-    for (int64_t i = tid; i < wc; i += kDecThreads) {
+    // MSB-first stream bytes (after the header byte) -> LSB-first bit words
+    auto stream_word = [](const uint32_t *raw, int64_t wi, int64_t nbits) -> uint32_t {
+        // payload bytes 4wi..4wi+3 are stream bytes 1+4wi.. : straddle raw[wi], raw[wi+1]
+        const uint64_t two = (uint64_t)raw[wi] | ((uint64_t)raw[wi + 1] << 32);
+        const uint32_t pay = (uint32_t)(two >> 8);                  // 4 payload bytes, little-endian order
+        // reverse the bits inside each byte: brev reverses all 32, bswap puts the bytes back
+        uint32_t v = __builtin_bswap32(__brev(pay));
+        const int64_t rem = nbits - wi * 32;
+        if (rem < 32) v &= rem <= 0 ? 0u : ((1u << rem) - 1u);
+        return v;
+    };
+    for (int64_t i = tid; i < wc; i += kMergeThreads) {
         uint32_t v = 0;
-        if (send_mc) v = mask_stream_word(in_mc, i, n_c);
+        if (send_mc) v = stream_word(rawc, i, n_c);
         else if (mode == 4) {                                                   // ones (:355)
             v = 0xFFFFFFFFu;
             const int64_t rem = n_c - i * 32;
@@ -791,9 +837,9 @@ __global__ __launch_bounds__(kDecThreads) void decompress_kernel(DecompressArgs 
         mcb[i] = v;
     }
     __syncthreads();
-    for (int64_t i = tid; i < wm; i += kDecThreads) {
+    for (int64_t i = tid; i < wm; i += kMergeThreads) {
         uint32_t v = 0;
-        if (send_mm) v = mask_stream_word(in_mm, i, n_m);
+        if (send_mm) v = stream_word(rawm, i, n_m);
         else if (mode == 3 || mode == 5) {
             for (int k = 0; k < 32; ++k) {
                 const int64_t j = i * 32 + k;
@@ -810,7 +856,7 @@ __global__ __launch_bounds__(kDecThreads) void decompress_kernel(DecompressArgs 
     }
     __syncthreads();
     uint32_t carry = 0, total;
-    for (int64_t base = 0; base < wc; base += kDecThreads) {
+    for (int64_t base = 0; base < wc; base += kMergeThreads) {
         const int64_t i = base + tid;
         const uint32_t c = i < wc ? (uint32_t)__popc(mcb[i]) : 0u;
         const uint32_t ex = block_exclusive_scan(c, scan_smem, &total);
@@ -819,7 +865,7 @@ __global__ __launch_bounds__(kDecThreads) void decompress_kernel(DecompressArgs 
     }
     const uint32_t cnt_c = carry;
     carry = 0;
-    for (int64_t base = 0; base < wm; base += kDecThreads) {
+    for (int64_t base = 0; base < wm; base += kMergeThreads) {
         const int64_t i = base + tid;
         const uint32_t c = i < wm ? (uint32_t)__popc(mmb[i]) : 0u;
         const uint32_t ex = block_exclusive_scan(c, scan_smem, &total);
@@ -828,10 +874,36 @@ __global__ __launch_bounds__(kDecThreads) void decompress_kernel(DecompressArgs 
     }
     const uint32_t cnt_m = carry;
     __syncthreads();
-    CGIC_STAMP(8);
+    CGIC_STAMP(12);
 
-    // ---- scatter + merge + gather
-    const int64_t dc_c = s_cnt[0], dc_m = s_cnt[1], dc_f = s_cnt[2];
+    auto fine_flag = [&](int64_t y, int64_t x, bool *pbc, bool *pbm) -> bool {
+        const int64_t j2 = (y >> 1) * w2 + (x >> 1), j4 = (y >> 2) * w4 + (x >> 2);
+        const bool bc = (mcb[j4 >> 5] >> (j4 & 31)) & 1u;
+        const bool bm = (mmb[j2 >> 5] >> (j2 & 31)) & 1u;
+        *pbc = bc; *pbm = bm;
+        switch (mode) {
+        case 0: return (1 - (int)bm - (int)bc) == 1;                            // :280
+        case 1: return !bm;                                                     // :302
+        case 2: return !bc;                                                     // :320
+        case 6: return true;                                                    // :380
+        default: return false;
+        }
+    };
+    // fine symbols consumed by the rows above this band (exact for any mask bits)
+    uint32_t fbase = 0;
+    {
+        uint32_t mine = 0;
+        for (int64_t i = tid; i < r0 * w; i += kMergeThreads) {
+            bool bc, bm;
+            const int64_t y = i / w;
+            mine += fine_flag(y, i - y * w, &bc, &bm) ? 1u : 0u;
+        }
+        (void)block_exclusive_scan(mine, scan_smem, &fbase);
+    }
+    CGIC_STAMP(13);
+
+    const uint16_t *ds_c = a.stage_sym ? lsym : gsym, *ds_m = ds_c + n_c, *ds_f = ds_m + n_m;
+    const int64_t dc_c = s_hdr[2], dc_m = s_hdr[3], dc_f = s_hdr[4];
     const bool has_c = mode == 0 || mode == 2 || mode == 3 || mode == 4;
     const bool has_m = mode == 0 || mode == 1 || mode == 3 || mode == 5;
     const bool has_f = mode == 0 || mode == 1 || mode == 2 || mode == 6;
@@ -842,13 +914,12 @@ __global__ __launch_bounds__(kDecThreads) void decompress_kernel(DecompressArgs 
     if (has_c && dc_c >= 0 && dc_c != cnt_c) st = CGIC_ERR_INVALID;
     if (has_m && dc_m >= 0 && dc_m != cnt_m) st = CGIC_ERR_INVALID;
     const bool use_c = has_c && dc_c >= 0, use_m = has_m && dc_m >= 0, use_f = has_f && dc_f >= 0;
-    auto sym_at = [&](int64_t k) -> int64_t { return a.dsym_in_lds ? (int64_t)lsym[k] : (int64_t)gsym[k]; };
 
     int64_t *ind_out = a.ind_out ? a.ind_out + b * n_f : nullptr;
     float *zq = a.zq ? a.zq + b * 4 * n_f : nullptr;
-    uint32_t fcarry = 0;
+    uint32_t fcarry = fbase;
     int bad_index = 0;
-    for (int64_t base = 0; base < n_f; base += (int64_t)kDecThreads * kMergeItems) {
+    for (int64_t base = r0 * w; base < r1 * w; base += (int64_t)kMergeThreads * kMergeItems) {
         uint32_t fl = 0;       // fine flags of my items
         const int64_t i0 = base + (int64_t)tid * kMergeItems;
         int64_t vals[kMergeItems];
@@ -856,23 +927,15 @@ __global__ __launch_bounds__(kDecThreads) void decompress_kernel(DecompressArgs 
         for (int k = 0; k < kMergeItems; ++k) {
             const int64_t i = i0 + k;
             vals[k] = 0;
-            if (i >= n_f) continue;
+            if (i >= r1 * w) continue;
             const int64_t y = i / w, x = i - y * w;
             const int64_t j2 = (y >> 1) * w2 + (x >> 1), j4 = (y >> 2) * w4 + (x >> 2);
-            const bool bc = (mcb[j4 >> 5] >> (j4 & 31)) & 1u;
-            const bool bm = (mmb[j2 >> 5] >> (j2 & 31)) & 1u;
-            bool bf;
-            switch (mode) {
-            case 0: bf = (1 - (int)bm - (int)bc) == 1; break;                   // :280
-            case 1: bf = !bm; break;                                            // :302
-            case 2: bf = !bc; break;                                            // :320
-            case 6: bf = true; break;                                           // :380
-            default: bf = false; break;
-            }
+            bool bc, bm;
+            const bool bf = fine_flag(y, x, &bc, &bm);
             fl |= (uint32_t)bf << k;
             int64_t v = 0;
-            if (bc && use_c) v += sym_at(pcb[j4 >> 5] + __popc(mcb[j4 >> 5] & ((1u << (j4 & 31)) - 1u)));
-            if (bm && use_m) v += sym_at(n_c + pmb[j2 >> 5] + __popc(mmb[j2 >> 5] & ((1u << (j2 & 31)) - 1u)));
+            if (bc && use_c) v += ds_c[pcb[j4 >> 5] + __popc(mcb[j4 >> 5] & ((1u << (j4 & 31)) - 1u))];
+            if (bm && use_m) v += ds_m[pmb[j2 >> 5] + __popc(mmb[j2 >> 5] & ((1u << (j2 & 31)) - 1u))];
             vals[k] = v;
             if (a.mc_out && (y & 3) == 0 && (x & 3) == 0) a.mc_out[b * n_c + j4] = bc;
             if (a.mm_out && (y & 1) == 0 && (x & 1) == 0) a.mm_out[b * n_m + j2] = bm;
@@ -883,26 +946,27 @@ __global__ __launch_bounds__(kDecThreads) void decompress_kernel(DecompressArgs 
 #pragma unroll
         for (int k = 0; k < kMergeItems; ++k) {
             const int64_t i = i0 + k;
-            if (i >= n_f) continue;
+            if (i >= r1 * w) continue;
             int64_t v = vals[k];
             if ((fl >> k) & 1u) {
-                if (use_f && (int64_t)frank < dc_f) v += sym_at(n_c + n_m + frank);   // t[t==1] = decoded (:292)
+                if (use_f && (int64_t)frank < dc_f) v += ds_f[frank];           // t[t==1] = decoded (:292)
                 ++frank;
             }
             if (ind_out) ind_out[i] = v;                                        // sum of the three grids (:293)
             if (zq) {
                 if (v < 0 || v >= a.K) { bad_index = 1; v = 0; }
-                const float4 e = reinterpret_cast<const float4 *>(a.codebook)[v];   // exact rows (:391-392)
+                const float4 e = a.stage_cb ? cbk[v] : reinterpret_cast<const float4 *>(a.codebook)[v];   // exact rows (:391-392)
                 zq[i] = e.x; zq[n_f + i] = e.y; zq[2 * n_f + i] = e.z; zq[3 * n_f + i] = e.w;
             }
         }
         fcarry += ftotal;
     }
-    if (has_f && (dc_f >= 0 ? dc_f != (int64_t)fcarry : fcarry != 0)) st = CGIC_ERR_INVALID;
+    CGIC_STAMP(14);
+    // the last band sees the total number of fine positions
+    if (r1 == h && has_f && (dc_f >= 0 ? dc_f != (int64_t)fcarry : fcarry != 0)) st = CGIC_ERR_INVALID;
     if (bad_index) s_status = CGIC_ERR_INVALID;
     __syncthreads();
-    CGIC_STAMP(9);
-    if (tid == 0 && a.status) a.status[b] = st ? st : s_status;
+    if (tid == 0 && a.status && (st || s_status)) atomicMin(&a.status[b], st ? st : s_status);
 }
 
 __global__ void gather_kernel(const int64_t *__restrict__ ind, int64_t B, int64_t hw,
@@ -929,9 +993,15 @@ static size_t align16(size_t v) { return (v + 15) & ~(size_t)15; }
 using namespace cgic;
 
 #ifdef CGIC_PHASE_CLOCKS
+extern "C" int cgic_debug_reset_span(void)
+{
+    long long init[4] = {0x7fffffffffffffffLL, 0, 0, 0};
+    CGIC_HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_phase_clk), init, sizeof(init), sizeof(long long) * 28));
+    return CGIC_OK;
+}
 extern "C" int cgic_debug_phase_clocks(long long *out16)
 {
-    CGIC_HIP_TRY(hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_phase_clk), sizeof(long long) * 16));
+    CGIC_HIP_TRY(hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_phase_clk), sizeof(long long) * 32));
     return CGIC_OK;
 }
 #endif
@@ -983,7 +1053,7 @@ static int check_grid(int64_t B, int64_t h, int64_t w, int mode)
 extern "C" int cgic_compress_streams(const cgic_table *t, const int64_t *ind, const int32_t *mask_c,
                                      const int32_t *mask_m, const int32_t *mask_f, int64_t B, int64_t h,
                                      int64_t w, int mode, uint8_t *out, int64_t slot, int32_t *nbytes,
-                                     void *workspace, cgic_stream_t stream)
+                                     int64_t *hist, void *workspace, cgic_stream_t stream)
 {
     int rc = check_grid(B, h, w, mode);
     if (rc) return rc;
@@ -1002,10 +1072,12 @@ extern "C" int cgic_compress_streams(const cgic_table *t, const int64_t *ind, co
     a.ind = ind; a.mc = mask_c; a.mm = mask_m; a.mf = mask_f; a.h = h; a.w = w;
     a.stream_mask = kModeStreams[mode];
     a.out = out; a.slot = slot; a.nbytes = nbytes;
+    CGIC_REQUIRE(!hist || cgic_table_num_symbols(t) <= kLdsPos, CGIC_ERR_UNSUPPORTED, "compress_streams: hist needs n <= %d", kLdsPos);
+    a.hist = (unsigned long long *)hist;
     a.ws_stride = (int64_t)ws_stride(h, w);
     a.ws_end = (uint32_t *)workspace;
     a.ws_sym = workspace ? (uint16_t *)((char *)workspace + (size_t)B * 3 * ws_stride(h, w) * sizeof(uint32_t)) : nullptr;
-    hipLaunchKernelGGL(compress_streams_kernel, dim3(CGIC_NUM_STREAMS, (unsigned)B), dim3(kEncThreads), 0,
+    hipLaunchKernelGGL(compress_streams_kernel, dim3(CGIC_NUM_STREAMS + (hist ? 1 : 0), (unsigned)B), dim3(kEncThreads), 0,
                        (hipStream_t)stream, a);
     return launch_check("compress_streams_kernel");
 }
@@ -1043,22 +1115,13 @@ extern "C" int cgic_decode_stream(const cgic_table *t, const uint8_t *in, int64_
     return launch_check("decode_stream_kernel");
 }
 
-static size_t decompress_lds_bytes(int64_t h, int64_t w, bool sym_in_lds)
-{
-    const size_t wc = (size_t)(((h / 4) * (w / 4) + 31) / 32), wm = (size_t)(((h / 2) * (w / 2) + 31) / 32);
-    size_t b = sizeof(uint32_t) * (kDecLutMax + kDecWaves * kSegWinWords + 2 * (wc + wm)) + sizeof(SegShared);
-    if (b < sizeof(uint32_t) * (kDecLutMax + 3 * kWinWords)) b = sizeof(uint32_t) * (kDecLutMax + 3 * kWinWords);
-    if (sym_in_lds) b += sizeof(uint16_t) * (size_t)((h / 4) * (w / 4) + (h / 2) * (w / 2) + h * w) + 16;
-    return b;
-}
 static const size_t kLdsBudget = 150 * 1024;
 
 extern "C" size_t cgic_decompress_workspace_bytes(int64_t B, int64_t h, int64_t w)
 {
     if (B <= 0 || h <= 0 || w <= 0) return 0;
-    if (decompress_lds_bytes(h, w, true) <= kLdsBudget) return 0;      // decoded symbols stay in LDS
     const size_t per = (size_t)((h / 4) * (w / 4) + (h / 2) * (w / 2) + h * w);
-    return align16((size_t)B * per * sizeof(int32_t));
+    return align16((size_t)B * per * sizeof(uint16_t)) + align16((size_t)B * 3 * sizeof(int32_t));
 }
 
 extern "C" int cgic_decompress_streams(const cgic_table *t, const uint8_t *in, int64_t slot, const int32_t *nbytes,
@@ -1069,31 +1132,47 @@ extern "C" int cgic_decompress_streams(const cgic_table *t, const uint8_t *in, i
 {
     int rc = check_grid(B, h, w, mode);
     if (rc) return rc;
-    CGIC_REQUIRE(t && in && nbytes, CGIC_ERR_INVALID, "decompress_streams: NULL argument");
+    CGIC_REQUIRE(t && in && nbytes && workspace, CGIC_ERR_INVALID, "decompress_streams: NULL argument");
     CGIC_REQUIRE(slot % 16 == 0 && slot >= 16 && slot < ((int64_t)1 << 28), CGIC_ERR_INVALID,
                  "decompress_streams: slot must be a multiple of 16 below 2^28");
     CGIC_REQUIRE(!z_q || (codebook && e_dim == 4 && K > 0), CGIC_ERR_UNSUPPORTED,
                  "decompress_streams: fused gather needs a [K,4] codebook");
     CGIC_REQUIRE(cgic_table_num_symbols(t) <= 65536, CGIC_ERR_UNSUPPORTED, "table too large");
-    const bool in_lds = decompress_lds_bytes(h, w, true) <= kLdsBudget;
-    CGIC_REQUIRE(in_lds || workspace, CGIC_ERR_INVALID, "decompress_streams: workspace required for %lldx%lld grids",
-                 (long long)h, (long long)w);
-    const size_t lds = decompress_lds_bytes(h, w, in_lds);
-    CGIC_REQUIRE(lds <= kLdsBudget, CGIC_ERR_UNSUPPORTED, "decompress_streams: grid too large for the mask bitsets");
     if (B == 0) return CGIC_OK;
-    DecompressArgs d;
+    const size_t per = (size_t)((h / 4) * (w / 4) + (h / 2) * (w / 2) + h * w);
+    hipStream_t s = (hipStream_t)stream;
+    DecodeArgs d;
     rc = table_device_view(t, &d.tab);
     if (rc) return rc;
-    d.in = in; d.slot = slot; d.nbytes = nbytes; d.h = h; d.w = w; d.mode = mode;
-    d.stream_mask = kModeStreams[mode];
-    d.dsym_in_lds = in_lds ? 1 : 0;
-    d.ws_dsym = (int32_t *)workspace;
-    d.ind_out = ind_out; d.mc_out = mask_c_out; d.mm_out = mask_m_out; d.mf_out = mask_f_out;
-    d.codebook = codebook; d.K = K; d.zq = z_q; d.status = status;
-    if (lds > 48 * 1024)
-        CGIC_HIP_TRY(hipFuncSetAttribute((const void *)decompress_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(decompress_kernel, dim3((unsigned)B), dim3(kDecThreads), lds, (hipStream_t)stream, d);
-    return launch_check("decompress_kernel");
+    d.in = in; d.slot = slot; d.nbytes = nbytes; d.h = h; d.w = w; d.stream_mask = kModeStreams[mode];
+    d.dsym = (uint16_t *)workspace;
+    d.dcount = (int32_t *)((char *)workspace + align16((size_t)B * per * sizeof(uint16_t)));
+    d.status = status;
+    size_t lds_d = sizeof(uint32_t) * (kDecLutMax + kDecWaves * kSegWinWords) + sizeof(SegShared);
+    if (lds_d < sizeof(uint32_t) * (kDecLutMax + kWinWords)) lds_d = sizeof(uint32_t) * (kDecLutMax + kWinWords);
+    if (lds_d > 48 * 1024)
+        CGIC_HIP_TRY(hipFuncSetAttribute((const void *)decode_streams_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_d));
+    hipLaunchKernelGGL(decode_streams_kernel, dim3(3, (unsigned)B), dim3(kDecThreads), lds_d, s, d);
+    rc = launch_check("decode_streams_kernel");
+    if (rc) return rc;
+    MergeArgs m;
+    m.in = in; m.slot = slot; m.nbytes = nbytes; m.h = h; m.w = w; m.mode = mode;
+    m.dsym = d.dsym; m.dcount = d.dcount; m.ind_out = ind_out;
+    m.mc_out = mask_c_out; m.mm_out = mask_m_out; m.mf_out = mask_f_out;
+    m.codebook = codebook; m.K = K; m.zq = z_q; m.status = status;
+    const size_t wc = (size_t)(((h / 4) * (w / 4) + 31) / 32), wm = (size_t)(((h / 2) * (w / 2) + 31) / 32);
+    size_t lds_m = (3 * (wc + wm) + 4) * sizeof(uint32_t);
+    CGIC_REQUIRE(lds_m <= kLdsBudget, CGIC_ERR_UNSUPPORTED, "decompress_streams: grid too large for the mask bitsets");
+    m.stage_cb = (z_q && lds_m + (size_t)K * 16 <= 64 * 1024) ? 1 : 0;
+    if (m.stage_cb) lds_m += (size_t)K * 16;
+    m.stage_sym = (per % 2 == 0 && lds_m + per * 2 + 4 <= 64 * 1024) ? 1 : 0;
+    if (m.stage_sym) lds_m += ((per + 1) / 2) * 4;
+    // mask-stream slots must cover the word-wise staging reads
+    CGIC_REQUIRE((size_t)slot >= (wm + 2) * 4, CGIC_ERR_CAPACITY, "decompress_streams: slot smaller than a mask stream");
+    if (lds_m > 48 * 1024)
+        CGIC_HIP_TRY(hipFuncSetAttribute((const void *)merge_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_m));
+    hipLaunchKernelGGL(merge_kernel, dim3(kMergeBands, (unsigned)B), dim3(kMergeThreads), lds_m, s, m);
+    return launch_check("merge_kernel");
 }
 
 extern "C" int cgic_embedding_gather_f32(const int64_t *ind, int64_t B, int64_t hw, const float *codebook, int K,

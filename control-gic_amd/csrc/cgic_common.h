@@ -56,6 +56,25 @@ struct Table;  // host object behind cgic_table
 int table_device_view(const cgic_table *t, TableDev *out);  // uploads lazily
 
 #if defined(__HIPCC__)
+// Debug-only phase stamps (make dbg -> libcgic_hip_dbg.so, -DCGIC_PHASE_CLOCKS): workgroup 0 /
+// thread 0 records the shader clock at phase boundaries.  Compiled out of the product library.
+#ifdef CGIC_PHASE_CLOCKS
+extern __device__ long long g_phase_clk[32];
+#define CGIC_STAMP(i) do { if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) g_phase_clk[i] = clock64(); \
+        if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 192 && (i) >= 2 && (i) <= 7) g_phase_clk[8 + (i)] = clock64(); } while (0)
+// span of a whole launch over ALL workgroups (constant 100 MHz clock): [28] = earliest start, [29] = latest end,
+// [30]/[31] = start/end of the workgroup that ended last (as block id pair packed)
+#define CGIC_SPAN_BEGIN() long long _span_t0 = 0; do { if (threadIdx.x == 0) { _span_t0 = wall_clock64(); atomicMin((unsigned long long *)&g_phase_clk[28], (unsigned long long)_span_t0); } } while (0)
+#define CGIC_SPAN_END() do { if (threadIdx.x == 0) { long long _t1 = wall_clock64(); unsigned long long _old = atomicMax((unsigned long long *)&g_phase_clk[29], (unsigned long long)_t1); if ((unsigned long long)_t1 > _old) { g_phase_clk[30] = _t1 - _span_t0; g_phase_clk[31] = blockIdx.x + 1000 * blockIdx.y; } } } while (0)
+// STAMP2: the fine-stream workgroup of image 0 in grid (5, B) kernels
+#define CGIC_STAMP2(i) do { if (blockIdx.x == 2 && blockIdx.y == 0 && threadIdx.x == 0) g_phase_clk[i] = clock64(); } while (0)
+#else
+#define CGIC_STAMP(i) do {} while (0)
+#define CGIC_STAMP2(i) do {} while (0)
+#define CGIC_SPAN_BEGIN() do {} while (0)
+#define CGIC_SPAN_END() do {} while (0)
+#endif
+
 // ---- wave / block primitives ---------------------------------------------------
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & (kWave - 1)); }
 

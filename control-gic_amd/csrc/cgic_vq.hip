@@ -16,6 +16,8 @@
 // Compiled with -ffp-contract=off; every fused op is an explicit fmaf / MFMA.
 #include "cgic_common.h"
 
+#include <stdlib.h>
+
 #include <map>
 #include <mutex>
 
@@ -62,8 +64,10 @@ __device__ __forceinline__ float dist_valu(float z0, float z1, float z2, float z
 
 // Last-arriving block sums the per-block partials in a fixed order (deterministic whichever
 // block is last) and writes loss = m + beta*m (quantize.py:85-90).  Hand-off per
-// cdna_hip_programming.md G16: plain stores -> barrier -> agent release -> ticket; the last
-// block does one agent acquire before reading.  `ticket` lives in library-owned device memory,
+// cdna_hip_programming.md G16 form R1: the 8-byte partial is stored write-through (relaxed
+// agent-scope atomic store = sc1), drained with s_waitcnt, then the ticket is taken -- no
+// release fence: a per-workgroup buffer_wbl2 measured ~10 us per launch at 1024 workgroups
+// (and 60 us at 4096).  The last block does one agent acquire and reads with sc1 loads.  `ticket` lives in library-owned device memory,
 // zeroed once at allocation; the last block resets it, so no per-call memset node is needed.
 __device__ __forceinline__ void finish_loss(double block_sum, double *sq_partial, unsigned int *ticket,
                                             double count, float beta, int legacy, float *loss)
@@ -72,8 +76,7 @@ __device__ __forceinline__ void finish_loss(double block_sum, double *sq_partial
     __shared__ unsigned int s_last;
     const int tid = threadIdx.x;
     if (tid == 0) {
-        sq_partial[blockIdx.x] = block_sum;
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        __hip_atomic_store(&sq_partial[blockIdx.x], block_sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         s_last = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1;
     }
@@ -324,29 +327,49 @@ struct VqWs {
     double *partial;        // caller's workspace: double partial[nblk]
 };
 
-// One ticket word per (device, stream-hash) slot, zeroed when first allocated.  Launches that
-// share a slot must be stream-ordered (same stream) -- two different streams land on different
-// slots unless their handles collide modulo kTicketSlots.
-constexpr int kTicketSlots = 64;
+// Every launch that needs the loss gets its OWN ticket word (64-byte slot, zero on entry, reset to
+// zero by the last workgroup), so launches on different streams never share one:
+//  * eager launches take the next slot of a 4096-slot ring (a slot is reused only after 4095 later
+//    launches, far beyond any stream queue depth);
+//  * launches being captured into a hipGraph take a slot that is never handed out again (the graph
+//    may be replayed at any time later), from 64 Ki-slot chunks.
+// Slots live in library-owned device memory zeroed at allocation: no per-call memset node.
+constexpr size_t kSlotWords = 16;
+constexpr size_t kRingSlots = 4096, kChunkSlots = 65536;
+struct TicketPool {
+    unsigned int *ring = nullptr;
+    size_t ring_next = 0;
+    unsigned int *chunk = nullptr;
+    size_t chunk_next = kChunkSlots;
+};
 static int vq_ws(void *workspace, hipStream_t s, VqWs *out)
 {
     static std::mutex mu;
-    static std::map<int, unsigned int *> pool;
+    static std::map<int, TicketPool> pools;
     out->partial = (double *)workspace;
     out->ticket = nullptr;
     if (!workspace) return CGIC_OK;
     int dev = 0;
     CGIC_HIP_TRY(hipGetDevice(&dev));
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    CGIC_HIP_TRY(hipStreamIsCapturing(s, &cap));
     std::lock_guard<std::mutex> lock(mu);
-    auto it = pool.find(dev);
-    if (it == pool.end()) {
-        unsigned int *p = nullptr;
-        CGIC_HIP_TRY(hipMalloc((void **)&p, sizeof(unsigned int) * kTicketSlots * 16));
-        CGIC_HIP_TRY(hipMemset(p, 0, sizeof(unsigned int) * kTicketSlots * 16));    // once per device
-        it = pool.emplace(dev, p).first;
+    TicketPool &p = pools[dev];
+    if (cap == hipStreamCaptureStatusNone) {
+        if (!p.ring) {
+            // both pools are created on the first EAGER call (allocation is illegal during capture)
+            CGIC_HIP_TRY(hipMalloc((void **)&p.ring, sizeof(unsigned int) * kSlotWords * kRingSlots));
+            CGIC_HIP_TRY(hipMemset(p.ring, 0, sizeof(unsigned int) * kSlotWords * kRingSlots));
+            CGIC_HIP_TRY(hipMalloc((void **)&p.chunk, sizeof(unsigned int) * kSlotWords * kChunkSlots));
+            CGIC_HIP_TRY(hipMemset(p.chunk, 0, sizeof(unsigned int) * kSlotWords * kChunkSlots));
+            p.chunk_next = 0;
+        }
+        out->ticket = p.ring + (p.ring_next++ % kRingSlots) * kSlotWords;
+    } else {
+        CGIC_REQUIRE(p.chunk && p.chunk_next < kChunkSlots, CGIC_ERR_INVALID,
+                     "vq: call once outside stream capture on this device before capturing (or too many captured launches)");
+        out->ticket = p.chunk + (p.chunk_next++) * kSlotWords;
     }
-    const size_t slot = ((uintptr_t)s >> 6) % kTicketSlots;
-    out->ticket = it->second + slot * 16;       // 64-byte spacing
     return CGIC_OK;
 }
 
@@ -386,7 +409,12 @@ extern "C" int cgic_vq_forward_f32(const float *z, int64_t B, int64_t hw, const 
     if (rc) return rc;
     // per-wave tile: measured on MI355X (tools/probe_vq.hip) ZT=4 at 4 waves/SIMD is the fastest
     // for large N; smaller N shrinks the tile so that all 256 CUs get work
-    if (N >= (int64_t)1 << 22) rc = launch_mfma<8>(z, hw, N, codebook, K, indices, z_q, ws, beta, legacy, loss, s);
+    static const int force_zt = getenv("CGIC_VQ_ZT") ? atoi(getenv("CGIC_VQ_ZT")) : 0;     // tuning knob (dev)
+    if (force_zt == 8) rc = launch_mfma<8>(z, hw, N, codebook, K, indices, z_q, ws, beta, legacy, loss, s);
+    else if (force_zt == 4) rc = launch_mfma<4>(z, hw, N, codebook, K, indices, z_q, ws, beta, legacy, loss, s);
+    else if (force_zt == 2) rc = launch_mfma<2>(z, hw, N, codebook, K, indices, z_q, ws, beta, legacy, loss, s);
+    else if (force_zt == 1) rc = launch_mfma<1>(z, hw, N, codebook, K, indices, z_q, ws, beta, legacy, loss, s);
+    else if (N >= (int64_t)1 << 22) rc = launch_mfma<8>(z, hw, N, codebook, K, indices, z_q, ws, beta, legacy, loss, s);
     else if (N >= (int64_t)256 * 512) rc = launch_mfma<4>(z, hw, N, codebook, K, indices, z_q, ws, beta, legacy, loss, s);
     else if (N >= (int64_t)128 * 512) rc = launch_mfma<2>(z, hw, N, codebook, K, indices, z_q, ws, beta, legacy, loss, s);
     else rc = launch_mfma<1>(z, hw, N, codebook, K, indices, z_q, ws, beta, legacy, loss, s);

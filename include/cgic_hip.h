@@ -181,6 +181,9 @@ int cgic_decode_stream(const cgic_table *t, const uint8_t *in, int64_t nbytes, i
  *           write that stream (model.py:225-260); 0 = written but empty file;
  *           <= -10 = (CGIC_ERR_* - 10) for that stream (a symbol outside the
  *           table -- KeyError in the reference -- or slot too small)
+ *   hist    device [n_symbols] int64 or NULL: += occurrences of every index of
+ *           ind (all B*h*w of them) -- the usage counter of quantize.py:79-81,
+ *           taken in the same launch
  *   Streams are produced by: masked select in row-major order of each
  *   granularity's own grid (ind[:, ::4, ::4][mask_c==1] ..., :219-221),
  *   Huffman coding with `t`, 1-bit packing of mask_c / mask_m (:230-231).
@@ -200,7 +203,7 @@ int cgic_mode_streams(int mode); /* bit i set = stream i is written in this mode
 int cgic_compress_streams(const cgic_table *t, const int64_t *ind, const int32_t *mask_c,
                           const int32_t *mask_m, const int32_t *mask_f, int64_t B, int64_t h,
                           int64_t w, int mode, uint8_t *out, int64_t slot, int32_t *nbytes,
-                          void *workspace, cgic_stream_t stream);
+                          int64_t *hist, void *workspace, cgic_stream_t stream);
 size_t cgic_decompress_workspace_bytes(int64_t B, int64_t h, int64_t w);
 int cgic_decompress_streams(const cgic_table *t, const uint8_t *in, int64_t slot, const int32_t *nbytes,
                             int64_t B, int64_t h, int64_t w, int mode, int64_t *ind_out,

@@ -331,3 +331,59 @@ def test_decompress_flags_corrupt_streams(golden):
     rb = cg.CompressedBatch.from_host(bad, mode, 64, 64, comp.data.shape[2], DEV)
     _, _, _, status = codec.decompress(rb)
     assert int(status[0]) == 0 and int(status[1]) != 0                   # the reference raises there
+
+
+# ---------------------------------------------------------------------------- pipeline
+def test_chunked_pipeline_equals_unchunked(golden):
+    """HotPathPipeline cuts the batch into concurrent stream chains; per-image semantics make the
+    result identical to the single-chain run, including under hipGraph capture + replay."""
+    gc = golden("coders")
+    rng = np.random.default_rng(11)
+    B = 16
+    x = _t(rng.random((B, 3, 64, 64), dtype=np.float32))
+    z = _t(rng.standard_normal((B, 4, 16, 16), dtype=np.float32))
+    vq = _make_vq(rng.standard_normal((1024, 4)).astype(np.float32))
+    vq.usage_counter.copy_(_t(gc["zipf_freq"].astype(np.float32)))
+    ref = cg.HotPathPipeline(vq, 0.1, 0.8, chunks=1)
+    h1 = torch.zeros(1024, dtype=torch.int64, device=DEV)
+    r1 = ref.run(x, z, h1)[0]
+    torch.cuda.synchronize()
+    for chunks in (3, 4):
+        pipe = cg.HotPathPipeline(vq, 0.1, 0.8, chunks=chunks)
+        hn = torch.zeros(1024, dtype=torch.int64, device=DEV)
+        rs = pipe.run(x, z, hn)
+        torch.cuda.synchronize()
+        assert torch.equal(hn, h1)
+        assert torch.equal(torch.cat([r["ind"] for r in rs]), r1["ind"])
+        assert torch.equal(torch.cat([r["z_q"] for r in rs]), r1["z_q"])
+        assert torch.equal(torch.cat([r["dec"][0] for r in rs]), r1["dec"][0])
+        host = [im for r in rs for im in r["comp"].to_host()]
+        assert host == r1["comp"].to_host()
+        # per-chunk losses are (1+beta) * mean over their own chunk; the batch value is their weighted mean
+        w = [r["ind"].numel() for r in rs]
+        m = sum(float(r["loss"]) * n for r, n in zip(rs, w)) / sum(w)
+        assert abs(m - float(r1["loss"])) <= 2e-6 * abs(float(r1["loss"]))
+    # graph capture + replay of a chunked step
+    pipe = cg.HotPathPipeline(vq, 0.1, 0.8, chunks=4)
+    hg = torch.zeros(1024, dtype=torch.int64, device=DEV)
+    pipe.run(x, z, hg)
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        pipe.run(x, z, hg)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=side):
+            rs = pipe.run(x, z, hg)
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    hg.zero_()
+    for _ in range(3):
+        g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(hg, 3 * h1)
+    assert torch.equal(torch.cat([r["ind"] for r in rs]), r1["ind"])
+    assert [im for r in rs for im in r["comp"].to_host()] == r1["comp"].to_host()
+    eager = cg.HotPathPipeline(vq, 0.1, 0.8, chunks=4).run(x, z)
+    torch.cuda.synchronize()
+    assert float(rs[0]["loss"]) == float(eager[0]["loss"])

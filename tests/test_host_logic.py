@@ -131,6 +131,4 @@ def test_slot_and_workspace_sizes():
     assert slot % 16 == 0 and slot >= 4096 * h.table.max_len // 8 + 2
     assert l.cgic_compress_workspace_bytes(64, 64, 64) == 0                 # 4096 positions fit LDS
     assert l.cgic_compress_workspace_bytes(1, 192, 192) >= 3 * 36864 * 6    # 768^2 tile: global scratch
-    assert l.cgic_decompress_workspace_bytes(2, 64, 64) == 0               # decoded symbols stay in LDS
-    assert l.cgic_decompress_workspace_bytes(1, 192, 192) == 0             # a 768^2 tile still fits (u16 symbols)
-    assert l.cgic_decompress_workspace_bytes(2, 512, 512) >= 2 * (16384 + 65536 + 262144) * 4
+    assert l.cgic_decompress_workspace_bytes(2, 64, 64) >= 2 * (256 + 1024 + 4096) * 2 + 24   # u16 symbols + counts
