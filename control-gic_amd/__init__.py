@@ -13,9 +13,10 @@ from .entropy import Entropy, entropy_maps
 from .indices_coding import HuffmanCoding
 from .mask_coding import BinaryCoding
 from .codec import GrainCodec, CompressedBatch, mode_streams, STREAM_NAMES
-from . import pipeline
+from . import pipeline, highres, container, model
 from .pipeline import HotPathPipeline
+from .model import install, compress_batch, grain_merge
 
 __all__ = ["VectorQuantize2", "VectorQuantizer", "TripleGrainFixedEntropyRouter", "Entropy", "entropy_maps",
            "HuffmanCoding", "BinaryCoding", "GrainCodec", "CompressedBatch", "mode_streams", "STREAM_NAMES",
-           "HotPathPipeline", "CgicError", "LIB_PATH"]
+           "HotPathPipeline", "install", "compress_batch", "grain_merge", "highres", "container", "CgicError", "LIB_PATH"]

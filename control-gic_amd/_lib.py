@@ -54,6 +54,7 @@ PROTOTYPES = {
     "cgic_decompress_workspace_bytes": (_sz, [_i64, _i64, _i64]),
     "cgic_decompress_streams": (_int, [_vp, _vp, _i64, _vp, _i64, _i64, _i64, _int, _vp, _vp, _vp, _vp, _vp, _int,
                                        _int, _vp, _vp, _vp, _vp]),
+    "cgic_grain_merge_f32": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _int, _i64, _i64, _vp, _vp]),
     "cgic_embedding_gather_f32": (_int, [_vp, _i64, _i64, _vp, _int, _int, _vp, _vp, _vp]),
 }
 

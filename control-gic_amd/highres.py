@@ -1,0 +1,126 @@
+"""Tiling driver for high-resolution images -- the hot-path side of inference_high_resolution.py.
+
+The reference pads the image to a multiple of 16 (centred zero pad, :145-173,:227-228), cuts it into a
+non-overlapping 768-px grid with ragged last row/column (:112-125) and calls `model.compress` once per tile
+at B=1 (:246), overwriting the same five .bin files every time; bpp is accumulated as
+sum(bpp_tile * tile_w * tile_h) / (W * H) of the UNPADDED image (:250,:256).
+
+Here tiles of equal shape are batched through the kernels together (router thresholds stay per tile =
+per image of the batch), the streams stay on the device, and the accounting is the reference's.
+"""
+import math
+
+import torch
+
+from .codec import GrainCodec
+
+TILE = 768
+
+
+def compute_padding(in_h, in_w, min_div=16):
+    """(left, right, top, bottom) pad and the matching unpad -- inference_high_resolution.py:145-173"""
+    out_h = (in_h + min_div - 1) // min_div * min_div
+    out_w = (in_w + min_div - 1) // min_div * min_div
+    left = (out_w - in_w) // 2
+    right = out_w - in_w - left
+    top = (out_h - in_h) // 2
+    bottom = out_h - in_h - top
+    return (left, right, top, bottom), (-left, -right, -top, -bottom)
+
+
+def tile_grid(h, w, tile=TILE):
+    """row-major list of (y, x, tile_h, tile_w) -- nonoverlapping_grid_indices, :112-125 + the loop at :236-244"""
+    ys = list(range(0, h, tile))
+    xs = list(range(0, w, tile))
+    ths = [tile] * (h // tile) + ([h % tile] if h % tile else [])
+    tws = [tile] * (w // tile) + ([w % tile] if w % tile else [])
+    return [(y, x, th, tw) for y, th in zip(ys, ths) for x, tw in zip(xs, tws)]
+
+
+def gaussian_weights(tile_width, tile_height, device=None):
+    """[1,3,tile_h,tile_w] float64 blend weights -- _gaussian_weights, :127-143 (note the reference's
+    asymmetric midpoints: (w-1)/2 for x, h/2 for y)"""
+    var = 0.01
+    mx = (tile_width - 1) / 2
+    xp = [math.exp(-(x - mx) * (x - mx) / (tile_width * tile_width) / (2 * var)) / math.sqrt(2 * math.pi * var)
+          for x in range(tile_width)]
+    my = tile_height / 2
+    yp = [math.exp(-(y - my) * (y - my) / (tile_height * tile_height) / (2 * var)) / math.sqrt(2 * math.pi * var)
+          for y in range(tile_height)]
+    wts = torch.tensor(yp, dtype=torch.float64)[:, None] * torch.tensor(xp, dtype=torch.float64)[None, :]
+    return wts.to(device).expand(1, 3, tile_height, tile_width)
+
+
+class TiledImage:
+    """result of compress_tiled: per shape-group CompressedBatch + where each tile sits"""
+
+    def __init__(self, image_hw, pad, tiles, groups):
+        self.image_hw = image_hw          # (H, W) unpadded
+        self.pad = pad                    # (left, right, top, bottom)
+        self.tiles = tiles                # [(y, x, th, tw)] row-major, padded coordinates
+        self.groups = groups              # [(tile indices, CompressedBatch, encode outputs)]
+
+    def tile_bpp(self):
+        bpp = [None] * len(self.tiles)
+        for idxs, comp, _ in self.groups:
+            for i, v in zip(idxs, comp.bpp()):
+                bpp[i] = v
+        return bpp
+
+    def bpp(self):
+        """bit_sum / (W * H) of the unpadded image -- inference_high_resolution.py:250,256"""
+        bits = sum(b * tw * th for b, (_, _, th, tw) in zip(self.tile_bpp(), self.tiles))
+        return bits / self.image_hw[1] / self.image_hw[0]
+
+    def streams(self):
+        """per tile (row-major) {stream name: bytes}"""
+        out = [None] * len(self.tiles)
+        for idxs, comp, _ in self.groups:
+            for i, s in zip(idxs, comp.to_host()):
+                out[i] = s
+        return out
+
+
+def compress_tiled(x, encode, codec, tile=TILE):
+    """x [1,3,H,W] on the device; encode(tiles [T,3,th,tw]) -> (ind [T*h*w] int64, masks [3 x int32], mode)
+    with per-tile routing (the reference's per-tile B=1 call); codec: GrainCodec.  -> TiledImage"""
+    if x.dim() != 4 or x.shape[0] != 1:
+        raise ValueError("compress_tiled takes one image [1,3,H,W] (the reference script uses batch 1)")
+    H, W = x.shape[-2:]
+    pad, _ = compute_padding(H, W)
+    xp = torch.nn.functional.pad(x, pad, mode="constant", value=0)
+    tiles = tile_grid(xp.shape[-2], xp.shape[-1], tile)
+    by_shape = {}
+    for i, (_, _, th, tw) in enumerate(tiles):
+        by_shape.setdefault((th, tw), []).append(i)
+    groups = []
+    for (th, tw), idxs in by_shape.items():
+        batch = torch.stack([xp[0, :, tiles[i][0]:tiles[i][0] + th, tiles[i][1]:tiles[i][1] + tw] for i in idxs])
+        ind, masks, mode = encode(batch)
+        groups.append((idxs, codec.compress(ind, masks, mode), (ind, masks, mode)))
+    return TiledImage((H, W), pad, tiles, groups)
+
+
+def decompress_tiled(tiled, codec, decode=None):
+    """-> per-tile (ind, masks, z_q) in row-major order; with decode(z_q, masks) -> pixels also the blended,
+    clamped, unpadded reconstruction (:248-255; tiles do not overlap, so the weights cancel)"""
+    per_tile = [None] * len(tiled.tiles)
+    for idxs, comp, _ in tiled.groups:
+        ind, masks, zq, status = codec.decompress(comp)
+        if int(status.abs().max()) != 0:
+            raise RuntimeError("corrupt tile stream")
+        for k, i in enumerate(idxs):
+            per_tile[i] = (ind[k:k + 1], [m[k:k + 1] for m in masks], zq[k:k + 1])
+    if decode is None:
+        return per_tile, None
+    H, W = tiled.image_hw
+    left, right, top, bottom = tiled.pad
+    dev = per_tile[0][2].device
+    rec = torch.zeros((1, 3, H + top + bottom, W + left + right), device=dev)
+    contrib = torch.zeros_like(rec)
+    for (y, x, th, tw), (ind, masks, zq) in zip(tiled.tiles, per_tile):
+        wts = gaussian_weights(tw, th, dev)
+        rec[:, :, y:y + th, x:x + tw] += decode(zq, masks) * wts                 # :248 (float32 += float64 product)
+        contrib[:, :, y:y + th, x:x + tw] += wts
+    rec = (rec / contrib).clamp(0, 1)
+    return per_tile, rec[:, :, top:top + H, left:left + W]

@@ -211,6 +211,18 @@ int cgic_decompress_streams(const cgic_table *t, const uint8_t *in, int64_t slot
                             const float *codebook, int K, int e_dim, float *z_q, int32_t *status,
                             void *workspace, cgic_stream_t stream);
 
+/* ---------------------------------------------------------------------------
+ * Three-grain latent merge in front of the quantiser --
+ * CGIC/modules/vqvae/vqvae_blocks.py:361-366:
+ *   h = up4(h_coarse)*up4(mask0) + up2(h_medium)*up2(mask1) + h_fine*mask2
+ *   h_coarse device [B,C,h/4,w/4], h_medium [B,C,h/2,w/2], h_fine [B,C,h,w] fp32
+ *   mask_c/m/f device int32 [B,h/4,w/4] / [B,h/2,w/2] / [B,h,w] (the router's)
+ *   out device [B,C,h,w] fp32 -- same products, same left-to-right sums: bit-identical
+ * ------------------------------------------------------------------------- */
+int cgic_grain_merge_f32(const float *h_coarse, const float *h_medium, const float *h_fine,
+                         const int32_t *mask_c, const int32_t *mask_m, const int32_t *mask_f, int64_t B,
+                         int C, int64_t h, int64_t w, float *out, cgic_stream_t stream);
+
 /* embedding gather on its own (model.py:121,391-392): out[b, c, p] = codebook[ind[b, p], c] */
 int cgic_embedding_gather_f32(const int64_t *ind, int64_t B, int64_t hw, const float *codebook, int K,
                               int e_dim, float *out, int32_t *status, cgic_stream_t stream);

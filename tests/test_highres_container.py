@@ -1,0 +1,220 @@
+"""High-resolution tiling (inference_high_resolution.py) and the container format.
+CPU part: grid/padding/bpp accounting + oracle against the reference's per-tile files;
+GPU part: the HIP path on the same golden (BASELINE config 4 in miniature: 800x1040 -> 4 ragged tiles)."""
+import numpy as np
+import pytest
+import torch
+
+import control_gic_amd as cg
+from control_gic_amd import container, highres
+from conftest import unpack_mask
+
+
+def _tiles(g):
+    return [(int(y), int(x), int(th), int(tw)) for y, th in zip(g["h_list"], g["tile_h"]) for x, tw in zip(g["w_list"], g["tile_w"])]
+
+
+def test_padding_and_grid_match_reference(golden):
+    g = golden("hires_800x1040")
+    H, W = (int(v) for v in g["image_hw"])
+    pad, unpad = highres.compute_padding(H, W)
+    assert list(pad) == list(g["pad"]) and unpad == tuple(-p for p in pad)
+    ph, pw = (int(v) for v in g["padded_hw"])
+    assert (H + pad[2] + pad[3], W + pad[0] + pad[1]) == (ph, pw)
+    assert highres.tile_grid(ph, pw) == _tiles(g)
+    # DIV2K-typical 2040x1356: pad to 2048x1360, 3 x 2 tiles, ragged last row/column
+    pad2, _ = highres.compute_padding(1356, 2040)
+    assert pad2 == (4, 4, 2, 2)
+    grid = highres.tile_grid(1360, 2048)
+    assert [(t[2], t[3]) for t in grid] == [(768, 768), (768, 768), (768, 512), (592, 768), (592, 768), (592, 512)]
+    assert highres.tile_grid(768, 768) == [(0, 0, 768, 768)] and highres.tile_grid(16, 16) == [(0, 0, 16, 16)]
+
+
+def test_gaussian_weights_shape_and_asymmetry():
+    w = highres.gaussian_weights(6, 4)
+    assert tuple(w.shape) == (1, 3, 4, 6) and w.dtype == torch.float64
+    xs = w[0, 0, 0]
+    assert torch.allclose(xs, xs.flip(0))                     # x midpoint (w-1)/2: symmetric
+    ys = w[0, 0, :, 0]
+    assert not torch.allclose(ys, ys.flip(0))                 # y midpoint h/2: the reference's off-by-half
+
+
+def test_oracle_reproduces_every_tile(orc, golden):
+    g = golden("hires_800x1040")
+    htab = orc.HuffmanTable(golden("coders")["zipf_freq"])
+    c, m = (float(v) for v in g["ratio"])
+    bits = 0.0
+    for t, (y, x, th, tw) in enumerate(_tiles(g)):
+        mc, mm, mf, _, mode = orc.router(g[f"t{t}_e16"], g[f"t{t}_e8"], c, m)
+        assert mode == int(g[f"t{t}_mode"])
+        for k, a in zip("cmf", (mc, mm, mf)):
+            assert np.array_equal(a[0, 0], unpack_mask(g[f"t{t}_m{k}"], a.shape[-2:]))
+        _, _, idx = orc.vq(g[f"t{t}_z"], g["codebook"])
+        ind = idx.reshape(th // 4, tw // 4)
+        assert np.array_equal(ind, g[f"t{t}_ind"].astype(np.int64))
+        streams = orc.compress_image(ind, mc[0, 0], mm[0, 0], mf[0, 0], mode, htab)
+        for n, v in streams.items():
+            assert v == g[f"t{t}_{n}"].tobytes()
+        bpp = sum(map(len, streams.values())) * 8 / (th * tw)
+        assert bpp == float(g[f"t{t}_bpp"])
+        bits += bpp * tw * th
+    assert bits / int(g["image_hw"][1]) / int(g["image_hw"][0]) == float(g["bpp_image"])
+
+
+def test_container_roundtrip_and_bpp(golden):
+    g = golden("compress_cfg1")
+    entries = []
+    for i, key in enumerate(sorted({k[:-5] for k in g if k.endswith("_mode")})):
+        streams = {n: g[f"{key}_{n}"].tobytes() for n in cg.STREAM_NAMES if f"{key}_{n}" in g}
+        entries.append(dict(image_id=i, y=0, x=0, height=256, width=256, mode=int(g[key + "_mode"]), streams=streams))
+        assert container.bits_per_pixel(entries[-1:], (256, 256)) == float(g[key + "_bpp"])
+    blob = container.pack(entries)
+    assert container.unpack(blob) == entries
+    assert len(blob) == 12 + 44 * len(entries) + sum(len(v) for e in entries for v in e["streams"].values())
+    with pytest.raises(ValueError):
+        container.unpack(blob[:-1])
+    with pytest.raises(ValueError):
+        container.unpack(blob + b"\0")
+    with pytest.raises(ValueError):
+        container.unpack(b"XXXX" + blob[4:])
+    assert container.unpack(container.pack([])) == []
+
+
+class _V:
+    def __init__(self, v): self.v = v
+    def item(self): return self.v
+
+
+@pytest.mark.gpu
+def test_tiled_compress_matches_reference_files(golden):
+    g = golden("hires_800x1040")
+    gc = golden("coders")
+    dev = "cuda"
+    tiles = _tiles(g)
+    cbk = torch.from_numpy(g["codebook"]).to(dev)
+    vq = cg.VectorQuantizer(1024, 4, beta=0.25).to(dev).eval()
+    vq.embedding.weight.data.copy_(cbk)
+    codec = cg.GrainCodec({str(int(k)): _V(float(gc["zipf_freq"][int(k)])) for k in gc["zipf_order"]}, vq.embedding.weight)
+    c, m = (float(v) for v in g["ratio"])
+    router = cg.TripleGrainFixedEntropyRouter(c, m, per_image=True)
+    by_shape = {(th, tw): t for t, (_, _, th, tw) in enumerate(tiles)}
+
+    def encode(batch):
+        # stand-in for the conv encoder: the latent / entropy maps the reference's encoder produced for this tile
+        t = by_shape[(batch.shape[-2], batch.shape[-1])]
+        mask, _, _, mode = router(torch.from_numpy(g[f"t{t}_e16"]).to(dev), torch.from_numpy(g[f"t{t}_e8"]).to(dev))
+        ind = vq.indices(torch.from_numpy(g[f"t{t}_z"]).to(dev))
+        return ind, mask, mode
+
+    H, W = (int(v) for v in g["image_hw"])
+    x = torch.rand(1, 3, H, W, device=dev)
+    tiled = highres.compress_tiled(x, encode, codec)
+    assert tiled.tiles == tiles
+    for t, s in enumerate(tiled.streams()):
+        assert set(s) == set(cg.STREAM_NAMES)
+        for n, v in s.items():
+            assert v == g[f"t{t}_{n}"].tobytes(), f"tile {t} {n}.bin"
+    assert tiled.tile_bpp() == [float(g[f"t{t}_bpp"]) for t in range(len(tiles))]
+    assert tiled.bpp() == float(g["bpp_image"])                                   # bpp match, reference accounting
+    # container: every tile survives (the reference overwrites its five files per tile)
+    entries = container.entries_from_tiled(tiled, image_id=7)
+    back = container.unpack(container.pack(entries))
+    assert back == entries and [(e["y"], e["x"], e["height"], e["width"]) for e in back] == tiles
+    # decode side: indices of every tile, and the blend of a trivial decoder
+    per_tile, rec = highres.decompress_tiled(tiled, codec, decode=lambda zq, masks: torch.full(
+        (1, 3, zq.shape[-2] * 4, zq.shape[-1] * 4), 0.25, device=dev))
+    for t, (ind, masks, zq) in enumerate(per_tile):
+        assert np.array_equal(ind[0].cpu().numpy(), g[f"t{t}_ind"].astype(np.int64))   # masks are exclusive: merge == ind
+        assert np.array_equal(zq[0].cpu().numpy(), g["codebook"][g[f"t{t}_ind"].astype(np.int64)].transpose(2, 0, 1))
+    assert tuple(rec.shape) == (1, 3, H, W) and torch.allclose(rec, torch.full_like(rec, 0.25), atol=1e-6)
+
+
+@pytest.mark.gpu
+def test_grain_merge_bit_exact():
+    g = torch.Generator().manual_seed(3)
+    B, C, h, w = 3, 4, 24, 40
+    hc = torch.randn(B, C, h // 4, w // 4, generator=g).cuda()
+    hm = torch.randn(B, C, h // 2, w // 2, generator=g).cuda()
+    hf = torch.randn(B, C, h, w, generator=g).cuda()
+    e16 = torch.rand(B, h // 4, w // 4, generator=g).cuda()
+    e8 = torch.rand(B, h // 2, w // 2, generator=g).cuda()
+    for c, m in ((0.1, 0.8), (0.0, 0.5), (0.5, 0.0), (0.5, 0.5), (1.0, 0.0), (0.0, 1.0), (0.0, 0.0)):
+        mask, _, _, _ = cg.TripleGrainFixedEntropyRouter(c, m, per_image=True)(e16, e8)
+        up2 = torch.nn.Upsample(scale_factor=2, mode="nearest")
+        up4 = torch.nn.Upsample(scale_factor=4, mode="nearest")
+        ref = up4(hc) * up4(mask[0].float()) + up2(hm) * up2(mask[1].float()) + hf * mask[2]   # vqvae_blocks.py:364-366
+        out = cg.grain_merge(hc, hm, hf, mask)
+        assert torch.equal(out, ref.float())
+
+
+@pytest.mark.gpu
+def test_install_and_compress_on_a_cgic_shaped_model(tmp_path, orc):
+    """install() on a model with the reference's attribute layout (a stub with tiny stock-torch conv encoder /
+    decoder stands in for the 130 M-parameter nets): compress() keeps the reference contract, compress_batch
+    == looping compress at B=1."""
+    dev = "cuda"
+
+    class StubEncoder(torch.nn.Module):            # shape contract of vqvae_blocks.py:303-374
+        def __init__(self):
+            super().__init__()
+            self.c16 = torch.nn.Conv2d(3, 4, 16, 16)
+            self.c8 = torch.nn.Conv2d(3, 4, 8, 8)
+            self.c4 = torch.nn.Conv2d(3, 4, 4, 4)
+            self.router_config = {"target": "somewhere.else.Router", "params": {"coarse_grain_ratio": 0.1, "medium_grain_ratio": 0.8}}
+
+        def forward(self, x, e16, e8):
+            import importlib
+            mod, cls = self.router_config["target"].rsplit(".", 1)
+            router = getattr(importlib.import_module(mod), cls)(**self.router_config["params"])
+            mask, gate, fine_ratio, mode = router(e16, e8)
+            h = cg.grain_merge(self.c16(x), self.c8(x), self.c4(x), mask)
+            return {"h": h, "indices": None, "mask": mask, "fine_ratio": fine_ratio, "compression_mode": mode}
+
+    class StubCGIC(torch.nn.Module):               # attribute names of model.py:42-60
+        def __init__(self):
+            super().__init__()
+            self.encoder = StubEncoder()
+            self.quantize = cg.VectorQuantizer(1024, 4, beta=0.25)
+            self.quant_conv = torch.nn.Conv2d(4, 4, 1)
+            self.post_quant_conv = torch.nn.Conv2d(4, 4, 1)
+            self.dec = torch.nn.ConvTranspose2d(4, 3, 4, 4)
+            self.entropy_calculation_p8 = torch.nn.Identity()
+            self.entropy_calculation_p16 = torch.nn.Identity()
+
+        def encode(self, x):                       # model.py:99-112
+            e8 = self.entropy_calculation_p8(x)
+            e16 = self.entropy_calculation_p16(x)
+            d = self.encoder(x, e16, e8)
+            quant, emb_loss, ind = self.quantize(self.quant_conv(d["h"]))
+            return quant, emb_loss, d["indices"], d["mask"], ind, d["fine_ratio"], d["compression_mode"]
+
+        def decode(self, quant, mask):             # model.py:114-117
+            return self.dec(self.post_quant_conv(quant))
+
+    torch.manual_seed(0)
+    model = StubCGIC().to(dev).eval()
+    model.quantize.embedding.weight.data.normal_()
+    model.quantize.usage_counter.copy_(torch.arange(1024, 0, -1, dtype=torch.float32))
+    sd_before = {k: v.clone() for k, v in model.state_dict().items()}
+    cg.install(model)
+    assert isinstance(model.entropy_calculation_p8, cg.Entropy) and model.encoder.router_config["target"].endswith("TripleGrainFixedEntropyRouter")
+    assert all(torch.equal(v, model.state_dict()[k]) for k, v in sd_before.items())
+    x = torch.rand(3, 3, 64, 96, device=dev)
+    with torch.no_grad():
+        dec_b, bpp_b, comp = model.compress_batch(x)
+        outs = [model.compress(x[b:b + 1], str(tmp_path)) for b in range(3)]
+    assert tuple(dec_b.shape) == (3, 3, 64, 96)
+    for b, (dec, bpp, pmap) in enumerate(outs):
+        assert pmap is None and bpp == bpp_b[b] and torch.equal(dec[0], dec_b[b])
+    files = sorted(p.name for p in tmp_path.iterdir())
+    assert files == sorted(n + ".bin" for n in cg.STREAM_NAMES)                     # the reference's five files
+    assert {n: (tmp_path / (n + ".bin")).read_bytes() for n in cg.STREAM_NAMES} == comp.to_host()[2]
+    with pytest.raises(IndexError):
+        model.compress(x, str(tmp_path))
+    # the streams are what the oracle writes for the same indices / masks
+    with torch.no_grad():
+        _, _, _, mask, ind, _, mode = model.encode(x)
+    htab = orc.HuffmanTable(np.arange(1024, 0, -1, dtype=np.int64))
+    for b in range(3):
+        ref = orc.compress_image(ind.view(3, 16, 24)[b].cpu().numpy(), *(m[b, 0].cpu().numpy() for m in mask), mode, htab)
+        assert comp.to_host()[b] == ref
