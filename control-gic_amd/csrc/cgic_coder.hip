@@ -428,21 +428,6 @@ struct DecodeOneArgs {
     int64_t *count;
 };
 
-__global__ __launch_bounds__(kWave) void decode_stream_kernel(DecodeOneArgs a)
-{
-    __shared__ uint32_t lut[kDecLutMax];
-    __shared__ uint32_t win[kWinWords];
-    load_lut(a.tab, lut);
-    __syncthreads();
-    int overflow = 0;
-    int64_t *dst = a.syms;
-    WaveDecoder d{a.tab, lut, win, a.in, (int)a.nbytes, 0, 0};
-    const int cap = a.cap > 0x7FFFFFFF ? 0x7FFFFFFF : (int)a.cap;
-    int cnt = d.run(cap, [&](int k, int sym) { dst[k] = sym; }, &overflow);
-    overflow = __any(overflow);
-    if (threadIdx.x == 0) *a.count = overflow ? (int64_t)CGIC_ERR_CAPACITY : (int64_t)cnt;
-}
-
 // -------------------------------------------------------------------------------------------
 // Parallel prefix-code decoding inside ONE stream (fast mode, max code length <= 64 bits).
 //
@@ -467,6 +452,8 @@ constexpr int kSegWin = 1024;                      // LDS window of stream bytes
 constexpr int kSegWinWords = kSegWin / 4 + 4;           // 65 x 16 B: one uint4 per lane + one tail
 constexpr int kBig = 1 << 28;                      // "past the end of the stream"
 constexpr int kU = 4;                              // chunks in flight per wave
+constexpr int kLdsTrieNodes = 2048;                // decode tries up to this many nodes are staged in LDS (16 KB)
+constexpr int kPackBig = 0xFF;                     // packed "past the end" marker (max real next = 63 + 64)
 constexpr int kMergeItems = 4;
 
 struct BitWindow {
@@ -561,44 +548,50 @@ __device__ __forceinline__ void decode_segmented(const TableDev &t, const uint32
     }
     // ---- pass A: range function (F, C) by pointer doubling; kU chunks in flight per wave so that
     // the LDS round trips of independent chunks overlap (one wave per SIMD has no other cover)
-    CGIC_STAMP(2);
+    CGIC_STAMP3(2);
     int F = lane, C = 0;
     if (active && c1 > c0) {
         bw.fill(1 + ((c0 * kWave) >> 3));
+        if (c0 == 0) CGIC_STAMP3(16);
         for (int c = c0; c < c1; c += kU) {
             if (!bw.covers((c + kU + 2) * kWave)) bw.fill(1 + ((c * kWave) >> 3));
-            int nxt[kU], cnt[kU];
+            // (next, count) packed in one word -> ONE ds_bpermute per doubling round (the LDS crossbar is
+            // what bounds this pass): bits 0..7 = next position (0..127, kPackBig = past the stream),
+            // bits 8..15 = codewords on the way
+            int pk[kU];
 #pragma unroll
             for (int u = 0; u < kU; ++u) {
                 int sym;
                 const int L = c + u < c1 ? codeword_at(t, lut, bw, (c + u) * kWave + lane, nbits, &sym) : 0;
-                nxt[u] = L ? lane + L : kBig;
-                cnt[u] = L ? 1 : 0;
+                pk[u] = L ? ((lane + L) | (1 << 8)) : kPackBig;
             }
+            if (c == 0) CGIC_STAMP3(17);
             for (int r = 0; r < t.dbl_rounds; ++r) {
 #pragma unroll
                 for (int u = 0; u < kU; ++u) {
-                    const int jn = __shfl(nxt[u], nxt[u] & 63, kWave);
-                    const int cn = __shfl(cnt[u], nxt[u] & 63, kWave);
-                    if (nxt[u] < kWave) { cnt[u] += cn; nxt[u] = jn; }
+                    const int nx = pk[u] & 0xFF;
+                    const int o = __shfl(pk[u], nx & 63, kWave);
+                    if (nx < kWave) pk[u] = (o & 0xFF) | ((pk[u] & 0xFF00) + (o & 0xFF00));
                 }
             }
+            if (c == 0) CGIC_STAMP3(18);
 #pragma unroll
             for (int u = 0; u < kU; ++u) {
                 if (c + u < c1) {
-                    const int jx = __shfl(nxt[u], F & 63, kWave);
-                    const int cx = __shfl(cnt[u], F & 63, kWave);
-                    if (F < kWave) { C += cx; F = jx; }
-                    F = F >= kBig / 2 ? kBig : F - kWave;
+                    const int o = __shfl(pk[u], F & 63, kWave);
+                    if (F < kWave) { C += o >> 8; F = o & 0xFF; }
+                    F = F >= kPackBig ? kBig : F - kWave;
                 }
             }
+            if (c == 0) CGIC_STAMP3(19);
+            if (c == kU) CGIC_STAMP3(20);
         }
     }
     sh->F[wave][lane] = F;
     sh->C[wave][lane] = C;
-    CGIC_STAMP(3);
+    CGIC_STAMP3(3);
     __syncthreads();
-    CGIC_STAMP(4);
+    CGIC_STAMP3(4);
     // ---- pass B: true entry offset + output index of this wave's range
     int e = 0, n = 0;
     if (active) {
@@ -607,11 +600,13 @@ __device__ __forceinline__ void decode_segmented(const TableDev &t, const uint32
             n += sh->C[v][e];
             e = sh->F[v][e];
         }
+        e = __builtin_amdgcn_readfirstlane(e);       // wave-uniform by construction; tell the compiler
+        n = __builtin_amdgcn_readfirstlane(n);
         if (k == nw - 1 && lane == 0) *count_out = e < kWave ? n + sh->C[wave][e] : n;
     }
     // ---- pass C: decode the range from its true entry offset (lookups for kU chunks issued
     // together, then the scalar chains one after the other)
-    CGIC_STAMP(5);
+    CGIC_STAMP3(5);
     if (active && c1 > c0 && e < kWave) {
         if (!bw.covers((c0 + kU + 2) * kWave) || 1 + ((c0 * kWave) >> 3) < bw.wb) bw.fill(1 + ((c0 * kWave) >> 3));
         for (int c = c0; c < c1 && e < kWave; c += kU) {
@@ -625,12 +620,16 @@ __device__ __forceinline__ void decode_segmented(const TableDev &t, const uint32
 #pragma unroll
             for (int u = 0; u < kU; ++u) {
                 if (c + u < c1 && e < kWave) {
+                    // scalar chain: everything derives from readfirstlane / readlane results, so the
+                    // compiler keeps it in SGPRs (a value loaded from LDS would make the loop an
+                    // exec-masked vector loop: 16 instructions + a 64-bit vector shift per symbol)
                     unsigned long long starts = 0;
-                    int i = e;
+                    int i = __builtin_amdgcn_readfirstlane(e);
                     while (i < kWave) {
                         const int Li = __builtin_amdgcn_readlane(Ls[u], i);
-                        starts |= (unsigned long long)(Li != 0) << i;
-                        i = Li ? i + Li : kBig;
+                        if (Li == 0) { i = kBig; break; }
+                        starts |= 1ull << i;
+                        i += Li;
                     }
                     e = i >= kBig / 2 ? kBig : i - kWave;
                     const int rank = __popcll(starts & ((1ull << lane) - 1ull));
@@ -640,9 +639,51 @@ __device__ __forceinline__ void decode_segmented(const TableDev &t, const uint32
             }
         }
     }
-    CGIC_STAMP(6);
+    CGIC_STAMP3(6);
     __syncthreads();
-    CGIC_STAMP(7);
+    CGIC_STAMP3(7);
+}
+
+// single-stream decode (HuffmanCoding / BinaryCoding .decompress_string): one 1024-thread workgroup,
+// the same segmented decoder; tables with codes longer than 64 bits take the one-wave serial path
+__global__ __launch_bounds__(kDecThreads) void decode_stream_kernel(DecodeOneArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t sm[];
+    __shared__ int s_count;
+    uint32_t *lut = sm;
+    uint32_t *win = lut + kDecLutMax;
+    SegShared *seg = reinterpret_cast<SegShared *>(win + kDecWaves * kSegWinWords);
+    const int tid = threadIdx.x, lane = lane_id(), wave = tid >> 6;
+    if (tid == 0) s_count = 0;
+    load_lut(a.tab, lut);
+    if (a.tab.n_nodes <= kLdsTrieNodes) {
+        int32_t *ltrie = reinterpret_cast<int32_t *>(seg + 1);
+        for (int i = tid; i < 2 * a.tab.n_nodes; i += kDecThreads) ltrie[i] = a.tab.child[i];
+        a.tab.child = ltrie;
+    }
+    __syncthreads();
+    const int nb = (int)a.nbytes;
+    if (nb <= 0) {
+        if (tid == 0) *a.count = -1;                              // empty file -> None (:158-159)
+        return;
+    }
+    const int cap = a.cap > 0x7FFFFFFF ? 0x7FFFFFFF : (int)a.cap;
+    int64_t *dst = a.syms;
+    auto put = [&](int k, int sym) { dst[k] = sym; };
+    if (a.tab.max_len <= 64) {
+        int nw = (nb + 15) >> 4;
+        nw = nw < 1 ? 1 : (nw > kDecWaves ? kDecWaves : nw);
+        decode_segmented(a.tab, lut, win + wave * kSegWinWords, seg, a.in, nb, (int)a.in[0], 0, wave < nw ? nw : 0, wave, cap,
+                         put, &s_count);
+    } else if (wave == 0) {
+        int overflow = 0;
+        WaveDecoder d{a.tab, lut, win, a.in, nb, 0, 0};
+        int cnt = d.run(cap, put, &overflow);
+        if (__any(overflow)) cnt = cap + 1;
+        if (lane == 0) s_count = cnt;
+    }
+    __syncthreads();
+    if (tid == 0) *a.count = s_count > cap ? (int64_t)CGIC_ERR_CAPACITY : (int64_t)s_count;
 }
 
 // -------------------------------------------------------------------------------------------
@@ -691,10 +732,17 @@ __global__ __launch_bounds__(kDecThreads) void decode_streams_kernel(DecodeArgs 
         s_pad = in[0];
         s_count = 0;
     }
-    CGIC_STAMP(0);
+    CGIC_STAMP3(0);
     load_lut(a.tab, lut);
+    // the decode trie (codes longer than the LUT window) next to the LUT: a speculative bit offset that
+    // lands on a long-code prefix must not cost a global-memory round trip per trie step
+    if (a.tab.n_nodes <= kLdsTrieNodes) {
+        int32_t *ltrie = reinterpret_cast<int32_t *>(seg + 1);
+        for (int i = tid; i < 2 * a.tab.n_nodes; i += kDecThreads) ltrie[i] = a.tab.child[i];
+        a.tab.child = ltrie;
+    }
     __syncthreads();
-    CGIC_STAMP(1);
+    CGIC_STAMP3(1);
     const int nb = s_nb;
     if (nb <= 0) {
         if (tid == 0) *dc = nb == 0 ? -1 : -2;
@@ -716,6 +764,7 @@ __global__ __launch_bounds__(kDecThreads) void decode_streams_kernel(DecodeArgs 
         if (lane == 0) s_count = cnt;
     }
     __syncthreads();
+    CGIC_STAMP3(8);
     if (tid == 0) *dc = s_count > cap ? -3 : s_count;
 }
 
@@ -738,20 +787,6 @@ struct MergeArgs {
     int32_t *status;
     int stage_sym, stage_cb;   // keep the image's decoded symbols / the codebook in LDS
 };
-
-// LSB-first bit array word `wi` (bits 32wi..32wi+31) of an MSB-first mask stream
-__device__ __forceinline__ uint32_t mask_stream_word(const uint8_t *in, int64_t wi, int64_t nbits)
-{
-    uint32_t v = 0;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const int64_t byte = wi * 4 + k;
-        if (byte * 8 < nbits) v |= (uint32_t)(__brev((uint32_t)in[1 + byte]) >> 24) << (8 * k);
-    }
-    const int64_t rem = nbits - wi * 32;
-    if (rem < 32) v &= rem <= 0 ? 0u : ((1u << rem) - 1u);
-    return v;
-}
 
 __global__ __launch_bounds__(kMergeThreads) void merge_kernel(MergeArgs a)
 {
@@ -1111,7 +1146,10 @@ extern "C" int cgic_decode_stream(const cgic_table *t, const uint8_t *in, int64_
     int rc = table_device_view(t, &a.tab);
     if (rc) return rc;
     a.in = in; a.nbytes = nbytes; a.syms = syms; a.cap = cap; a.count = count;
-    hipLaunchKernelGGL(decode_stream_kernel, dim3(1), dim3(kWave), 0, (hipStream_t)stream, a);
+    size_t lds = sizeof(uint32_t) * (kDecLutMax + kDecWaves * kSegWinWords) + sizeof(SegShared) + sizeof(int32_t) * 2 * kLdsTrieNodes;
+    if (lds < sizeof(uint32_t) * (kDecLutMax + kWinWords)) lds = sizeof(uint32_t) * (kDecLutMax + kWinWords);
+    CGIC_HIP_TRY(hipFuncSetAttribute((const void *)decode_stream_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(decode_stream_kernel, dim3(1), dim3(kDecThreads), lds, (hipStream_t)stream, a);
     return launch_check("decode_stream_kernel");
 }
 
@@ -1148,7 +1186,7 @@ extern "C" int cgic_decompress_streams(const cgic_table *t, const uint8_t *in, i
     d.dsym = (uint16_t *)workspace;
     d.dcount = (int32_t *)((char *)workspace + align16((size_t)B * per * sizeof(uint16_t)));
     d.status = status;
-    size_t lds_d = sizeof(uint32_t) * (kDecLutMax + kDecWaves * kSegWinWords) + sizeof(SegShared);
+    size_t lds_d = sizeof(uint32_t) * (kDecLutMax + kDecWaves * kSegWinWords) + sizeof(SegShared) + sizeof(int32_t) * 2 * kLdsTrieNodes;
     if (lds_d < sizeof(uint32_t) * (kDecLutMax + kWinWords)) lds_d = sizeof(uint32_t) * (kDecLutMax + kWinWords);
     if (lds_d > 48 * 1024)
         CGIC_HIP_TRY(hipFuncSetAttribute((const void *)decode_streams_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_d));

@@ -182,6 +182,7 @@ int table_device_view(const cgic_table *ct, TableDev *out)
     out->words = t->words;
     out->max_len = t->max_len;
     out->lut_bits = t->lut_bits;
+    out->n_nodes = (int)(t->child.size() / 2);
     int min_len = t->max_len;
     for (int v : t->len) if (v > 0 && v < min_len) min_len = v;
     if (min_len < 1) min_len = 1;
