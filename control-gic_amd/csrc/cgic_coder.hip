@@ -32,6 +32,7 @@ namespace cgic {
 
 #ifdef CGIC_PHASE_CLOCKS
 __device__ long long g_phase_clk[32];
+__device__ long long g_blk_t[2 * 4096];
 #endif
 
 constexpr int kEncThreads = 1024;         // x kEncItems = 4096 positions per scan round: one round per 256x256 stream
@@ -249,8 +250,9 @@ __global__ __launch_bounds__(kEncThreads) void compress_streams_kernel(CompressA
         // ind[:, ::4, ::4][mask_c == 1] etc.: row-major over the granularity's own grid (:219-221)
         auto sym_at = [&](int64_t i, bool *flag) -> int64_t {
             // both loads are issued unconditionally so that they share one memory round trip
-            const int64_t y = i / gw, x = i - y * gw;
-            const int64_t v = ind[((y << sh) * w) + (x << sh)];
+            const int ii = (int)i, gwi = (int)gw;                       // 32-bit divide (h*w < 2^26)
+            const int y = ii / gwi, x = ii - y * gwi;
+            const int64_t v = ind[((int64_t)(y << sh) * w) + (x << sh)];
             *flag = mask[i] == 1;
             return v;
         };
@@ -930,8 +932,8 @@ __global__ __launch_bounds__(kMergeThreads) void merge_kernel(MergeArgs a)
         uint32_t mine = 0;
         for (int64_t i = tid; i < r0 * w; i += kMergeThreads) {
             bool bc, bm;
-            const int64_t y = i / w;
-            mine += fine_flag(y, i - y * w, &bc, &bm) ? 1u : 0u;
+            const int y = (int)i / (int)w;
+            mine += fine_flag(y, (int)i - y * (int)w, &bc, &bm) ? 1u : 0u;
         }
         (void)block_exclusive_scan(mine, scan_smem, &fbase);
     }
@@ -963,8 +965,8 @@ __global__ __launch_bounds__(kMergeThreads) void merge_kernel(MergeArgs a)
             const int64_t i = i0 + k;
             vals[k] = 0;
             if (i >= r1 * w) continue;
-            const int64_t y = i / w, x = i - y * w;
-            const int64_t j2 = (y >> 1) * w2 + (x >> 1), j4 = (y >> 2) * w4 + (x >> 2);
+            const int y = (int)i / (int)w, x = (int)i - y * (int)w;        // 32-bit divide (h*w < 2^26)
+            const int64_t j2 = (int64_t)(y >> 1) * w2 + (x >> 1), j4 = (int64_t)(y >> 2) * w4 + (x >> 2);
             bool bc, bm;
             const bool bf = fine_flag(y, x, &bc, &bm);
             fl |= (uint32_t)bf << k;
@@ -1028,6 +1030,11 @@ static size_t align16(size_t v) { return (v + 15) & ~(size_t)15; }
 using namespace cgic;
 
 #ifdef CGIC_PHASE_CLOCKS
+extern "C" int cgic_debug_block_times(long long *out, int n)
+{
+    CGIC_HIP_TRY(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_blk_t), sizeof(long long) * 2 * (size_t)n));
+    return CGIC_OK;
+}
 extern "C" int cgic_debug_reset_span(void)
 {
     long long init[4] = {0x7fffffffffffffffLL, 0, 0, 0};

@@ -140,19 +140,31 @@ __global__ __launch_bounds__(kRouterThreads) void router_kernel(RouterArgs a)
         if (i < N16) mc[i] = g ? 1 : 0;
     }
     __syncthreads();
+    // 32-bit index math throughout (N8 < 2^31 is checked on the host): a 64-bit divide is ~100 instructions
+    const int n8i = (int)n8, w8i = (int)w8, n16i = (int)n16, w16i = (int)w16;
     auto gc_of8 = [&](int64_t i) -> bool {   // coarse gate of the parent of medium element i
-        int64_t b = i / n8, r = i - b * n8;
-        int64_t y = r / w8, x = r - y * w8;
-        int64_t c = b * n16 + (y >> 1) * w16 + (x >> 1);
+        const int ii = (int)i;
+        const int b = ii / n8i, r = ii - b * n8i;
+        const int y = r / w8i, x = r - y * w8i;
+        const int c = b * n16i + (y >> 1) * w16i + (x >> 1);
         return (gc_bits[c >> 6] >> (c & 63)) & 1ull;
     };
 
     CGIC_STAMP(3);
     // ---- medium gate
     float thr_m = 0.f;
-    if (mode == 0)        // :27-31: sort e8 * (1 - up2(gate_coarse))
-        thr_m = radix_select([&](int64_t i) { return e8[i] * (1.0f - (gc_of8(i) ? 1.0f : 0.0f)); }, N8, a.rank_m, sh);
-    else if (mode == 1)   // :40-43
+    if (mode == 0) {      // :27-31: sort e8 * (1 - up2(gate_coarse))
+        if (a.stage) {
+            // materialise the masked values once (LDS), so the four radix passes are plain LDS sweeps
+            float *l8m = const_cast<float *>(e8) + N8;
+            for (int64_t i = tid; i < N8; i += kRouterThreads) l8m[i] = e8[i] * (1.0f - (gc_of8(i) ? 1.0f : 0.0f));
+            __syncthreads();
+            thr_m = radix_select([&](int64_t i) { return l8m[i]; }, N8, a.rank_m, sh);
+        } else {
+            thr_m = radix_select([&](int64_t i) { return e8[i] * (1.0f - (gc_of8(i) ? 1.0f : 0.0f)); }, N8, a.rank_m, sh);
+        }
+    }
+    if (mode == 1)        // :40-43
         thr_m = radix_select([&](int64_t i) { return e8[i]; }, N8, a.rank_m, sh);
     auto gm_of8 = [&](int64_t i) -> bool {
         switch (mode) {
@@ -243,8 +255,8 @@ extern "C" int cgic_router_f32(const float *e16, const float *e8, int64_t B, int
     a.rank_m = (unsigned int)(k_m != 0 ? k_m - 1 : 0);
     size_t lds = 1040 + 8 * (size_t)((N16 + 63) / 64);
     CGIC_REQUIRE(lds <= 150 * 1024, CGIC_ERR_UNSUPPORTED, "router: segment of %lld coarse patches exceeds LDS", (long long)N16);
-    a.stage = lds + 4 * (size_t)(N16 + N8) <= 96 * 1024 ? 1 : 0;
-    if (a.stage) lds += 4 * (size_t)(N16 + N8);
+    a.stage = lds + 4 * (size_t)(N16 + 2 * N8) <= 96 * 1024 ? 1 : 0;      // e16, e8 and the masked copy of e8
+    if (a.stage) lds += 4 * (size_t)(N16 + 2 * N8);
     if (lds > 64 * 1024)
         CGIC_HIP_TRY(hipFuncSetAttribute((const void *)router_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(router_kernel, dim3((unsigned)nseg), dim3(kRouterThreads), lds, (hipStream_t)stream, a);

@@ -120,8 +120,11 @@ __global__ __launch_bounds__(kVqThreads, ZT <= 4 ? 4 : 2) void vq_mfma_kernel(
     float *cbT = smem;                // [4][K]
     float *ee = smem + 4 * K;         // [K]
 
+    CGIC_STAMP(0);
+    CGIC_BLK_BEGIN();
     stage_codebook(cb, K, cbT, ee);
     __syncthreads();
+    CGIC_STAMP(1);
 
     const int lane = lane_id();
     const int wave = threadIdx.x >> 6;
@@ -129,6 +132,16 @@ __global__ __launch_bounds__(kVqThreads, ZT <= 4 ? 4 : 2) void vq_mfma_kernel(
     const int g = lane >> 4;   // B-operand k index / C-row group
     const int64_t wave_base = ((int64_t)blockIdx.x * 4 + wave) * (16 * ZT);
 
+    // (image, position) of the wave's first vector: ONE 64-bit division per wave; every other
+    // address follows by adding and carrying (a 64-bit divide costs ~100 instructions, and the
+    // previous per-tile divides in prologue + epilogue were a quarter of the kernel's issue time)
+    const int64_t b0 = wave_base / hw;
+    const int64_t p0 = wave_base - b0 * hw;
+    auto locate = [&](int t, int64_t *b, int64_t *p) {
+        int64_t pp = p0 + 16 * t + j, bb = b0;
+        while (pp >= hw) { pp -= hw; ++bb; }
+        *b = bb; *p = pp;
+    };
     // B operand: lane holds z[n_j][k=g] for each tile; zz per column.
     float zv[ZT], zz[ZT], best[ZT];
     int bt[ZT];
@@ -137,7 +150,8 @@ __global__ __launch_bounds__(kVqThreads, ZT <= 4 ? 4 : 2) void vq_mfma_kernel(
         int64_t n = wave_base + 16 * t + j;
         float v = 0.f;
         if (n < N) {
-            int64_t b = n / hw, p = n - b * hw;
+            int64_t b, p;
+            locate(t, &b, &p);
             v = z[(b * 4 + g) * hw + p];
         }
         zv[t] = v;
@@ -148,6 +162,7 @@ __global__ __launch_bounds__(kVqThreads, ZT <= 4 ? 4 : 2) void vq_mfma_kernel(
         bt[t] = 0;
     }
 
+    CGIC_STAMP(2);
     const int ntile = K >> 4;
     for (int ct = 0; ct < ntile; ++ct) {
         // A operand: A[i = lane&15][k = lane>>4] = e[16*ct + i][k]
@@ -169,6 +184,7 @@ __global__ __launch_bounds__(kVqThreads, ZT <= 4 ? 4 : 2) void vq_mfma_kernel(
         }
     }
 
+    CGIC_STAMP(3);
     // Resolve the row inside the winning tile, then combine the 4 row groups
     // (lanes j, j+16, j+32, j+48): lexicographic (d, index).
     double sq = 0.0;
@@ -180,9 +196,23 @@ __global__ __launch_bounds__(kVqThreads, ZT <= 4 ? 4 : 2) void vq_mfma_kernel(
         const int c0 = 16 * bt[t] + 4 * g;
         float d = best[t];
         int i = c0;
+        {
+            // the lane's 4 candidate codes c0..c0+3 are contiguous in the transposed codebook:
+            // five 16-byte LDS reads instead of twenty 4-byte ones
+            const f32x4 e0 = *reinterpret_cast<const f32x4 *>(&cbT[c0]);
+            const f32x4 e1 = *reinterpret_cast<const f32x4 *>(&cbT[K + c0]);
+            const f32x4 e2 = *reinterpret_cast<const f32x4 *>(&cbT[2 * K + c0]);
+            const f32x4 e3 = *reinterpret_cast<const f32x4 *>(&cbT[3 * K + c0]);
+            const f32x4 en = *reinterpret_cast<const f32x4 *>(&ee[c0]);
 #pragma unroll
-        for (int r = 3; r >= 0; --r)      // descending: the lowest matching row wins
-            i = dist_valu(z0, z1, z2, z3, zz[t], cbT, ee, K, c0 + r) == d ? c0 + r : i;
+            for (int r = 3; r >= 0; --r) {   // descending: the lowest matching row wins
+                float mm = z0 * e0[r];
+                mm = __builtin_fmaf(z1, e1[r], mm);
+                mm = __builtin_fmaf(z2, e2[r], mm);
+                mm = __builtin_fmaf(z3, e3[r], mm);
+                i = __builtin_fmaf(-2.0f, mm, zz[t] + en[r]) == d ? c0 + r : i;
+            }
+        }
 #pragma unroll
         for (int off = 16; off < 64; off <<= 1) {
             float od = __shfl_xor(d, off, kWave);
@@ -199,7 +229,8 @@ __global__ __launch_bounds__(kVqThreads, ZT <= 4 ? 4 : 2) void vq_mfma_kernel(
                 float e = cbT[g * K + i];
                 float diff = e - zv[t];
                 if (zq_out) {
-                    int64_t b = n / hw, p = n - b * hw;
+                    int64_t b, p;
+                    locate(t, &b, &p);
                     zq_out[(b * 4 + g) * hw + p] = zv[t] + diff;
                 }
                 sq += (double)diff * (double)diff;
@@ -208,6 +239,7 @@ __global__ __launch_bounds__(kVqThreads, ZT <= 4 ? 4 : 2) void vq_mfma_kernel(
         }
     }
 
+    CGIC_STAMP(4);
     if (sq_partial) {
         // deterministic block reduction: fixed shuffle tree, then waves in order
         __shared__ double wsum[4];
@@ -217,6 +249,8 @@ __global__ __launch_bounds__(kVqThreads, ZT <= 4 ? 4 : 2) void vq_mfma_kernel(
         __syncthreads();
         finish_loss(((wsum[0] + wsum[1]) + wsum[2]) + wsum[3], sq_partial, ticket, (double)N * 4.0, beta, legacy, loss);
     }
+    CGIC_STAMP(5);
+    CGIC_BLK_END();
 }
 
 // Plain-VALU restatement: one latent vector per thread, codebook broadcast from
