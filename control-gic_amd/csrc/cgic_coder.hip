@@ -484,9 +484,12 @@ struct BitWindow {
     __device__ __forceinline__ uint32_t fetch32(int p) const
     {
         const int o = 1 + (p >> 3) - wb + wsh;
-        const uint32_t a = win[o >> 2], b = win[(o >> 2) + 1];
-        const uint64_t w = ((uint64_t)__builtin_bswap32(a) << 32) | __builtin_bswap32(b);
-        return (uint32_t)((w << (8 * (o & 3) + (p & 7))) >> 32);
+        const uint32_t a = __builtin_bswap32(win[o >> 2]), b = __builtin_bswap32(win[(o >> 2) + 1]);
+        const uint32_t sh = (uint32_t)(8 * (o & 3) + (p & 7));          // 0..31 bits into the big-endian pair
+        // (a << sh) | (b >> (32 - sh)) as ONE v_alignbit_b32 (a 64-bit vector shift is several times dearer);
+        // alignbit's shift is mod 32, so sh == 0 needs the select
+        const uint32_t r = __builtin_amdgcn_alignbit(a, b, 32u - sh);
+        return sh ? r : a;
     }
     __device__ __forceinline__ int bit(int p) const
     {

@@ -102,8 +102,9 @@ __global__ __launch_bounds__(kEntThreads) void entropy_maps_kernel(
     const float inv_step = 15.5f;        // (nbins-1)/2 bins per unit; only picks the candidate window
     float s16 = 0.f;
 
-#pragma unroll 1
-    for (int sp = 0; sp < 4; ++sp) {     // 8x8 sub-patches, row-major: (0,0) (0,1) (1,0) (1,1)
+    // sum over the 64 pixels of 8x8 sub-patch `sp` of every bin's kernel value; every lane returns the
+    // total of bin (lane & 31) (both half-waves hold the same 32 totals)
+    auto subpatch_sum = [&](int sp) -> float {
         const int sy = sp >> 1, sx = sp & 1;
         // lane = pixel (row-major inside the 8x8 patch, like nn.Unfold)
         const int py = lane >> 3, px = lane & 7;
@@ -122,7 +123,7 @@ __global__ __launch_bounds__(kEntThreads) void entropy_maps_kernel(
             T[jb * kTileStride + lane] = kv;
         }
         __builtin_amdgcn_wave_barrier();
-        // lane = (bin, half): sum 32 pixels in order, then the two halves
+        // lane = (bin, half): sum 32 pixels in a fixed order, then the two halves
         const float4 *row = reinterpret_cast<const float4 *>(&T[bin * kTileStride + half * 32]);
         float4 a4 = row[0];
 #pragma unroll
@@ -136,16 +137,26 @@ __global__ __launch_bounds__(kEntThreads) void entropy_maps_kernel(
         // clear what this pixel deposited, ready for the next sub-patch
 #pragma unroll
         for (int q = 0; q < 5; ++q) T[(jlo + q) * kTileStride + lane] = 0.f;
-        s16 += s;
+        __builtin_amdgcn_wave_barrier();
+        return s;
+    };
+
+#pragma unroll 1
+    for (int pr = 0; pr < 2; ++pr) {     // sub-patch pairs (0,0)(0,1) then (1,0)(1,1), row-major like nn.Unfold
+        const float sA = subpatch_sum(2 * pr);
+        const float sB = subpatch_sum(2 * pr + 1);
+        s16 += sA;
+        s16 += sB;
         if (e8) {
-            float ent = patch_entropy(s, 1.0f / 64.0f);
-            if (lane == 0) {
+            // finalise BOTH 8x8 patches in one pass: half-wave 0 takes A, half-wave 1 takes B (the
+            // butterfly offsets 1..16 of sum32 stay inside a 32-lane half)
+            const float ent = patch_entropy(half ? sB : sA, 1.0f / 64.0f);
+            if ((lane & 31) == 0) {
                 const int64_t h8 = H / 8, w8 = W / 8;
-                e8[(b * h8 + (row0 / 8 + sy)) * w8 + (col0 / 8 + wave * 2 + sx)] = ent;
+                e8[(b * h8 + (row0 / 8 + pr)) * w8 + (col0 / 8 + wave * 2 + half)] = ent;
             }
         }
-        __builtin_amdgcn_wave_barrier();
-        CGIC_STAMP(20 + sp);
+        CGIC_STAMP(20 + pr);
     }
     if (e16) {
         float ent = patch_entropy(s16, 1.0f / 256.0f);
