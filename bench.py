@@ -2,7 +2,7 @@
 """bench.py -- encode+decode MPixels/s of the Control-GIC hot path on MI355X.
 
 One "step" = one pass of the hot path over one batch of synthetic input already resident in HBM:
-  encode: entropy maps (p8+p16) -> per-image router -> VQ argmin (+z_q, usage histogram)
+  encode: entropy maps (p8+p16) -> [VQ forward (indices, z_q, loss) + per-image router, one launch]
           -> masked select + Huffman + mask packing  (the five .bin streams per image)
   decode: prefix decode -> mask/index scatter + x2/x4 merge -> embedding gather
 Workload = BASELINE.json configs[1]: batch 64 of 256x256, codebook 1024x4, ratio (0.1, 0.8, 0.1).
@@ -64,10 +64,10 @@ class HotPath:
         self.pipe = cg.pipeline.HotPathPipeline(self.vq, ratio[0], ratio[1], chunks=chunks, frequency=self.codec.huffman, fork_vq=fork_vq)
 
     def encode(self):
-        from control_gic_amd.quantize import _vq_forward
+        from control_gic_amd.quantize import vq_forward_route
         e8, e16 = self.cg.entropy_maps(self.x)
-        mask, _, _, mode = self.router(e16, e8, want_gate=False)
-        zq, loss, ind = _vq_forward(self.z, self.vq.embedding.weight, 0.25, True, None)
+        zq, loss, ind, mask, _, mode = vq_forward_route(self.z, self.vq.embedding.weight, 0.25, True, e16, e8,
+                                                        self.router.coarse_grain_ratio, self.router.medium_grain_ratio)
         comp = self.codec.compress(ind, mask, mode, hist=self.hist)
         return e8, e16, mask, mode, zq, ind, comp
 
@@ -101,7 +101,10 @@ def stage_breakdown(hp, iters=30):
     comp = hp.codec.compress(ind, mask, mode)
     st = {}
     st["entropy_maps"] = time_events(lambda: cg.entropy_maps(hp.x), iters)
-    st["router"] = time_events(lambda: hp.router(e16, e8, want_gate=False), iters)
+    st["router_alone"] = time_events(lambda: hp.router(e16, e8, want_gate=False), iters)
+    from control_gic_amd.quantize import vq_forward_route
+    st["vq+router_fused_launch"] = time_events(lambda: vq_forward_route(hp.z, hp.vq.embedding.weight, 0.25, True, e16, e8,
+                                                                         hp.router.coarse_grain_ratio, hp.router.medium_grain_ratio), iters)
     # the dominant kernel on its own (one launch per call: indices + z_q + loss, no histogram pass)
     st["vq_kernel"] = time_events(lambda: _vq_forward(hp.z, hp.vq.embedding.weight, 0.25, True, None), max(iters, 100))
     st["vq_kernel_indices_only"] = time_events(lambda: hp.vq.indices(hp.z), iters)
@@ -261,7 +264,7 @@ def main():
                        "sharding": "images round-robin over ranks; one RCCL all-reduce of the int64[1024] histogram per run"},
             "bpp": round(bpp, 6), "bpp_match": bool(ok),
             "stages_us": stages,
-            "roofline": {"kernel": "vq_mfma_kernel<4>", "bound": "mfma", "achieved": round(achieved, 3),
+            "roofline": {"kernel": "vq_mfma_kernel<4> (runs as vq_router_kernel<4> with 64 router workgroups appended in the timed step)", "bound": "mfma", "achieved": round(achieved, 3),
                          "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4),
                          "traffic": traffic,
                          "note": "algorithmic flops = 2*N*K*D of the distance contraction per launch / HIP-event "

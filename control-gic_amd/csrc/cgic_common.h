@@ -53,6 +53,11 @@ struct TableDev {
     int dbl_rounds;   // pointer-doubling rounds that cover a 64-bit chunk: ceil(log2(ceil(64 / min_len)))
 };
 
+// `n` consecutive self-resetting ticket words (zero on entry; the kernel that uses one must leave it zero),
+// 64 bytes apart: ptr[0], ptr[16], ptr[32] ... (kTicketStride words).  See cgic_table.hip.
+constexpr int kTicketStride = 16;
+int acquire_tickets(hipStream_t stream, int n, unsigned int **ptr);
+
 struct Table;  // host object behind cgic_table
 int table_device_view(const cgic_table *t, TableDev *out);  // uploads lazily
 

@@ -1,0 +1,220 @@
+// cgic_router_dev.h -- device code of the granularity router (RouterTriple.py:15-95), shared by the
+// stand-alone launch (cgic_router.hip) and the horizontally fused VQ+router launch (cgic_vq.hip).
+#pragma once
+#include "cgic_common.h"
+
+#include <math.h>
+
+namespace cgic {
+
+constexpr int kRouterThreads = 1024;   // stand-alone launch; the VQ-fused launch runs the same body with 256
+
+__device__ __forceinline__ uint32_t f2key(float f)
+{
+    if (f != f) return 0xFFFFFFFFu;                       // NaN sorts last
+    uint32_t u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float key2f(uint32_t k)
+{
+    if (k == 0xFFFFFFFFu) return __uint_as_float(0x7FC00000u);
+    uint32_t u = (k & 0x80000000u) ? (k & 0x7FFFFFFFu) : ~k;
+    return __uint_as_float(u);
+}
+
+struct RouterShared {
+    unsigned int hist[256];
+    unsigned int prefix;
+    unsigned int rank;
+};
+
+// k-th smallest (0-based rank) of n values produced by val(i); all NT threads of the block call.
+template <int NT, typename F>
+__device__ float radix_select(F val, int64_t n, unsigned int rank0, RouterShared *sh)
+{
+    const int tid = threadIdx.x;
+    if (tid == 0) { sh->prefix = 0; sh->rank = rank0; }
+    unsigned int himask = 0;
+#pragma unroll 1
+    for (int shift = 24; shift >= 0; shift -= 8) {
+        if (tid < 256) sh->hist[tid] = 0;
+        __syncthreads();
+        const unsigned int prefix = sh->prefix;
+        // (a wave-aggregated variant -- one ballot per distinct digit per wave -- was measured 2x
+        // SLOWER than plain LDS atomics here, even though entropy values crowd into 2-3 bins of the
+        // first pass: 5.3 + 10.6 us vs 2.8 + 5.8 us for the two selects of a 256x256 image)
+        for (int64_t i = tid; i < n; i += NT) {
+            uint32_t key = f2key(val(i));
+            if ((key & himask) == prefix) atomicAdd(&sh->hist[(key >> shift) & 0xFF], 1u);
+        }
+        __syncthreads();
+        if (tid < kWave) {
+            // lane handles 4 consecutive digits; find the digit holding `rank`
+            const unsigned int rank = sh->rank;
+            unsigned int c0 = sh->hist[4 * tid], c1 = sh->hist[4 * tid + 1];
+            unsigned int c2 = sh->hist[4 * tid + 2], c3 = sh->hist[4 * tid + 3];
+            unsigned int s = c0 + c1 + c2 + c3;
+            unsigned int incl = wave_inclusive_scan(s);
+            unsigned int excl = incl - s;
+            if (excl <= rank && rank < incl) {
+                unsigned int r = rank - excl, d = 4 * tid;
+                if (r >= c0) { r -= c0; ++d; if (r >= c1) { r -= c1; ++d; if (r >= c2) { r -= c2; ++d; } } }
+                sh->prefix = prefix | (d << shift);
+                sh->rank = r;
+            }
+        }
+        himask |= 0xFFu << shift;
+        __syncthreads();
+    }
+    const float thr = key2f(sh->prefix);
+    __syncthreads();   // everyone has read prefix before a later call resets it
+    return thr;
+}
+
+struct RouterArgs {
+    const float *e16;
+    const float *e8;
+    int32_t *mask_c, *mask_m, *mask_f;
+    float *gate;
+    int64_t per;      // images per segment
+    int64_t h16, w16;
+    int mode;
+    unsigned int rank_c;   // 0-based rank of the coarse threshold in the segment
+    unsigned int rank_m;
+    int stage;             // 1: the segment's e16/e8 are copied to LDS once (all select passes read LDS)
+};
+
+// The whole router for segment `seg`, executed by a block of NT threads; `dyn` = dynamic LDS of at least
+// router_lds_bytes() bytes.
+template <int NT>
+__device__ __forceinline__ void router_body(const RouterArgs &a, int64_t seg, unsigned char *dyn)
+{
+    RouterShared *sh = reinterpret_cast<RouterShared *>(dyn);
+    unsigned long long *gc_bits = reinterpret_cast<unsigned long long *>(dyn + 1040);  // [ceil(N16/64)]
+
+    const int tid = threadIdx.x;
+    const int lane = lane_id();
+    CGIC_STAMP(0);
+    const int64_t h16 = a.h16, w16 = a.w16, h8 = 2 * h16, w8 = 2 * w16, h4 = 4 * h16, w4 = 4 * w16;
+    const int64_t n16 = h16 * w16, n8 = h8 * w8, n4 = h4 * w4;
+    const int64_t N16 = a.per * n16, N8 = a.per * n8, N4 = a.per * n4;
+    const float *e16 = a.e16 + seg * N16;
+    const float *e8 = a.e8 + seg * N8;
+    if (a.stage) {
+        // one round trip to HBM/L2 instead of one per radix pass (8 passes + 3 elementwise sweeps)
+        float *l16 = reinterpret_cast<float *>(gc_bits + ((N16 + 63) >> 6));
+        float *l8 = l16 + N16;
+        for (int64_t i = tid; i < N16; i += NT) l16[i] = e16[i];
+        for (int64_t i = tid; i < N8; i += NT) l8[i] = e8[i];
+        e16 = l16;
+        e8 = l8;
+        __syncthreads();
+    }
+    CGIC_STAMP(1);
+    int32_t *mc = a.mask_c + seg * N16;
+    int32_t *mm = a.mask_m + seg * N8;
+    int32_t *mf = a.mask_f + seg * N4;
+    const int mode = a.mode;
+    const bool has_thr_c = mode == 0 || mode == 2 || mode == 3;
+
+    // ---- coarse gate (RouterTriple.py:21-25 / 52-56 / 63-66)
+    float thr_c = 0.f;
+    if (has_thr_c) thr_c = radix_select<NT>([&](int64_t i) { return e16[i]; }, N16, a.rank_c, sh);
+    CGIC_STAMP(2);
+    const int64_t N16r = (N16 + 63) & ~(int64_t)63;
+    for (int64_t i = tid; i < N16r; i += NT) {
+        bool g = false;
+        if (i < N16) g = has_thr_c ? (e16[i] < thr_c) : (mode == 4);
+        unsigned long long bal = __ballot(g);
+        if (lane == 0) gc_bits[i >> 6] = bal;
+        if (i < N16) mc[i] = g ? 1 : 0;
+    }
+    __syncthreads();
+    // 32-bit index math throughout (N8 < 2^31 is checked on the host): a 64-bit divide is ~100 instructions
+    const int n8i = (int)n8, w8i = (int)w8, n16i = (int)n16, w16i = (int)w16;
+    auto gc_of8 = [&](int64_t i) -> bool {   // coarse gate of the parent of medium element i
+        const int ii = (int)i;
+        const int b = ii / n8i, r = ii - b * n8i;
+        const int y = r / w8i, x = r - y * w8i;
+        const int c = b * n16i + (y >> 1) * w16i + (x >> 1);
+        return (gc_bits[c >> 6] >> (c & 63)) & 1ull;
+    };
+
+    CGIC_STAMP(3);
+    // ---- medium gate
+    float thr_m = 0.f;
+    if (mode == 0) {      // :27-31: sort e8 * (1 - up2(gate_coarse))
+        if (a.stage) {
+            // materialise the masked values once (LDS), so the four radix passes are plain LDS sweeps
+            float *l8m = const_cast<float *>(e8) + N8;
+            for (int64_t i = tid; i < N8; i += NT) l8m[i] = e8[i] * (1.0f - (gc_of8(i) ? 1.0f : 0.0f));
+            __syncthreads();
+            thr_m = radix_select<NT>([&](int64_t i) { return l8m[i]; }, N8, a.rank_m, sh);
+        } else {
+            thr_m = radix_select<NT>([&](int64_t i) { return e8[i] * (1.0f - (gc_of8(i) ? 1.0f : 0.0f)); }, N8, a.rank_m, sh);
+        }
+    }
+    if (mode == 1)        // :40-43
+        thr_m = radix_select<NT>([&](int64_t i) { return e8[i]; }, N8, a.rank_m, sh);
+    auto gm_of8 = [&](int64_t i) -> bool {
+        switch (mode) {
+        case 0: return (e8[i] < thr_m) && !gc_of8(i);      // :32
+        case 1: return e8[i] < thr_m;                       // :44
+        case 3: return !gc_of8(i);                          // :68
+        case 5: return true;                                // :81
+        default: return false;
+        }
+    };
+    CGIC_STAMP(4);
+    for (int64_t i = tid; i < N8; i += NT) mm[i] = gm_of8(i) ? 1 : 0;
+    CGIC_STAMP(5);
+
+    // ---- fine gate + optional gate tensor (:34,47,58,69,77,83,87,93): 4 consecutive x per thread
+    // (w4 is a multiple of 4, so a quad never straddles a row, a medium pair or a coarse cell)
+    float *gate = a.gate ? a.gate + seg * N4 * 3 : nullptr;
+    const int W4 = (int)w4, W8 = (int)w8, W16 = (int)w16, NQ = (int)(N4 >> 2), n4i = (int)n4, qrow = W4 >> 2;
+    for (int q = tid; q < NQ; q += NT) {
+        const int i = q << 2;
+        const int b = i / n4i, r = i - b * n4i;
+        const int y = r / W4, x = r - y * W4;
+        const int64_t c = (int64_t)b * n16 + (y >> 2) * W16 + (x >> 2);
+        const bool gc = (gc_bits[c >> 6] >> (c & 63)) & 1ull;
+        const int64_t m0 = (int64_t)b * n8 + (y >> 1) * W8 + (x >> 1);
+        const bool gm0 = gm_of8(m0), gm1 = gm_of8(m0 + 1);
+        bool gf0, gf1;
+        switch (mode) {
+        case 0: gf0 = !gc && !gm0; gf1 = !gc && !gm1; break;
+        case 1: gf0 = !gm0; gf1 = !gm1; break;
+        case 2: gf0 = gf1 = !gc; break;
+        case 6: gf0 = gf1 = true; break;
+        default: gf0 = gf1 = false; break;
+        }
+        *reinterpret_cast<int4 *>(mf + i) = make_int4(gf0, gf0, gf1, gf1);
+        if (gate) {
+            float *row = gate + ((int64_t)b * h4 + y) * 3 * w4;
+            const float c1 = gc ? 1.f : 0.f, a0 = gm0 ? 1.f : 0.f, a1 = gm1 ? 1.f : 0.f;
+            *reinterpret_cast<float4 *>(row + x) = make_float4(c1, c1, c1, c1);
+            *reinterpret_cast<float4 *>(row + w4 + x) = make_float4(a0, a0, a1, a1);
+            *reinterpret_cast<float4 *>(row + 2 * w4 + x) = make_float4(gf0 ? 1.f : 0.f, gf0 ? 1.f : 0.f, gf1 ? 1.f : 0.f, gf1 ? 1.f : 0.f);
+        }
+        (void)qrow;
+    }
+    CGIC_STAMP(6);
+}
+
+
+__host__ __device__ inline size_t router_lds_bytes(int64_t N16, int64_t N8, int *stage)
+{
+    size_t lds = 1040 + 8 * (size_t)((N16 + 63) / 64);
+    const int st = lds + 4 * (size_t)(N16 + 2 * N8) <= 96 * 1024 ? 1 : 0;      // e16, e8 and the masked copy of e8
+    if (st) lds += 4 * (size_t)(N16 + 2 * N8);
+    if (stage) *stage = st;
+    return lds;
+}
+
+// host-side argument preparation shared by the stand-alone and the VQ-fused launch
+int router_prepare(const float *e16, const float *e8, int64_t B, int64_t h16, int64_t w16, double c_ratio,
+                   double m_ratio, int per_image, int32_t *mask_c, int32_t *mask_m, int32_t *mask_f, float *gate,
+                   RouterArgs *out, int64_t *nseg, size_t *lds);
+
+}  // namespace cgic

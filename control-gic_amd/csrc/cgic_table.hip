@@ -37,6 +37,54 @@ int hip_fail(hipError_t e, const char *what, const char *file, int line)
     return CGIC_ERR_HIP;
 }
 
+// ---- ticket pool ------------------------------------------------------------------------------
+// Kernels that hand work to "the last workgroup to arrive" need counters that are zero when the
+// launch starts.  A memset node per launch costs ~5 us as a fill kernel, so the library owns
+// zero-initialised device memory and every user resets its counter when it is done:
+//  * eager launches take the next slots of a ring (a slot is reused only after thousands of
+//    later launches, far beyond any stream queue depth);
+//  * launches being captured into a hipGraph take slots that are never handed out again (the
+//    graph may be replayed at any time later).
+// Both pools are created on the first EAGER call on a device (allocation is illegal in capture).
+constexpr size_t kRingSlots = 16384, kChunkSlots = 262144;
+struct TicketPool {
+    unsigned int *ring = nullptr;
+    size_t ring_next = 0;
+    unsigned int *chunk = nullptr;
+    size_t chunk_next = kChunkSlots;
+};
+
+int acquire_tickets(hipStream_t s, int n, unsigned int **ptr)
+{
+    static std::mutex mu;
+    static std::map<int, TicketPool> pools;
+    CGIC_REQUIRE(n > 0 && (size_t)n <= kRingSlots / 4, CGIC_ERR_INVALID, "acquire_tickets: bad count %d", n);
+    int dev = 0;
+    CGIC_HIP_TRY(hipGetDevice(&dev));
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    CGIC_HIP_TRY(hipStreamIsCapturing(s, &cap));
+    std::lock_guard<std::mutex> lock(mu);
+    TicketPool &p = pools[dev];
+    if (cap == hipStreamCaptureStatusNone) {
+        if (!p.ring) {
+            CGIC_HIP_TRY(hipMalloc((void **)&p.ring, sizeof(unsigned int) * kTicketStride * kRingSlots));
+            CGIC_HIP_TRY(hipMemset(p.ring, 0, sizeof(unsigned int) * kTicketStride * kRingSlots));
+            CGIC_HIP_TRY(hipMalloc((void **)&p.chunk, sizeof(unsigned int) * kTicketStride * kChunkSlots));
+            CGIC_HIP_TRY(hipMemset(p.chunk, 0, sizeof(unsigned int) * kTicketStride * kChunkSlots));
+            p.chunk_next = 0;
+        }
+        if (p.ring_next % kRingSlots + (size_t)n > kRingSlots) p.ring_next += kRingSlots - p.ring_next % kRingSlots;   // no wrap inside a range
+        *ptr = p.ring + (p.ring_next % kRingSlots) * kTicketStride;
+        p.ring_next += (size_t)n;
+    } else {
+        CGIC_REQUIRE(p.chunk && p.chunk_next + (size_t)n <= kChunkSlots, CGIC_ERR_INVALID,
+                     "call once outside stream capture on this device before capturing (or too many captured launches)");
+        *ptr = p.chunk + p.chunk_next * kTicketStride;
+        p.chunk_next += (size_t)n;
+    }
+    return CGIC_OK;
+}
+
 struct DevImage {
     int32_t *len = nullptr;
     uint32_t *code = nullptr;

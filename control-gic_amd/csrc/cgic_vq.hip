@@ -14,7 +14,7 @@
 //   mm = fma(z3,e3, fma(z2,e2, fma(z1,e1, z0*e0)))
 //   d  = fl(fl(zz + ee) - 2*mm)                   argmin, lowest index on ties
 // Compiled with -ffp-contract=off; every fused op is an explicit fmaf / MFMA.
-#include "cgic_common.h"
+#include "cgic_router_dev.h"
 
 #include <stdlib.h>
 
@@ -70,22 +70,23 @@ __device__ __forceinline__ float dist_valu(float z0, float z1, float z2, float z
 // (and 60 us at 4096).  The last block does one agent acquire and reads with sc1 loads.  `ticket` lives in library-owned device memory,
 // zeroed once at allocation; the last block resets it, so no per-call memset node is needed.
 __device__ __forceinline__ void finish_loss(double block_sum, double *sq_partial, unsigned int *ticket,
-                                            double count, float beta, int legacy, float *loss)
+                                            double count, float beta, int legacy, float *loss,
+                                            unsigned int blk, unsigned int nblk)
 {
     __shared__ double red[kVqThreads];
     __shared__ unsigned int s_last;
     const int tid = threadIdx.x;
     if (tid == 0) {
-        __hip_atomic_store(&sq_partial[blockIdx.x], block_sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&sq_partial[blk], block_sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        s_last = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1;
+        s_last = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == nblk - 1;
     }
     __syncthreads();
     if (!s_last) return;
     if (tid == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     __syncthreads();
     double a = 0.0;
-    for (unsigned int i = tid; i < gridDim.x; i += kVqThreads)
+    for (unsigned int i = tid; i < nblk; i += kVqThreads)
         a += __hip_atomic_load(&sq_partial[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     red[tid] = a;
     __syncthreads();
@@ -110,13 +111,31 @@ __device__ __forceinline__ void finish_loss(double block_sum, double *sq_partial
 // one tile on the VALU (bit-identical to the MFMA: same fmaf chain) and taking the first row equal
 // to the minimum.  Strict '<' on tiles + first-equal on rows + (value, index) lexicographic merge
 // across the 4 row groups == lowest index among exact minima, like torch.argmin.
+struct VqArgs {
+    const float *z;
+    int64_t hw, N;
+    const float *cb;
+    int K;
+    int64_t *idx_out;
+    float *zq_out;
+    double *sq_partial;
+    unsigned int *ticket;
+    float beta;
+    int legacy;
+    float *loss;
+    unsigned int nblk;        // VQ workgroups (a fused launch has router workgroups behind them)
+};
+
 template <int ZT>
-__global__ __launch_bounds__(kVqThreads, ZT <= 4 ? 4 : 2) void vq_mfma_kernel(
-    const float *__restrict__ z, int64_t hw, int64_t N, const float *__restrict__ cb, int K,
-    int64_t *__restrict__ idx_out, float *__restrict__ zq_out, double *__restrict__ sq_partial,
-    unsigned int *__restrict__ ticket, float beta, int legacy, float *__restrict__ loss)
+__device__ __forceinline__ void vq_mfma_body(const VqArgs &a, float *smem)
 {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const float *__restrict__ z = a.z;
+    const int64_t hw = a.hw, N = a.N;
+    const float *__restrict__ cb = a.cb;
+    const int K = a.K;
+    int64_t *__restrict__ idx_out = a.idx_out;
+    float *__restrict__ zq_out = a.zq_out;
+    double *__restrict__ sq_partial = a.sq_partial;
     float *cbT = smem;                // [4][K]
     float *ee = smem + 4 * K;         // [K]
 
@@ -247,10 +266,34 @@ __global__ __launch_bounds__(kVqThreads, ZT <= 4 ? 4 : 2) void vq_mfma_kernel(
         for (int off = 32; off > 0; off >>= 1) sq += __shfl_down(sq, off, kWave);
         if (lane == 0) wsum[wave] = sq;
         __syncthreads();
-        finish_loss(((wsum[0] + wsum[1]) + wsum[2]) + wsum[3], sq_partial, ticket, (double)N * 4.0, beta, legacy, loss);
+        finish_loss(((wsum[0] + wsum[1]) + wsum[2]) + wsum[3], sq_partial, a.ticket, (double)N * 4.0, a.beta, a.legacy, a.loss,
+                    blockIdx.x, a.nblk);
     }
     CGIC_STAMP(5);
     CGIC_BLK_END();
+}
+
+template <int ZT>
+__global__ __launch_bounds__(kVqThreads, ZT <= 4 ? 4 : 2) void vq_mfma_kernel(VqArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    vq_mfma_body<ZT>(a, smem);
+}
+
+// Horizontal fusion: the per-image router workgroups ride behind the VQ workgroups of the same launch.
+// The router is latency-bound (one workgroup per image, ~10 us of barriers and LDS sweeps) and needs
+// nothing from the VQ; VQ needs nothing from the router; both only need the kernels before them.  As
+// extra workgroups of this grid the router runs in the shadow of the ~45 us VQ instead of occupying its
+// own ~15 us slot on the stream (graph branches were measured to cost more than they hide).
+template <int ZT>
+__global__ __launch_bounds__(kVqThreads, ZT <= 4 ? 4 : 2) void vq_router_kernel(VqArgs a, RouterArgs r)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    if (blockIdx.x >= a.nblk) {
+        router_body<kVqThreads>(r, (int64_t)(blockIdx.x - a.nblk), reinterpret_cast<unsigned char *>(smem));
+        return;
+    }
+    vq_mfma_body<ZT>(a, smem);
 }
 
 // Plain-VALU restatement: one latent vector per thread, codebook broadcast from
@@ -308,7 +351,7 @@ __global__ __launch_bounds__(kVqThreads) void vq_valu_kernel(
         for (int off = 32; off > 0; off >>= 1) sq += __shfl_down(sq, off, kWave);
         if (lane == 0) wsum[wave] = sq;
         __syncthreads();
-        finish_loss(((wsum[0] + wsum[1]) + wsum[2]) + wsum[3], sq_partial, ticket, (double)N * 4.0, beta, legacy, loss);
+        finish_loss(((wsum[0] + wsum[1]) + wsum[2]) + wsum[3], sq_partial, ticket, (double)N * 4.0, beta, legacy, loss, blockIdx.x, gridDim.x);
     }
 }
 
@@ -361,62 +404,53 @@ struct VqWs {
     double *partial;        // caller's workspace: double partial[nblk]
 };
 
-// Every launch that needs the loss gets its OWN ticket word (64-byte slot, zero on entry, reset to
-// zero by the last workgroup), so launches on different streams never share one:
-//  * eager launches take the next slot of a 4096-slot ring (a slot is reused only after 4095 later
-//    launches, far beyond any stream queue depth);
-//  * launches being captured into a hipGraph take a slot that is never handed out again (the graph
-//    may be replayed at any time later), from 64 Ki-slot chunks.
-// Slots live in library-owned device memory zeroed at allocation: no per-call memset node.
-constexpr size_t kSlotWords = 16;
-constexpr size_t kRingSlots = 4096, kChunkSlots = 65536;
-struct TicketPool {
-    unsigned int *ring = nullptr;
-    size_t ring_next = 0;
-    unsigned int *chunk = nullptr;
-    size_t chunk_next = kChunkSlots;
-};
 static int vq_ws(void *workspace, hipStream_t s, VqWs *out)
 {
-    static std::mutex mu;
-    static std::map<int, TicketPool> pools;
     out->partial = (double *)workspace;
     out->ticket = nullptr;
     if (!workspace) return CGIC_OK;
-    int dev = 0;
-    CGIC_HIP_TRY(hipGetDevice(&dev));
-    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-    CGIC_HIP_TRY(hipStreamIsCapturing(s, &cap));
-    std::lock_guard<std::mutex> lock(mu);
-    TicketPool &p = pools[dev];
-    if (cap == hipStreamCaptureStatusNone) {
-        if (!p.ring) {
-            // both pools are created on the first EAGER call (allocation is illegal during capture)
-            CGIC_HIP_TRY(hipMalloc((void **)&p.ring, sizeof(unsigned int) * kSlotWords * kRingSlots));
-            CGIC_HIP_TRY(hipMemset(p.ring, 0, sizeof(unsigned int) * kSlotWords * kRingSlots));
-            CGIC_HIP_TRY(hipMalloc((void **)&p.chunk, sizeof(unsigned int) * kSlotWords * kChunkSlots));
-            CGIC_HIP_TRY(hipMemset(p.chunk, 0, sizeof(unsigned int) * kSlotWords * kChunkSlots));
-            p.chunk_next = 0;
-        }
-        out->ticket = p.ring + (p.ring_next++ % kRingSlots) * kSlotWords;
-    } else {
-        CGIC_REQUIRE(p.chunk && p.chunk_next < kChunkSlots, CGIC_ERR_INVALID,
-                     "vq: call once outside stream capture on this device before capturing (or too many captured launches)");
-        out->ticket = p.chunk + (p.chunk_next++) * kSlotWords;
-    }
-    return CGIC_OK;
+    return acquire_tickets(s, 1, &out->ticket);
 }
 
 template <int ZT>
 static int launch_mfma(const float *z, int64_t hw, int64_t N, const float *cb, int K, int64_t *idx,
-                       float *zq, VqWs ws, float beta, int legacy, float *loss, hipStream_t s)
+                       float *zq, VqWs ws, float beta, int legacy, float *loss, hipStream_t s,
+                       const RouterArgs *router, int64_t router_blocks, size_t router_lds)
 {
     const int64_t per_block = 4 * 16 * ZT;
-    const int nblk = (int)((N + per_block - 1) / per_block);
+    VqArgs a;
+    a.z = z; a.hw = hw; a.N = N; a.cb = cb; a.K = K; a.idx_out = idx; a.zq_out = zq;
+    a.sq_partial = loss ? ws.partial : nullptr; a.ticket = ws.ticket; a.beta = beta; a.legacy = legacy; a.loss = loss;
+    a.nblk = (unsigned int)((N + per_block - 1) / per_block);
     size_t lds = sizeof(float) * (size_t)K * 5;
-    hipLaunchKernelGGL(vq_mfma_kernel<ZT>, dim3(nblk), dim3(kVqThreads), lds, s, z, hw, N, cb, K, idx, zq,
-                       loss ? ws.partial : nullptr, ws.ticket, beta, legacy, loss);
-    return launch_check("vq_mfma_kernel");
+    if (!router) {
+        hipLaunchKernelGGL(vq_mfma_kernel<ZT>, dim3(a.nblk), dim3(kVqThreads), lds, s, a);
+        return launch_check("vq_mfma_kernel");
+    }
+    if (router_lds > lds) lds = router_lds;
+    if (lds > 64 * 1024)
+        CGIC_HIP_TRY(hipFuncSetAttribute((const void *)vq_router_kernel<ZT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(vq_router_kernel<ZT>, dim3(a.nblk + (unsigned int)router_blocks), dim3(kVqThreads), lds, s, a, *router);
+    return launch_check("vq_router_kernel");
+}
+
+static int vq_dispatch(const float *z, int64_t hw, int64_t N, const float *codebook, int K, int64_t *indices, float *z_q,
+                       VqWs ws, float beta, int legacy, float *loss, hipStream_t s, const RouterArgs *router,
+                       int64_t router_blocks, size_t router_lds)
+{
+    // per-wave tile: measured on MI355X (tools/probe_vq.hip) ZT=4 at 4 waves/SIMD is the fastest
+    // for large N; smaller N shrinks the tile so that all 256 CUs get work
+    static const int force_zt = getenv("CGIC_VQ_ZT") ? atoi(getenv("CGIC_VQ_ZT")) : 0;     // tuning knob (dev)
+#define CGIC_VQ_LAUNCH(ZT) launch_mfma<ZT>(z, hw, N, codebook, K, indices, z_q, ws, beta, legacy, loss, s, router, router_blocks, router_lds)
+    if (force_zt == 8) return CGIC_VQ_LAUNCH(8);
+    if (force_zt == 4) return CGIC_VQ_LAUNCH(4);
+    if (force_zt == 2) return CGIC_VQ_LAUNCH(2);
+    if (force_zt == 1) return CGIC_VQ_LAUNCH(1);
+    if (N >= (int64_t)1 << 22) return CGIC_VQ_LAUNCH(8);
+    if (N >= (int64_t)256 * 512) return CGIC_VQ_LAUNCH(4);
+    if (N >= (int64_t)128 * 512) return CGIC_VQ_LAUNCH(2);
+    return CGIC_VQ_LAUNCH(1);
+#undef CGIC_VQ_LAUNCH
 }
 
 }  // namespace cgic
@@ -441,19 +475,33 @@ extern "C" int cgic_vq_forward_f32(const float *z, int64_t B, int64_t hw, const 
     VqWs ws;
     rc = vq_ws(loss ? workspace : nullptr, s, &ws);
     if (rc) return rc;
-    // per-wave tile: measured on MI355X (tools/probe_vq.hip) ZT=4 at 4 waves/SIMD is the fastest
-    // for large N; smaller N shrinks the tile so that all 256 CUs get work
-    static const int force_zt = getenv("CGIC_VQ_ZT") ? atoi(getenv("CGIC_VQ_ZT")) : 0;     // tuning knob (dev)
-    if (force_zt == 8) rc = launch_mfma<8>(z, hw, N, codebook, K, indices, z_q, ws, beta, legacy, loss, s);
-    else if (force_zt == 4) rc = launch_mfma<4>(z, hw, N, codebook, K, indices, z_q, ws, beta, legacy, loss, s);
-    else if (force_zt == 2) rc = launch_mfma<2>(z, hw, N, codebook, K, indices, z_q, ws, beta, legacy, loss, s);
-    else if (force_zt == 1) rc = launch_mfma<1>(z, hw, N, codebook, K, indices, z_q, ws, beta, legacy, loss, s);
-    else if (N >= (int64_t)1 << 22) rc = launch_mfma<8>(z, hw, N, codebook, K, indices, z_q, ws, beta, legacy, loss, s);
-    else if (N >= (int64_t)256 * 512) rc = launch_mfma<4>(z, hw, N, codebook, K, indices, z_q, ws, beta, legacy, loss, s);
-    else if (N >= (int64_t)128 * 512) rc = launch_mfma<2>(z, hw, N, codebook, K, indices, z_q, ws, beta, legacy, loss, s);
-    else rc = launch_mfma<1>(z, hw, N, codebook, K, indices, z_q, ws, beta, legacy, loss, s);
+    rc = vq_dispatch(z, hw, N, codebook, K, indices, z_q, ws, beta, legacy, loss, s, nullptr, 0, 0);
     if (rc == CGIC_OK && hist) rc = launch_hist(indices, N, K, hist, s);
     return rc;
+}
+
+extern "C" int cgic_vq_forward_route_f32(const float *z, int64_t B, int64_t hw, const float *codebook, int K, int e_dim,
+                                         float beta, int legacy, int64_t *indices, float *z_q, float *loss,
+                                         void *workspace, const float *e16, const float *e8, int64_t h16, int64_t w16,
+                                         double coarse_ratio, double medium_ratio, int per_image, int32_t *mask_c,
+                                         int32_t *mask_m, int32_t *mask_f, float *gate, int *mode_out,
+                                         cgic_stream_t stream)
+{
+    int rc = vq_check(z, B, hw, codebook, K, e_dim, loss, workspace, false);
+    if (rc) return rc;
+    if (mode_out) *mode_out = cgic_router_mode(coarse_ratio, medium_ratio);
+    const int64_t N = B * hw;
+    if (N == 0) return CGIC_OK;
+    RouterArgs r;
+    int64_t nseg;
+    size_t rlds;
+    rc = router_prepare(e16, e8, B, h16, w16, coarse_ratio, medium_ratio, per_image, mask_c, mask_m, mask_f, gate, &r, &nseg, &rlds);
+    if (rc) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    VqWs ws;
+    rc = vq_ws(loss ? workspace : nullptr, s, &ws);
+    if (rc) return rc;
+    return vq_dispatch(z, hw, N, codebook, K, indices, z_q, ws, beta, legacy, loss, s, &r, nseg, rlds);
 }
 
 extern "C" int cgic_vq_forward_valu_f32(const float *z, int64_t B, int64_t hw, const float *codebook, int K,

@@ -12,7 +12,7 @@ import torch
 
 from .codec import GrainCodec
 from .entropy import entropy_maps
-from .quantize import _vq_forward
+from .quantize import _vq_forward, vq_forward_route
 from .router import TripleGrainFixedEntropyRouter
 
 
@@ -49,8 +49,10 @@ class HotPathPipeline:
             cur.wait_event(join)
         else:
             e8, e16 = entropy_maps(x)
-            mask, _, _, mode = self.router(e16, e8, want_gate=False)
-            zq, loss, ind = _vq_forward(z, self.vq.embedding.weight, self.vq.beta, self.vq.legacy, None)
+            # VQ and the per-image router share one launch (the router rides in the VQ kernel's shadow)
+            zq, loss, ind, mask, _, mode = vq_forward_route(
+                z, self.vq.embedding.weight, self.vq.beta, self.vq.legacy, e16, e8,
+                self.router.coarse_grain_ratio, self.router.medium_grain_ratio, per_image=True)
         comp = self.codec.compress(ind, mask, mode, hist=hist)      # usage histogram rides on the coder launch
         dec = self.codec.decompress(comp) if decode else None
         return {"e8": e8, "e16": e16, "mask": mask, "mode": mode, "z_q": zq, "loss": loss, "ind": ind,

@@ -98,6 +98,40 @@ def _vq_forward(z, weight, beta, legacy, hist, want_zq=True, want_loss=True, ker
     return z_q, loss, idx
 
 
+def vq_forward_route(z, weight, beta, legacy, e16, e8, coarse_ratio, medium_ratio, per_image=True, want_gate=False,
+                     want_zq=True, want_loss=True):
+    """VectorQuantize2.forward and TripleGrainFixedEntropyRouter.forward in ONE launch (the router's per-image
+    workgroups ride behind the VQ workgroups; see cgic_vq_forward_route_f32).  Returns
+    (z_q, loss, indices, [mask_c, mask_m, mask_f], gate, mode) -- identical to the two separate calls."""
+    import ctypes
+    _lib.require_device(z, weight, e16, e8)
+    B, C, h, w = z.shape
+    z = z.contiguous()
+    weight = weight.detach().contiguous()
+    e16 = e16.contiguous().float()
+    e8 = e8.contiguous().float()
+    _, h16, w16 = e16.shape
+    if tuple(e8.shape) != (B, 2 * h16, 2 * w16) or e16.shape[0] != B:
+        raise ValueError("entropy maps do not match the latent batch")
+    dev = z.device
+    N = B * h * w
+    idx = torch.empty(N, dtype=torch.int64, device=dev)
+    z_q = torch.empty_like(z) if want_zq else None
+    loss = torch.empty((), dtype=torch.float32, device=dev) if want_loss else None
+    ws = torch.empty(_lib.lib().cgic_vq_workspace_bytes(N), dtype=torch.uint8, device=dev) if want_loss else None
+    mc = torch.empty((B, 1, h16, w16), dtype=torch.int32, device=dev)
+    mm = torch.empty((B, 1, 2 * h16, 2 * w16), dtype=torch.int32, device=dev)
+    mf = torch.empty((B, 1, 4 * h16, 4 * w16), dtype=torch.int32, device=dev)
+    gate = torch.empty((B, 1, 4 * h16, 12 * w16), dtype=torch.float32, device=dev) if want_gate else None
+    mode = ctypes.c_int(0)
+    with torch.cuda.device(dev):
+        _lib.call("cgic_vq_forward_route_f32", _lib.ptr(z), B, h * w, _lib.ptr(weight), weight.shape[0], C, float(beta),
+                  int(bool(legacy)), _lib.ptr(idx), _lib.ptr(z_q), _lib.ptr(loss), _lib.ptr(ws), _lib.ptr(e16), _lib.ptr(e8),
+                  h16, w16, float(coarse_ratio), float(medium_ratio), int(bool(per_image)), _lib.ptr(mc), _lib.ptr(mm),
+                  _lib.ptr(mf), _lib.ptr(gate), ctypes.byref(mode), _lib.current_stream(dev))
+    return z_q, loss, idx, [mc, mm, mf], gate, mode.value
+
+
 class VectorQuantize2(nn.Module):
     def __init__(self, n_e, e_dim, beta, remap=None, unknown_index="random", sane_index_shape=False,
                  legacy=True):

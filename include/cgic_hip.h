@@ -70,6 +70,15 @@ size_t cgic_vq_workspace_bytes(int64_t n_vectors);
 int cgic_vq_forward_f32(const float *z, int64_t B, int64_t hw, const float *codebook, int K, int e_dim,
                         float beta, int legacy, int64_t *indices, float *z_q, float *loss,
                         int64_t *hist, void *workspace, cgic_stream_t stream);
+/* cgic_vq_forward_f32 and cgic_router_f32 in ONE launch: the router's per-image workgroups ride behind
+ * the VQ workgroups of the same grid (neither needs the other's output; both need what precedes them,
+ * i.e. the latent and the entropy maps).  Same contracts as the two separate calls. */
+int cgic_vq_forward_route_f32(const float *z, int64_t B, int64_t hw, const float *codebook, int K, int e_dim,
+                              float beta, int legacy, int64_t *indices, float *z_q, float *loss,
+                              void *workspace, const float *e16, const float *e8, int64_t h16, int64_t w16,
+                              double coarse_ratio, double medium_ratio, int per_image, int32_t *mask_c,
+                              int32_t *mask_m, int32_t *mask_f, float *gate, int *mode_out,
+                              cgic_stream_t stream);
 /* same contract, plain-VALU kernel (no MFMA); kept as an independent
  * implementation for cross-checking the MFMA kernel's rounding */
 int cgic_vq_forward_valu_f32(const float *z, int64_t B, int64_t hw, const float *codebook, int K,

@@ -387,3 +387,21 @@ def test_chunked_pipeline_equals_unchunked(golden):
     eager = cg.HotPathPipeline(vq, 0.1, 0.8, chunks=4).run(x, z)
     torch.cuda.synchronize()
     assert float(rs[0]["loss"]) == float(eager[0]["loss"])
+
+
+def test_fused_vq_router_launch_equals_separate_calls(orc):
+    """cgic_vq_forward_route_f32: router workgroups appended to the VQ grid -- identical outputs"""
+    from control_gic_amd.quantize import _vq_forward, vq_forward_route
+    rng = np.random.default_rng(21)
+    for (B, h16, w16) in ((64, 16, 16), (3, 12, 9), (1, 48, 48)):
+        z = _t(rng.standard_normal((B, 4, 4 * h16, 4 * w16), dtype=np.float32))
+        w = _t(rng.standard_normal((1024, 4), dtype=np.float32))
+        e16 = _t((rng.random((B, h16, w16)) * 2.6).astype(np.float32))
+        e8 = _t((rng.random((B, 2 * h16, 2 * w16)) * 2.6).astype(np.float32))
+        for c, m in ((0.1, 0.8), (0.0, 0.5), (0.5, 0.5), (0.0, 0.0)):
+            for per_image in (True, False):
+                zq, loss, idx, mask, gate, mode = vq_forward_route(z, w, 0.25, True, e16, e8, c, m, per_image=per_image, want_gate=True)
+                zq2, loss2, idx2 = _vq_forward(z, w, 0.25, True, None)
+                mask2, gate2, _, mode2 = cg.TripleGrainFixedEntropyRouter(c, m, per_image=per_image)(e16, e8)
+                assert mode == mode2 and torch.equal(idx, idx2) and torch.equal(zq, zq2) and float(loss) == float(loss2)
+                assert all(torch.equal(a, b) for a, b in zip(mask, mask2)) and torch.equal(gate, gate2)
