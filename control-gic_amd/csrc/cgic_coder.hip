@@ -498,15 +498,30 @@ struct BitWindow {
         const int o = 1 + (p >> 3) - wb + wsh;
         return (int)((win[o >> 2] >> (8 * (o & 3) + 7 - (p & 7))) & 1u);
     }
+    // the same as fetch32 with the address split: consecutive 64-bit chunks of one lane differ by
+    // exactly two words and keep the same shift, so a chunk loop only adds 2 to `wi`
+    __device__ __forceinline__ void locate(int p, int *wi, uint32_t *sh) const
+    {
+        const int o = 1 + (p >> 3) - wb + wsh;
+        *wi = o >> 2;
+        *sh = (uint32_t)(8 * (o & 3) + (p & 7));
+    }
+    __device__ __forceinline__ uint32_t fetch32_at(int wi, uint32_t sh) const
+    {
+        const uint32_t a = __builtin_bswap32(win[wi]), b = __builtin_bswap32(win[wi + 1]);
+        const uint32_t r = __builtin_amdgcn_alignbit(a, b, 32u - sh);
+        return sh ? r : a;
+    }
 };
 
 // codeword starting at payload bit p: returns its length (0 = no complete codeword before
 // nbits) and symbol.  Per-lane; long codes walk the trie (window must cover p + 64 + 32 bits).
+// `bits` = the 32 payload bits starting at p (BitWindow::fetch32(p)).
 __device__ __forceinline__ int codeword_at(const TableDev &t, const uint32_t *lut, const BitWindow &bw,
-                                           int p, int nbits, int *sym)
+                                           int p, int nbits, int *sym, uint32_t bits)
 {
     if (p >= nbits) return 0;
-    const uint32_t e = lut[bw.fetch32(p) >> (32 - t.lut_bits)];
+    const uint32_t e = lut[bits >> (32 - t.lut_bits)];
     int L = (int)(e & 0xFF);
     int S = (int)(e >> 8);
     if (L == 0) {
@@ -526,6 +541,11 @@ __device__ __forceinline__ int codeword_at(const TableDev &t, const uint32_t *lu
     if (p + L > nbits) return 0;       // trailing partial codeword: dropped by the reference
     *sym = S;
     return L;
+}
+__device__ __forceinline__ int codeword_at(const TableDev &t, const uint32_t *lut, const BitWindow &bw,
+                                           int p, int nbits, int *sym)
+{
+    return p < nbits ? codeword_at(t, lut, bw, p, nbits, sym, bw.fetch32(p)) : 0;
 }
 
 struct SegShared {
@@ -572,10 +592,13 @@ __device__ __forceinline__ void decode_segmented(const TableDev &t, const uint32
             // what bounds this pass): bits 0..7 = next position (0..127, kPackBig = past the stream),
             // bits 8..15 = codewords on the way
             int pk[kU];
+            int wi0;
+            uint32_t sh0;
+            bw.locate(c * kWave + lane, &wi0, &sh0);
 #pragma unroll
             for (int u = 0; u < kU; ++u) {
                 int sym = 0;
-                const int L = c + u < c1 ? codeword_at(t, lut, bw, (c + u) * kWave + lane, nbits, &sym) : 0;
+                const int L = c + u < c1 ? codeword_at(t, lut, bw, (c + u) * kWave + lane, nbits, &sym, bw.fetch32_at(wi0 + 2 * u, sh0)) : 0;
                 pk[u] = L ? ((lane + L) | (1 << 8)) : kPackBig;
                 if (fast && c + u < c1) {
                     ft->len[(c + u) * kWave + lane] = (uint8_t)L;
@@ -588,7 +611,7 @@ __device__ __forceinline__ void decode_segmented(const TableDev &t, const uint32
                 for (int u = 0; u < kU; ++u) {
                     const int nx = pk[u] & 0xFF;
                     const int o = __shfl(pk[u], nx & 63, kWave);
-                    if (nx < kWave) pk[u] = (o & 0xFF) | ((pk[u] & 0xFF00) + (o & 0xFF00));
+                    if (nx < kWave) pk[u] = o + (pk[u] & 0xFF00);       // new next | (count + count on the way); counts <= 64
                 }
             }
             if (c == 0) CGIC_STAMP3(18);
