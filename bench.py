@@ -34,6 +34,21 @@ def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
+class stdout_to_stderr:
+    """RCCL prints a version banner on the process's stdout (fd 1) when a communicator is created; the
+    contract is ONE JSON line on stdout, so fd 1 points at stderr while that happens."""
+
+    def __enter__(self):
+        sys.stdout.flush()
+        self._saved = os.dup(1)
+        os.dup2(2, 1)
+
+    def __exit__(self, *exc):
+        sys.stdout.flush()
+        os.dup2(self._saved, 1)
+        os.close(self._saved)
+
+
 def zipf_freq():
     return np.floor(2.0e6 / (1 + np.arange(1024)) ** 1.1).astype(np.int64)
 
@@ -184,10 +199,17 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist = None
-    if world > 1:
+    if world > 1 or "RANK" in os.environ:                   # under torch.distributed.run also with one rank
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)      # "nccl" is RCCL on ROCm
+        os.environ.setdefault("MASTER_PORT", "29500")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", str(world))
+        with stdout_to_stderr():
+            dist.init_process_group("nccl", device_id=dev)  # "nccl" is RCCL on ROCm
+            warm = torch.zeros(1024, dtype=torch.int64, device=dev)
+            dist.all_reduce(warm)                           # creates the communicator (and its banner) now
+            torch.cuda.synchronize()
 
     B, H, W = a.batch, a.size, a.size
     ratio = (0.1, 0.8)
