@@ -1,0 +1,85 @@
+#!/usr/bin/env python3
+"""BASELINE config 5 in miniature: a mixed stream of Kodak-sized (768x512) and DIV2K-sized (2040x1356, tiled)
+synthetic images, sharded round-robin over the ranks of one node, ONE RCCL all-reduce of the int64[1024] usage
+histogram at the end and a 2-scalar reduction for the dataset-average bpp.
+
+    python examples/mixed_stream.py                       # 1 GPU
+    python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 examples/mixed_stream.py
+
+The conv encoder of the codec is out of scope: `encode()` below stands in for it with a cheap deterministic
+latent (average-pooled image channels), then runs the real hot path: entropy maps -> [VQ + per-tile router]
+-> stream coder; tiles of equal shape go through the kernels as one batch.
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import control_gic_amd as cg                                                       # noqa: E402
+from control_gic_amd import container, dist as cdist, highres                      # noqa: E402
+from control_gic_amd.quantize import vq_forward_route                              # noqa: E402
+
+
+def main():
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if "RANK" in os.environ:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.distributed.init_process_group("nccl", device_id=dev)
+
+    sizes = [(512, 768)] * 6 + [(1356, 2040)] * 2 + [(512, 768)] * 6 + [(1356, 2040)] * 2      # (H, W) stream order
+    vq = cg.VectorQuantizer(1024, 4, beta=0.25).to(dev).eval()
+    vq.embedding.weight.data.copy_(torch.from_numpy(np.random.default_rng(12345).standard_normal((1024, 4), dtype=np.float32)))
+    vq.usage_counter.copy_(torch.from_numpy(np.floor(2.0e6 / (1 + np.arange(1024)) ** 1.1).astype(np.float32)))
+    codec = cg.GrainCodec(vq.embedding_counter, vq.embedding.weight)
+    hist = torch.zeros(1024, dtype=torch.int64, device=dev)
+
+    def encode(tiles):
+        e8, e16 = cg.entropy_maps(tiles)
+        z = torch.nn.functional.avg_pool2d(torch.cat([tiles, tiles[:, :1]], 1), 4) * 4 - 2     # stand-in latent [T,4,h,w]
+        _, _, ind, mask, _, mode = vq_forward_route(z, vq.embedding.weight, 0.25, True, e16, e8, 0.1, 0.8,
+                                                    per_image=True, want_zq=False, want_loss=False)
+        cg._lib.call("cgic_index_histogram", ind.data_ptr(), ind.numel(), 1024, hist.data_ptr(), cg._lib.current_stream(dev))
+        return ind, mask, mode
+
+    bits = pixels = 0
+    blobs = []
+    for i in cdist.shard(len(sizes), rank, world):
+        H, W = sizes[i]
+        x = torch.from_numpy(np.random.default_rng(100 + i).random((1, 3, H, W), dtype=np.float32)).to(dev)
+        x = x[:, :, :H // 16 * 16, :W // 16 * 16] if H <= 768 and W <= 768 else x       # small images: centre-crop rule of inference.py:66-70
+        tiled = highres.compress_tiled(x, encode, codec)
+        entries = container.entries_from_tiled(tiled, image_id=i)
+        blobs.append(container.pack(entries))
+        bits += sum(len(v) for e in entries for v in e["streams"].values()) * 8
+        pixels += x.shape[-1] * x.shape[-2]
+        # decode side on the same rank: every tile must come back (masks exactly; indices wherever the fine grain kept them)
+        per_tile, _ = highres.decompress_tiled(tiled, codec)
+        for idxs, _, (ind0, masks0, _) in tiled.groups:
+            T = len(idxs)
+            fine = masks0[2].reshape(T, -1).bool()
+            got = torch.cat([per_tile[t][0].reshape(1, -1) for t in idxs])
+            assert torch.equal(got[fine], ind0.reshape(T, -1)[fine])
+            for g in range(3):
+                assert torch.equal(torch.cat([per_tile[t][1][g] for t in idxs]).reshape(T, -1), masks0[g].reshape(T, -1))
+    cdist.all_reduce_histogram(hist)                       # the path's only collective
+    bpp = cdist.average_bpp(bits, pixels, device=dev)
+    if rank == 0:
+        total = int(hist.sum())
+        want = sum(((h + 15) // 16 * 4) * ((w + 15) // 16 * 4) if (h > 768 or w > 768) else (h // 16 * 4) * (w // 16 * 4) for h, w in sizes)
+        print(f"ranks {world}: {len(sizes)} images, average bpp {bpp:.5f}, histogram total {total} (latent vectors: {want}), "
+              f"container bytes on rank 0: {sum(map(len, blobs))}")
+        assert total == want
+    if torch.distributed.is_initialized():
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

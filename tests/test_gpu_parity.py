@@ -1,6 +1,7 @@
 """GPU: the HIP path (through the C ABI of libcgic_hip.so) against the golden vectors of the real
 reference and against the CPU oracle on seeded inputs.  Integer / byte / index results are
 compared bit-exactly; fp32 tolerances are written next to each assert."""
+import os
 import numpy as np
 import pytest
 import torch
@@ -405,3 +406,16 @@ def test_fused_vq_router_launch_equals_separate_calls(orc):
                 mask2, gate2, _, mode2 = cg.TripleGrainFixedEntropyRouter(c, m, per_image=per_image)(e16, e8)
                 assert mode == mode2 and torch.equal(idx, idx2) and torch.equal(zq, zq2) and float(loss) == float(loss2)
                 assert all(torch.equal(a, b) for a, b in zip(mask, mask2)) and torch.equal(gate, gate2)
+
+
+def test_mixed_stream_example_runs():
+    """examples/mixed_stream.py (BASELINE config 5 in miniature): tiled + untiled images, histogram total == number of
+    latent vectors, every tile decodes back -- asserted inside the script"""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(root, "examples", "mixed_stream.py")], capture_output=True, text=True,
+                       timeout=600, env=env)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "histogram total 991232" in r.stdout
