@@ -69,11 +69,12 @@ __device__ __forceinline__ float dist_valu(float z0, float z1, float z2, float z
 // release fence: a per-workgroup buffer_wbl2 measured ~10 us per launch at 1024 workgroups
 // (and 60 us at 4096).  The last block does one agent acquire and reads with sc1 loads.  `ticket` lives in library-owned device memory,
 // zeroed once at allocation; the last block resets it, so no per-call memset node is needed.
+template <int NT>
 __device__ __forceinline__ void finish_loss(double block_sum, double *sq_partial, unsigned int *ticket,
                                             double count, float beta, int legacy, float *loss,
                                             unsigned int blk, unsigned int nblk)
 {
-    __shared__ double red[kVqThreads];
+    __shared__ double red[NT];
     __shared__ unsigned int s_last;
     const int tid = threadIdx.x;
     if (tid == 0) {
@@ -86,11 +87,11 @@ __device__ __forceinline__ void finish_loss(double block_sum, double *sq_partial
     if (tid == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     __syncthreads();
     double a = 0.0;
-    for (unsigned int i = tid; i < nblk; i += kVqThreads)
+    for (unsigned int i = tid; i < nblk; i += NT)
         a += __hip_atomic_load(&sq_partial[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     red[tid] = a;
     __syncthreads();
-    for (int off = kVqThreads / 2; off > 0; off >>= 1) {
+    for (int off = NT / 2; off > 0; off >>= 1) {
         if (tid < off) red[tid] += red[tid + off];
         __syncthreads();
     }
@@ -266,7 +267,7 @@ __device__ __forceinline__ void vq_mfma_body(const VqArgs &a, float *smem)
         for (int off = 32; off > 0; off >>= 1) sq += __shfl_down(sq, off, kWave);
         if (lane == 0) wsum[wave] = sq;
         __syncthreads();
-        finish_loss(((wsum[0] + wsum[1]) + wsum[2]) + wsum[3], sq_partial, a.ticket, (double)N * 4.0, a.beta, a.legacy, a.loss,
+        finish_loss<kVqThreads>(((wsum[0] + wsum[1]) + wsum[2]) + wsum[3], sq_partial, a.ticket, (double)N * 4.0, a.beta, a.legacy, a.loss,
                     blockIdx.x, a.nblk);
     }
     CGIC_STAMP(5);
@@ -294,6 +295,396 @@ __global__ __launch_bounds__(kVqThreads, ZT <= 4 ? 4 : 2) void vq_router_kernel(
         return;
     }
     vq_mfma_body<ZT>(a, smem);
+}
+
+// =====================================================================================================
+// Filter path (K % 64 == 0, K <= 1024; the reference's codebook is 1024 x 4): the bf16 matrix cores find
+// the candidates, fp32 decides.  The exact loop above costs ~7 issue slots per (16 codes x 16 vectors)
+// tile, 4 of them the fp32 MFMA (which does not overlap VALU work on gfx950); it cannot be made cheaper
+// and still deliver every distance.  But argmin only needs the distances that can win:
+//
+//  * score  f(k) = ee_k - 2 z.e_k  (the distance minus zz, which does not change the argmin) comes out of
+//    ONE v_mfma_f32_16x16x32_bf16 per tile: z_j, -2 e_kj and ee_k are each split exactly into three bf16
+//    (8+8+8 significand bits, by truncation); the 32 K-slots carry, per dimension, the six products
+//    zh.wh zh.wm zm.wh zh.wl zl.wh zm.wm, plus ee's three pieces against 1.0.  Dropped terms and fp32
+//    accumulation leave |f - F| <= 2^-17.6 S, S = max ee + 2 max|e| sum|z_j| (measured: ~2^-22 S).
+//  * per lane, a running (smallest, second smallest, where) over PAIRS of tiles: 4 v_min3 + cmp + cndmask
+//    + med3 + min for 2 MFMAs -- 4 slots per tile, and a 16-cycle bf16 MFMA hides beside them.
+//  * every code whose reference distance could be minimal has f <= f_min + M,
+//    M = 2 (|f - F| + |d_ref - zz - F|) <= 1.2e-5 S + 2.5e-7 zz  (d_ref's own rounding: 2^-23 zz + 2^-21 S).
+//    If the winner's pair-of-tiles is the only place holding such codes (second-smallest pair value of every
+//    row group above the threshold, one hot row group), its 8 codes are evaluated with the exact fp32
+//    sequence and the lowest-index minimum is the reference's argmin.  Otherwise (0.1-0.5 % of N(0,1)
+//    vectors) the wave scans all K codes exactly for that vector; a group with many such vectors reruns
+//    the exact fp32-MFMA loop.  Results are bit-identical to the exact kernels for every finite input.
+// =====================================================================================================
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+constexpr int kVqfThreads = 512;               // 8 waves, one workgroup per CU (84 KB of LDS at K = 1024)
+constexpr int kVqfWaves = kVqfThreads / 64;
+constexpr int kVqfMaxK = 1024;
+constexpr int kVqfBulk = 12;                   // more flagged vectors than this in a 64-vector group: rerun it exactly on the MFMA
+
+// x == h + m + l exactly, three bf16 by truncation (|m| < 2^-7 |x|, |l| < 2^-14 |x|)
+__device__ __forceinline__ void split3(float x, unsigned int &h, unsigned int &m, unsigned int &l)
+{
+    const unsigned int xb = __float_as_uint(x);
+    h = xb >> 16;
+    const float r1 = x - __uint_as_float(xb & 0xFFFF0000u);
+    const unsigned int rb = __float_as_uint(r1);
+    m = rb >> 16;
+    const float r2 = r1 - __uint_as_float(rb & 0xFFFF0000u);
+    l = __float_as_uint(r2) >> 16;
+}
+
+// the reference's rounding sequence for one codebook row
+__device__ __forceinline__ float dist_row(float z0, float z1, float z2, float z3, float zz, const float4 e)
+{
+    float mm = z0 * e.x;
+    mm = __builtin_fmaf(z1, e.y, mm);
+    mm = __builtin_fmaf(z2, e.z, mm);
+    mm = __builtin_fmaf(z3, e.w, mm);
+    return __builtin_fmaf(-2.0f, mm, zz + sumsq4(e.x, e.y, e.z, e.w));
+}
+
+template <int ZT>
+__device__ __forceinline__ void vq_filter_body(const VqArgs &a, unsigned char *smem)
+{
+    constexpr int NT = kVqfThreads, NW = kVqfWaves;
+    const float *__restrict__ z = a.z;
+    const int64_t hw = a.hw, N = a.N;
+    const int K = a.K, ntile = K >> 4, np = K >> 5;
+    int64_t *__restrict__ idx_out = a.idx_out;
+    float *__restrict__ zq_out = a.zq_out;
+    uint4 *ldsA = reinterpret_cast<uint4 *>(smem);                         // [K/16][64] bf16x8 A operands
+    float4 *cbs = reinterpret_cast<float4 *>(smem + (size_t)K * 64);       // [K] fp32 rows
+    __shared__ unsigned int s_max[2];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int j = lane & 15;   // column: which latent vector of the tile
+    const int g = lane >> 4;   // K-slot group of the operands (= dimension) / row group of the result
+
+    CGIC_STAMP(0);
+    CGIC_BLK_BEGIN();
+    // ---- stage: fp32 rows, then the split A operands built from them
+    if (tid < 2) s_max[tid] = 0;
+    for (int i = tid; i < K; i += NT) cbs[i] = reinterpret_cast<const float4 *>(a.cb)[i];
+    __syncthreads();
+    {
+        float emax = 0.f, eemax = 0.f;
+#pragma unroll 4
+        for (int i = tid; i < ntile * 64; i += NT) {
+            const int l = i & 63, gg = l >> 4;
+            const float4 e = cbs[((i >> 6) << 4) + (l & 15)];
+            const float ee = sumsq4(e.x, e.y, e.z, e.w);
+            const float ec = gg == 0 ? e.x : gg == 1 ? e.y : gg == 2 ? e.z : e.w;
+            unsigned int wh, wm, wl, eh, em, el;
+            split3(-2.0f * ec, wh, wm, wl);
+            split3(ee, eh, em, el);
+            uint4 av;
+            av.x = wh | (wm << 16);
+            av.y = wh | (wl << 16);
+            av.z = wh | (wm << 16);
+            av.w = gg == 0 ? eh : gg == 1 ? em : gg == 2 ? el : 0u;
+            ldsA[i] = av;
+            emax = fmaxf(emax, fabsf(ec));
+            eemax = fmaxf(eemax, ee);
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            emax = fmaxf(emax, __shfl_xor(emax, off, kWave));
+            eemax = fmaxf(eemax, __shfl_xor(eemax, off, kWave));
+        }
+        // non-negative floats order like their bit patterns; a NaN lands above every finite value
+        if (lane == 0) { atomicMax(&s_max[0], __float_as_uint(emax)); atomicMax(&s_max[1], __float_as_uint(eemax)); }
+    }
+    __syncthreads();
+    const float Emax = __uint_as_float(s_max[0]), EEmax = __uint_as_float(s_max[1]);
+    CGIC_STAMP(1);
+
+    // ---- this wave's contiguous range of 16*ZT-vector groups
+    const int64_t ngroups = (N + 16 * ZT - 1) / (16 * ZT);
+    const int64_t nwaves = (int64_t)a.nblk * NW;
+    const int64_t per = (ngroups + nwaves - 1) / nwaves;
+    const int64_t g_lo = ((int64_t)blockIdx.x * NW + wave) * per;
+    const int64_t g_hi = g_lo + per < ngroups ? g_lo + per : ngroups;
+
+    // (image, position) of a group's first vector: one 64-bit division per wave, then add and carry
+    int64_t b0 = 0, p0 = 0;
+    if (g_lo < g_hi) {
+        b0 = (g_lo * (16 * ZT)) / hw;
+        p0 = g_lo * (16 * ZT) - b0 * hw;
+    }
+    auto locate = [&](int64_t bb, int64_t pp, int t, int64_t *b, int64_t *p) {
+        pp += 16 * t + j;
+        while (pp >= hw) { pp -= hw; ++bb; }
+        *b = bb; *p = pp;
+    };
+    auto load_group = [&](int64_t grp, int64_t bb, int64_t pp, float (&out)[ZT]) {
+#pragma unroll
+        for (int t = 0; t < ZT; ++t) {
+            const int64_t n = grp * (16 * ZT) + 16 * t + j;
+            float v = 0.f;
+            if (n < N) {
+                int64_t b, p;
+                locate(bb, pp, t, &b, &p);
+                v = z[(b * 4 + g) * hw + p];
+            }
+            out[t] = v;
+        }
+    };
+
+    double sq = 0.0;
+    float zn[ZT];
+    if (g_lo < g_hi) load_group(g_lo, b0, p0, zn);
+
+    for (int64_t grp = g_lo; grp < g_hi; ++grp) {
+        const int64_t base = grp * (16 * ZT);
+        const int64_t gb = b0, gp = p0;
+        float zv[ZT], m1[ZT], m2[ZT];
+        int bt[ZT];
+        bf16x8 bop[ZT];
+#pragma unroll
+        for (int t = 0; t < ZT; ++t) {
+            zv[t] = zn[t];
+            unsigned int h, m, l;
+            split3(zv[t], h, m, l);
+            uint4 bb;
+            bb.x = h | (h << 16);
+            bb.y = m | (h << 16);
+            bb.z = l | (m << 16);
+            bb.w = 0x3F80u;                       // 1.0 against ee's piece; slot 7 = 0
+            bop[t] = __builtin_bit_cast(bf16x8, bb);
+            m1[t] = __builtin_inff();
+            m2[t] = __builtin_inff();
+            bt[t] = 0;
+        }
+        // next group's latents are in flight during this group's scan
+        p0 += 16 * ZT;
+        while (p0 >= hw) { p0 -= hw; ++b0; }
+        if (grp + 1 < g_hi) load_group(grp + 1, b0, p0, zn);
+        CGIC_STAMP(2);
+
+        // ---- scan: pairs of code tiles, ping-pong -- the MFMAs of pair p+1 run while the VALU digests pair p
+        f32x4 X0[ZT], X1[ZT], Y0[ZT], Y1[ZT];
+        const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+        auto issue = [&](int p, f32x4 (&A0)[ZT], f32x4 (&A1)[ZT]) {
+            const int pp = p < np ? p : np - 1;
+            const bf16x8 a0 = __builtin_bit_cast(bf16x8, ldsA[(2 * pp) * 64 + lane]);
+            const bf16x8 a1 = __builtin_bit_cast(bf16x8, ldsA[(2 * pp + 1) * 64 + lane]);
+#pragma unroll
+            for (int t = 0; t < ZT; ++t) {
+                A0[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, bop[t], zero4, 0, 0, 0);
+                A1[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, bop[t], zero4, 0, 0, 0);
+            }
+        };
+        auto digest = [&](int p, const f32x4 (&A0)[ZT], const f32x4 (&A1)[ZT]) {
+#pragma unroll
+            for (int t = 0; t < ZT; ++t) {
+                // chain seeded with a constant: v_min3_f32 takes the raw MFMA outputs without a canonicalising v_max
+                float u = __builtin_fminf(__builtin_fminf(__builtin_inff(), A0[t][0]), A0[t][1]);
+                u = __builtin_fminf(__builtin_fminf(u, A0[t][2]), A0[t][3]);
+                u = __builtin_fminf(__builtin_fminf(u, A1[t][0]), A1[t][1]);
+                u = __builtin_fminf(__builtin_fminf(u, A1[t][2]), A1[t][3]);
+                bt[t] = u < m1[t] ? p : bt[t];
+                m2[t] = __builtin_amdgcn_fmed3f(m1[t], m2[t], u);     // second smallest pair value
+                m1[t] = __builtin_fminf(m1[t], u);
+            }
+        };
+        issue(0, X0, X1);
+        for (int p = 0; p < np; p += 2) {
+            issue(p + 1, Y0, Y1);
+            digest(p, X0, X1);
+            issue(p + 2, X0, X1);      // the last one is a harmless repeat of the final pair
+            digest(p + 1, Y0, Y1);
+        }
+        CGIC_STAMP(3);
+
+        // ---- decide
+        float z0[ZT], z1[ZT], z2[ZT], z3[ZT], zz[ZT];
+        int win[ZT];
+        unsigned int flagged[ZT];
+        int nflag = 0;
+#pragma unroll
+        for (int t = 0; t < ZT; ++t) {
+            const float v = zv[t];
+            z0[t] = __shfl(v, j, kWave); z1[t] = __shfl(v, 16 + j, kWave);
+            z2[t] = __shfl(v, 32 + j, kWave); z3[t] = __shfl(v, 48 + j, kWave);
+            zz[t] = sumsq4(z0[t], z1[t], z2[t], z3[t]);
+            float mt = m1[t];
+            mt = __builtin_fminf(mt, __shfl_xor(mt, 16, kWave));
+            mt = __builtin_fminf(mt, __shfl_xor(mt, 32, kWave));
+            const float S = EEmax + 2.0f * Emax * (((fabsf(z0[t]) + fabsf(z1[t])) + fabsf(z2[t])) + fabsf(z3[t]));
+            const float M = 1.2e-5f * S + 2.5e-7f * zz[t] + 1e-30f;
+            float thr = mt + M;
+            thr += fabsf(thr) * 2.4e-7f;
+            // anything not comparable (NaN / Inf anywhere above) must count as "flagged": test the negation
+            const bool hot = !(m1[t] > thr);                // this lane's best pair holds a candidate
+            const unsigned long long hm = __ballot(hot);
+            const unsigned long long mine = (hm >> j) & 0x0001000100010001ull;     // the 4 row groups of vector j
+            const bool flag = !(m2[t] > thr) || __builtin_popcountll(mine) != 1;
+            const unsigned long long fm = __ballot(flag);
+            flagged[t] = (unsigned int)((fm | (fm >> 16) | (fm >> 32) | (fm >> 48)) & 0xFFFFu);   // per vector, wave-uniform
+            nflag += __builtin_popcount(flagged[t]);
+            // exact fp32 on the 8 codes of the winning (pair, row group): two per lane, lowest index wins ties
+            const int gw = (__builtin_ctzll(mine | (1ull << 63)) >> 4) & 3;
+            const int bp = __shfl(bt[t], 16 * gw + j, kWave);
+            float d = __builtin_inff();
+            int i = 0;
+#pragma unroll
+            for (int r = 1; r >= 0; --r) {
+                const int c = 32 * bp + 16 * (g >> 1) + 4 * gw + 2 * (g & 1) + r;
+                const float dd = dist_row(z0[t], z1[t], z2[t], z3[t], zz[t], cbs[c]);
+                const bool take = dd <= d;
+                d = take ? dd : d;
+                i = take ? c : i;
+            }
+#pragma unroll
+            for (int off = 16; off < 64; off <<= 1) {
+                const float od = __shfl_xor(d, off, kWave);
+                const int oi = __shfl_xor(i, off, kWave);
+                const bool take = od < d || (od == d && oi < i);
+                d = take ? od : d;
+                i = take ? oi : i;
+            }
+            win[t] = i;
+        }
+        nflag = __builtin_amdgcn_readfirstlane(nflag);
+
+        if (nflag > kVqfBulk) {
+            // many near-ties (degenerate codebooks, zz >> ee, non-finite input): the exact fp32-MFMA scan of
+            // vq_mfma_body for the whole group, operands from the fp32 rows in LDS
+            float best[ZT];
+            int bt2[ZT];
+#pragma unroll
+            for (int t = 0; t < ZT; ++t) { best[t] = __builtin_inff(); bt2[t] = 0; }
+            for (int ct = 0; ct < ntile; ++ct) {
+                const float av = reinterpret_cast<const float *>(cbs)[(16 * ct + j) * 4 + g];
+                f32x4 e4;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float4 e = cbs[16 * ct + 4 * g + r];
+                    e4[r] = sumsq4(e.x, e.y, e.z, e.w);
+                }
+#pragma unroll
+                for (int t = 0; t < ZT; ++t) {
+                    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av, zv[t], acc, 0, 0, 0);
+                    const float d0 = __builtin_fmaf(-2.0f, acc[0], zz[t] + e4[0]);
+                    const float d1 = __builtin_fmaf(-2.0f, acc[1], zz[t] + e4[1]);
+                    const float d2 = __builtin_fmaf(-2.0f, acc[2], zz[t] + e4[2]);
+                    const float d3 = __builtin_fmaf(-2.0f, acc[3], zz[t] + e4[3]);
+                    const float q1 = __builtin_fminf(__builtin_fminf(best[t], d0), d1);
+                    const float q2 = __builtin_fminf(__builtin_fminf(q1, d2), d3);
+                    bt2[t] = q2 < best[t] ? ct : bt2[t];
+                    best[t] = q2;
+                }
+            }
+#pragma unroll
+            for (int t = 0; t < ZT; ++t) {
+                const int c0 = 16 * bt2[t] + 4 * g;
+                float d = best[t];
+                int i = c0;
+#pragma unroll
+                for (int r = 3; r >= 0; --r)
+                    i = dist_row(z0[t], z1[t], z2[t], z3[t], zz[t], cbs[c0 + r]) == d ? c0 + r : i;
+#pragma unroll
+                for (int off = 16; off < 64; off <<= 1) {
+                    const float od = __shfl_xor(d, off, kWave);
+                    const int oi = __shfl_xor(i, off, kWave);
+                    const bool take = od < d || (od == d && oi < i);
+                    d = take ? od : d;
+                    i = take ? oi : i;
+                }
+                win[t] = i;
+            }
+        } else if (nflag) {
+            // a few near-ties: the whole wave scans all K codes exactly for each such vector
+#pragma unroll
+            for (int t = 0; t < ZT; ++t) {
+                unsigned int todo = __builtin_amdgcn_readfirstlane(flagged[t]);
+                while (todo) {
+                    const int vj = __builtin_ctz(todo);
+                    todo &= todo - 1;
+                    const float y0 = __shfl(zv[t], vj, kWave), y1 = __shfl(zv[t], 16 + vj, kWave);
+                    const float y2 = __shfl(zv[t], 32 + vj, kWave), y3 = __shfl(zv[t], 48 + vj, kWave);
+                    const float yy = sumsq4(y0, y1, y2, y3);
+                    float bd = __builtin_inff();
+                    int bi = 0;
+#pragma unroll 4
+                    for (int c = K - 64 + lane; c >= 0; c -= 64) {       // descending: the lowest index wins ties
+                        const float dd = dist_row(y0, y1, y2, y3, yy, cbs[c]);
+                        const bool take = dd <= bd;
+                        bd = take ? dd : bd;
+                        bi = take ? c : bi;
+                    }
+#pragma unroll
+                    for (int off = 1; off < 64; off <<= 1) {
+                        const float od = __shfl_xor(bd, off, kWave);
+                        const int oi = __shfl_xor(bi, off, kWave);
+                        const bool take = od < bd || (od == bd && oi < bi);
+                        bd = take ? od : bd;
+                        bi = take ? oi : bi;
+                    }
+                    win[t] = j == vj ? bi : win[t];
+                }
+            }
+        }
+        CGIC_STAMP(4);
+
+        // ---- outputs: this lane owns channel g of vector n
+#pragma unroll
+        for (int t = 0; t < ZT; ++t) {
+            const int64_t n = base + 16 * t + j;
+            if (n < N) {
+                if (zq_out || a.sq_partial) {
+                    const float e = reinterpret_cast<const float *>(cbs)[win[t] * 4 + g];
+                    const float diff = e - zv[t];
+                    if (zq_out) {
+                        int64_t b, p;
+                        locate(gb, gp, t, &b, &p);
+                        zq_out[(b * 4 + g) * hw + p] = zv[t] + diff;
+                    }
+                    sq += (double)diff * (double)diff;
+                }
+                if (g == 0 && idx_out) idx_out[n] = (int64_t)win[t];
+            }
+        }
+    }
+
+    CGIC_STAMP(5);
+    if (a.sq_partial) {
+        // deterministic block reduction: fixed shuffle tree, then waves in order
+        __shared__ double wsum[NW];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) sq += __shfl_down(sq, off, kWave);
+        if (lane == 0) wsum[wave] = sq;
+        __syncthreads();
+        double bs = 0.0;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) bs += wsum[w];
+        finish_loss<NT>(bs, a.sq_partial, a.ticket, (double)N * 4.0, a.beta, a.legacy, a.loss, blockIdx.x, a.nblk);
+    }
+    CGIC_STAMP(6);
+    CGIC_BLK_END();
+}
+
+template <int ZT>
+__global__ __launch_bounds__(kVqfThreads, 1) void vq_filter_kernel(VqArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_f[];
+    vq_filter_body<ZT>(a, smem_f);
+}
+
+// the fused launch of the filter path: router workgroups behind the VQ workgroups (see vq_router_kernel)
+template <int ZT>
+__global__ __launch_bounds__(kVqfThreads, 1) void vq_filter_router_kernel(VqArgs a, RouterArgs r)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_f[];
+    if (blockIdx.x >= a.nblk) {
+        router_body<kVqfThreads>(r, (int64_t)(blockIdx.x - a.nblk), smem_f);
+        return;
+    }
+    vq_filter_body<ZT>(a, smem_f);
 }
 
 // Plain-VALU restatement: one latent vector per thread, codebook broadcast from
@@ -351,7 +742,7 @@ __global__ __launch_bounds__(kVqThreads) void vq_valu_kernel(
         for (int off = 32; off > 0; off >>= 1) sq += __shfl_down(sq, off, kWave);
         if (lane == 0) wsum[wave] = sq;
         __syncthreads();
-        finish_loss(((wsum[0] + wsum[1]) + wsum[2]) + wsum[3], sq_partial, ticket, (double)N * 4.0, beta, legacy, loss, blockIdx.x, gridDim.x);
+        finish_loss<kVqThreads>(((wsum[0] + wsum[1]) + wsum[2]) + wsum[3], sq_partial, ticket, (double)N * 4.0, beta, legacy, loss, blockIdx.x, gridDim.x);
     }
 }
 
@@ -434,6 +825,50 @@ static int launch_mfma(const float *z, int64_t hw, int64_t N, const float *cb, i
     return launch_check("vq_router_kernel");
 }
 
+static int device_cu_count(int *out)
+{
+    static std::mutex mu;
+    static std::map<int, int> cus;
+    int dev = 0;
+    CGIC_HIP_TRY(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lock(mu);
+    auto it = cus.find(dev);
+    if (it == cus.end()) {
+        int n = 0;
+        CGIC_HIP_TRY(hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev));
+        it = cus.emplace(dev, n > 0 ? n : 256).first;
+    }
+    *out = it->second;
+    return CGIC_OK;
+}
+
+template <int ZT>
+static int launch_filter(const float *z, int64_t hw, int64_t N, const float *cb, int K, int64_t *idx, float *zq,
+                         VqWs ws, float beta, int legacy, float *loss, hipStream_t s, const RouterArgs *router,
+                         int64_t router_blocks, size_t router_lds)
+{
+    int cus = 0;
+    int rc = device_cu_count(&cus);
+    if (rc) return rc;
+    const int64_t ngroups = (N + 16 * ZT - 1) / (16 * ZT);
+    int64_t nblk = (ngroups + kVqfWaves - 1) / kVqfWaves;
+    if (nblk > cus) nblk = cus;                      // one resident workgroup per CU; waves loop over groups
+    VqArgs a;
+    a.z = z; a.hw = hw; a.N = N; a.cb = cb; a.K = K; a.idx_out = idx; a.zq_out = zq;
+    a.sq_partial = loss ? ws.partial : nullptr; a.ticket = ws.ticket; a.beta = beta; a.legacy = legacy; a.loss = loss;
+    a.nblk = (unsigned int)nblk;
+    size_t lds = (size_t)K * 80;
+    if (!router) {
+        CGIC_HIP_TRY(hipFuncSetAttribute((const void *)vq_filter_kernel<ZT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(vq_filter_kernel<ZT>, dim3(a.nblk), dim3(kVqfThreads), lds, s, a);
+        return launch_check("vq_filter_kernel");
+    }
+    if (router_lds > lds) lds = router_lds;
+    CGIC_HIP_TRY(hipFuncSetAttribute((const void *)vq_filter_router_kernel<ZT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(vq_filter_router_kernel<ZT>, dim3(a.nblk + (unsigned int)router_blocks), dim3(kVqfThreads), lds, s, a, *router);
+    return launch_check("vq_filter_router_kernel");
+}
+
 static int vq_dispatch(const float *z, int64_t hw, int64_t N, const float *codebook, int K, int64_t *indices, float *z_q,
                        VqWs ws, float beta, int legacy, float *loss, hipStream_t s, const RouterArgs *router,
                        int64_t router_blocks, size_t router_lds)
@@ -441,6 +876,17 @@ static int vq_dispatch(const float *z, int64_t hw, int64_t N, const float *codeb
     // per-wave tile: measured on MI355X (tools/probe_vq.hip) ZT=4 at 4 waves/SIMD is the fastest
     // for large N; smaller N shrinks the tile so that all 256 CUs get work
     static const int force_zt = getenv("CGIC_VQ_ZT") ? atoi(getenv("CGIC_VQ_ZT")) : 0;     // tuning knob (dev)
+    static const int exact_only = getenv("CGIC_VQ_EXACT") ? atoi(getenv("CGIC_VQ_EXACT")) : 0;   // dev: A/B against the exact loop
+    if (!exact_only && K % 64 == 0 && K <= kVqfMaxK) {
+#define CGIC_VQF_LAUNCH(ZT) launch_filter<ZT>(z, hw, N, codebook, K, indices, z_q, ws, beta, legacy, loss, s, router, router_blocks, router_lds)
+        if (force_zt == 8) return CGIC_VQF_LAUNCH(8);
+        if (force_zt == 2) return CGIC_VQF_LAUNCH(2);
+        if (force_zt == 1) return CGIC_VQF_LAUNCH(1);
+        if (force_zt == 4 || N >= (int64_t)128 * 1024) return CGIC_VQF_LAUNCH(4);
+        if (N >= (int64_t)64 * 1024) return CGIC_VQF_LAUNCH(2);
+        return CGIC_VQF_LAUNCH(1);
+#undef CGIC_VQF_LAUNCH
+    }
 #define CGIC_VQ_LAUNCH(ZT) launch_mfma<ZT>(z, hw, N, codebook, K, indices, z_q, ws, beta, legacy, loss, s, router, router_blocks, router_lds)
     if (force_zt == 8) return CGIC_VQ_LAUNCH(8);
     if (force_zt == 4) return CGIC_VQ_LAUNCH(4);

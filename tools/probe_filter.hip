@@ -1,0 +1,342 @@
+// dev probe: bf16-MFMA candidate filter + exact fp32 resolve for the VQ argmin (not part of the product).
+//   hipcc -O3 -ffp-contract=off --offload-arch=gfx950 probe_filter.hip -o probe_filter && ./probe_filter
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <vector>
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+constexpr int kWave = 64;
+
+__host__ __device__ inline float sumsq4(float a, float b, float c, float d)
+{
+    float s = a * a;
+    s = s + b * b;
+    s = s + c * c;
+    s = s + d * d;
+    return s;
+}
+
+// x == h + m + l exactly (three bf16 by truncation), |m| < 2^-7 |x|, |l| < 2^-14 |x|
+__device__ inline void split3(float x, unsigned &h, unsigned &m, unsigned &l)
+{
+    unsigned xb = __float_as_uint(x);
+    h = xb >> 16;
+    float r1 = x - __uint_as_float(xb & 0xFFFF0000u);
+    unsigned rb = __float_as_uint(r1);
+    m = rb >> 16;
+    float r2 = r1 - __uint_as_float(rb & 0xFFFF0000u);
+    l = __float_as_uint(r2) >> 16;
+}
+
+__device__ inline float exact_dist(float z0, float z1, float z2, float z3, float zz, float4 e)
+{
+    float mm = z0 * e.x;
+    mm = __builtin_fmaf(z1, e.y, mm);
+    mm = __builtin_fmaf(z2, e.z, mm);
+    mm = __builtin_fmaf(z3, e.w, mm);
+    return __builtin_fmaf(-2.0f, mm, zz + sumsq4(e.x, e.y, e.z, e.w));
+}
+
+struct Stats { unsigned long long flagged; unsigned long long t[6]; unsigned long long nw; };
+
+constexpr int NT = 512, NW = NT / 64;
+template <int ZT, int MODE>   // MODE 0 full, 1 = no loop, 2 = no resolve (timing)
+__global__ __launch_bounds__(NT, 1) void vq_filter(const float *__restrict__ z, int64_t hw, int64_t N,
+                                                    const float *__restrict__ cb, int K, int64_t *__restrict__ idx_out,
+                                                    Stats *stats)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint4 *ldsA = reinterpret_cast<uint4 *>(smem);      // [K/16][64]
+    float4 *cbs = reinterpret_cast<float4 *>(smem + (size_t)K * 64);   // [K] fp32 rows
+    __shared__ unsigned int s_emax, s_eemax;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int j = lane & 15, g = lane >> 4;
+    const int ntile = K >> 4;
+
+    const long long T0 = wall_clock64();
+    if (tid == 0) { s_emax = 0; s_eemax = 0; }
+    __syncthreads();
+    {
+        float emax = 0.f, eemax = 0.f;
+        for (int i = tid; i < K; i += NT) cbs[i] = reinterpret_cast<const float4 *>(cb)[i];
+        for (int i = tid; i < ntile * 64; i += NT) {
+            const int t = i >> 6, l = i & 63, m = l & 15, gg = l >> 4;
+            const float4 e = reinterpret_cast<const float4 *>(cb)[16 * t + m];
+            const float ee = sumsq4(e.x, e.y, e.z, e.w);
+            const float ec = gg == 0 ? e.x : gg == 1 ? e.y : gg == 2 ? e.z : e.w;
+            unsigned wh, wm, wl, eh, em, el;
+            split3(-2.0f * ec, wh, wm, wl);
+            split3(ee, eh, em, el);
+            const unsigned ep = gg == 0 ? eh : gg == 1 ? em : gg == 2 ? el : 0u;
+            uint4 a;
+            a.x = wh | (wm << 16);
+            a.y = wh | (wl << 16);
+            a.z = wh | (wm << 16);
+            a.w = ep;
+            ldsA[i] = a;
+            emax = fmaxf(emax, fabsf(ec));
+            eemax = fmaxf(eemax, ee);
+        }
+        for (int off = 32; off > 0; off >>= 1) {
+            emax = fmaxf(emax, __shfl_xor(emax, off, kWave));
+            eemax = fmaxf(eemax, __shfl_xor(eemax, off, kWave));
+        }
+        if (lane == 0) { atomicMax(&s_emax, __float_as_uint(emax)); atomicMax(&s_eemax, __float_as_uint(eemax)); }
+    }
+    __syncthreads();
+    const float Emax = __uint_as_float(s_emax), EEmax = __uint_as_float(s_eemax);
+    const long long T1 = wall_clock64();
+    long long tl = 0, tm = 0, tr = 0;
+
+    const int64_t ngroups = (N + 16 * ZT - 1) / (16 * ZT);
+    for (int64_t grp = (int64_t)blockIdx.x * NW + wave; grp < ngroups; grp += (int64_t)gridDim.x * NW) {
+        const int64_t base = grp * (16 * ZT);
+        const long long Ta = wall_clock64();
+        float zv[ZT], m1[ZT], m2[ZT];
+        int bt[ZT];
+        bf16x8 bop[ZT];
+#pragma unroll
+        for (int t = 0; t < ZT; ++t) {
+            const int64_t n = base + 16 * t + j;
+            float v = 0.f;
+            if (n < N) {
+                const int64_t b = n / hw, p = n - b * hw;
+                v = z[(b * 4 + g) * hw + p];
+            }
+            zv[t] = v;
+            unsigned h, m, l;
+            split3(v, h, m, l);
+            uint4 bb;
+            bb.x = h | (h << 16);
+            bb.y = m | (h << 16);
+            bb.z = l | (m << 16);
+            bb.w = 0x3F80u;
+            bop[t] = __builtin_bit_cast(bf16x8, bb);
+            m1[t] = __builtin_inff();
+            m2[t] = __builtin_inff();
+            bt[t] = 0;
+        }
+        const long long Tb = wall_clock64();
+        // pairs of code tiles, ping-pong: the MFMAs of pair p+1 are in flight while the VALU digests pair p
+        const int np = ntile >> 1;
+        f32x4 X0[ZT], X1[ZT], Y0[ZT], Y1[ZT];
+        const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+        auto issue = [&](int p, f32x4 (&A0)[ZT], f32x4 (&A1)[ZT]) {
+            const int pp = p < np ? p : np - 1;
+            const bf16x8 a0 = __builtin_bit_cast(bf16x8, ldsA[(2 * pp) * 64 + lane]);
+            const bf16x8 a1 = __builtin_bit_cast(bf16x8, ldsA[(2 * pp + 1) * 64 + lane]);
+#pragma unroll
+            for (int t = 0; t < ZT; ++t) {
+                A0[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, bop[t], zero4, 0, 0, 0);
+                A1[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, bop[t], zero4, 0, 0, 0);
+            }
+        };
+        auto digest = [&](int p, const f32x4 (&A0)[ZT], const f32x4 (&A1)[ZT]) {
+#pragma unroll
+            for (int t = 0; t < ZT; ++t) {
+                // chain seeded with a constant: v_min3_f32 takes the raw MFMA outputs without a canonicalising v_max
+                float u = __builtin_fminf(__builtin_fminf(__builtin_inff(), A0[t][0]), A0[t][1]);
+                u = __builtin_fminf(__builtin_fminf(u, A0[t][2]), A0[t][3]);
+                u = __builtin_fminf(__builtin_fminf(u, A1[t][0]), A1[t][1]);
+                u = __builtin_fminf(__builtin_fminf(u, A1[t][2]), A1[t][3]);
+                bt[t] = u < m1[t] ? p : bt[t];
+                m2[t] = __builtin_amdgcn_fmed3f(m1[t], m2[t], u);
+                m1[t] = __builtin_fminf(m1[t], u);
+            }
+        };
+        if (MODE != 1) issue(0, X0, X1);
+        for (int p = 0; p < (MODE == 1 ? 0 : np); p += 2) {
+            issue(p + 1, Y0, Y1);
+            digest(p, X0, X1);
+            issue(p + 2, X0, X1);
+            digest(p + 1, Y0, Y1);
+        }
+        const long long Tc = wall_clock64();
+        tl += Tb - Ta; tm += Tc - Tb;
+        if (MODE == 2) {
+#pragma unroll
+            for (int t = 0; t < ZT; ++t) { const int64_t n = base + 16 * t + j; if (n < N && g == 0) idx_out[n] = bt[t] + (m2[t] < m1[t]); }
+            continue;
+        }
+        // resolve
+        unsigned long long nflag = 0;
+#pragma unroll
+        for (int t = 0; t < ZT; ++t) {
+            const float v = zv[t];
+            const float z0 = __shfl(v, j, kWave), z1 = __shfl(v, 16 + j, kWave);
+            const float z2 = __shfl(v, 32 + j, kWave), z3 = __shfl(v, 48 + j, kWave);
+            const float zz = sumsq4(z0, z1, z2, z3);
+            float mt = m1[t];
+            mt = fminf(mt, __shfl_xor(mt, 16, kWave));
+            mt = fminf(mt, __shfl_xor(mt, 32, kWave));
+            const float S = EEmax + 2.0f * Emax * (fabsf(z0) + fabsf(z1) + fabsf(z2) + fabsf(z3));
+            const float M = 1.2e-5f * S + 2.5e-7f * zz + 1e-30f;
+            float thr = mt + M;
+            thr += fabsf(thr) * 2.4e-7f;
+            const bool hot = m1[t] <= thr;                 // this lane's best pair holds a candidate
+            const unsigned long long hm = __ballot(hot);
+            const unsigned int hv = (unsigned int)(hm >> j) & 0x0001000100010001ull ? 0u : 0u;   // (placeholder, see below)
+            (void)hv;
+            const unsigned long long mine = (hm >> j) & 0x0001000100010001ull;     // the 4 row groups of vector j
+            const bool flag = m2[t] <= thr || __builtin_popcountll(mine) > 1;
+            const unsigned long long fm = __ballot(flag);
+            const unsigned int f16 = (unsigned int)((fm | (fm >> 16) | (fm >> 32) | (fm >> 48)) & 0xFFFFu);   // per vector
+            // exact resolve: the 8 codes of the winning (pair, row group), two per lane
+            const int gw = (int)(__builtin_ctzll(mine | (1ull << 63)) >> 4) & 3;
+            const int bp = __shfl(bt[t], 16 * gw + j, kWave);
+            float d = __builtin_inff();
+            int i = 0;
+#pragma unroll
+            for (int r = 1; r >= 0; --r) {     // descending: the lowest index wins ties
+                const int c = 32 * bp + 16 * (g >> 1) + 4 * gw + 2 * (g & 1) + r;
+                const float4 e = cbs[c];
+                const float dd = exact_dist(z0, z1, z2, z3, zz, e);
+                const bool take = dd <= d;
+                d = take ? dd : d;
+                i = take ? c : i;
+            }
+#pragma unroll
+            for (int off = 16; off < 64; off <<= 1) {
+                const float od = __shfl_xor(d, off, kWave);
+                const int oi = __shfl_xor(i, off, kWave);
+                const bool take = od < d || (od == d && oi < i);
+                d = take ? od : d;
+                i = take ? oi : i;
+            }
+            // flagged vectors: the whole wave scans all K codes exactly
+            unsigned int todo = f16;
+            while (todo) {
+                const int vj = __builtin_ctz(todo);
+                todo &= todo - 1;
+                const float y0 = __shfl(v, vj, kWave), y1 = __shfl(v, 16 + vj, kWave);
+                const float y2 = __shfl(v, 32 + vj, kWave), y3 = __shfl(v, 48 + vj, kWave);
+                const float yy = sumsq4(y0, y1, y2, y3);
+                float bd = __builtin_inff();
+                int bi = 0;
+#pragma unroll 4
+                for (int c = K - 64 + lane; c >= 0; c -= 64) {   // descending: lowest index wins ties
+                    const float4 e = cbs[c];
+                    const float dd = exact_dist(y0, y1, y2, y3, yy, e);
+                    const bool take = dd <= bd;
+                    bd = take ? dd : bd;
+                    bi = take ? c : bi;
+                }
+#pragma unroll
+                for (int off = 1; off < 64; off <<= 1) {
+                    const float od = __shfl_xor(bd, off, kWave);
+                    const int oi = __shfl_xor(bi, off, kWave);
+                    const bool take = od < bd || (od == bd && oi < bi);
+                    bd = take ? od : bd;
+                    bi = take ? oi : bi;
+                }
+                if (j == vj) i = bi;
+                ++nflag;
+            }
+            const int64_t n = base + 16 * t + j;
+            if (n < N && g == 0) idx_out[n] = i;
+        }
+        tr += wall_clock64() - Tc;
+        if (stats && lane == 0 && nflag) atomicAdd(&stats->flagged, nflag);
+    }
+    if (stats && lane == 0) { atomicAdd(&stats->t[0], (unsigned long long)(T1 - T0)); atomicAdd(&stats->t[1], (unsigned long long)tl); atomicAdd(&stats->t[2], (unsigned long long)tm); atomicAdd(&stats->t[3], (unsigned long long)tr); atomicAdd(&stats->t[4], (unsigned long long)(wall_clock64() - T0)); atomicAdd(&stats->nw, 1ull); }
+}
+
+static float frand(uint64_t &s)
+{
+    // Box-Muller on an LCG
+    s = s * 6364136223846793005ull + 1442695040888963407ull;
+    double u1 = ((s >> 11) + 1.0) / 9007199254740993.0;
+    s = s * 6364136223846793005ull + 1442695040888963407ull;
+    double u2 = ((s >> 11) + 1.0) / 9007199254740993.0;
+    return (float)(sqrt(-2.0 * log(u1)) * cos(6.283185307179586 * u2));
+}
+
+template <int ZT, int MODE>
+static float timeit(const float *z, int64_t hw, int64_t N, const float *cb, int K, int64_t *idx, Stats *st, int nblk)
+{
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0);
+    hipEventCreate(&e1);
+    size_t lds = (size_t)K * 80;
+    hipFuncSetAttribute((const void *)vq_filter<ZT, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    for (int i = 0; i < 3; ++i) hipLaunchKernelGGL((vq_filter<ZT, MODE>), dim3(nblk), dim3(NT), lds, 0, z, hw, N, cb, K, idx, st);
+    hipEventRecord(e0);
+    for (int i = 0; i < 20; ++i) hipLaunchKernelGGL((vq_filter<ZT, MODE>), dim3(nblk), dim3(NT), lds, 0, z, hw, N, cb, K, idx, st);
+    hipEventRecord(e1);
+    hipEventSynchronize(e1);
+    float ms;
+    hipEventElapsedTime(&ms, e0, e1);
+    return ms * 1e3f / 20;
+}
+
+int main(int argc, char **argv)
+{
+    const int B = 64, hw = 4096, K = 1024;
+    const int64_t N = (int64_t)B * hw;
+    const float cb_scale = argc > 1 ? (float)atof(argv[1]) : 1.0f;
+    std::vector<float> hz((size_t)N * 4), hcb((size_t)K * 4);
+    uint64_t s = 12345;
+    for (auto &v : hz) v = frand(s);
+    for (auto &v : hcb) v = frand(s) * cb_scale;
+    float *z, *cb;
+    int64_t *idx;
+    Stats *st;
+    hipMalloc(&z, hz.size() * 4);
+    hipMalloc(&cb, hcb.size() * 4);
+    hipMalloc(&idx, N * 8);
+    hipMalloc(&st, sizeof(Stats));
+    hipMemset(st, 0, sizeof(Stats));
+    hipMemcpy(z, hz.data(), hz.size() * 4, hipMemcpyHostToDevice);
+    hipMemcpy(cb, hcb.data(), hcb.size() * 4, hipMemcpyHostToDevice);
+
+    // correctness: one launch, compare with the exact formula on the host for a sample of vectors
+    {
+        size_t lds = (size_t)K * 80;
+        hipFuncSetAttribute((const void *)vq_filter<4, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL((vq_filter<4, 0>), dim3(256), dim3(NT), lds, 0, z, (int64_t)hw, N, cb, K, idx, st);
+        hipError_t err = hipDeviceSynchronize();
+        printf("launch: %s\n", hipGetErrorString(err));
+        std::vector<int64_t> hi(N);
+        hipMemcpy(hi.data(), idx, N * 8, hipMemcpyDeviceToHost);
+        Stats hs;
+        hipMemcpy(&hs, st, sizeof(hs), hipMemcpyDeviceToHost);
+        long bad = 0, checked = 0;
+        for (int64_t n = 0; n < N; n += 7) {
+            const int64_t b = n / hw, p = n % hw;
+            const float z0 = hz[(b * 4 + 0) * hw + p], z1 = hz[(b * 4 + 1) * hw + p];
+            const float z2 = hz[(b * 4 + 2) * hw + p], z3 = hz[(b * 4 + 3) * hw + p];
+            const float zz = sumsq4(z0, z1, z2, z3);
+            float bd = 0;
+            int bi = -1;
+            for (int k = 0; k < K; ++k) {
+                const float *e = &hcb[(size_t)k * 4];
+                float mm = z0 * e[0];
+                mm = fmaf(z1, e[1], mm);
+                mm = fmaf(z2, e[2], mm);
+                mm = fmaf(z3, e[3], mm);
+                const float d = fmaf(-2.0f, mm, zz + sumsq4(e[0], e[1], e[2], e[3]));
+                if (bi < 0 || d < bd) { bd = d; bi = k; }
+            }
+            ++checked;
+            if (bi != hi[n]) {
+                if (bad < 5) printf("  mismatch n=%lld want %d got %lld\n", (long long)n, bi, (long long)hi[n]);
+                ++bad;
+            }
+        }
+        printf("per-wave avg (us): stage %.2f load %.2f loop %.2f resolve %.2f total %.2f (waves %llu)\n", hs.t[0] * 0.01 / hs.nw, hs.t[1] * 0.01 / hs.nw, hs.t[2] * 0.01 / hs.nw, hs.t[3] * 0.01 / hs.nw, hs.t[4] * 0.01 / hs.nw, hs.nw);
+        printf("checked %ld vectors, %ld mismatches; flagged %llu of %lld (%.3f%%)\n", checked, bad, hs.flagged, (long long)N,
+               100.0 * hs.flagged / N);
+    }
+    printf("ZT=4 nblk=256  full %.2f us | no-loop %.2f | no-resolve %.2f\n",
+           timeit<4, 0>(z, hw, N, cb, K, idx, nullptr, 256), timeit<4, 1>(z, hw, N, cb, K, idx, nullptr, 256),
+           timeit<4, 2>(z, hw, N, cb, K, idx, nullptr, 256));
+    printf("ZT=4 nblk=512  full %.2f us\n", timeit<4, 0>(z, hw, N, cb, K, idx, nullptr, 512));
+    printf("ZT=8 nblk=256  full %.2f us\n", timeit<8, 0>(z, hw, N, cb, K, idx, nullptr, 256));
+    printf("ZT=2 nblk=256  full %.2f us\n", timeit<2, 0>(z, hw, N, cb, K, idx, nullptr, 256));
+    return 0;
+}
