@@ -188,7 +188,7 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a hipGraph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--chunks", type=int, default=1, help="process the batch as this many concurrent stream chains")
-    ap.add_argument("--fork-vq", action="store_true", help="run VQ on a side stream next to entropy -> router")
+    ap.add_argument("--fork-vq", type=int, nargs="?", const=1, default=0, help="1: VQ on a side stream next to entropy -> router; 2: router on a side stream next to VQ")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))

@@ -102,6 +102,36 @@ __device__ __forceinline__ void finish_loss(double block_sum, double *sq_partial
     }
 }
 
+// Variant for the filter path: the partials (one per group of vectors, any number) are already stored and
+// drained by every wave of the workgroup; take the ticket, the last workgroup sums them in index order.
+template <int NT>
+__device__ __forceinline__ void finish_loss_groups(double *sq_partial, unsigned int npart, unsigned int *ticket,
+                                                   double count, float beta, int legacy, float *loss, unsigned int nblk)
+{
+    __shared__ double red[NT];
+    __shared__ unsigned int s_last;
+    const int tid = threadIdx.x;
+    if (tid == 0) s_last = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == nblk - 1;
+    __syncthreads();
+    if (!s_last) return;
+    if (tid == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    __syncthreads();
+    double a = 0.0;
+    for (unsigned int i = tid; i < npart; i += NT)
+        a += __hip_atomic_load(&sq_partial[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    red[tid] = a;
+    __syncthreads();
+    for (int off = NT / 2; off > 0; off >>= 1) {
+        if (tid < off) red[tid] += red[tid + off];
+        __syncthreads();
+    }
+    if (tid == 0) {
+        const float m = (float)(red[0] / count);
+        *loss = legacy ? (m + beta * m) : (beta * m + m);
+        __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
+    }
+}
+
 // ZT = latent tiles (of 16 vectors) per wave; a wave owns 16*ZT vectors and scans all K codes;
 // a block owns 4 * 16 * ZT vectors.  __launch_bounds__(256, 2): a <=256-VGPR budget makes hipcc
 // pick the VGPR-destination MFMA form (no v_accvgpr_read per output).
@@ -320,7 +350,7 @@ __global__ __launch_bounds__(kVqThreads, ZT <= 4 ? 4 : 2) void vq_router_kernel(
 // =====================================================================================================
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
-constexpr int kVqfThreads = 512;               // 8 waves, one workgroup per CU (84 KB of LDS at K = 1024)
+constexpr int kVqfThreads = 512;               // 8 waves, one workgroup per CU (80 KB of LDS at K = 1024)
 constexpr int kVqfWaves = kVqfThreads / 64;
 constexpr int kVqfMaxK = 1024;
 constexpr int kVqfBulk = 12;                   // more flagged vectors than this in a 64-vector group: rerun it exactly on the MFMA
@@ -335,6 +365,64 @@ __device__ __forceinline__ void split3(float x, unsigned int &h, unsigned int &m
     m = rb >> 16;
     const float r2 = r1 - __uint_as_float(rb & 0xFFFF0000u);
     l = __float_as_uint(r2) >> 16;
+}
+
+// Cross-row-group exchanges on the VALU (gfx950 v_permlane16_swap / v_permlane32_swap) -- no LDS round trip.
+// Lane = (column j = lane & 15, row group g = lane >> 4).
+//   rows16(x): .x = x of row groups (0,0,2,2), .y = x of row groups (1,1,3,3)
+//   rows32(x): .x = x of the lower 32 lanes in both halves, .y = the upper 32 lanes' in both halves
+__device__ __forceinline__ uint2 rows16(unsigned int x)
+{
+    const auto r = __builtin_amdgcn_permlane16_swap(x, x, false, false);
+    return make_uint2(r[0], r[1]);
+}
+__device__ __forceinline__ uint2 rows32(unsigned int x)
+{
+    const auto r = __builtin_amdgcn_permlane32_swap(x, x, false, false);
+    return make_uint2(r[0], r[1]);
+}
+// reduce over the 4 row groups of each column; every lane of the column gets the result
+__device__ __forceinline__ float colmin(float x)
+{
+    uint2 a = rows16(__float_as_uint(x));
+    x = __builtin_fminf(__uint_as_float(a.x), __uint_as_float(a.y));
+    a = rows32(__float_as_uint(x));
+    return __builtin_fminf(__uint_as_float(a.x), __uint_as_float(a.y));
+}
+__device__ __forceinline__ int colmax(int x)
+{
+    uint2 a = rows16((unsigned int)x);
+    x = (int)a.x > (int)a.y ? (int)a.x : (int)a.y;
+    a = rows32((unsigned int)x);
+    return (int)a.x > (int)a.y ? (int)a.x : (int)a.y;
+}
+__device__ __forceinline__ int colsum(int x)
+{
+    uint2 a = rows16((unsigned int)x);
+    x = (int)(a.x + a.y);
+    a = rows32((unsigned int)x);
+    return (int)(a.x + a.y);
+}
+// lexicographic (d, i) minimum over the 4 row groups of each column
+__device__ __forceinline__ void colargmin(float &d, int &i)
+{
+    uint2 dd = rows16(__float_as_uint(d)), ii = rows16((unsigned int)i);
+    {
+        const float da = __uint_as_float(dd.x), db = __uint_as_float(dd.y);
+        const int ia = (int)ii.x, ib = (int)ii.y;
+        const bool take = db < da || (db == da && ib < ia);
+        d = take ? db : da;
+        i = take ? ib : ia;
+    }
+    dd = rows32(__float_as_uint(d));
+    ii = rows32((unsigned int)i);
+    {
+        const float da = __uint_as_float(dd.x), db = __uint_as_float(dd.y);
+        const int ia = (int)ii.x, ib = (int)ii.y;
+        const bool take = db < da || (db == da && ib < ia);
+        d = take ? db : da;
+        i = take ? ib : ia;
+    }
 }
 
 // the reference's rounding sequence for one codebook row
@@ -356,9 +444,13 @@ __device__ __forceinline__ void vq_filter_body(const VqArgs &a, unsigned char *s
     const int K = a.K, ntile = K >> 4, np = K >> 5;
     int64_t *__restrict__ idx_out = a.idx_out;
     float *__restrict__ zq_out = a.zq_out;
-    uint4 *ldsA = reinterpret_cast<uint4 *>(smem);                         // [K/16][64] bf16x8 A operands
+    // A operands, 16 bytes per (tile, lane): {u0, u1, u0, u0} with u0 = wh | wm << 16, u1 = wl | ee piece << 16,
+    // against B = {zh|zh, zh|1.0, zm|zm, zl|0}: slots wh.zh wm.zh | wl.zh ee.1 | wh.zm wm.zm | wh.zl 0.
+    // (8 bytes per lane + two v_mov per tile was measured 1 us slower; LDS size is not what limits residency.)
+    uint4 *ldsA = reinterpret_cast<uint4 *>(smem);                         // [K/16][64]
     float4 *cbs = reinterpret_cast<float4 *>(smem + (size_t)K * 64);       // [K] fp32 rows
     __shared__ unsigned int s_max[2];
+    __shared__ unsigned int s_next;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int j = lane & 15;   // column: which latent vector of the tile
     const int g = lane >> 4;   // K-slot group of the operands (= dimension) / row group of the result
@@ -367,6 +459,7 @@ __device__ __forceinline__ void vq_filter_body(const VqArgs &a, unsigned char *s
     CGIC_BLK_BEGIN();
     // ---- stage: fp32 rows, then the split A operands built from them
     if (tid < 2) s_max[tid] = 0;
+    if (tid == 0) s_next = NW;              // groups 0..NW-1 of the workgroup's range are the waves' first ones
     for (int i = tid; i < K; i += NT) cbs[i] = reinterpret_cast<const float4 *>(a.cb)[i];
     __syncthreads();
     {
@@ -380,12 +473,8 @@ __device__ __forceinline__ void vq_filter_body(const VqArgs &a, unsigned char *s
             unsigned int wh, wm, wl, eh, em, el;
             split3(-2.0f * ec, wh, wm, wl);
             split3(ee, eh, em, el);
-            uint4 av;
-            av.x = wh | (wm << 16);
-            av.y = wh | (wl << 16);
-            av.z = wh | (wm << 16);
-            av.w = gg == 0 ? eh : gg == 1 ? em : gg == 2 ? el : 0u;
-            ldsA[i] = av;
+            const unsigned int ep = gg == 0 ? eh : gg == 1 ? em : gg == 2 ? el : 0u;
+            ldsA[i] = make_uint4(wh | (wm << 16), wl | (ep << 16), wh | (wm << 16), wh | (wm << 16));
             emax = fmaxf(emax, fabsf(ec));
             eemax = fmaxf(eemax, ee);
         }
@@ -401,19 +490,28 @@ __device__ __forceinline__ void vq_filter_body(const VqArgs &a, unsigned char *s
     const float Emax = __uint_as_float(s_max[0]), EEmax = __uint_as_float(s_max[1]);
     CGIC_STAMP(1);
 
-    // ---- this wave's contiguous range of 16*ZT-vector groups
+    // ---- groups of 16*ZT vectors: the workgroup owns a contiguous range, its waves take groups from a shared
+    // counter.  (Static shares leave the SIMD's younger wave behind: VALU issue is arbitrated by age, the older
+    // wave finishes early and the younger one then runs alone at half the issue rate.)
     const int64_t ngroups = (N + 16 * ZT - 1) / (16 * ZT);
-    const int64_t nwaves = (int64_t)a.nblk * NW;
-    const int64_t per = (ngroups + nwaves - 1) / nwaves;
-    const int64_t g_lo = ((int64_t)blockIdx.x * NW + wave) * per;
-    const int64_t g_hi = g_lo + per < ngroups ? g_lo + per : ngroups;
-
-    // (image, position) of a group's first vector: one 64-bit division per wave, then add and carry
-    int64_t b0 = 0, p0 = 0;
-    if (g_lo < g_hi) {
-        b0 = (g_lo * (16 * ZT)) / hw;
-        p0 = g_lo * (16 * ZT) - b0 * hw;
-    }
+    const int64_t per_blk = (ngroups + a.nblk - 1) / a.nblk;
+    const int64_t blk_lo = (int64_t)blockIdx.x * per_blk < ngroups ? (int64_t)blockIdx.x * per_blk : ngroups;
+    const int64_t blk_hi = blk_lo + per_blk < ngroups ? blk_lo + per_blk : ngroups;
+    auto grab = [&]() -> int64_t {
+        int v = 0;
+        if (lane == 0) v = (int)atomicAdd(&s_next, 1u);
+        return blk_lo + __builtin_amdgcn_readfirstlane(v);
+    };
+    // (image, position) of a group's first vector
+    auto origin = [&](int64_t grp, int64_t *b, int64_t *p) {
+        const int64_t n0 = grp * (16 * ZT);
+        if (((n0 | hw) >> 32) == 0) {
+            const unsigned int q = (unsigned int)n0 / (unsigned int)hw;
+            *b = q; *p = (int64_t)((unsigned int)n0 - q * (unsigned int)hw);
+        } else {
+            *b = n0 / hw; *p = n0 - *b * hw;
+        }
+    };
     auto locate = [&](int64_t bb, int64_t pp, int t, int64_t *b, int64_t *p) {
         pp += 16 * t + j;
         while (pp >= hw) { pp -= hw; ++bb; }
@@ -433,13 +531,17 @@ __device__ __forceinline__ void vq_filter_body(const VqArgs &a, unsigned char *s
         }
     };
 
-    double sq = 0.0;
     float zn[ZT];
-    if (g_lo < g_hi) load_group(g_lo, b0, p0, zn);
+    int64_t cur = blk_lo + wave, cb0 = 0, cp0 = 0;
+    if (cur < blk_hi) {
+        origin(cur, &cb0, &cp0);
+        load_group(cur, cb0, cp0, zn);
+    }
 
-    for (int64_t grp = g_lo; grp < g_hi; ++grp) {
+    while (cur < blk_hi) {
+        const int64_t grp = cur;
         const int64_t base = grp * (16 * ZT);
-        const int64_t gb = b0, gp = p0;
+        const int64_t gb = cb0, gp = cp0;
         float zv[ZT], m1[ZT], m2[ZT];
         int bt[ZT];
         bf16x8 bop[ZT];
@@ -450,18 +552,20 @@ __device__ __forceinline__ void vq_filter_body(const VqArgs &a, unsigned char *s
             split3(zv[t], h, m, l);
             uint4 bb;
             bb.x = h | (h << 16);
-            bb.y = m | (h << 16);
-            bb.z = l | (m << 16);
-            bb.w = 0x3F80u;                       // 1.0 against ee's piece; slot 7 = 0
+            bb.y = h | (0x3F80u << 16);           // 1.0 against ee's piece
+            bb.z = m | (m << 16);
+            bb.w = l;                             // slot 7 = 0
             bop[t] = __builtin_bit_cast(bf16x8, bb);
             m1[t] = __builtin_inff();
             m2[t] = __builtin_inff();
             bt[t] = 0;
         }
-        // next group's latents are in flight during this group's scan
-        p0 += 16 * ZT;
-        while (p0 >= hw) { p0 -= hw; ++b0; }
-        if (grp + 1 < g_hi) load_group(grp + 1, b0, p0, zn);
+        // reserve the next group now: its latents are in flight during this group's scan
+        cur = grab();
+        if (cur < blk_hi) {
+            origin(cur, &cb0, &cp0);
+            load_group(cur, cb0, cp0, zn);
+        }
         CGIC_STAMP(2);
 
         // ---- scan: pairs of code tiles, ping-pong -- the MFMAs of pair p+1 run while the VALU digests pair p
@@ -506,28 +610,29 @@ __device__ __forceinline__ void vq_filter_body(const VqArgs &a, unsigned char *s
         int nflag = 0;
 #pragma unroll
         for (int t = 0; t < ZT; ++t) {
-            const float v = zv[t];
-            z0[t] = __shfl(v, j, kWave); z1[t] = __shfl(v, 16 + j, kWave);
-            z2[t] = __shfl(v, 32 + j, kWave); z3[t] = __shfl(v, 48 + j, kWave);
+            {   // all four components of column j in every lane: three swaps
+                const uint2 eo = rows16(__float_as_uint(zv[t]));         // (z0,z0,z2,z2) / (z1,z1,z3,z3)
+                const uint2 e = rows32(eo.x), o = rows32(eo.y);
+                z0[t] = __uint_as_float(e.x); z2[t] = __uint_as_float(e.y);
+                z1[t] = __uint_as_float(o.x); z3[t] = __uint_as_float(o.y);
+            }
             zz[t] = sumsq4(z0[t], z1[t], z2[t], z3[t]);
-            float mt = m1[t];
-            mt = __builtin_fminf(mt, __shfl_xor(mt, 16, kWave));
-            mt = __builtin_fminf(mt, __shfl_xor(mt, 32, kWave));
+            const float mt = colmin(m1[t]);
             const float S = EEmax + 2.0f * Emax * (((fabsf(z0[t]) + fabsf(z1[t])) + fabsf(z2[t])) + fabsf(z3[t]));
             const float M = 1.2e-5f * S + 2.5e-7f * zz[t] + 1e-30f;
             float thr = mt + M;
             thr += fabsf(thr) * 2.4e-7f;
             // anything not comparable (NaN / Inf anywhere above) must count as "flagged": test the negation
             const bool hot = !(m1[t] > thr);                // this lane's best pair holds a candidate
-            const unsigned long long hm = __ballot(hot);
-            const unsigned long long mine = (hm >> j) & 0x0001000100010001ull;     // the 4 row groups of vector j
-            const bool flag = !(m2[t] > thr) || __builtin_popcountll(mine) != 1;
-            const unsigned long long fm = __ballot(flag);
-            flagged[t] = (unsigned int)((fm | (fm >> 16) | (fm >> 32) | (fm >> 48)) & 0xFFFFu);   // per vector, wave-uniform
+            const bool more = !(m2[t] > thr);               // ... and so does another pair of this lane
+            // settled iff exactly one hot row group and no second pair anywhere in the column
+            const bool flag = colsum((hot ? 1 : 0) + (more ? 4 : 0)) != 1;
+            flagged[t] = (unsigned int)(__ballot(flag) & 0xFFFFull);          // per vector, wave-uniform
             nflag += __builtin_popcount(flagged[t]);
             // exact fp32 on the 8 codes of the winning (pair, row group): two per lane, lowest index wins ties
-            const int gw = (__builtin_ctzll(mine | (1ull << 63)) >> 4) & 3;
-            const int bp = __shfl(bt[t], 16 * gw + j, kWave);
+            int key = colmax(hot ? ((bt[t] << 2) | g) : -1);
+            key = key < 0 ? 0 : key;                        // no hot lane at all (then the column is flagged anyway)
+            const int bp = key >> 2, gw = key & 3;
             float d = __builtin_inff();
             int i = 0;
 #pragma unroll
@@ -538,14 +643,7 @@ __device__ __forceinline__ void vq_filter_body(const VqArgs &a, unsigned char *s
                 d = take ? dd : d;
                 i = take ? c : i;
             }
-#pragma unroll
-            for (int off = 16; off < 64; off <<= 1) {
-                const float od = __shfl_xor(d, off, kWave);
-                const int oi = __shfl_xor(i, off, kWave);
-                const bool take = od < d || (od == d && oi < i);
-                d = take ? od : d;
-                i = take ? oi : i;
-            }
+            colargmin(d, i);
             win[t] = i;
         }
         nflag = __builtin_amdgcn_readfirstlane(nflag);
@@ -632,6 +730,7 @@ __device__ __forceinline__ void vq_filter_body(const VqArgs &a, unsigned char *s
         CGIC_STAMP(4);
 
         // ---- outputs: this lane owns channel g of vector n
+        double sq = 0.0;
 #pragma unroll
         for (int t = 0; t < ZT; ++t) {
             const int64_t n = base + 16 * t + j;
@@ -649,20 +748,20 @@ __device__ __forceinline__ void vq_filter_body(const VqArgs &a, unsigned char *s
                 if (g == 0 && idx_out) idx_out[n] = (int64_t)win[t];
             }
         }
+        if (a.sq_partial) {
+            // one partial per GROUP (not per wave): whichever wave took the group, the final sum has the same
+            // operands in the same order.  Fixed shuffle tree; write-through store, drained before the ticket.
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) sq += __shfl_down(sq, off, kWave);
+            if (lane == 0) __hip_atomic_store(&a.sq_partial[grp], sq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
     }
 
     CGIC_STAMP(5);
     if (a.sq_partial) {
-        // deterministic block reduction: fixed shuffle tree, then waves in order
-        __shared__ double wsum[NW];
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) sq += __shfl_down(sq, off, kWave);
-        if (lane == 0) wsum[wave] = sq;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's partials have reached L2
         __syncthreads();
-        double bs = 0.0;
-#pragma unroll
-        for (int w = 0; w < NW; ++w) bs += wsum[w];
-        finish_loss<NT>(bs, a.sq_partial, a.ticket, (double)N * 4.0, a.beta, a.legacy, a.loss, blockIdx.x, a.nblk);
+        finish_loss_groups<NT>(a.sq_partial, (unsigned int)ngroups, a.ticket, (double)N * 4.0, a.beta, a.legacy, a.loss, a.nblk);
     }
     CGIC_STAMP(6);
     CGIC_BLK_END();
@@ -675,7 +774,12 @@ __global__ __launch_bounds__(kVqfThreads, 1) void vq_filter_kernel(VqArgs a)
     vq_filter_body<ZT>(a, smem_f);
 }
 
-// the fused launch of the filter path: router workgroups behind the VQ workgroups (see vq_router_kernel)
+// The fused launch of the filter path: router workgroups behind the VQ workgroups (see vq_router_kernel).  A VQ
+// workgroup takes the CU's LDS (80 KB) and 2 x 166 VGPRs per SIMD, and dynamic LDS / the VGPR budget are per
+// launch, so a router workgroup starts when the first VQ workgroups retire: the fusion saves the launch gap, not
+// the router's ~10 us.  Measured alternatives, all slower at B=64: router workgroups first with the late VQ
+// workgroups carrying fewer groups (43.2 us vs 42.5), 8-byte A operands + a 128-VGPR build so that both kinds
+// share a CU (47.6 -- two VQ workgroups then also share CUs), the router on a forked graph branch (+9 us).
 template <int ZT>
 __global__ __launch_bounds__(kVqfThreads, 1) void vq_filter_router_kernel(VqArgs a, RouterArgs r)
 {
@@ -852,7 +956,7 @@ static int launch_filter(const float *z, int64_t hw, int64_t N, const float *cb,
     if (rc) return rc;
     const int64_t ngroups = (N + 16 * ZT - 1) / (16 * ZT);
     int64_t nblk = (ngroups + kVqfWaves - 1) / kVqfWaves;
-    if (nblk > cus) nblk = cus;                      // one resident workgroup per CU; waves loop over groups
+    if (nblk > cus) nblk = cus;                      // one resident workgroup per CU; waves take groups from a counter
     VqArgs a;
     a.z = z; a.hw = hw; a.N = N; a.cb = cb; a.K = K; a.idx_out = idx; a.zq_out = zq;
     a.sq_partial = loss ? ws.partial : nullptr; a.ticket = ws.ticket; a.beta = beta; a.legacy = legacy; a.loss = loss;
@@ -905,8 +1009,8 @@ using namespace cgic;
 
 extern "C" size_t cgic_vq_workspace_bytes(int64_t n_vectors)
 {
-    // one double per block of the smallest tiling (64 vectors per block)
-    return sizeof(double) * (size_t)((n_vectors + 63) / 64 + 1);
+    // one double per group of the smallest tiling (16 vectors per group)
+    return sizeof(double) * (size_t)((n_vectors + 15) / 16 + 1);
 }
 
 extern "C" int cgic_vq_forward_f32(const float *z, int64_t B, int64_t hw, const float *codebook, int K,

@@ -23,7 +23,7 @@ class HotPathPipeline:
         self.codec = GrainCodec(frequency if frequency is not None else quantizer.embedding_counter,
                                 quantizer.embedding.weight)
         self.chunks = max(1, int(chunks))
-        self.fork_vq = bool(fork_vq)      # run VQ(+hist) on a side stream next to entropy -> router
+        self.fork_vq = int(fork_vq)       # 1: VQ(+hist) on a side stream next to entropy -> router; 2: router on a side stream next to VQ
         self._streams = None
         self._side = None
 
@@ -33,7 +33,22 @@ class HotPathPipeline:
         return self._streams
 
     def _chain(self, x, z, hist, decode):
-        if self.fork_vq:
+        if self.fork_vq == 2:
+            # entropy, then the router on a side stream next to the VQ kernel
+            cur = torch.cuda.current_stream(x.device)
+            if self._side is None or self._side.device != x.device:
+                self._side = torch.cuda.Stream(x.device)
+            e8, e16 = entropy_maps(x)
+            fork = torch.cuda.Event()
+            fork.record(cur)
+            self._side.wait_event(fork)
+            with torch.cuda.stream(self._side):
+                mask, _, _, mode = self.router(e16, e8, want_gate=False)
+                join = torch.cuda.Event()
+                join.record(self._side)
+            zq, loss, ind = _vq_forward(z, self.vq.embedding.weight, self.vq.beta, self.vq.legacy, None)
+            cur.wait_event(join)
+        elif self.fork_vq:
             cur = torch.cuda.current_stream(x.device)
             if self._side is None or self._side.device != x.device:
                 self._side = torch.cuda.Stream(x.device)

@@ -44,7 +44,10 @@ __device__ inline float exact_dist(float z0, float z1, float z2, float z3, float
 
 struct Stats { unsigned long long flagged; unsigned long long t[6]; unsigned long long nw; };
 
-constexpr int NT = 512, NW = NT / 64;
+#ifndef PF_NT
+#define PF_NT 512
+#endif
+constexpr int NT = PF_NT, NW = NT / 64;
 template <int ZT, int MODE>   // MODE 0 full, 1 = no loop, 2 = no resolve (timing)
 __global__ __launch_bounds__(NT, 1) void vq_filter(const float *__restrict__ z, int64_t hw, int64_t N,
                                                     const float *__restrict__ cb, int K, int64_t *__restrict__ idx_out,
@@ -125,6 +128,7 @@ __global__ __launch_bounds__(NT, 1) void vq_filter(const float *__restrict__ z, 
         // pairs of code tiles, ping-pong: the MFMAs of pair p+1 are in flight while the VALU digests pair p
         const int np = ntile >> 1;
         f32x4 X0[ZT], X1[ZT], Y0[ZT], Y1[ZT];
+        for (int t = 0; t < ZT; ++t) { X0[t] = X1[t] = Y0[t] = Y1[t] = f32x4{zv[t], 1.f, 2.f, 3.f}; }
         const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
         auto issue = [&](int p, f32x4 (&A0)[ZT], f32x4 (&A1)[ZT]) {
             const int pp = p < np ? p : np - 1;
@@ -132,11 +136,13 @@ __global__ __launch_bounds__(NT, 1) void vq_filter(const float *__restrict__ z, 
             const bf16x8 a1 = __builtin_bit_cast(bf16x8, ldsA[(2 * pp + 1) * 64 + lane]);
 #pragma unroll
             for (int t = 0; t < ZT; ++t) {
-                A0[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, bop[t], zero4, 0, 0, 0);
-                A1[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, bop[t], zero4, 0, 0, 0);
+                if (MODE == 4) { asm volatile("" : "+v"(A0[t]), "+v"(A1[t])); continue; }
+                A0[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, bop[t], MODE == 3 ? A0[t] : zero4, 0, 0, 0);
+                A1[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, bop[t], MODE == 3 ? A1[t] : zero4, 0, 0, 0);
             }
         };
         auto digest = [&](int p, const f32x4 (&A0)[ZT], const f32x4 (&A1)[ZT]) {
+            if (MODE == 3) return;
 #pragma unroll
             for (int t = 0; t < ZT; ++t) {
                 // chain seeded with a constant: v_min3_f32 takes the raw MFMA outputs without a canonicalising v_max
@@ -158,6 +164,11 @@ __global__ __launch_bounds__(NT, 1) void vq_filter(const float *__restrict__ z, 
         }
         const long long Tc = wall_clock64();
         tl += Tb - Ta; tm += Tc - Tb;
+        if (MODE >= 3) {
+#pragma unroll
+            for (int t = 0; t < ZT; ++t) { const int64_t n = base + 16 * t + j; if (n < N && g == 0) idx_out[n] = bt[t] + (m2[t] < m1[t]) + (int)(X0[t][0] + X1[t][1] + Y0[t][2] + Y1[t][3]); }
+            continue;
+        }
         if (MODE == 2) {
 #pragma unroll
             for (int t = 0; t < ZT; ++t) { const int64_t n = base + 16 * t + j; if (n < N && g == 0) idx_out[n] = bt[t] + (m2[t] < m1[t]); }
@@ -335,6 +346,10 @@ int main(int argc, char **argv)
     printf("ZT=4 nblk=256  full %.2f us | no-loop %.2f | no-resolve %.2f\n",
            timeit<4, 0>(z, hw, N, cb, K, idx, nullptr, 256), timeit<4, 1>(z, hw, N, cb, K, idx, nullptr, 256),
            timeit<4, 2>(z, hw, N, cb, K, idx, nullptr, 256));
+    printf("scan only: both %.2f us | mfma only %.2f | valu only %.2f\n", timeit<4, 2>(z, hw, N, cb, K, idx, nullptr, 256),
+           timeit<4, 3>(z, hw, N, cb, K, idx, nullptr, 256), timeit<4, 4>(z, hw, N, cb, K, idx, nullptr, 256));
+    printf("scan only, half the CUs' worth of waves (nblk=128 => 1 group per wave x 2 waves/SIMD on half the CUs): both %.2f | mfma %.2f | valu %.2f\n",
+           timeit<4, 2>(z, hw, N / 2, cb, K, idx, nullptr, 256), timeit<4, 3>(z, hw, N / 2, cb, K, idx, nullptr, 256), timeit<4, 4>(z, hw, N / 2, cb, K, idx, nullptr, 256));
     printf("ZT=4 nblk=512  full %.2f us\n", timeit<4, 0>(z, hw, N, cb, K, idx, nullptr, 512));
     printf("ZT=8 nblk=256  full %.2f us\n", timeit<8, 0>(z, hw, N, cb, K, idx, nullptr, 256));
     printf("ZT=2 nblk=256  full %.2f us\n", timeit<2, 0>(z, hw, N, cb, K, idx, nullptr, 256));

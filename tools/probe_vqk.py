@@ -13,15 +13,12 @@ for name, f in (("full (z_q + loss)", lambda: _vq_forward(z, w, 0.25, True, None
     for _ in range(3): f()
     torch.cuda.synchronize()
     c = (ctypes.c_longlong * 32)(); l.cgic_debug_phase_clocks(c); c = list(c)
-    print(name, " | ".join(f"{n} {(c[i+1]-c[i])/2.29e3:.2f}" for i, n in enumerate(["stage codebook", "load z + zz", "main loop", "resolve+stores", "loss"])), "| total %.2f us; events %.1f us" % ((c[5]-c[0])/2.29e3, time_events(f, 100)))
-import numpy as np
-f = lambda: _vq_forward(z, w, 0.25, True, None)
-f(); torch.cuda.synchronize()
-n = 1024
-buf = (ctypes.c_longlong * (2 * n))(); l.cgic_debug_block_times(buf, n)
-t = np.array(list(buf), dtype=np.int64).reshape(n, 2)
-t0 = t[:, 0].min()
-st = (t[:, 0] - t0) / 100.0; en = (t[:, 1] - t0) / 100.0
-print("workgroups: start min/median/max = %.1f / %.1f / %.1f us; end min/median/max = %.1f / %.1f / %.1f us; duration median %.1f us" % (st.min(), np.median(st), st.max(), en.min(), np.median(en), en.max(), np.median(en - st)))
-hist, edges = np.histogram(st, bins=12)
-print("start-time histogram (us):", [(round(float(a), 1), int(c)) for a, c in zip(edges[:-1], hist)])
+    print(name, " | ".join(f"{n} {(c[i+1]-c[i])/2.29e3:.2f}" for i, n in enumerate(["stage codebook", "split z (last group)", "scan", "decide", "outputs", "loss"])), "| total %.2f us; events %.1f us" % ((c[6]-c[0])/2.29e3, time_events(f, 100)))
+for name, f in (("full", lambda: _vq_forward(z, w, 0.25, True, None)), ("indices only", lambda: _vq_forward(z, w, 0.25, True, None, False, False))):
+    f(); f(); torch.cuda.synchronize()
+    n = 256
+    buf = (ctypes.c_longlong * (2 * n))(); l.cgic_debug_block_times(buf, n)
+    t = np.array(list(buf), dtype=np.int64).reshape(n, 2)
+    t0 = t[:, 0].min()
+    st = (t[:, 0] - t0) / 100.0; en = (t[:, 1] - t0) / 100.0
+    print(name, "workgroups: start max %.1f us; end percentiles 0/25/50/75/90/99/100 = %s us" % (st.max(), " / ".join("%.1f" % np.percentile(en, q) for q in (0, 25, 50, 75, 90, 99, 100))))
