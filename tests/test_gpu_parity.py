@@ -95,6 +95,49 @@ def test_vq_vs_oracle_and_cross_kernel(orc, shape, scale):
     assert np.array_equal(e, cb.numpy()[oidx])
 
 
+def _vq_filter_cases():
+    g = torch.Generator().manual_seed(77)
+    cb = torch.randn(1024, 4, generator=g)
+    z = torch.randn(3, 4, 5, 7, generator=g)                       # N = 105: ragged last group
+    big = torch.randn(4, 4, 32, 32, generator=g)
+    dup = cb.clone(); dup[512:] = dup[:512]                        # every code twice: the lower index must win
+    onrow = cb[torch.randint(0, 1024, (2 * 16 * 16,), generator=g)].reshape(2, 16, 16, 4).permute(0, 3, 1, 2).contiguous()
+    return {
+        "zero_codebook": (big, torch.zeros(1024, 4)),              # every distance ties -> index 0, whole groups flagged
+        "duplicate_codes": (big, dup),
+        "latents_on_codes": (onrow, cb),                           # distance ~0 for the winner
+        "constant_latents": (torch.full((2, 4, 16, 16), 0.37), cb),
+        "ragged": (z, cb),
+        "zz_dominates": (big * 1.0e4, cb * 1.0e-3),                # fl(zz + ee) swallows ee: masses of exact ties
+        "huge_latents": (big * 1.0e18, cb),                        # zz overflows to inf, like the reference
+        "tiny_everything": (big * 1.0e-25, cb * 1.0e-25),          # products underflow
+        "K64": (big, cb[:64].clone()),
+        "K256": (big, cb[:256].clone()),
+        "K48_exact_loop": (big, cb[:48].clone()),                  # K % 64 != 0 -> fp32 MFMA loop
+        "K2048_exact_loop": (big, torch.randn(2048, 4, generator=g)),
+    }
+
+
+@pytest.mark.parametrize("case", sorted(_vq_filter_cases()))
+def test_vq_filter_path_degenerate_inputs(case):
+    """the bf16-filter path (kernel="mfma", K % 64 == 0, K <= 1024) against the plain-VALU restatement of the
+    reference's rounding sequence: indices and z_q bit-exact whatever the filter flags"""
+    from control_gic_amd.quantize import _vq_forward
+    z, cb = _vq_filter_cases()[case]
+    z, cb = z.to(DEV), cb.to(DEV)
+    zq_a, loss_a, idx_a = _vq_forward(z, cb, 0.25, True, None, kernel="mfma")
+    zq_b, loss_b, idx_b = _vq_forward(z, cb, 0.25, True, None, kernel="valu")
+    assert int(idx_a.min()) >= 0 and int(idx_a.max()) < cb.shape[0]
+    assert torch.equal(idx_a, idx_b)
+    assert torch.equal(zq_a, zq_b)
+    la, lb = float(loss_a), float(loss_b)
+    assert (la == lb) or abs(la - lb) <= 1e-6 * abs(lb)            # == covers inf
+    if case == "zero_codebook":
+        assert int(idx_a.max()) == 0
+    if case == "duplicate_codes":
+        assert int(idx_a.max()) < 512
+
+
 def test_vq_backward_matches_reference_formula():
     g = torch.Generator().manual_seed(5)
     z = torch.randn(2, 4, 8, 8, generator=g).to(DEV).requires_grad_(True)

@@ -257,6 +257,30 @@ __global__ __launch_bounds__(NT, 1) void vq_filter(const float *__restrict__ z, 
     if (stats && lane == 0) { atomicAdd(&stats->t[0], (unsigned long long)(T1 - T0)); atomicAdd(&stats->t[1], (unsigned long long)tl); atomicAdd(&stats->t[2], (unsigned long long)tm); atomicAdd(&stats->t[3], (unsigned long long)tr); atomicAdd(&stats->t[4], (unsigned long long)(wall_clock64() - T0)); atomicAdd(&stats->nw, 1ull); }
 }
 
+// dumps the raw filter scores f(k) of the first 16 vectors (column tile 0) for an error measurement
+__global__ void dump_scores(const float *__restrict__ z, int64_t hw, const float *__restrict__ cb, int K, float *__restrict__ out)
+{
+    const int lane = threadIdx.x, j = lane & 15, g = lane >> 4;
+    const float v = z[(0 * 4 + g) * hw + j];
+    unsigned h, m, l;
+    split3(v, h, m, l);
+    uint4 bb; bb.x = h | (h << 16); bb.y = m | (h << 16); bb.z = l | (m << 16); bb.w = 0x3F80u;
+    const bf16x8 bop = __builtin_bit_cast(bf16x8, bb);
+    for (int t = 0; t < K / 16; ++t) {
+        const int mrow = lane & 15;
+        const float4 e = reinterpret_cast<const float4 *>(cb)[16 * t + mrow];
+        const float ee = sumsq4(e.x, e.y, e.z, e.w);
+        const float ec = g == 0 ? e.x : g == 1 ? e.y : g == 2 ? e.z : e.w;
+        unsigned wh, wm, wl, eh, em, el;
+        split3(-2.0f * ec, wh, wm, wl);
+        split3(ee, eh, em, el);
+        uint4 a; a.x = wh | (wm << 16); a.y = wh | (wl << 16); a.z = wh | (wm << 16); a.w = g == 0 ? eh : g == 1 ? em : g == 2 ? el : 0u;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), bop, acc, 0, 0, 0);
+        for (int i = 0; i < 4; ++i) out[(size_t)j * K + 16 * t + 4 * g + i] = acc[i];    // [vector j][code]
+    }
+}
+
 static float frand(uint64_t &s)
 {
     // Box-Muller on an LCG
@@ -305,6 +329,29 @@ int main(int argc, char **argv)
     hipMemcpy(z, hz.data(), hz.size() * 4, hipMemcpyHostToDevice);
     hipMemcpy(cb, hcb.data(), hcb.size() * 4, hipMemcpyHostToDevice);
 
+    {   // filter error: |f - F| / S over 16 vectors x K codes
+        float *dsc; hipMalloc(&dsc, 16 * K * 4);
+        hipLaunchKernelGGL(dump_scores, dim3(1), dim3(64), 0, 0, z, (int64_t)hw, cb, K, dsc);
+        std::vector<float> sc(16 * K);
+        hipMemcpy(sc.data(), dsc, sc.size() * 4, hipMemcpyDeviceToHost);
+        float emax = 0, eemax = 0;
+        for (int k = 0; k < K; ++k) { for (int d = 0; d < 4; ++d) emax = fmaxf(emax, fabsf(hcb[k * 4 + d])); eemax = fmaxf(eemax, sumsq4(hcb[k*4], hcb[k*4+1], hcb[k*4+2], hcb[k*4+3])); }
+        double worst = 0, worst_rel_sk = 0;
+        for (int j = 0; j < 16; ++j) {
+            const float zj[4] = {hz[0 * hw + j], hz[1 * hw + j], hz[2 * hw + j], hz[3 * hw + j]};
+            const double S = eemax + 2.0 * emax * (fabs(zj[0]) + fabs(zj[1]) + fabs(zj[2]) + fabs(zj[3]));
+            for (int k = 0; k < K; ++k) {
+                const float *e = &hcb[(size_t)k * 4];
+                const double ee = sumsq4(e[0], e[1], e[2], e[3]);
+                double F = ee, Sk = ee;
+                for (int d = 0; d < 4; ++d) { F -= 2.0 * (double)zj[d] * (double)e[d]; Sk += 2.0 * fabs((double)zj[d] * (double)e[d]); }
+                const double err = fabs((double)sc[(size_t)j * K + k] - F);
+                if (err / S > worst) worst = err / S;
+                if (err / Sk > worst_rel_sk) worst_rel_sk = err / Sk;
+            }
+        }
+        printf("filter error: max |f - F| / S = 2^%.1f (bound used 2^-17.6); relative to the code's own S_k: 2^%.1f\n", log2(worst), log2(worst_rel_sk));
+    }
     // correctness: one launch, compare with the exact formula on the host for a sample of vectors
     {
         size_t lds = (size_t)K * 80;
