@@ -17,10 +17,10 @@
 //                   any length (the reference's table can reach 1023 bits) need no special case.
 //          masks:   64 positions per wave -> one __ballot -> 8 bit-reversed bytes.
 //  decode  one wave per stream: every lane speculatively decodes "a codeword starting at
-//          bit base+lane" through a 12-bit LUT in LDS (64 starts in one LDS round trip); a
+//          bit base+lane" through a 13-bit LUT in LDS (64 starts in one LDS round trip); a
 //          wave-uniform scalar chain (v_readlane) then walks the true codeword boundaries,
 //          ~10 cycles per symbol instead of a dependent LDS/HBM lookup per symbol.  Codes
-//          longer than 12 bits fall back to a trie walk at the point the chain reaches them.
+//          longer than 13 bits fall back to a trie walk at the point the chain reaches them.
 //  merge   rank = prefix popcount of the bit-packed masks (read straight from the mask
 //          streams); one block per image scatters the three symbol lists, sums the x1/x2/x4
 //          grids and gathers codebook rows.
@@ -38,7 +38,7 @@ __device__ long long g_blk_t[2 * 4096];
 constexpr int kEncThreads = 1024;         // x kEncItems = 4096 positions per scan round: one round per 256x256 stream
 constexpr int kEncItems = 4;            // consecutive positions per thread per scan round
 constexpr int kLdsPos = 8192;           // streams up to this many positions keep phase-A results in LDS
-constexpr int kDecLutMax = 4096;        // 12-bit LUT
+constexpr int kDecLutMax = 1 << kLutBitsMax;        // 13-bit LUT
 
 // -------------------------------------------------------------------------------------------
 // encode
@@ -453,7 +453,7 @@ constexpr int kDecWaves = kDecThreads / kWave;
 constexpr int kSegWin = 1024;                      // LDS window of stream bytes per wave
 constexpr int kSegWinWords = kSegWin / 4 + 4;           // 65 x 16 B: one uint4 per lane + one tail
 constexpr int kBig = 1 << 28;                      // "past the end of the stream"
-constexpr int kU = 4;                              // chunks in flight per wave
+constexpr int kU = 10;                             // chunks in flight per wave (a 256x256 medium stream is ~150 chunks = 10 per wave: one round)
 constexpr int kLdsTrieNodes = 2048;                // decode tries up to this many nodes are staged in LDS (16 KB)
 constexpr int kFastChunks = 192;                   // streams up to this many chunks (1.5 KB) cache per-position
                                                    // lengths / symbols / chunk functions for the lane-per-chunk pass C
@@ -609,9 +609,11 @@ __device__ __forceinline__ void decode_segmented(const TableDev &t, const uint32
             for (int r = 0; r < t.dbl_rounds; ++r) {
 #pragma unroll
                 for (int u = 0; u < kU; ++u) {
-                    const int nx = pk[u] & 0xFF;
-                    const int o = __shfl(pk[u], nx & 63, kWave);
-                    if (nx < kWave) pk[u] = o + (pk[u] & 0xFF00);       // new next | (count + count on the way); counts <= 64
+                    if (c + u < c1) {                           // wave-uniform
+                        const int nx = pk[u] & 0xFF;
+                        const int o = __shfl(pk[u], nx & 63, kWave);
+                        if (nx < kWave) pk[u] = o + (pk[u] & 0xFF00);   // new next | (count + count on the way); counts <= 64
+                    }
                 }
             }
             if (c == 0) CGIC_STAMP3(18);
@@ -778,7 +780,7 @@ __global__ __launch_bounds__(kDecThreads) void decode_streams_kernel(DecodeArgs 
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t sm[];
     __shared__ int s_count;
-    uint32_t *lut = sm;                                 // [4096]
+    uint32_t *lut = sm;                                 // [kDecLutMax]
     uint32_t *win = lut + kDecLutMax;                   // [16][kSegWinWords] (slow mode: 1 x kWinWords)
     SegShared *seg = reinterpret_cast<SegShared *>(win + kDecWaves * kSegWinWords);
     const int tid = threadIdx.x, lane = lane_id(), wave = tid >> 6;

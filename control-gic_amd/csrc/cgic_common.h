@@ -39,6 +39,8 @@ inline int launch_check(const char *kernel)
     return CGIC_OK;
 }
 
+constexpr int kLutBitsMax = 13;   // decode LUT width (entries of 4 bytes: 32 KB of LDS in the decode kernels)
+
 // ---- device-side table view ----------------------------------------------------
 struct TableDev {
     const int32_t *len;    // [n] code length in bits

@@ -23,52 +23,57 @@ __device__ __forceinline__ float key2f(uint32_t k)
 }
 
 struct RouterShared {
-    unsigned int hist[256];
-    unsigned int prefix;
-    unsigned int rank;
+    unsigned int hist[3][256];      // rotating: pass p counts into [p % 3] while [(p + 1) % 3] is being cleared
 };
 
 // k-th smallest (0-based rank) of n values produced by val(i); all NT threads of the block call.
+// 4 passes of 8 bits, ONE barrier per pass: every wave finds the digit holding the rank by itself from the
+// finished histogram (a 256-bin scan is 4 loads + one wave scan), so there is nothing to broadcast, and the
+// histogram of pass p+1 was cleared during pass p (three rotating buffers: a slow wave may still be reading
+// pass p-1's while a fast one clears).  The previous 3-barriers-per-pass version cost 2.8 + 5.8 us for the two
+// selects of a 256x256 image.
 template <int NT, typename F>
 __device__ float radix_select(F val, int64_t n, unsigned int rank0, RouterShared *sh)
 {
     const int tid = threadIdx.x;
-    if (tid == 0) { sh->prefix = 0; sh->rank = rank0; }
-    unsigned int himask = 0;
+    const int lane = lane_id();
+    for (int i = tid; i < 512; i += NT) (&sh->hist[0][0])[i] = 0;      // buffers 0 and 1
+    __syncthreads();
+    unsigned int prefix = 0, rank = rank0, himask = 0;
+    int pass = 0;
 #pragma unroll 1
-    for (int shift = 24; shift >= 0; shift -= 8) {
-        if (tid < 256) sh->hist[tid] = 0;
-        __syncthreads();
-        const unsigned int prefix = sh->prefix;
+    for (int shift = 24; shift >= 0; shift -= 8, ++pass) {
+        unsigned int *h = sh->hist[pass % 3];
         // (a wave-aggregated variant -- one ballot per distinct digit per wave -- was measured 2x
         // SLOWER than plain LDS atomics here, even though entropy values crowd into 2-3 bins of the
-        // first pass: 5.3 + 10.6 us vs 2.8 + 5.8 us for the two selects of a 256x256 image)
+        // first pass)
         for (int64_t i = tid; i < n; i += NT) {
             uint32_t key = f2key(val(i));
-            if ((key & himask) == prefix) atomicAdd(&sh->hist[(key >> shift) & 0xFF], 1u);
+            if ((key & himask) == prefix) atomicAdd(&h[(key >> shift) & 0xFF], 1u);
+        }
+        if (pass >= 1) {
+            unsigned int *hz = sh->hist[(pass + 1) % 3];
+            for (int i = tid; i < 256; i += NT) hz[i] = 0;
         }
         __syncthreads();
-        if (tid < kWave) {
-            // lane handles 4 consecutive digits; find the digit holding `rank`
-            const unsigned int rank = sh->rank;
-            unsigned int c0 = sh->hist[4 * tid], c1 = sh->hist[4 * tid + 1];
-            unsigned int c2 = sh->hist[4 * tid + 2], c3 = sh->hist[4 * tid + 3];
-            unsigned int s = c0 + c1 + c2 + c3;
-            unsigned int incl = wave_inclusive_scan(s);
-            unsigned int excl = incl - s;
-            if (excl <= rank && rank < incl) {
-                unsigned int r = rank - excl, d = 4 * tid;
-                if (r >= c0) { r -= c0; ++d; if (r >= c1) { r -= c1; ++d; if (r >= c2) { r -= c2; ++d; } } }
-                sh->prefix = prefix | (d << shift);
-                sh->rank = r;
-            }
-        }
+        // every wave: lane handles 4 consecutive digits; find the digit holding `rank`
+        const unsigned int c0 = h[4 * lane], c1 = h[4 * lane + 1], c2 = h[4 * lane + 2], c3 = h[4 * lane + 3];
+        const unsigned int s = c0 + c1 + c2 + c3;
+        const unsigned int incl = wave_inclusive_scan(s);
+        const unsigned int excl = incl - s;
+        const bool mine = excl <= rank && rank < incl;
+        unsigned int r = rank - excl, d = 4 * lane;
+        if (r >= c0) { r -= c0; ++d; if (r >= c1) { r -= c1; ++d; if (r >= c2) { r -= c2; ++d; } } }
+        const unsigned long long who = __ballot(mine);
+        const int src = who ? __builtin_ctzll(who) : 0;            // (rank >= n cannot happen: checked on the host)
+        d = __shfl(d, src, kWave);
+        r = __shfl(r, src, kWave);
+        prefix |= d << shift;
+        rank = r;
         himask |= 0xFFu << shift;
-        __syncthreads();
     }
-    const float thr = key2f(sh->prefix);
-    __syncthreads();   // everyone has read prefix before a later call resets it
-    return thr;
+    __syncthreads();   // all waves are done with the histograms before a later call clears them
+    return key2f(prefix);
 }
 
 struct RouterArgs {
@@ -90,7 +95,7 @@ template <int NT>
 __device__ __forceinline__ void router_body(const RouterArgs &a, int64_t seg, unsigned char *dyn)
 {
     RouterShared *sh = reinterpret_cast<RouterShared *>(dyn);
-    unsigned long long *gc_bits = reinterpret_cast<unsigned long long *>(dyn + 1040);  // [ceil(N16/64)]
+    unsigned long long *gc_bits = reinterpret_cast<unsigned long long *>(dyn + 3072);  // [ceil(N16/64)]
 
     const int tid = threadIdx.x;
     const int lane = lane_id();
@@ -205,7 +210,7 @@ __device__ __forceinline__ void router_body(const RouterArgs &a, int64_t seg, un
 
 __host__ __device__ inline size_t router_lds_bytes(int64_t N16, int64_t N8, int *stage)
 {
-    size_t lds = 1040 + 8 * (size_t)((N16 + 63) / 64);
+    size_t lds = 3072 + 8 * (size_t)((N16 + 63) / 64);
     const int st = lds + 4 * (size_t)(N16 + 2 * N8) <= 96 * 1024 ? 1 : 0;      // e16, e8 and the masked copy of e8
     if (st) lds += 4 * (size_t)(N16 + 2 * N8);
     if (stage) *stage = st;

@@ -175,7 +175,9 @@ static void finish_table(Table *t)
         }
     }
     // LUT on the first lut_bits bits
-    t->lut_bits = t->max_len < 12 ? (t->max_len < 1 ? 1 : t->max_len) : 12;
+    // 13 bits: the whole of a Zipf-like 1024-symbol table (max_len 13) resolves with ONE LDS read per position;
+    // with 12 bits, 5 % of the bit positions of a stream walked the trie, and a wave waits for its slowest lane
+    t->lut_bits = t->max_len < kLutBitsMax ? (t->max_len < 1 ? 1 : t->max_len) : kLutBitsMax;
     const int LB = t->lut_bits;
     t->lut.assign((size_t)1 << LB, 0);
     for (uint32_t w = 0; w < (1u << LB); ++w) {
