@@ -458,7 +458,7 @@ constexpr int kLdsTrieNodes = 2048;                // decode tries up to this ma
 constexpr int kFastChunks = 192;                   // streams up to this many chunks (1.5 KB) cache per-position
                                                    // lengths / symbols / chunk functions for the lane-per-chunk pass C
 constexpr int kPackBig = 0xFF;                     // packed "past the end" marker (max real next = 63 + 64)
-constexpr int kMergeItems = 4;
+constexpr int kMergeItems = 2;
 
 struct BitWindow {
     uint32_t *win;           // LDS, kSegWinWords
@@ -837,7 +837,7 @@ __global__ __launch_bounds__(kDecThreads) void decode_streams_kernel(DecodeArgs 
     if (tid == 0) *dc = s_count > cap ? -3 : s_count;
 }
 
-constexpr int kMergeThreads = 256;
+constexpr int kMergeThreads = 512;
 constexpr int kMergeBands = 4;
 
 struct MergeArgs {
@@ -930,54 +930,86 @@ __global__ __launch_bounds__(kMergeThreads) void merge_kernel(MergeArgs a)
         if (rem < 32) v &= rem <= 0 ? 0u : ((1u << rem) - 1u);
         return v;
     };
-    for (int64_t i = tid; i < wc; i += kMergeThreads) {
-        uint32_t v = 0;
-        if (send_mc) v = stream_word(rawc, i, n_c);
-        else if (mode == 4) {                                                   // ones (:355)
-            v = 0xFFFFFFFFu;
-            const int64_t rem = n_c - i * 32;
-            if (rem < 32) v &= (1u << rem) - 1u;
-        }
-        mcb[i] = v;
-    }
-    __syncthreads();
-    for (int64_t i = tid; i < wm; i += kMergeThreads) {
-        uint32_t v = 0;
-        if (send_mm) v = stream_word(rawm, i, n_m);
-        else if (mode == 3 || mode == 5) {
-            for (int k = 0; k < 32; ++k) {
-                const int64_t j = i * 32 + k;
-                if (j >= n_m) break;
-                bool bit = true;                                                // mode 5: ones (:368)
-                if (mode == 3) {                                                // 1 - up2(mask_coarse) (:332)
-                    const int64_t y = j / w2, x = j - y * w2, c = (y >> 1) * w4 + (x >> 1);
-                    bit = !((mcb[c >> 5] >> (c & 31)) & 1u);
+    uint32_t cnt_c, cnt_m;
+    __shared__ uint32_t s_cnt[2];
+    const bool derived_mm = mode == 3 || mode == 5;       // medium mask built from the coarse one / all ones
+    if (wc <= kWave && wm <= kWave && !derived_mm) {
+        // small masks (<= 2048 positions): wave 0 builds the coarse bitset + prefix, wave 1 the medium one, each with
+        // one wave scan -- one barrier instead of two loops + two block scans (8 barriers)
+        const int lane = lane_id(), wave = tid >> 6;
+        if (wave < 2) {
+            const bool co = wave == 0;
+            const int64_t nw_ = co ? wc : wm, nb_ = co ? n_c : n_m;
+            uint32_t v = 0;
+            if (lane < nw_) {
+                if (co ? send_mc : send_mm) v = stream_word(co ? rawc : rawm, lane, nb_);
+                else if (co && mode == 4) {                                         // ones (:355)
+                    v = 0xFFFFFFFFu;
+                    const int64_t rem = nb_ - (int64_t)lane * 32;
+                    if (rem < 32) v &= (1u << rem) - 1u;
                 }
-                v |= (uint32_t)bit << k;
             }
+            const uint32_t c = (uint32_t)__popc(v);
+            const uint32_t inc = wave_inclusive_scan(c);
+            if (lane < nw_) {
+                (co ? mcb : mmb)[lane] = v;
+                (co ? pcb : pmb)[lane] = inc - c;
+            }
+            if (lane == kWave - 1) s_cnt[wave] = inc;
         }
-        mmb[i] = v;
+        __syncthreads();
+        cnt_c = s_cnt[0];
+        cnt_m = s_cnt[1];
+    } else {
+        for (int64_t i = tid; i < wc; i += kMergeThreads) {
+            uint32_t v = 0;
+            if (send_mc) v = stream_word(rawc, i, n_c);
+            else if (mode == 4) {                                                   // ones (:355)
+                v = 0xFFFFFFFFu;
+                const int64_t rem = n_c - i * 32;
+                if (rem < 32) v &= (1u << rem) - 1u;
+            }
+            mcb[i] = v;
+        }
+        __syncthreads();
+        for (int64_t i = tid; i < wm; i += kMergeThreads) {
+            uint32_t v = 0;
+            if (send_mm) v = stream_word(rawm, i, n_m);
+            else if (mode == 3 || mode == 5) {
+                for (int k = 0; k < 32; ++k) {
+                    const int64_t j = i * 32 + k;
+                    if (j >= n_m) break;
+                    bool bit = true;                                                // mode 5: ones (:368)
+                    if (mode == 3) {                                                // 1 - up2(mask_coarse) (:332)
+                        const int64_t y = j / w2, x = j - y * w2, c = (y >> 1) * w4 + (x >> 1);
+                        bit = !((mcb[c >> 5] >> (c & 31)) & 1u);
+                    }
+                    v |= (uint32_t)bit << k;
+                }
+            }
+            mmb[i] = v;
+        }
+        __syncthreads();
+        uint32_t carry = 0, total;
+        for (int64_t base = 0; base < wc; base += kMergeThreads) {
+            const int64_t i = base + tid;
+            const uint32_t c = i < wc ? (uint32_t)__popc(mcb[i]) : 0u;
+            const uint32_t ex = block_exclusive_scan(c, scan_smem, &total);
+            if (i < wc) pcb[i] = carry + ex;
+            carry += total;
+        }
+        cnt_c = carry;
+        carry = 0;
+        for (int64_t base = 0; base < wm; base += kMergeThreads) {
+            const int64_t i = base + tid;
+            const uint32_t c = i < wm ? (uint32_t)__popc(mmb[i]) : 0u;
+            const uint32_t ex = block_exclusive_scan(c, scan_smem, &total);
+            if (i < wm) pmb[i] = carry + ex;
+            carry += total;
+        }
+        cnt_m = carry;
+        __syncthreads();
     }
-    __syncthreads();
-    uint32_t carry = 0, total;
-    for (int64_t base = 0; base < wc; base += kMergeThreads) {
-        const int64_t i = base + tid;
-        const uint32_t c = i < wc ? (uint32_t)__popc(mcb[i]) : 0u;
-        const uint32_t ex = block_exclusive_scan(c, scan_smem, &total);
-        if (i < wc) pcb[i] = carry + ex;
-        carry += total;
-    }
-    const uint32_t cnt_c = carry;
-    carry = 0;
-    for (int64_t base = 0; base < wm; base += kMergeThreads) {
-        const int64_t i = base + tid;
-        const uint32_t c = i < wm ? (uint32_t)__popc(mmb[i]) : 0u;
-        const uint32_t ex = block_exclusive_scan(c, scan_smem, &total);
-        if (i < wm) pmb[i] = carry + ex;
-        carry += total;
-    }
-    const uint32_t cnt_m = carry;
-    __syncthreads();
     CGIC_STAMP(12);
 
     auto fine_flag = [&](int64_t y, int64_t x, bool *pbc, bool *pbm) -> bool {
