@@ -30,13 +30,25 @@ constexpr int kTileStride = 68;  // 64 pixels + 4 pad dwords: conflict-free b128
 struct BinsArg { float v[kBins]; };   // passed by value in the kernarg segment
 
 // Butterfly over the 32 bins held by lanes {0..31} (and, mirrored, {32..63}); every lane ends with
-// the same total, summed in the same fixed order => deterministic.  (A DPP row-reduction +
-// v_readlane variant was measured SLOWER on MI355X: 48.7 vs 39.6 us at B=64.)
+// the same total, summed in the same fixed order => deterministic.  Offsets 1, 2, 4, 8 are DPP operands of
+// the adds (quad_perm / row_half_mirror / row_mirror on values that are already uniform inside the smaller
+// group = xor), offset 16 is a v_permlane16_swap: no LDS round trip (five ds_bpermute + waits cost ~55 ns per
+// sum, six sums per 16x16 patch).  Same association as the ds_bpermute butterfly it replaces, bit for bit.
+// (An earlier DPP + v_readlane variant was measured SLOWER: 48.7 vs 39.6 us at B=64.)
+template <int CTRL>
+__device__ __forceinline__ float dpp_add(float v)
+{
+    return v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
 __device__ __forceinline__ float sum32(float v)
 {
-#pragma unroll
-    for (int off = 1; off < 32; off <<= 1) v += __shfl_xor(v, off, kWave);
-    return v;
+    v = dpp_add<0xB1>(v);        // quad_perm [1,0,3,2]: xor 1
+    v = dpp_add<0x4E>(v);        // quad_perm [2,3,0,1]: xor 2
+    v = dpp_add<0x141>(v);       // row_half_mirror: xor 4 for quad-uniform values
+    v = dpp_add<0x140>(v);       // row_mirror: xor 8 for values uniform over 8 lanes
+    unsigned int a = __float_as_uint(v), b = a;
+    swap16(a, b);
+    return __uint_as_float(a) + __uint_as_float(b);      // xor 16
 }
 
 // entropy of one histogram: lane (b = lane&31) holds sum over pixels of bin b
@@ -132,7 +144,7 @@ __global__ __launch_bounds__(kEntThreads) void entropy_maps_kernel(
             a4.x += v.x; a4.y += v.y; a4.z += v.z; a4.w += v.w;
         }
         float s = (a4.x + a4.y) + (a4.z + a4.w);
-        s += __shfl_xor(s, 32, kWave);
+        s += __shfl_xor(s, 32, kWave);     // (a v_permlane32_swap here instead was measured 18 us SLOWER per launch)
         __builtin_amdgcn_wave_barrier();
         // clear what this pixel deposited, ready for the next sub-patch
 #pragma unroll

@@ -338,19 +338,21 @@ __global__ __launch_bounds__(kVqThreads, ZT <= 4 ? 4 : 2) void vq_router_kernel(
 //    (8+8+8 significand bits, by truncation); the 32 K-slots carry, per dimension, the six products
 //    zh.wh zh.wm zm.wh zh.wl zl.wh zm.wm, plus ee's three pieces against 1.0.  Dropped terms and fp32
 //    accumulation leave |f - F| <= 2^-17.6 S, S = max ee + 2 max|e| sum|z_j| (measured: ~2^-22 S).
-//  * per lane, a running (smallest, second smallest, where) over PAIRS of tiles: 4 v_min3 + cmp + cndmask
-//    + med3 + min for 2 MFMAs -- 4 slots per tile, and a 16-cycle bf16 MFMA hides beside them.
+//  * per lane, a running (smallest, second smallest, where) over QUADS of tiles (64 codes): 8 v_min3 + cmp +
+//    cndmask + med3 + min for 4 MFMAs -- 3 VALU per tile instead of 12, and an 8 ns MFMA instead of 14.5.
 //  * every code whose reference distance could be minimal has f <= f_min + M,
 //    M = 2 (|f - F| + |d_ref - zz - F|) <= 1.2e-5 S + 2.5e-7 zz  (d_ref's own rounding: 2^-23 zz + 2^-21 S).
-//    If the winner's pair-of-tiles is the only place holding such codes (second-smallest pair value of every
-//    row group above the threshold, one hot row group), its 8 codes are evaluated with the exact fp32
+//    S is the smaller of the codebook-maxima bound and (|z| + sqrt D)(3|z| + sqrt D), D = zz + f_min + slack (the
+//    winner and whatever can beat it lie within sqrt D of z).
+//    If the winner's quad is the only place holding such codes (second-smallest quad value of every
+//    row group above the threshold, one hot row group), its 16 codes are evaluated with the exact fp32
 //    sequence and the lowest-index minimum is the reference's argmin.  Otherwise (0.1-0.5 % of N(0,1)
 //    vectors) the wave scans all K codes exactly for that vector; a group with many such vectors reruns
 //    the exact fp32-MFMA loop.  Results are bit-identical to the exact kernels for every finite input.
 // =====================================================================================================
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
-constexpr int kVqfThreads = 512;               // 8 waves, one workgroup per CU (80 KB of LDS at K = 1024)
+constexpr int kVqfThreads = 512;               // 8 waves, one workgroup per CU (84 KB of LDS at K = 1024)
 constexpr int kVqfWaves = kVqfThreads / 64;
 constexpr int kVqfMaxK = 1024;
 constexpr int kVqfBulk = 12;                   // more flagged vectors than this in a 64-vector group: rerun it exactly on the MFMA
@@ -373,13 +375,15 @@ __device__ __forceinline__ void split3(float x, unsigned int &h, unsigned int &m
 //   rows32(x): .x = x of the lower 32 lanes in both halves, .y = the upper 32 lanes' in both halves
 __device__ __forceinline__ uint2 rows16(unsigned int x)
 {
-    const auto r = __builtin_amdgcn_permlane16_swap(x, x, false, false);
-    return make_uint2(r[0], r[1]);
+    unsigned int a = x, b = x;
+    swap16(a, b);
+    return make_uint2(a, b);
 }
 __device__ __forceinline__ uint2 rows32(unsigned int x)
 {
-    const auto r = __builtin_amdgcn_permlane32_swap(x, x, false, false);
-    return make_uint2(r[0], r[1]);
+    unsigned int a = x, b = x;
+    swap32(a, b);
+    return make_uint2(a, b);
 }
 // reduce over the 4 row groups of each column; every lane of the column gets the result
 __device__ __forceinline__ float colmin(float x)
@@ -426,13 +430,13 @@ __device__ __forceinline__ void colargmin(float &d, int &i)
 }
 
 // the reference's rounding sequence for one codebook row
-__device__ __forceinline__ float dist_row(float z0, float z1, float z2, float z3, float zz, const float4 e)
+__device__ __forceinline__ float dist_row(float z0, float z1, float z2, float z3, float zz, const float4 e, float ee)
 {
     float mm = z0 * e.x;
     mm = __builtin_fmaf(z1, e.y, mm);
     mm = __builtin_fmaf(z2, e.z, mm);
     mm = __builtin_fmaf(z3, e.w, mm);
-    return __builtin_fmaf(-2.0f, mm, zz + sumsq4(e.x, e.y, e.z, e.w));
+    return __builtin_fmaf(-2.0f, mm, zz + ee);
 }
 
 template <int ZT>
@@ -449,6 +453,7 @@ __device__ __forceinline__ void vq_filter_body(const VqArgs &a, unsigned char *s
     // (8 bytes per lane + two v_mov per tile was measured 1 us slower; LDS size is not what limits residency.)
     uint4 *ldsA = reinterpret_cast<uint4 *>(smem);                         // [K/16][64]
     float4 *cbs = reinterpret_cast<float4 *>(smem + (size_t)K * 64);       // [K] fp32 rows
+    float *ees = reinterpret_cast<float *>(smem + (size_t)K * 80);         // [K] their squared norms
     __shared__ unsigned int s_max[2];
     __shared__ unsigned int s_next;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -475,6 +480,7 @@ __device__ __forceinline__ void vq_filter_body(const VqArgs &a, unsigned char *s
             split3(ee, eh, em, el);
             const unsigned int ep = gg == 0 ? eh : gg == 1 ? em : gg == 2 ? el : 0u;
             ldsA[i] = make_uint4(wh | (wm << 16), wl | (ep << 16), wh | (wm << 16), wh | (wm << 16));
+            if (gg == 0) ees[((i >> 6) << 4) + (l & 15)] = ee;
             emax = fmaxf(emax, fabsf(ec));
             eemax = fmaxf(eemax, ee);
         }
@@ -568,8 +574,10 @@ __device__ __forceinline__ void vq_filter_body(const VqArgs &a, unsigned char *s
         }
         CGIC_STAMP(2);
 
-        // ---- scan: pairs of code tiles, ping-pong -- the MFMAs of pair p+1 run while the VALU digests pair p
+        // ---- scan: QUADS of code tiles (64 codes), as two ping-pong pairs -- the MFMAs of one pair run while the
+        // VALU digests the other.  One running-minimum chain per quad, one (smallest, second, where) update per quad.
         f32x4 X0[ZT], X1[ZT], Y0[ZT], Y1[ZT];
+        float uq[ZT];
         const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
         auto issue = [&](int p, f32x4 (&A0)[ZT], f32x4 (&A1)[ZT]) {
             const int pp = p < np ? p : np - 1;
@@ -581,25 +589,25 @@ __device__ __forceinline__ void vq_filter_body(const VqArgs &a, unsigned char *s
                 A1[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, bop[t], zero4, 0, 0, 0);
             }
         };
-        auto digest = [&](int p, const f32x4 (&A0)[ZT], const f32x4 (&A1)[ZT]) {
-#pragma unroll
-            for (int t = 0; t < ZT; ++t) {
-                // chain seeded with a constant: v_min3_f32 takes the raw MFMA outputs without a canonicalising v_max
-                float u = __builtin_fminf(__builtin_fminf(__builtin_inff(), A0[t][0]), A0[t][1]);
-                u = __builtin_fminf(__builtin_fminf(u, A0[t][2]), A0[t][3]);
-                u = __builtin_fminf(__builtin_fminf(u, A1[t][0]), A1[t][1]);
-                u = __builtin_fminf(__builtin_fminf(u, A1[t][2]), A1[t][3]);
-                bt[t] = u < m1[t] ? p : bt[t];
-                m2[t] = __builtin_amdgcn_fmed3f(m1[t], m2[t], u);     // second smallest pair value
-                m1[t] = __builtin_fminf(m1[t], u);
-            }
+        auto chain = [&](float u, const f32x4 &A0, const f32x4 &A1) -> float {
+            u = __builtin_fminf(__builtin_fminf(u, A0[0]), A0[1]);       // v_min3_f32 on the raw MFMA outputs
+            u = __builtin_fminf(__builtin_fminf(u, A0[2]), A0[3]);
+            u = __builtin_fminf(__builtin_fminf(u, A1[0]), A1[1]);
+            return __builtin_fminf(__builtin_fminf(u, A1[2]), A1[3]);
         };
         issue(0, X0, X1);
         for (int p = 0; p < np; p += 2) {
             issue(p + 1, Y0, Y1);
-            digest(p, X0, X1);
+#pragma unroll
+            for (int t = 0; t < ZT; ++t) uq[t] = chain(__builtin_inff(), X0[t], X1[t]);    // seeded with a constant: no canonicalising v_max
             issue(p + 2, X0, X1);      // the last one is a harmless repeat of the final pair
-            digest(p + 1, Y0, Y1);
+#pragma unroll
+            for (int t = 0; t < ZT; ++t) {
+                const float u = chain(uq[t], Y0[t], Y1[t]);
+                bt[t] = u < m1[t] ? (p >> 1) : bt[t];
+                m2[t] = __builtin_amdgcn_fmed3f(m1[t], m2[t], u);     // second smallest quad value
+                m1[t] = __builtin_fminf(m1[t], u);
+            }
         }
         CGIC_STAMP(3);
 
@@ -618,27 +626,35 @@ __device__ __forceinline__ void vq_filter_body(const VqArgs &a, unsigned char *s
             }
             zz[t] = sumsq4(z0[t], z1[t], z2[t], z3[t]);
             const float mt = colmin(m1[t]);
-            const float S = EEmax + 2.0f * Emax * (((fabsf(z0[t]) + fabsf(z1[t])) + fabsf(z2[t])) + fabsf(z3[t]));
+            // S bounds ee_k + 2 sum|z_j e_kj| for every code that can matter: by the codebook maxima, and -- the winner
+            // and every code that can beat it lie within sqrt(D) of z, D = zz + f_min + slack -- by
+            // (|z| + sqrt D)^2 + 2 |z| (|z| + sqrt D); the smaller of the two (v_sqrt_f32 is good to 1 ulp: x 1.001)
+            const float S0 = EEmax + 2.0f * Emax * (((fabsf(z0[t]) + fabsf(z1[t])) + fabsf(z2[t])) + fabsf(z3[t]));
+            const float M0 = 1.2e-5f * S0 + 2.5e-7f * zz[t] + 1e-30f;
+            const float D = fmaxf(zz[t] * 1.0001f + mt + 2.0f * M0, 0.f);
+            const float nz = __builtin_amdgcn_sqrtf(zz[t]) * 1.001f, sd = __builtin_amdgcn_sqrtf(D) * 1.001f;
+            const float S1 = (nz + sd) * (3.0f * nz + sd);
+            const float S = S1 < S0 ? S1 : S0;                  // (a NaN S1 keeps S0)
             const float M = 1.2e-5f * S + 2.5e-7f * zz[t] + 1e-30f;
             float thr = mt + M;
             thr += fabsf(thr) * 2.4e-7f;
             // anything not comparable (NaN / Inf anywhere above) must count as "flagged": test the negation
-            const bool hot = !(m1[t] > thr);                // this lane's best pair holds a candidate
-            const bool more = !(m2[t] > thr);               // ... and so does another pair of this lane
-            // settled iff exactly one hot row group and no second pair anywhere in the column
+            const bool hot = !(m1[t] > thr);                // this lane's best quad holds a candidate
+            const bool more = !(m2[t] > thr);               // ... and so does another quad of this lane
+            // settled iff exactly one hot row group and no second quad anywhere in the column
             const bool flag = colsum((hot ? 1 : 0) + (more ? 4 : 0)) != 1;
             flagged[t] = (unsigned int)(__ballot(flag) & 0xFFFFull);          // per vector, wave-uniform
             nflag += __builtin_popcount(flagged[t]);
-            // exact fp32 on the 8 codes of the winning (pair, row group): two per lane, lowest index wins ties
+            // exact fp32 on the 16 codes of the winning (quad, row group): four per lane, lowest index wins ties
             int key = colmax(hot ? ((bt[t] << 2) | g) : -1);
             key = key < 0 ? 0 : key;                        // no hot lane at all (then the column is flagged anyway)
-            const int bp = key >> 2, gw = key & 3;
+            const int bq = key >> 2, gw = key & 3;
             float d = __builtin_inff();
             int i = 0;
 #pragma unroll
-            for (int r = 1; r >= 0; --r) {
-                const int c = 32 * bp + 16 * (g >> 1) + 4 * gw + 2 * (g & 1) + r;
-                const float dd = dist_row(z0[t], z1[t], z2[t], z3[t], zz[t], cbs[c]);
+            for (int r = 3; r >= 0; --r) {
+                const int c = 64 * bq + 16 * g + 4 * gw + r;
+                const float dd = dist_row(z0[t], z1[t], z2[t], z3[t], zz[t], cbs[c], ees[c]);
                 const bool take = dd <= d;
                 d = take ? dd : d;
                 i = take ? c : i;
@@ -657,12 +673,7 @@ __device__ __forceinline__ void vq_filter_body(const VqArgs &a, unsigned char *s
             for (int t = 0; t < ZT; ++t) { best[t] = __builtin_inff(); bt2[t] = 0; }
             for (int ct = 0; ct < ntile; ++ct) {
                 const float av = reinterpret_cast<const float *>(cbs)[(16 * ct + j) * 4 + g];
-                f32x4 e4;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float4 e = cbs[16 * ct + 4 * g + r];
-                    e4[r] = sumsq4(e.x, e.y, e.z, e.w);
-                }
+                const f32x4 e4 = *reinterpret_cast<const f32x4 *>(&ees[16 * ct + 4 * g]);
 #pragma unroll
                 for (int t = 0; t < ZT; ++t) {
                     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
@@ -684,7 +695,7 @@ __device__ __forceinline__ void vq_filter_body(const VqArgs &a, unsigned char *s
                 int i = c0;
 #pragma unroll
                 for (int r = 3; r >= 0; --r)
-                    i = dist_row(z0[t], z1[t], z2[t], z3[t], zz[t], cbs[c0 + r]) == d ? c0 + r : i;
+                    i = dist_row(z0[t], z1[t], z2[t], z3[t], zz[t], cbs[c0 + r], ees[c0 + r]) == d ? c0 + r : i;
 #pragma unroll
                 for (int off = 16; off < 64; off <<= 1) {
                     const float od = __shfl_xor(d, off, kWave);
@@ -710,7 +721,7 @@ __device__ __forceinline__ void vq_filter_body(const VqArgs &a, unsigned char *s
                     int bi = 0;
 #pragma unroll 4
                     for (int c = K - 64 + lane; c >= 0; c -= 64) {       // descending: the lowest index wins ties
-                        const float dd = dist_row(y0, y1, y2, y3, yy, cbs[c]);
+                        const float dd = dist_row(y0, y1, y2, y3, yy, cbs[c], ees[c]);
                         const bool take = dd <= bd;
                         bd = take ? dd : bd;
                         bi = take ? c : bi;
@@ -961,7 +972,7 @@ static int launch_filter(const float *z, int64_t hw, int64_t N, const float *cb,
     a.z = z; a.hw = hw; a.N = N; a.cb = cb; a.K = K; a.idx_out = idx; a.zq_out = zq;
     a.sq_partial = loss ? ws.partial : nullptr; a.ticket = ws.ticket; a.beta = beta; a.legacy = legacy; a.loss = loss;
     a.nblk = (unsigned int)nblk;
-    size_t lds = (size_t)K * 80;
+    size_t lds = (size_t)K * 84;
     if (!router) {
         CGIC_HIP_TRY(hipFuncSetAttribute((const void *)vq_filter_kernel<ZT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL(vq_filter_kernel<ZT>, dim3(a.nblk), dim3(kVqfThreads), lds, s, a);

@@ -9,7 +9,9 @@
   X(16, "v_and_or_b32 %0, %0, %1, %2") X(17, "v_fma_f32 %0, %0, %1, %2") X(18, "v_lshl_add_u32 %0, %0, 1, %1") X(19, "v_cndmask_b32 %0, %0, %1, vcc") \
   X(20, "v_cmp_lt_f32 vcc, %0, %1") X(21, "v_cmp_lt_u32 vcc, %0, %1") X(22, "v_fmac_f32 %0, %1, %2") X(23, "v_mul_f32 %0, %1, %2") \
   X(24, "v_exp_f32 %0, %0") X(25, "v_rcp_f32 %0, %0") X(26, "v_mul_legacy_f32 %0, %0, %1") X(27, "v_add3_u32 %0, %0, %1, %2") \
-  X(28, "v_max3_f32 %0, %0, %1, %2") X(29, "v_perm_b32 %0, %0, %1, %2") X(30, "v_xor_b32 %0, %0, %1") X(31, "v_min_f32 %0, %1, %2")
+  X(28, "v_max3_f32 %0, %0, %1, %2") X(29, "v_perm_b32 %0, %0, %1, %2") X(30, "v_xor_b32 %0, %0, %1") X(31, "v_min_f32 %0, %1, %2") \
+  X(32, "v_add_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1") X(33, "v_add_f32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf bound_ctrl:1") \
+  X(34, "v_add_f32_dpp %0, %1, %0 row_half_mirror row_mask:0xf bank_mask:0xf bound_ctrl:1") X(35, "s_nop 1\n\tv_permlane16_swap_b32 %0, %1") X(36, "v_mov_b32_dpp %0, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1")
 template <int OP>
 __global__ void k(float *out, int iters, float seed)
 {
@@ -18,7 +20,7 @@ __global__ void k(float *out, int iters, float seed)
     for (int it = 0; it < iters; ++it) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-#define X(n, s) if (OP == n) asm volatile(s : "+v"(a[i]) : "v"(b), "v"(c) : "vcc");
+#define X(n, s) if (OP == n) asm volatile(s : "+v"(a[i]), "+v"(b) : "v"(c) : "vcc");
             OPS(X)
 #undef X
         }
