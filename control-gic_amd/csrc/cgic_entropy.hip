@@ -9,7 +9,8 @@
 // into gray in registers and parked in LDS.  Per 8x8 sub-patch a wave does
 // lane = pixel: only the bins within +-2 of the pixel's own bin can be non-zero
 // in fp32 (exp underflows to exactly 0 beyond 14.42 sigma = 2.24 bin widths,
-// in the reference too), so 5 exps per pixel instead of 32; the 64x32 kernel
+// in the reference too) and only +-1 can matter (beyond: < 3e-17 per pixel, see
+// subpatch_sum), so 3 exps per pixel instead of 32; the 64x32 kernel
 // values are deposited in a wave-private LDS tile and summed per bin in a
 // fixed order (lane = bin) -- deterministic, no float atomics.  The four 8x8
 // sums accumulate into the 16x16 patch's histogram.
@@ -25,6 +26,7 @@ namespace cgic {
 
 constexpr int kEntThreads = 256;
 constexpr int kBins = 32;
+constexpr int kWin = 3;           // bins evaluated per pixel: the nearest one and its two neighbours
 constexpr int kTileStride = 68;  // 64 pixels + 4 pad dwords: conflict-free b128 column reads
 
 struct BinsArg { float v[kBins]; };   // passed by value in the kernarg segment
@@ -51,14 +53,18 @@ __device__ __forceinline__ float sum32(float v)
     return __uint_as_float(a) + __uint_as_float(b);      // xor 16
 }
 
-// entropy of one histogram: lane (b = lane&31) holds sum over pixels of bin b
+// entropy of one histogram: lane (b = lane&31) holds sum over pixels of bin b.
+// pdf / norm as pdf * v_rcp_f32(norm) and log as v_log_f32 * ln 2 (1 ulp each) instead of the IEEE divide and
+// OCML logf (~30 instructions): this op is held to 2e-5 absolute against the CPU reference and measures ~1e-6
+// either way.  v_log_f32 does not take denormals, and an empty bin is pdf = eps = 1e-40: its term
+// eps * log(eps) = -9e-39 is dropped (contributes < 3e-37 over 32 bins).
 __device__ __forceinline__ float patch_entropy(float s, float inv_npix)
 {
     const float eps = 1e-40f;
     float pdf = s * inv_npix;                   // torch.mean over pixels (1/64, 1/256: exact) (:456)
     float norm = sum32(pdf) + eps;              // sum over bins + epsilon     (:457)
-    pdf = pdf / norm + eps;                     //                             (:458)
-    float t = pdf * logf(pdf);
+    pdf = pdf * __builtin_amdgcn_rcpf(norm) + eps;                          // (:458)
+    float t = pdf > 1e-30f ? pdf * (__builtin_amdgcn_logf(pdf) * 0.6931471805599453f) : 0.f;
     return -sum32(t);                           //                             (:459)
 }
 
@@ -121,14 +127,16 @@ __global__ __launch_bounds__(kEntThreads) void entropy_maps_kernel(
         // lane = pixel (row-major inside the 8x8 patch, like nn.Unfold)
         const int py = lane >> 3, px = lane & 7;
         const float gv = gray[sy * 8 + py][wave * 16 + sx * 8 + px];
-        // candidate window: nearest bin +-2 covers every fp32-nonzero kernel value
+        // candidate window: nearest bin +-1.  A bin further than 1.5 bin widths holds exp(-0.5 (0.0968/sigma)^2) <= 3e-17
+        // (sigma <= 0.0111; 4.5e-21 at the reference's 0.01): nonzero in fp32 and summed by the reference, but worth
+        // < 1e-15 of entropy -- far below this op's 2e-5 tolerance and its ~1e-6 transcendental noise.
         float fc = rintf((gv - bin0) * inv_step);
         fc = fminf(fmaxf(fc, 0.f), 31.f);
         int jc = (gv == gv) ? (int)fc : 0;
-        int jlo = jc - 2 < 0 ? 0 : jc - 2;
-        jlo = jlo > kBins - 5 ? kBins - 5 : jlo;
+        int jlo = jc - 1 < 0 ? 0 : jc - 1;
+        jlo = jlo > kBins - kWin ? kBins - kWin : jlo;
 #pragma unroll
-        for (int q = 0; q < 5; ++q) {
+        for (int q = 0; q < kWin; ++q) {
             const int jb = jlo + q;
             const float res = gv - bins[jb];                       // residuals          (:453)
             const float kv = __builtin_amdgcn_exp2f(exp2_scale * (res * res));   // exp(-0.5 (res/sigma)^2) (:454)
@@ -148,7 +156,7 @@ __global__ __launch_bounds__(kEntThreads) void entropy_maps_kernel(
         __builtin_amdgcn_wave_barrier();
         // clear what this pixel deposited, ready for the next sub-patch
 #pragma unroll
-        for (int q = 0; q < 5; ++q) T[(jlo + q) * kTileStride + lane] = 0.f;
+        for (int q = 0; q < kWin; ++q) T[(jlo + q) * kTileStride + lane] = 0.f;
         __builtin_amdgcn_wave_barrier();
         return s;
     };
@@ -192,10 +200,10 @@ extern "C" int cgic_entropy_maps_f32(const float *x, int64_t B, int64_t H, int64
     CGIC_REQUIRE(B >= 0 && H > 0 && W > 0 && H % 16 == 0 && W % 16 == 0, CGIC_ERR_INVALID,
                  "entropy: H=%lld W=%lld must be positive multiples of 16", (long long)H, (long long)W);
     CGIC_REQUIRE(B <= 65535 && H / 16 <= 65535, CGIC_ERR_UNSUPPORTED, "entropy: batch/height exceed the grid limits");
-    // The +-2-bin candidate window is exact only when 2.5 bin widths >= the fp32
-    // underflow radius of the Gaussian: 14.42 * sigma <= 2.5 * (2/31)
+    // The +-1-bin candidate window drops kernel values <= exp(-0.5 (1.5 * (2/31) / sigma)^2): 3e-17 at the bound
+    // below, 4.5e-21 at the reference's sigma
     CGIC_REQUIRE(sigma > 0.f && sigma <= 0.0111f, CGIC_ERR_UNSUPPORTED,
-                 "entropy: sigma=%g; the 5-bin window assumes the reference's sigma=0.01 (model.py:481)", sigma);
+                 "entropy: sigma=%g; the 3-bin window assumes the reference's sigma=0.01 (model.py:481)", sigma);
     for (int i = 1; i < kBins; ++i)
         CGIC_REQUIRE(fabsf((bins[i] - bins[i - 1]) - 2.0f / 31.0f) < 1e-5f, CGIC_ERR_UNSUPPORTED,
                      "entropy: bins are not linspace(-1, 1, 32)");
