@@ -102,31 +102,28 @@ __device__ __forceinline__ void finish_loss(double block_sum, double *sq_partial
     }
 }
 
-// Variant for the filter path: the partials (one per group of vectors, any number) are already stored and
-// drained by every wave of the workgroup; take the ticket, the last workgroup sums them in index order.
-template <int NT>
-__device__ __forceinline__ void finish_loss_groups(double *sq_partial, unsigned int npart, unsigned int *ticket,
-                                                   double count, float beta, int legacy, float *loss, unsigned int nblk)
+// Variant for the filter path, executed by ONE wave: lane 0 publishes the workgroup's partial (write-through
+// store, drained, then the ticket); the wave of the last workgroup sums all partials in a fixed order.
+__device__ __forceinline__ void finish_loss_wave(double block_sum, double *sq_partial, unsigned int *ticket, double count,
+                                                 float beta, int legacy, float *loss, unsigned int blk, unsigned int nblk)
 {
-    __shared__ double red[NT];
-    __shared__ unsigned int s_last;
-    const int tid = threadIdx.x;
-    if (tid == 0) s_last = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == nblk - 1;
-    __syncthreads();
-    if (!s_last) return;
-    if (tid == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    __syncthreads();
-    double a = 0.0;
-    for (unsigned int i = tid; i < npart; i += NT)
-        a += __hip_atomic_load(&sq_partial[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    red[tid] = a;
-    __syncthreads();
-    for (int off = NT / 2; off > 0; off >>= 1) {
-        if (tid < off) red[tid] += red[tid + off];
-        __syncthreads();
+    const int lane = lane_id();
+    int last = 0;
+    if (lane == 0) {
+        __hip_atomic_store(&sq_partial[blk], block_sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        last = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == nblk - 1;
     }
-    if (tid == 0) {
-        const float m = (float)(red[0] / count);
+    last = __builtin_amdgcn_readfirstlane(last);
+    if (!last) return;
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    double a = 0.0;
+    for (unsigned int i = lane; i < nblk; i += kWave)
+        a += __hip_atomic_load(&sq_partial[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) a += __shfl_down(a, off, kWave);
+    if (lane == 0) {
+        const float m = (float)(a / count);
         *loss = legacy ? (m + beta * m) : (beta * m + m);
         __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
     }
@@ -454,6 +451,7 @@ __device__ __forceinline__ void vq_filter_body(const VqArgs &a, unsigned char *s
     uint4 *ldsA = reinterpret_cast<uint4 *>(smem);                         // [K/16][64]
     float4 *cbs = reinterpret_cast<float4 *>(smem + (size_t)K * 64);       // [K] fp32 rows
     float *ees = reinterpret_cast<float *>(smem + (size_t)K * 80);         // [K] their squared norms
+    double *gsum = reinterpret_cast<double *>(smem + (size_t)K * 84);      // [groups of this workgroup] loss partials
     __shared__ unsigned int s_max[2];
     __shared__ unsigned int s_next;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -462,40 +460,6 @@ __device__ __forceinline__ void vq_filter_body(const VqArgs &a, unsigned char *s
 
     CGIC_STAMP(0);
     CGIC_BLK_BEGIN();
-    // ---- stage: fp32 rows, then the split A operands built from them
-    if (tid < 2) s_max[tid] = 0;
-    if (tid == 0) s_next = NW;              // groups 0..NW-1 of the workgroup's range are the waves' first ones
-    for (int i = tid; i < K; i += NT) cbs[i] = reinterpret_cast<const float4 *>(a.cb)[i];
-    __syncthreads();
-    {
-        float emax = 0.f, eemax = 0.f;
-#pragma unroll 4
-        for (int i = tid; i < ntile * 64; i += NT) {
-            const int l = i & 63, gg = l >> 4;
-            const float4 e = cbs[((i >> 6) << 4) + (l & 15)];
-            const float ee = sumsq4(e.x, e.y, e.z, e.w);
-            const float ec = gg == 0 ? e.x : gg == 1 ? e.y : gg == 2 ? e.z : e.w;
-            unsigned int wh, wm, wl, eh, em, el;
-            split3(-2.0f * ec, wh, wm, wl);
-            split3(ee, eh, em, el);
-            const unsigned int ep = gg == 0 ? eh : gg == 1 ? em : gg == 2 ? el : 0u;
-            ldsA[i] = make_uint4(wh | (wm << 16), wl | (ep << 16), wh | (wm << 16), wh | (wm << 16));
-            if (gg == 0) ees[((i >> 6) << 4) + (l & 15)] = ee;
-            emax = fmaxf(emax, fabsf(ec));
-            eemax = fmaxf(eemax, ee);
-        }
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) {
-            emax = fmaxf(emax, __shfl_xor(emax, off, kWave));
-            eemax = fmaxf(eemax, __shfl_xor(eemax, off, kWave));
-        }
-        // non-negative floats order like their bit patterns; a NaN lands above every finite value
-        if (lane == 0) { atomicMax(&s_max[0], __float_as_uint(emax)); atomicMax(&s_max[1], __float_as_uint(eemax)); }
-    }
-    __syncthreads();
-    const float Emax = __uint_as_float(s_max[0]), EEmax = __uint_as_float(s_max[1]);
-    CGIC_STAMP(1);
-
     // ---- groups of 16*ZT vectors: the workgroup owns a contiguous range, its waves take groups from a shared
     // counter.  (Static shares leave the SIMD's younger wave behind: VALU issue is arbitrated by age, the older
     // wave finishes early and the younger one then runs alone at half the issue rate.)
@@ -537,12 +501,48 @@ __device__ __forceinline__ void vq_filter_body(const VqArgs &a, unsigned char *s
         }
     };
 
+    // the first group's latents are requested before the codebook is staged: their HBM latency hides behind it
     float zn[ZT];
     int64_t cur = blk_lo + wave, cb0 = 0, cp0 = 0;
     if (cur < blk_hi) {
         origin(cur, &cb0, &cp0);
         load_group(cur, cb0, cp0, zn);
     }
+
+
+    // ---- stage: fp32 rows, then the split A operands built from them
+    if (tid < 2) s_max[tid] = 0;
+    if (tid == 0) s_next = NW;              // groups 0..NW-1 of the workgroup's range are the waves' first ones
+    for (int i = tid; i < K; i += NT) cbs[i] = reinterpret_cast<const float4 *>(a.cb)[i];
+    __syncthreads();
+    {
+        float emax = 0.f, eemax = 0.f;
+#pragma unroll 4
+        for (int i = tid; i < ntile * 64; i += NT) {
+            const int l = i & 63, gg = l >> 4;
+            const float4 e = cbs[((i >> 6) << 4) + (l & 15)];
+            const float ee = sumsq4(e.x, e.y, e.z, e.w);
+            const float ec = gg == 0 ? e.x : gg == 1 ? e.y : gg == 2 ? e.z : e.w;
+            unsigned int wh, wm, wl, eh, em, el;
+            split3(-2.0f * ec, wh, wm, wl);
+            split3(ee, eh, em, el);
+            const unsigned int ep = gg == 0 ? eh : gg == 1 ? em : gg == 2 ? el : 0u;
+            ldsA[i] = make_uint4(wh | (wm << 16), wl | (ep << 16), wh | (wm << 16), wh | (wm << 16));
+            if (gg == 0) ees[((i >> 6) << 4) + (l & 15)] = ee;
+            emax = fmaxf(emax, fabsf(ec));
+            eemax = fmaxf(eemax, ee);
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            emax = fmaxf(emax, __shfl_xor(emax, off, kWave));
+            eemax = fmaxf(eemax, __shfl_xor(eemax, off, kWave));
+        }
+        // non-negative floats order like their bit patterns; a NaN lands above every finite value
+        if (lane == 0) { atomicMax(&s_max[0], __float_as_uint(emax)); atomicMax(&s_max[1], __float_as_uint(eemax)); }
+    }
+    __syncthreads();
+    const float Emax = __uint_as_float(s_max[0]), EEmax = __uint_as_float(s_max[1]);
+    CGIC_STAMP(1);
 
     while (cur < blk_hi) {
         const int64_t grp = cur;
@@ -760,19 +760,28 @@ __device__ __forceinline__ void vq_filter_body(const VqArgs &a, unsigned char *s
             }
         }
         if (a.sq_partial) {
-            // one partial per GROUP (not per wave): whichever wave took the group, the final sum has the same
-            // operands in the same order.  Fixed shuffle tree; write-through store, drained before the ticket.
+            // one partial per GROUP (not per wave), parked in LDS: whichever wave took the group, the workgroup's sum
+            // has the same operands in the same order.  Fixed shuffle tree.
 #pragma unroll
             for (int off = 32; off > 0; off >>= 1) sq += __shfl_down(sq, off, kWave);
-            if (lane == 0) __hip_atomic_store(&a.sq_partial[grp], sq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (lane == 0) gsum[grp - blk_lo] = sq;
         }
     }
 
     CGIC_STAMP(5);
     if (a.sq_partial) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's partials have reached L2
+        // Only wave 0 stays for the hand-off: the other waves leave at the barrier WITHOUT draining their z_q /
+        // index stores (an s_waitcnt vmcnt(0) in every wave before the barrier cost ~4 us at the end of every
+        // workgroup); wave 0's own stores are long complete by the time it has waited for the others.
         __syncthreads();
-        finish_loss_groups<NT>(a.sq_partial, (unsigned int)ngroups, a.ticket, (double)N * 4.0, a.beta, a.legacy, a.loss, a.nblk);
+        if (wave == 0) {
+            const int ng = (int)(blk_hi - blk_lo);
+            double bs = 0.0;
+            for (int i = lane; i < ng; i += kWave) bs += gsum[i];
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) bs += __shfl_down(bs, off, kWave);
+            finish_loss_wave(bs, a.sq_partial, a.ticket, (double)N * 4.0, a.beta, a.legacy, a.loss, blockIdx.x, a.nblk);
+        }
     }
     CGIC_STAMP(6);
     CGIC_BLK_END();
@@ -968,11 +977,13 @@ static int launch_filter(const float *z, int64_t hw, int64_t N, const float *cb,
     const int64_t ngroups = (N + 16 * ZT - 1) / (16 * ZT);
     int64_t nblk = (ngroups + kVqfWaves - 1) / kVqfWaves;
     if (nblk > cus) nblk = cus;                      // one resident workgroup per CU; waves take groups from a counter
+    const int64_t kMaxGroups = 6144;                 // per workgroup: 8 bytes of LDS each for the loss partials
+    if ((ngroups + nblk - 1) / nblk > kMaxGroups) nblk = (ngroups + kMaxGroups - 1) / kMaxGroups;
     VqArgs a;
     a.z = z; a.hw = hw; a.N = N; a.cb = cb; a.K = K; a.idx_out = idx; a.zq_out = zq;
     a.sq_partial = loss ? ws.partial : nullptr; a.ticket = ws.ticket; a.beta = beta; a.legacy = legacy; a.loss = loss;
     a.nblk = (unsigned int)nblk;
-    size_t lds = (size_t)K * 84;
+    size_t lds = (size_t)K * 84 + (loss ? 8 * (size_t)((ngroups + nblk - 1) / nblk) : 0);
     if (!router) {
         CGIC_HIP_TRY(hipFuncSetAttribute((const void *)vq_filter_kernel<ZT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL(vq_filter_kernel<ZT>, dim3(a.nblk), dim3(kVqfThreads), lds, s, a);
@@ -1020,7 +1031,7 @@ using namespace cgic;
 
 extern "C" size_t cgic_vq_workspace_bytes(int64_t n_vectors)
 {
-    // one double per group of the smallest tiling (16 vectors per group)
+    // one double per workgroup; (n / 16 + 1) covers every tiling of both paths
     return sizeof(double) * (size_t)((n_vectors + 15) / 16 + 1);
 }
 
