@@ -292,7 +292,8 @@ def main():
                          "note": "algorithmic flops = 2*N*K*D of the fp32 distance contraction per launch / HIP-event "
                                  "average launch duration, priced against the dense fp32 MFMA peak (results are bit-identical "
                                  "to the fp32 sequence); the kernel itself issues bf16 MFMAs (32 K-slots per 4-dim contraction, "
-                                 "17.2 GFLOP per launch = 0.19 of the bf16 peak) and is bound by VALU issue, see DESIGN.md 4.1"},
+                                 f"{2.0 * N * 1024 * 32 / 1e9:.1f} GFLOP per launch = {2.0 * N * 1024 * 32 / t_dom / 2.5e15:.2f} of the 2.5 PFLOP/s bf16 peak) "
+                                 "and is bound by VALU + MFMA issue, see DESIGN.md 4.1"},
         }
         if not a.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(x, z, cb, ratio)
