@@ -15,8 +15,8 @@ from .mask_coding import BinaryCoding
 from .codec import GrainCodec, CompressedBatch, mode_streams, STREAM_NAMES
 from . import pipeline, highres, container, model
 from .pipeline import HotPathPipeline
-from .model import install, compress_batch, grain_merge
+from .model import install, compress_batch, grain_merge, avg_pool, decoder_blend_medium, decoder_blend_fine
 
 __all__ = ["VectorQuantize2", "VectorQuantizer", "TripleGrainFixedEntropyRouter", "Entropy", "entropy_maps",
            "HuffmanCoding", "BinaryCoding", "GrainCodec", "CompressedBatch", "mode_streams", "STREAM_NAMES",
-           "HotPathPipeline", "install", "compress_batch", "grain_merge", "highres", "container", "CgicError", "LIB_PATH"]
+           "HotPathPipeline", "install", "compress_batch", "grain_merge", "avg_pool", "decoder_blend_medium", "decoder_blend_fine", "highres", "container", "CgicError", "LIB_PATH"]

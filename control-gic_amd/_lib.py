@@ -57,6 +57,9 @@ PROTOTYPES = {
     "cgic_decompress_streams": (_int, [_vp, _vp, _i64, _vp, _i64, _i64, _i64, _int, _vp, _vp, _vp, _vp, _vp, _int,
                                        _int, _vp, _vp, _vp, _vp]),
     "cgic_grain_merge_f32": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _int, _i64, _i64, _vp, _vp]),
+    "cgic_avgpool_f32": (_int, [_vp, _i64, _i64, _i64, _int, _vp, _vp]),
+    "cgic_decoder_blend_medium_f32": (_int, [_vp, _vp, _vp, _vp, _i64, _int, _i64, _i64, _vp, _vp]),
+    "cgic_decoder_blend_fine_f32": (_int, [_vp, _vp, _vp, _vp, _vp, _i64, _int, _i64, _i64, _vp, _vp]),
     "cgic_embedding_gather_f32": (_int, [_vp, _i64, _i64, _vp, _int, _int, _vp, _vp, _vp]),
 }
 

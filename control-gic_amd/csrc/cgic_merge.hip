@@ -38,6 +38,81 @@ __global__ __launch_bounds__(256) void grain_merge_kernel(
     }
 }
 
+
+// ---- decoder side (reference: CGIC/modules/vqvae/decoder.py:304-305,366-378) ---------------------------------
+// avgpool_layer1/2 = AvgPool2d(4,4,0) / (2,2,0) on the coarse / medium branch, then inside the up path
+//   level -2:  h = h * up2(mask0) + h_medium * mask1                      (medium grid)
+//   level -3:  h = h * up4(mask0) + h * up2(mask1) + h_fine * mask2       (fine grid)
+// 512 channels at the reference's config: 0.5 GB per tensor at B=64 -- pure HBM streams.  One pass each, float4
+// per thread, the reference's products and left-to-right sums (bit-identical; in place is fine: out may alias h).
+// The average is the window's row-major running sum divided by the window size, the order of ATen's CPU kernel.
+
+__global__ __launch_bounds__(256) void avgpool_kernel(const float *__restrict__ x, int64_t planes, int64_t H, int64_t W, int k,
+                                                      float *__restrict__ out)
+{
+    const int64_t Ho = H / k, Wo = W / k;
+    const int64_t total = planes * Ho * Wo;
+    const float div = (float)(k * k);
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t xo = t % Wo, r = t / Wo;
+        const int64_t yo = r % Ho, pl = r / Ho;
+        const float *src = x + (pl * H + yo * k) * W + xo * k;
+        float sum = 0.f;
+        if (k == 4) {
+#pragma unroll
+            for (int dy = 0; dy < 4; ++dy) {
+                const float4 v = *reinterpret_cast<const float4 *>(src + dy * W);     // W % 4 == 0, xo * 4 aligned
+                sum += v.x; sum += v.y; sum += v.z; sum += v.w;
+            }
+        } else {
+#pragma unroll
+            for (int dy = 0; dy < 2; ++dy) {
+                const float2 v = *reinterpret_cast<const float2 *>(src + dy * W);
+                sum += v.x; sum += v.y;
+            }
+        }
+        out[t] = sum / div;
+    }
+}
+
+// FINE = false: medium grid [B,C,h,w], masks mask0 [B,h/2,w/2], mask1 [B,h,w]
+// FINE = true : fine grid   [B,C,h,w], masks mask0 [B,h/4,w/4], mask1 [B,h/2,w/2], mask2 [B,h,w]
+template <bool FINE>
+__global__ __launch_bounds__(256) void decoder_blend_kernel(
+    const float *__restrict__ hin, const float *__restrict__ own, const int32_t *__restrict__ m0,
+    const int32_t *__restrict__ m1, const int32_t *__restrict__ m2, int64_t B, int C, int64_t h, int64_t w,
+    float *__restrict__ out)
+{
+    const int64_t wq = w >> 2;
+    const int64_t total = B * C * h * wq;                       // one thread = 4 consecutive x
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t xq = t % wq, r = t / wq;
+        const int64_t y = r % h, bc = r / h;
+        const int64_t b = bc / C;
+        const int64_t x = xq << 2;
+        const float4 hv = *reinterpret_cast<const float4 *>(&hin[(bc * h + y) * w + x]);
+        const float4 ov = *reinterpret_cast<const float4 *>(&own[(bc * h + y) * w + x]);
+        float4 o;
+        if (FINE) {
+            const float a = (float)m0[(b * (h >> 2) + (y >> 2)) * (w >> 2) + xq];
+            const int2 q1 = *reinterpret_cast<const int2 *>(&m1[(b * (h >> 1) + (y >> 1)) * (w >> 1) + (x >> 1)]);
+            const int4 q2 = *reinterpret_cast<const int4 *>(&m2[(b * h + y) * w + x]);
+            o.x = (hv.x * a + hv.x * (float)q1.x) + ov.x * (float)q2.x;
+            o.y = (hv.y * a + hv.y * (float)q1.x) + ov.y * (float)q2.y;
+            o.z = (hv.z * a + hv.z * (float)q1.y) + ov.z * (float)q2.z;
+            o.w = (hv.w * a + hv.w * (float)q1.y) + ov.w * (float)q2.w;
+        } else {
+            const int2 q0 = *reinterpret_cast<const int2 *>(&m0[(b * (h >> 1) + (y >> 1)) * (w >> 1) + (x >> 1)]);
+            const int4 q1 = *reinterpret_cast<const int4 *>(&m1[(b * h + y) * w + x]);
+            o.x = hv.x * (float)q0.x + ov.x * (float)q1.x;
+            o.y = hv.y * (float)q0.x + ov.y * (float)q1.y;
+            o.z = hv.z * (float)q0.y + ov.z * (float)q1.z;
+            o.w = hv.w * (float)q0.y + ov.w * (float)q1.w;
+        }
+        *reinterpret_cast<float4 *>(&out[(bc * h + y) * w + x]) = o;
+    }
+}
+
 }  // namespace cgic
 
 using namespace cgic;
@@ -56,4 +131,50 @@ extern "C" int cgic_grain_merge_f32(const float *h_coarse, const float *h_medium
     hipLaunchKernelGGL(grain_merge_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream, h_coarse, h_medium, h_fine,
                        mask_c, mask_m, mask_f, B, C, h, w, out);
     return launch_check("grain_merge_kernel");
+}
+
+static int stream_grid(int64_t total)
+{
+    int64_t nblk = (total + 255) / 256;
+    if (nblk > 16384) nblk = 16384;       // 64 workgroups per CU, grid-stride beyond
+    return (int)nblk;
+}
+
+extern "C" int cgic_avgpool_f32(const float *x, int64_t planes, int64_t H, int64_t W, int k, float *out, cgic_stream_t stream)
+{
+    CGIC_REQUIRE(x && out, CGIC_ERR_INVALID, "avgpool: NULL tensor");
+    CGIC_REQUIRE(k == 2 || k == 4, CGIC_ERR_UNSUPPORTED, "avgpool: window %d; the decoder uses 4 and 2 (decoder.py:304-305)", k);
+    CGIC_REQUIRE(planes >= 0 && H > 0 && W > 0 && H % k == 0 && W % k == 0, CGIC_ERR_INVALID,
+                 "avgpool: %lldx%lld is not a multiple of the window", (long long)H, (long long)W);
+    const int64_t total = planes * (H / k) * (W / k);
+    if (total == 0) return CGIC_OK;
+    hipLaunchKernelGGL(avgpool_kernel, dim3(stream_grid(total)), dim3(256), 0, (hipStream_t)stream, x, planes, H, W, k, out);
+    return launch_check("avgpool_kernel");
+}
+
+extern "C" int cgic_decoder_blend_medium_f32(const float *h, const float *h_medium, const int32_t *mask_c, const int32_t *mask_m,
+                                             int64_t B, int C, int64_t hh, int64_t ww, float *out, cgic_stream_t stream)
+{
+    CGIC_REQUIRE(h && h_medium && mask_c && mask_m && out, CGIC_ERR_INVALID, "decoder_blend_medium: NULL tensor");
+    CGIC_REQUIRE(B >= 0 && C > 0 && hh > 0 && ww > 0 && hh % 2 == 0 && ww % 4 == 0, CGIC_ERR_INVALID,
+                 "decoder_blend_medium: medium grid %lldx%lld (need even height, width %% 4 == 0)", (long long)hh, (long long)ww);
+    const int64_t total = B * C * hh * (ww >> 2);
+    if (total == 0) return CGIC_OK;
+    hipLaunchKernelGGL(decoder_blend_kernel<false>, dim3(stream_grid(total)), dim3(256), 0, (hipStream_t)stream, h, h_medium, mask_c,
+                       mask_m, (const int32_t *)nullptr, B, C, hh, ww, out);
+    return launch_check("decoder_blend_kernel<medium>");
+}
+
+extern "C" int cgic_decoder_blend_fine_f32(const float *h, const float *h_fine, const int32_t *mask_c, const int32_t *mask_m,
+                                           const int32_t *mask_f, int64_t B, int C, int64_t hh, int64_t ww, float *out,
+                                           cgic_stream_t stream)
+{
+    CGIC_REQUIRE(h && h_fine && mask_c && mask_m && mask_f && out, CGIC_ERR_INVALID, "decoder_blend_fine: NULL tensor");
+    CGIC_REQUIRE(B >= 0 && C > 0 && hh > 0 && ww > 0 && hh % 4 == 0 && ww % 4 == 0, CGIC_ERR_INVALID,
+                 "decoder_blend_fine: fine grid %lldx%lld must be positive multiples of 4", (long long)hh, (long long)ww);
+    const int64_t total = B * C * hh * (ww >> 2);
+    if (total == 0) return CGIC_OK;
+    hipLaunchKernelGGL(decoder_blend_kernel<true>, dim3(stream_grid(total)), dim3(256), 0, (hipStream_t)stream, h, h_fine, mask_c,
+                       mask_m, mask_f, B, C, hh, ww, out);
+    return launch_check("decoder_blend_kernel<fine>");
 }

@@ -35,6 +35,49 @@ def grain_merge(h_coarse, h_medium, h_fine, mask):
     return out
 
 
+def avg_pool(x, k):
+    """torch.nn.AvgPool2d(k, k, 0) for k in (2, 4) -- decoder.py:304-305,366-367; bit-identical to the CPU kernel
+    (row-major running sum of the window, divided by k*k)"""
+    _lib.require_device(x)
+    x = x.contiguous().float()
+    B, C, H, W = x.shape
+    out = torch.empty((B, C, H // k, W // k), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        _lib.call("cgic_avgpool_f32", _lib.ptr(x), B * C, H, W, int(k), _lib.ptr(out), _lib.current_stream(x.device))
+    return out
+
+
+def decoder_blend_medium(h, h_medium, mask, out=None):
+    """h * up2(mask[0]) + h_medium * mask[1] on the medium grid (decoder.py:372-374); `out` may be `h` (in place)"""
+    _lib.require_device(h, h_medium, mask[0], mask[1])
+    h, hm = h.contiguous().float(), h_medium.contiguous().float()
+    mc, mm = mask[0].contiguous(), mask[1].contiguous()
+    B, C, hh, ww = h.shape
+    if tuple(hm.shape) != (B, C, hh, ww) or mc.numel() != B * (hh // 2) * (ww // 2) or mm.numel() != B * hh * ww:
+        raise ValueError("decoder_blend_medium: h, h_medium on the medium grid; mask[0] at half of it, mask[1] on it")
+    out = torch.empty_like(h) if out is None else out
+    with torch.cuda.device(h.device):
+        _lib.call("cgic_decoder_blend_medium_f32", _lib.ptr(h), _lib.ptr(hm), _lib.ptr(mc), _lib.ptr(mm), B, C, hh, ww,
+                  _lib.ptr(out), _lib.current_stream(h.device))
+    return out
+
+
+def decoder_blend_fine(h, h_fine, mask, out=None):
+    """h * up4(mask[0]) + h * up2(mask[1]) + h_fine * mask[2] on the fine grid (decoder.py:375-378)"""
+    _lib.require_device(h, h_fine, *mask)
+    h, hf = h.contiguous().float(), h_fine.contiguous().float()
+    mc, mm, mf = (m.contiguous() for m in mask)
+    B, C, hh, ww = h.shape
+    if tuple(hf.shape) != (B, C, hh, ww) or mc.numel() != B * (hh // 4) * (ww // 4) or mm.numel() != B * (hh // 2) * (ww // 2) \
+            or mf.numel() != B * hh * ww:
+        raise ValueError("decoder_blend_fine: h, h_fine on the fine grid; masks at 1/4, 1/2, 1/1 of it")
+    out = torch.empty_like(h) if out is None else out
+    with torch.cuda.device(h.device):
+        _lib.call("cgic_decoder_blend_fine_f32", _lib.ptr(h), _lib.ptr(hf), _lib.ptr(mc), _lib.ptr(mm), _lib.ptr(mf), B, C, hh, ww,
+                  _lib.ptr(out), _lib.current_stream(h.device))
+    return out
+
+
 def _codec_for(model, h_indices=None):
     c = getattr(model, "_cgic_codec", None)
     if c is None or c.codebook is not model.quantize.embedding.weight:

@@ -232,6 +232,25 @@ int cgic_grain_merge_f32(const float *h_coarse, const float *h_medium, const flo
                          const int32_t *mask_c, const int32_t *mask_m, const int32_t *mask_f, int64_t B,
                          int C, int64_t h, int64_t w, float *out, cgic_stream_t stream);
 
+/* ---------------------------------------------------------------------------
+ * Decoder-side masked blends and the two average pools in front of them --
+ * CGIC/modules/vqvae/decoder.py:304-305 (AvgPool2d(4,4,0) / AvgPool2d(2,2,0)), :366-367 (applied to the
+ * coarse / medium branch), :372-374 and :375-378 (inside the up path):
+ *   medium grid:  h = h * up2(mask0) + h_medium * mask1
+ *   fine grid:    h = h * up4(mask0) + h * up2(mask1) + h_fine * mask2
+ *   h, h_medium / h_fine, out   device [B,C,hh,ww] fp32 on the grid of the call (out may alias h)
+ *   mask_c / mask_m / mask_f    device int32 [B,·,·] at 1/4, 1/2, 1/1 of the FINE grid (the router's / the decoded ones)
+ *   same products, same left-to-right sums as the reference expressions: bit-identical.
+ * cgic_avgpool_f32: x [planes,H,W] -> out [planes,H/k,W/k], k in {2,4}; row-major running sum of the window
+ *   divided by k*k (the order of ATen's CPU kernel: bit-identical to the CPU reference).
+ * ------------------------------------------------------------------------- */
+int cgic_avgpool_f32(const float *x, int64_t planes, int64_t H, int64_t W, int k, float *out, cgic_stream_t stream);
+int cgic_decoder_blend_medium_f32(const float *h, const float *h_medium, const int32_t *mask_c, const int32_t *mask_m,
+                                  int64_t B, int C, int64_t hh, int64_t ww, float *out, cgic_stream_t stream);
+int cgic_decoder_blend_fine_f32(const float *h, const float *h_fine, const int32_t *mask_c, const int32_t *mask_m,
+                                const int32_t *mask_f, int64_t B, int C, int64_t hh, int64_t ww, float *out,
+                                cgic_stream_t stream);
+
 /* embedding gather on its own (model.py:121,391-392): out[b, c, p] = codebook[ind[b, p], c] */
 int cgic_embedding_gather_f32(const int64_t *ind, int64_t B, int64_t hw, const float *codebook, int K,
                               int e_dim, float *out, int32_t *status, cgic_stream_t stream);

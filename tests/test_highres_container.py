@@ -148,6 +148,39 @@ def test_grain_merge_bit_exact():
 
 
 @pytest.mark.gpu
+def test_decoder_blends_and_avgpool_bit_exact():
+    """decoder.py:304-305,366-378 -- the reference's own expressions (stock torch ops) are the oracle: the blends
+    evaluated on the device, the average pools on the CPU (ATen's CPU summation order is what the kernel follows)"""
+    g = torch.Generator().manual_seed(9)
+    B, C, h, w = 3, 6, 24, 40                                   # fine grid
+    hfine = torch.randn(B, C, h, w, generator=g)
+    hmed = torch.randn(B, C, h, w, generator=g)
+    hcoarse = torch.randn(B, C, h, w, generator=g)
+    up2 = torch.nn.Upsample(scale_factor=2, mode="nearest")
+    up4 = torch.nn.Upsample(scale_factor=4, mode="nearest")
+    p4, p2 = torch.nn.AvgPool2d(4, 4, 0), torch.nn.AvgPool2d(2, 2, 0)
+    assert torch.equal(cg.avg_pool(hcoarse.cuda(), 4).cpu(), p4(hcoarse))            # :304,366
+    assert torch.equal(cg.avg_pool(hmed.cuda(), 2).cpu(), p2(hmed))                  # :305,367
+    e16 = torch.rand(B, h // 4, w // 4, generator=g).cuda()
+    e8 = torch.rand(B, h // 2, w // 2, generator=g).cuda()
+    hm_in = torch.randn(B, C, h // 2, w // 2, generator=g).cuda()      # h at the medium level, medium branch
+    hm_own = p2(hmed).cuda()
+    hf_in = torch.randn(B, C, h, w, generator=g).cuda()
+    hf_own = hfine.cuda()
+    hf_in[0, 0, 0, :4] = -0.0                                   # signed zeros go through mul + add, not a select
+    for c, m in ((0.1, 0.8), (0.0, 0.5), (0.5, 0.0), (0.5, 0.5), (1.0, 0.0), (0.0, 1.0), (0.0, 0.0)):
+        mask, _, _, _ = cg.TripleGrainFixedEntropyRouter(c, m, per_image=True)(e16, e8)
+        ref_m = hm_in * up2(mask[0].float()) + hm_own * mask[1]                              # :373-374
+        ref_f = hf_in * up4(mask[0].float()) + hf_in * up2(mask[1].float()) + hf_own * mask[2]   # :376-378
+        out_m = cg.decoder_blend_medium(hm_in, hm_own, mask)
+        out_f = cg.decoder_blend_fine(hf_in, hf_own, mask)
+        assert torch.equal(out_m.view(torch.int32), ref_m.float().view(torch.int32))         # bit patterns, incl. -0.0
+        assert torch.equal(out_f.view(torch.int32), ref_f.float().view(torch.int32))
+        buf = hf_in.clone()
+        assert cg.decoder_blend_fine(buf, hf_own, mask, out=buf) is buf and torch.equal(buf, out_f)      # in place
+
+
+@pytest.mark.gpu
 def test_install_and_compress_on_a_cgic_shaped_model(tmp_path, orc):
     """install() on a model with the reference's attribute layout (a stub with tiny stock-torch conv encoder /
     decoder stands in for the 130 M-parameter nets): compress() keeps the reference contract, compress_batch
