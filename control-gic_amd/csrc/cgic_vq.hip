@@ -151,7 +151,10 @@ struct VqArgs {
     float beta;
     int legacy;
     float *loss;
-    unsigned int nblk;        // VQ workgroups (a fused launch has router workgroups behind them)
+    unsigned int nblk;        // VQ workgroups (a fused launch has router workgroups beside them)
+    // filter path: groups per workgroup.  Workgroups [0, n_early) own `g_early` groups each, the rest `g_late`
+    // (router workgroups in front of a fused launch delay the VQ workgroups that have to wait for their CUs)
+    unsigned int n_early, g_early, g_late;
 };
 
 template <int ZT>
@@ -437,7 +440,7 @@ __device__ __forceinline__ float dist_row(float z0, float z1, float z2, float z3
 }
 
 template <int ZT>
-__device__ __forceinline__ void vq_filter_body(const VqArgs &a, unsigned char *smem)
+__device__ __forceinline__ void vq_filter_body(const VqArgs &a, unsigned char *smem, const unsigned int vblk)
 {
     constexpr int NT = kVqfThreads, NW = kVqfWaves;
     const float *__restrict__ z = a.z;
@@ -464,9 +467,16 @@ __device__ __forceinline__ void vq_filter_body(const VqArgs &a, unsigned char *s
     // counter.  (Static shares leave the SIMD's younger wave behind: VALU issue is arbitrated by age, the older
     // wave finishes early and the younger one then runs alone at half the issue rate.)
     const int64_t ngroups = (N + 16 * ZT - 1) / (16 * ZT);
-    const int64_t per_blk = (ngroups + a.nblk - 1) / a.nblk;
-    const int64_t blk_lo = (int64_t)blockIdx.x * per_blk < ngroups ? (int64_t)blockIdx.x * per_blk : ngroups;
-    const int64_t blk_hi = blk_lo + per_blk < ngroups ? blk_lo + per_blk : ngroups;
+    int64_t blk_lo, blk_hi;
+    if (vblk < a.n_early) {
+        blk_lo = (int64_t)vblk * a.g_early;
+        blk_hi = blk_lo + a.g_early;
+    } else {
+        blk_lo = (int64_t)a.n_early * a.g_early + (int64_t)(vblk - a.n_early) * a.g_late;
+        blk_hi = blk_lo + a.g_late;
+    }
+    blk_lo = blk_lo < ngroups ? blk_lo : ngroups;
+    blk_hi = blk_hi < ngroups ? blk_hi : ngroups;
     auto grab = [&]() -> int64_t {
         int v = 0;
         if (lane == 0) v = (int)atomicAdd(&s_next, 1u);
@@ -780,7 +790,7 @@ __device__ __forceinline__ void vq_filter_body(const VqArgs &a, unsigned char *s
             for (int i = lane; i < ng; i += kWave) bs += gsum[i];
 #pragma unroll
             for (int off = 32; off > 0; off >>= 1) bs += __shfl_down(bs, off, kWave);
-            finish_loss_wave(bs, a.sq_partial, a.ticket, (double)N * 4.0, a.beta, a.legacy, a.loss, blockIdx.x, a.nblk);
+            finish_loss_wave(bs, a.sq_partial, a.ticket, (double)N * 4.0, a.beta, a.legacy, a.loss, vblk, a.nblk);
         }
     }
     CGIC_STAMP(6);
@@ -791,24 +801,38 @@ template <int ZT>
 __global__ __launch_bounds__(kVqfThreads, 1) void vq_filter_kernel(VqArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_f[];
-    vq_filter_body<ZT>(a, smem_f);
+    vq_filter_body<ZT>(a, smem_f, blockIdx.x);
 }
 
-// The fused launch of the filter path: router workgroups behind the VQ workgroups (see vq_router_kernel).  A VQ
-// workgroup takes the CU's LDS (80 KB) and 2 x 166 VGPRs per SIMD, and dynamic LDS / the VGPR budget are per
-// launch, so a router workgroup starts when the first VQ workgroups retire: the fusion saves the launch gap, not
-// the router's ~10 us.  Measured alternatives, all slower at B=64: router workgroups first with the late VQ
-// workgroups carrying fewer groups (43.2 us vs 42.5), 8-byte A operands + a 128-VGPR build so that both kinds
-// share a CU (47.6 -- two VQ workgroups then also share CUs), the router on a forked graph branch (+9 us).
+// The fused launch of the filter path (see vq_router_kernel).  A VQ workgroup takes the CU's LDS (84 KB) and
+// 2 x 166 VGPRs per SIMD, and dynamic LDS / the VGPR budget are per launch, so a router workgroup cannot share a CU
+// with one: behind the VQ workgroups it only starts when the VQ is over (30.4 + ~11 us).  The router workgroups
+// therefore come FIRST (`nrouter` of them, one CU each for ~11 us); the VQ workgroups that have to wait for those
+// CUs own fewer groups, the others more -- in steps of 4 groups, the unit in which a workgroup's time grows (8
+// waves, 2 per SIMD).  Measured alternatives at B=64: an evenly balanced uneven split (18 / 11 groups) 43.2 us,
+// 8-byte A operands + a 128-VGPR build so that both kinds share a CU 47.6 (two VQ workgroups then also share
+// CUs), a device-wide chunk queue 46.3, the router on a forked graph branch +9 us per step.
 template <int ZT>
-__global__ __launch_bounds__(kVqfThreads, 1) void vq_filter_router_kernel(VqArgs a, RouterArgs r)
+__global__ __launch_bounds__(kVqfThreads, 1) void vq_filter_router_kernel(VqArgs a, RouterArgs r, unsigned int nrouter)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_f[];
+    if (blockIdx.x < nrouter) {
+        router_body<kVqfThreads>(r, (int64_t)blockIdx.x, smem_f);
+        return;
+    }
+    vq_filter_body<ZT>(a, smem_f, blockIdx.x - nrouter);
+}
+
+// the same with the router workgroups BEHIND the VQ workgroups (when every VQ workgroup gets a CU at once anyway)
+template <int ZT>
+__global__ __launch_bounds__(kVqfThreads, 1) void vq_filter_router_behind_kernel(VqArgs a, RouterArgs r)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_f[];
     if (blockIdx.x >= a.nblk) {
         router_body<kVqfThreads>(r, (int64_t)(blockIdx.x - a.nblk), smem_f);
         return;
     }
-    vq_filter_body<ZT>(a, smem_f);
+    vq_filter_body<ZT>(a, smem_f, blockIdx.x);
 }
 
 // Plain-VALU restatement: one latent vector per thread, codebook broadcast from
@@ -983,7 +1007,23 @@ static int launch_filter(const float *z, int64_t hw, int64_t N, const float *cb,
     a.z = z; a.hw = hw; a.N = N; a.cb = cb; a.K = K; a.idx_out = idx; a.zq_out = zq;
     a.sq_partial = loss ? ws.partial : nullptr; a.ticket = ws.ticket; a.beta = beta; a.legacy = legacy; a.loss = loss;
     a.nblk = (unsigned int)nblk;
-    size_t lds = (size_t)K * 84 + (loss ? 8 * (size_t)((ngroups + nblk - 1) / nblk) : 0);
+    // groups per workgroup.  Router workgroups in front: the `late` VQ workgroups that must wait for a router's CU
+    // (~11 us at 256x256, ~0.0021 * hw groups of VQ work) own `g_late` groups, the others `g_early`, a multiple of 4
+    int64_t per = (ngroups + nblk - 1) / nblk, g_early = per, g_late = per, n_early = nblk;
+    static const int split_off = getenv("CGIC_VQ_NOSPLIT") ? atoi(getenv("CGIC_VQ_NOSPLIT")) : 0;    // dev: A/B
+    const int64_t late = router ? nblk + router_blocks - cus : 0;
+    bool router_first = false;
+    if (late > 0 && late < nblk && !split_off) {
+        const int64_t delta = (int64_t)(0.0021 * (double)hw * (4.0 / ZT) + 0.5);
+        for (int64_t ge = (per / 4 + 1) * 4; ge <= per + 12; ge += 4) {
+            const int64_t rest = ngroups - (nblk - late) * ge;
+            const int64_t gl = rest > 0 ? (rest + late - 1) / late : 0;
+            if (gl + delta <= ge) { g_early = ge; g_late = gl; n_early = nblk - late; router_first = true; break; }
+        }
+    }
+    a.n_early = (unsigned int)n_early; a.g_early = (unsigned int)g_early; a.g_late = (unsigned int)g_late;
+    const int64_t gmax = g_early > g_late ? g_early : g_late;
+    size_t lds = (size_t)K * 84 + (loss ? 8 * (size_t)gmax : 0);
     if (!router) {
         CGIC_HIP_TRY(hipFuncSetAttribute((const void *)vq_filter_kernel<ZT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL(vq_filter_kernel<ZT>, dim3(a.nblk), dim3(kVqfThreads), lds, s, a);
@@ -991,7 +1031,13 @@ static int launch_filter(const float *z, int64_t hw, int64_t N, const float *cb,
     }
     if (router_lds > lds) lds = router_lds;
     CGIC_HIP_TRY(hipFuncSetAttribute((const void *)vq_filter_router_kernel<ZT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(vq_filter_router_kernel<ZT>, dim3(a.nblk + (unsigned int)router_blocks), dim3(kVqfThreads), lds, s, a, *router);
+    if (router_first) {
+        hipLaunchKernelGGL(vq_filter_router_kernel<ZT>, dim3(a.nblk + (unsigned int)router_blocks), dim3(kVqfThreads), lds, s, a, *router,
+                           (unsigned int)router_blocks);
+    } else {
+        CGIC_HIP_TRY(hipFuncSetAttribute((const void *)vq_filter_router_behind_kernel<ZT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(vq_filter_router_behind_kernel<ZT>, dim3(a.nblk + (unsigned int)router_blocks), dim3(kVqfThreads), lds, s, a, *router);
+    }
     return launch_check("vq_filter_router_kernel");
 }
 
