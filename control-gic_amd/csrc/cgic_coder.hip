@@ -571,14 +571,32 @@ __device__ __forceinline__ void decode_segmented(const TableDev &t, const uint32
     int nbits = 0, nchunks = 0, c0 = 0, c1 = 0;
     BitWindow bw{win, in, nbytes, 0, 0};
     const bool active = nw > 0 && nbytes > 0;
-    if (active) {
+    if (nbytes > 0) {                                            // (every wave, also the idle ones: the segment loop below is uniform)
         nbits = pad == 0 ? 0 : (nbytes - 1) * 8 - pad;           // remove_padding :131-138
         if (nbits < 0) nbits = 0;
         nchunks = (nbits + kWave - 1) / kWave;
-        c0 = (int)((int64_t)k * nchunks / nw);
-        c1 = (int)((int64_t)(k + 1) * nchunks / nw);
     }
-    const bool fast = ft != nullptr && nchunks <= kFastChunks;      // wave-uniform (nchunks is per stream)
+    // Streams longer than the per-position tables (192 chunks = 1.5 KB) are decoded SEGMENT by segment of 160
+    // chunks, each with the full three passes and the lane-per-chunk final pass; the exit (offset, count) of one
+    // segment is the entry of the next.  (Before: one pass A over everything and a scalar chain per chunk --
+    // 128 us for the streams of a 768x768 tile.)  nchunks is per stream, so every wave agrees on the loop; a
+    // stream that long keeps all the workgroup's waves busy (the callers give one wave per 16 bytes), so every
+    // wave also computes the same exit.
+    const bool tables = ft != nullptr;
+    constexpr int kSegChunks = kDecWaves * kU;                  // 160: one pass-A round per wave and segment
+    static_assert(kSegChunks <= kFastChunks, "segment must fit the per-position tables");
+    const int nseg = tables && nchunks > kFastChunks ? (nchunks + kSegChunks - 1) / kSegChunks : 1;
+    int e_in = 0, n_in = 0;
+    for (int sg = 0; sg < nseg; ++sg) {
+    const int seg_lo = nseg > 1 ? sg * kSegChunks : 0;
+    const int seg_hi = nseg > 1 ? (seg_lo + kSegChunks < nchunks ? seg_lo + kSegChunks : nchunks) : nchunks;
+    if (active) {
+        c0 = seg_lo + (int)((int64_t)k * (seg_hi - seg_lo) / nw);
+        c1 = seg_lo + (int)((int64_t)(k + 1) * (seg_hi - seg_lo) / nw);
+    }
+    const bool fast = tables && seg_hi - seg_lo <= kFastChunks;      // wave-uniform
+    FastTables *ftb = ft;                                            // tables are indexed from the segment's first chunk
+    const int fo = seg_lo * kWave;
     // ---- pass A: range function (F, C) by pointer doubling; kU chunks in flight per wave so that
     // the LDS round trips of independent chunks overlap (one wave per SIMD has no other cover)
     CGIC_STAMP3(2);
@@ -601,8 +619,8 @@ __device__ __forceinline__ void decode_segmented(const TableDev &t, const uint32
                 const int L = c + u < c1 ? codeword_at(t, lut, bw, (c + u) * kWave + lane, nbits, &sym, bw.fetch32_at(wi0 + 2 * u, sh0)) : 0;
                 pk[u] = L ? ((lane + L) | (1 << 8)) : kPackBig;
                 if (fast && c + u < c1) {
-                    ft->len[(c + u) * kWave + lane] = (uint8_t)L;
-                    ft->sym[(c + u) * kWave + lane] = (uint16_t)sym;
+                    ftb->len[(c + u) * kWave + lane - fo] = (uint8_t)L;
+                    ftb->sym[(c + u) * kWave + lane - fo] = (uint16_t)sym;
                 }
             }
             if (c == 0) CGIC_STAMP3(17);
@@ -619,7 +637,7 @@ __device__ __forceinline__ void decode_segmented(const TableDev &t, const uint32
             if (c == 0) CGIC_STAMP3(18);
 #pragma unroll
             for (int u = 0; u < kU; ++u) {
-                if (fast && c + u < c1) ft->fn[(c + u) * kWave + lane] = (uint16_t)pk[u];
+                if (fast && c + u < c1) ftb->fn[(c + u) * kWave + lane - fo] = (uint16_t)pk[u];
                 if (c + u < c1) {
                     const int o = __shfl(pk[u], F & 63, kWave);
                     if (F < kWave) { C += o >> 8; F = o & 0xFF; }
@@ -635,17 +653,29 @@ __device__ __forceinline__ void decode_segmented(const TableDev &t, const uint32
     CGIC_STAMP3(3);
     __syncthreads();
     CGIC_STAMP3(4);
-    // ---- pass B: true entry offset + output index of this wave's range
-    int e = 0, n = 0;
+    // ---- pass B: true entry offset + output index of this wave's range, and the segment's exit
+    int e = e_in, n = n_in;
+    int e_out = e_in, n_out = n_in;
     if (active) {
-        for (int v = w0; v < w0 + k; ++v) {
-            if (e >= kWave) break;
-            n += sh->C[v][e];
-            e = sh->F[v][e];
+        // a single segment needs the walk only up to this wave (the last wave adds its own count for the total);
+        // with more segments every wave walks all of them to know where the next segment starts
+        const int vend = nseg > 1 ? w0 + nw : w0 + k;
+        for (int v = w0; v < vend; ++v) {
+            if (v == w0 + k) { e = e_out; n = n_out; }
+            if (e_out >= kWave) break;
+            n_out += sh->C[v][e_out];
+            e_out = sh->F[v][e_out];
         }
+        if (nseg == 1) { e = e_out; n = n_out; }
         e = __builtin_amdgcn_readfirstlane(e);       // wave-uniform by construction; tell the compiler
         n = __builtin_amdgcn_readfirstlane(n);
-        if (k == nw - 1 && lane == 0) *count_out = e < kWave ? n + sh->C[wave][e] : n;
+        e_out = __builtin_amdgcn_readfirstlane(e_out);
+        n_out = __builtin_amdgcn_readfirstlane(n_out);
+        if (nseg == 1) {
+            if (k == nw - 1 && lane == 0) *count_out = e < kWave ? n + sh->C[wave][e] : n;
+        } else if (sg == nseg - 1 && k == 0 && lane == 0) {
+            *count_out = n_out;
+        }
     }
     // ---- pass C: decode the range from its true entry offset
     CGIC_STAMP3(5);
@@ -660,16 +690,16 @@ __device__ __forceinline__ void decode_segmented(const TableDev &t, const uint32
             const int cend = cb + kWave < c1 ? cb + kWave : c1;
             for (int c = cb; c < cend && e < kWave; ++c) {
                 if (lane == c - cb) { my_e = e; my_n = n; }
-                const int v = ft->fn[c * kWave + e];
+                const int v = ftb->fn[c * kWave + e - fo];
                 n += v >> 8;
                 e = (v & 0xFF) >= kPackBig ? kBig : (v & 0xFF) - kWave;
             }
             const int c = cb + lane;
             int i = my_e, o = my_n;
             while (i < kWave) {
-                const int L = ft->len[c * kWave + i];
+                const int L = ftb->len[c * kWave + i - fo];
                 if (L == 0) break;
-                if (o < cap) put(o, (int)ft->sym[c * kWave + i]);
+                if (o < cap) put(o, (int)ftb->sym[c * kWave + i - fo]);
                 ++o;
                 i += L;
             }
@@ -710,6 +740,10 @@ __device__ __forceinline__ void decode_segmented(const TableDev &t, const uint32
     CGIC_STAMP3(6);
     __syncthreads();
     CGIC_STAMP3(7);
+    e_in = e_out;
+    n_in = n_out;
+    if (nseg > 1 && e_in >= kWave) break;            // the stream ended inside this segment (uniform: all waves computed it)
+    }   // segments
 }
 
 // single-stream decode (HuffmanCoding / BinaryCoding .decompress_string): one 1024-thread workgroup,
@@ -838,7 +872,7 @@ __global__ __launch_bounds__(kDecThreads) void decode_streams_kernel(DecodeArgs 
 }
 
 constexpr int kMergeThreads = 512;
-constexpr int kMergeBands = 4;
+constexpr int kMergeBands = 4;          // row bands per image at least; more for few large images (gridDim.x)
 
 struct MergeArgs {
     const uint8_t *in;
@@ -881,7 +915,8 @@ __global__ __launch_bounds__(kMergeThreads) void merge_kernel(MergeArgs a)
     uint32_t *pmb = pcb + wc;           // [wm]
     const int mode = a.mode;
     // this block's rows: bands of whole coarse rows (multiples of 4 fine rows)
-    const int64_t rows_per = ((h4 + kMergeBands - 1) / kMergeBands) * 4;
+    const int64_t nbands = gridDim.x;
+    const int64_t rows_per = ((h4 + nbands - 1) / nbands) * 4;
     const int64_t r0 = band * rows_per, r1 = r0 + rows_per < h ? r0 + rows_per : h;
     if (r0 >= h) return;
     CGIC_STAMP(10);
@@ -1316,7 +1351,14 @@ extern "C" int cgic_decompress_streams(const cgic_table *t, const uint8_t *in, i
     CGIC_REQUIRE((size_t)slot >= (wm + 2) * 4, CGIC_ERR_CAPACITY, "decompress_streams: slot smaller than a mask stream");
     if (lds_m > 48 * 1024)
         CGIC_HIP_TRY(hipFuncSetAttribute((const void *)merge_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_m));
-    hipLaunchKernelGGL(merge_kernel, dim3(kMergeBands, (unsigned)B), dim3(kMergeThreads), lds_m, s, m);
+    // 4 bands per image fill the GPU at B = 64; a few large tiles get more (every band re-derives the mask prefixes,
+    // so not more than needed): ~256 workgroups in all, at least 2 coarse rows per band
+    int64_t nbands = kMergeBands;
+    {
+        const int64_t h4 = h >> 2;
+        while (nbands * B < 256 && nbands * 2 <= h4 / 2) nbands *= 2;
+    }
+    hipLaunchKernelGGL(merge_kernel, dim3((unsigned)nbands, (unsigned)B), dim3(kMergeThreads), lds_m, s, m);
     return launch_check("merge_kernel");
 }
 

@@ -1018,7 +1018,8 @@ static int launch_filter(const float *z, int64_t hw, int64_t N, const float *cb,
         for (int64_t ge = (per / 4 + 1) * 4; ge <= per + 12; ge += 4) {
             const int64_t rest = ngroups - (nblk - late) * ge;
             const int64_t gl = rest > 0 ? (rest + late - 1) / late : 0;
-            if (gl + delta <= ge) { g_early = ge; g_late = gl; n_early = nblk - late; router_first = true; break; }
+            // (gl == 0: the router outlasts the whole VQ -- the early workgroups simply take everything)
+            if (gl + delta <= ge || gl == 0) { g_early = ge; g_late = gl; n_early = nblk - late; router_first = true; break; }
         }
     }
     a.n_early = (unsigned int)n_early; a.g_early = (unsigned int)g_early; a.g_late = (unsigned int)g_late;
