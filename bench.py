@@ -326,7 +326,7 @@ def main():
                                  "and is bound by VALU + MFMA issue, see DESIGN.md 4.1"},
         }
         if world == 1 and (B, H) == (64, 256):
-            res["div2k_tiles"] = extra_workload(dev, 8, 768)
+            res["div2k_tiles"] = [extra_workload(dev, 8, 768), extra_workload(dev, 32, 768, steps=30)]
         if not a.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(x, z, cb, ratio)
         if not ok:
