@@ -13,7 +13,7 @@ for name, f in (("full (z_q + loss)", lambda: _vq_forward(z, w, 0.25, True, None
     for _ in range(3): f()
     torch.cuda.synchronize()
     c = (ctypes.c_longlong * 32)(); l.cgic_debug_phase_clocks(c); c = list(c)
-    print(name, " | ".join(f"{n} {(c[i+1]-c[i])/2.29e3:.2f}" for i, n in enumerate(["stage codebook", "split z (last group)", "scan", "decide", "outputs", "loss"])), "| total %.2f us; events %.1f us" % ((c[6]-c[0])/2.29e3, time_events(f, 100)))
+    print(name, " | ".join(f"{n} {(c[i+1]-c[i])/2.29e3:.2f}" for i, n in enumerate(["stage codebook", "split z (last group)", "scan", "decide", "outputs", "loss"])), "| total %.2f us; events %.1f us" % ((c[6]-c[0])/2.29e3, time_events(f, 100)), "| wave 3: loop end at %.2f, kernel end %.2f us" % ((c[13]-c[0])/2.29e3, (c[14]-c[0])/2.29e3))
 for name, f in (("full", lambda: _vq_forward(z, w, 0.25, True, None)), ("indices only", lambda: _vq_forward(z, w, 0.25, True, None, False, False))):
     f(); f(); torch.cuda.synchronize()
     n = 256
