@@ -217,6 +217,7 @@ def main():
     ap.add_argument("--size", type=int, default=256)
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a hipGraph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip the DIV2K-tile data points (clean kernel profiles of the headline workload)")
     ap.add_argument("--chunks", type=int, default=1, help="process the batch as this many concurrent stream chains")
     ap.add_argument("--fork-vq", type=int, nargs="?", const=1, default=0, help="1: VQ on a side stream next to entropy -> router; 2: router on a side stream next to VQ")
     a = ap.parse_args()
@@ -325,7 +326,7 @@ def main():
                                  f"{2.0 * N * 1024 * 32 / 1e9:.1f} GFLOP per launch = {2.0 * N * 1024 * 32 / t_dom / 2.5e15:.2f} of the 2.5 PFLOP/s bf16 peak) "
                                  "and is bound by VALU + MFMA issue, see DESIGN.md 4.1"},
         }
-        if world == 1 and (B, H) == (64, 256):
+        if world == 1 and (B, H) == (64, 256) and not a.no_extra:
             res["div2k_tiles"] = [extra_workload(dev, 8, 768), extra_workload(dev, 32, 768, steps=30)]
         if not a.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(x, z, cb, ratio)
