@@ -561,7 +561,7 @@ struct FastTables {                   // per chunk x bit offset, filled by pass 
 // Decode stream bytes `in` with waves [w0, w0+nw) of the block; each participating wave calls
 // this with k = its index inside the stream.  Two block-wide barriers inside (ALL waves of the
 // block must reach them, also waves with nw == 0 work: pass nw=0 and they just sync).
-template <typename Put>
+template <bool MULTI = true, typename Put>
 __device__ __forceinline__ void decode_segmented(const TableDev &t, const uint32_t *lut, uint32_t *win,
                                                  SegShared *sh, const uint8_t *in, int nbytes, int pad, int w0, int nw,
                                                  int k, int cap, Put put, int *count_out, FastTables *ft = nullptr)
@@ -585,7 +585,7 @@ __device__ __forceinline__ void decode_segmented(const TableDev &t, const uint32
     const bool tables = ft != nullptr;
     constexpr int kSegChunks = kDecWaves * kU;                  // 160: one pass-A round per wave and segment
     static_assert(kSegChunks <= kFastChunks, "segment must fit the per-position tables");
-    const int nseg = tables && nchunks > kFastChunks ? (nchunks + kSegChunks - 1) / kSegChunks : 1;
+    const int nseg = MULTI && tables && nchunks > kFastChunks ? (nchunks + kSegChunks - 1) / kSegChunks : 1;     // MULTI = false: the caller knows
     int e_in = 0, n_in = 0;
     for (int sg = 0; sg < nseg; ++sg) {
     const int seg_lo = nseg > 1 ? sg * kSegChunks : 0;
@@ -856,8 +856,14 @@ __global__ __launch_bounds__(kDecThreads) void decode_streams_kernel(DecodeArgs 
         int nw = (nb + 15) >> 4;                         // no wave below ~2 chunks
         nw = nw < 1 ? 1 : (nw > kDecWaves ? kDecWaves : nw);
         FastTables *ft = reinterpret_cast<FastTables *>(reinterpret_cast<int32_t *>(seg + 1) + 2 * kLdsTrieNodes);
-        decode_segmented(a.tab, lut, win + wave * kSegWinWords, seg, in, nb, s_pad, 0, wave < nw ? nw : 0, wave, cap, put,
-                         &s_count, ft);
+        // two instantiations: the single-segment one (every stream of a 256x256 image at the usual ratios) keeps its
+        // tighter code -- the segment loop cost it 0.8 us
+        if (nb <= kFastChunks * 8)
+            decode_segmented<false>(a.tab, lut, win + wave * kSegWinWords, seg, in, nb, s_pad, 0, wave < nw ? nw : 0, wave, cap, put,
+                                    &s_count, ft);
+        else
+            decode_segmented<true>(a.tab, lut, win + wave * kSegWinWords, seg, in, nb, s_pad, 0, wave < nw ? nw : 0, wave, cap, put,
+                                   &s_count, ft);
     } else if (wave == 0) {
         // tables with codes longer than 64 bits: one wave, serial chain
         int overflow = 0;
