@@ -328,7 +328,7 @@ def main():
         }
         if world == 1 and (B, H) == (64, 256) and not a.no_extra:
             res["div2k_tiles"] = [extra_workload(dev, 8, 768), extra_workload(dev, 32, 768, steps=30)]
-        if not a.no_cpu_baseline:
+        if not a.no_cpu_baseline and world == 1:             # the CPU port is timed at N=1 only (rank 0's host cores)
             res["cpu_baseline"] = cpu_baseline(x, z, cb, ratio)
         if not ok:
             log("ERROR: bitstream / masks / indices differ from the oracle")

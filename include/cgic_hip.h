@@ -65,14 +65,18 @@ int cgic_device_count(void);
  *   hist     device [K]         int64 or NULL  += occurrences of each index
  *            (the usage counter of quantize.py:28,79-81, exact integers)
  *   workspace device, cgic_vq_workspace_bytes(B*hw) bytes, or NULL iff loss==NULL
+ * Two implementations behind the same contract, bit-identical results: for K % 64 == 0, K <= 1024 (the reference's
+ * 1024 x 4 codebook) a bf16-MFMA candidate filter with an exact fp32 resolve, otherwise (or with CGIC_VQ_EXACT=1
+ * in the environment) the fp32-MFMA loop over every code.  NaN / Inf in z or the codebook are outside the
+ * contract (a valid index comes back, not necessarily torch.argmin's).
  * ------------------------------------------------------------------------- */
 size_t cgic_vq_workspace_bytes(int64_t n_vectors);
 int cgic_vq_forward_f32(const float *z, int64_t B, int64_t hw, const float *codebook, int K, int e_dim,
                         float beta, int legacy, int64_t *indices, float *z_q, float *loss,
                         int64_t *hist, void *workspace, cgic_stream_t stream);
-/* cgic_vq_forward_f32 and cgic_router_f32 in ONE launch: the router's per-image workgroups ride behind
- * the VQ workgroups of the same grid (neither needs the other's output; both need what precedes them,
- * i.e. the latent and the entropy maps).  Same contracts as the two separate calls. */
+/* cgic_vq_forward_f32 and cgic_router_f32 in ONE launch: the router's per-image workgroups share the grid with
+ * the VQ workgroups (neither needs the other's output; both need what precedes them, i.e. the latent and
+ * the entropy maps).  Same contracts as the two separate calls. */
 int cgic_vq_forward_route_f32(const float *z, int64_t B, int64_t hw, const float *codebook, int K, int e_dim,
                               float beta, int legacy, int64_t *indices, float *z_q, float *loss,
                               void *workspace, const float *e16, const float *e8, int64_t h16, int64_t w16,
@@ -96,8 +100,9 @@ int cgic_index_histogram(const int64_t *indices, int64_t n, int K, int64_t *hist
  *   bins  host   [32] fp32  (torch.linspace(-1, 1, 32), model.py:480)
  *   e8    device [B, H/8,  W/8 ] fp32 or NULL
  *   e16   device [B, H/16, W/16] fp32 or NULL
- * fp32 throughout; exp/log are OCML's, so results match the CPU reference to
- * ~1e-6, not bit-for-bit (SURVEY.md section 7 "hard parts").
+ * fp32 throughout; exp / log / reciprocal are the GPU's (v_exp_f32, v_log_f32, v_rcp_f32) and only the 3 bins
+ * nearest to a pixel are evaluated (the rest is < 3e-17 per pixel), so results match the CPU reference to
+ * ~1e-6 (measured 7e-7; tests hold it to 2e-5), not bit-for-bit (SURVEY.md section 7 "hard parts").
  * ------------------------------------------------------------------------- */
 int cgic_entropy_maps_f32(const float *x, int64_t B, int64_t H, int64_t W, const float *bins,
                           int nbins, float sigma, float *e8, float *e16, cgic_stream_t stream);
