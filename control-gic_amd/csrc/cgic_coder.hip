@@ -458,6 +458,7 @@ constexpr int kLdsTrieNodes = 2048;                // decode tries up to this ma
 constexpr int kFastChunks = 192;                   // streams up to this many chunks (1.5 KB) cache per-position
                                                    // lengths / symbols / chunk functions for the lane-per-chunk pass C
 constexpr int kPackBig = 0xFF;                     // packed "past the end" marker (max real next = 63 + 64)
+constexpr int kDecParts = 8;                        // workgroups per stream when streams are split (large grids)
 constexpr int kMergeItems = 2;
 
 struct BitWindow {
@@ -564,8 +565,14 @@ struct FastTables {                   // per chunk x bit offset, filled by pass 
 template <bool MULTI = true, typename Put>
 __device__ __forceinline__ void decode_segmented(const TableDev &t, const uint32_t *lut, uint32_t *win,
                                                  SegShared *sh, const uint8_t *in, int nbytes, int pad, int w0, int nw,
-                                                 int k, int cap, Put put, int *count_out, FastTables *ft = nullptr)
+                                                 int k, int cap, Put put, int *count_out, FastTables *ft = nullptr,
+                                                 int part = 0, int nparts = 1, int e_in0 = 0, int n_in0 = 0,
+                                                 uint32_t *bf_out = nullptr)
 {
+    // part / nparts: this workgroup handles the part-th of nparts equal chunk ranges of the stream (split streams,
+    // see decode_functions_kernel); e_in0 / n_in0: bit offset into the range's first chunk where its first codeword
+    // starts and the symbols before it; bf_out != NULL: only build the range's function (entry offset -> exit
+    // offset | symbols << 8, 0xFF = past the end) and store its 64 entries there -- no symbols are written.
     const int lane = lane_id();
     const int wave = threadIdx.x >> 6;
     int nbits = 0, nchunks = 0, c0 = 0, c1 = 0;
@@ -585,11 +592,14 @@ __device__ __forceinline__ void decode_segmented(const TableDev &t, const uint32
     const bool tables = ft != nullptr;
     constexpr int kSegChunks = kDecWaves * kU;                  // 160: one pass-A round per wave and segment
     static_assert(kSegChunks <= kFastChunks, "segment must fit the per-position tables");
-    const int nseg = MULTI && tables && nchunks > kFastChunks ? (nchunks + kSegChunks - 1) / kSegChunks : 1;     // MULTI = false: the caller knows
-    int e_in = 0, n_in = 0;
+    const int per_part = (nchunks + nparts - 1) / nparts;
+    const int r_lo = part * per_part < nchunks ? part * per_part : nchunks;
+    const int r_hi = r_lo + per_part < nchunks ? r_lo + per_part : nchunks;
+    const int nseg = MULTI && tables && r_hi - r_lo > kFastChunks ? (r_hi - r_lo + kSegChunks - 1) / kSegChunks : 1;     // MULTI = false: the caller knows
+    int e_in = e_in0, n_in = n_in0;
     for (int sg = 0; sg < nseg; ++sg) {
-    const int seg_lo = nseg > 1 ? sg * kSegChunks : 0;
-    const int seg_hi = nseg > 1 ? (seg_lo + kSegChunks < nchunks ? seg_lo + kSegChunks : nchunks) : nchunks;
+    const int seg_lo = nseg > 1 ? r_lo + sg * kSegChunks : r_lo;
+    const int seg_hi = nseg > 1 ? (seg_lo + kSegChunks < r_hi ? seg_lo + kSegChunks : r_hi) : r_hi;
     if (active) {
         c0 = seg_lo + (int)((int64_t)k * (seg_hi - seg_lo) / nw);
         c1 = seg_lo + (int)((int64_t)(k + 1) * (seg_hi - seg_lo) / nw);
@@ -653,6 +663,19 @@ __device__ __forceinline__ void decode_segmented(const TableDev &t, const uint32
     CGIC_STAMP3(3);
     __syncthreads();
     CGIC_STAMP3(4);
+    if (bf_out) {
+        // the range's function for all 64 entry offsets at once: lane = entry offset, the waves' functions applied in order
+        if (wave == 0) {
+            int cur = lane, cnt = 0;
+            if (active) {
+                for (int v = w0; v < w0 + nw; ++v) {
+                    if (cur < kWave) { cnt += sh->C[v][cur]; cur = sh->F[v][cur]; }
+                }
+            }
+            bf_out[lane] = ((uint32_t)cnt << 8) | (uint32_t)(cur < kWave ? cur : 0xFF);
+        }
+        return;
+    }
     // ---- pass B: true entry offset + output index of this wave's range, and the segment's exit
     int e = e_in, n = n_in;
     int e_out = e_in, n_out = n_in;
@@ -808,6 +831,8 @@ struct DecodeArgs {
     uint16_t *dsym;          // [B, n_c + n_m + n_f]
     int32_t *dcount;         // [B, 3]: >=0 count, -1 empty file (None), -2 not sent, -3 overflow
     int32_t *status;         // [B] zeroed here for the merge kernel's atomicMin
+    int parts;               // workgroups per stream in the split-stream launches (kDecParts), else 1
+    uint32_t *bf;            // [B, 3, parts, 64] range functions written by decode_functions_kernel
 };
 
 __global__ __launch_bounds__(kDecThreads) void decode_streams_kernel(DecodeArgs a)
@@ -875,6 +900,100 @@ __global__ __launch_bounds__(kDecThreads) void decode_streams_kernel(DecodeArgs 
     __syncthreads();
     CGIC_STAMP3(8);
     if (tid == 0) *dc = s_count > cap ? -3 : s_count;
+}
+
+// ---- split streams (large grids: the streams of a 768x768 tile are ~1350 chunks; one workgroup needs nine 160-chunk
+// segments one after the other -- 108 us for 8 tiles on an otherwise idle GPU).  Two launches over the grid
+// (3 * parts, B), no workgroup waits for another:
+//   decode_functions_kernel: every workgroup builds the FUNCTION of its chunk range -- for each of the 64 bit offsets
+//     at which its first codeword might start: where the first codeword of the NEXT range starts and how many
+//     symbols lie between -- by the same pointer-doubling pass, and stores the 64 entries;
+//   decode_parts_kernel: composes the functions of the ranges before its own and decodes its range from the true offset.
+__device__ __forceinline__ void decode_part_prologue(DecodeArgs &a, uint32_t *lut, SegShared *seg, int s, int64_t b,
+                                                     const uint8_t *in, int *s_nb, int *s_pad)
+{
+    const int tid = threadIdx.x;
+    if (tid == 0) {
+        *s_nb = ((a.stream_mask >> s) & 1) ? a.nbytes[b * CGIC_NUM_STREAMS + s] : -2;
+        *s_pad = in[0];
+    }
+    load_lut(a.tab, lut);
+    if (a.tab.n_nodes <= kLdsTrieNodes) {
+        int32_t *ltrie = reinterpret_cast<int32_t *>(seg + 1);
+        for (int i = tid; i < 2 * a.tab.n_nodes; i += kDecThreads) ltrie[i] = a.tab.child[i];
+        a.tab.child = ltrie;
+    }
+}
+
+__global__ __launch_bounds__(kDecThreads) void decode_functions_kernel(DecodeArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t sm[];
+    __shared__ int s_count, s_nb, s_pad;
+    uint32_t *lut = sm;
+    uint32_t *win = lut + kDecLutMax;
+    SegShared *seg = reinterpret_cast<SegShared *>(win + kDecWaves * kSegWinWords);
+    const int tid = threadIdx.x, wave = tid >> 6;
+    const int s = blockIdx.x / a.parts, part = blockIdx.x % a.parts;
+    const int64_t b = blockIdx.y;
+    if (part == a.parts - 1) return;                             // nobody reads the last range's function
+    const uint8_t *in = a.in + (b * CGIC_NUM_STREAMS + s) * a.slot;
+    decode_part_prologue(a, lut, seg, s, b, in, &s_nb, &s_pad);
+    __syncthreads();
+    const int nb = s_nb;
+    uint32_t *bf = a.bf + ((b * 3 + s) * a.parts + part) * kWave;
+    if (nb <= 0) {
+        if (tid < kWave) bf[tid] = 0xFFu;                        // no stream: every entry is "past the end"
+        return;
+    }
+    decode_segmented<false>(a.tab, lut, win + wave * kSegWinWords, seg, in, nb, s_pad, 0, kDecWaves, wave, 0,
+                            [](int, int) {}, &s_count, (FastTables *)nullptr, part, a.parts, 0, 0, bf);
+}
+
+__global__ __launch_bounds__(kDecThreads) void decode_parts_kernel(DecodeArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t sm[];
+    __shared__ int s_count, s_nb, s_pad;
+    __shared__ uint32_t s_bf[kDecParts * kWave];
+    __shared__ int s_entry[2];
+    uint32_t *lut = sm;
+    uint32_t *win = lut + kDecLutMax;
+    SegShared *seg = reinterpret_cast<SegShared *>(win + kDecWaves * kSegWinWords);
+    const int tid = threadIdx.x, wave = tid >> 6;
+    const int s = blockIdx.x / a.parts, part = blockIdx.x % a.parts;
+    const int64_t b = blockIdx.y;
+    const int64_t n_c = (a.h >> 2) * (a.w >> 2), n_m = (a.h >> 1) * (a.w >> 1), n_f = a.h * a.w;
+    const int64_t off = s == 0 ? 0 : (s == 1 ? n_c : n_c + n_m);
+    const int cap = (int)(s == 0 ? n_c : (s == 1 ? n_m : n_f));
+    if (s == 0 && part == 0 && tid == 0 && a.status) a.status[b] = 0;
+    int32_t *dc = a.dcount + b * 3 + s;
+    const uint8_t *in = a.in + (b * CGIC_NUM_STREAMS + s) * a.slot;
+    if (tid == 0) s_count = 0;
+    const uint32_t *bf = a.bf + ((b * 3 + s) * a.parts) * kWave;
+    for (int i = tid; i < part * kWave; i += kDecThreads) s_bf[i] = bf[i];
+    decode_part_prologue(a, lut, seg, s, b, in, &s_nb, &s_pad);
+    __syncthreads();
+    const int nb = s_nb;
+    if (nb <= 0) {
+        if (tid == 0 && part == a.parts - 1) *dc = nb == 0 ? -1 : -2;
+        return;
+    }
+    if (tid == 0) {
+        int e = 0, n = 0;
+        for (int g = 0; g < part && e < kWave; ++g) {
+            const uint32_t v = s_bf[g * kWave + e];
+            n += (int)(v >> 8);
+            e = (v & 0xFF) == 0xFF ? kBig : (int)(v & 0xFF);
+        }
+        s_entry[0] = e; s_entry[1] = n;
+    }
+    __syncthreads();
+    uint16_t *dst = a.dsym + b * (n_c + n_m + n_f) + off;
+    auto put = [&](int k, int sym) { dst[k] = (uint16_t)sym; };
+    FastTables *ft = reinterpret_cast<FastTables *>(reinterpret_cast<int32_t *>(seg + 1) + 2 * kLdsTrieNodes);
+    decode_segmented<true>(a.tab, lut, win + wave * kSegWinWords, seg, in, nb, s_pad, 0, kDecWaves, wave, cap, put, &s_count, ft,
+                           part, a.parts, s_entry[0], s_entry[1]);
+    __syncthreads();
+    if (tid == 0 && part == a.parts - 1) *dc = s_count > cap ? -3 : s_count;      // the last part knows the total
 }
 
 constexpr int kMergeThreads = 512;
@@ -1306,7 +1425,8 @@ extern "C" size_t cgic_decompress_workspace_bytes(int64_t B, int64_t h, int64_t 
 {
     if (B <= 0 || h <= 0 || w <= 0) return 0;
     const size_t per = (size_t)((h / 4) * (w / 4) + (h / 2) * (w / 2) + h * w);
-    return align16((size_t)B * per * sizeof(uint16_t)) + align16((size_t)B * 3 * sizeof(int32_t));
+    return align16((size_t)B * per * sizeof(uint16_t)) + align16((size_t)B * 3 * sizeof(int32_t))
+           + align16((size_t)B * 3 * kDecParts * kWave * sizeof(uint32_t));                     // split-stream functions
 }
 
 extern "C" int cgic_decompress_streams(const cgic_table *t, const uint8_t *in, int64_t slot, const int32_t *nbytes,
@@ -1333,13 +1453,29 @@ extern "C" int cgic_decompress_streams(const cgic_table *t, const uint8_t *in, i
     d.dsym = (uint16_t *)workspace;
     d.dcount = (int32_t *)((char *)workspace + align16((size_t)B * per * sizeof(uint16_t)));
     d.status = status;
+    // grids beyond a 256x256 image (latent 64x64) have streams of many segments: split each over kDecParts workgroups
+    // (tables with >64-bit codes take the one-wave path of decode_streams_kernel)
+    d.parts = h * w > 64 * 64 && d.tab.max_len <= 64 ? kDecParts : 1;
+    d.bf = (uint32_t *)((char *)d.dcount + align16((size_t)B * 3 * sizeof(int32_t)));
     size_t lds_d = sizeof(uint32_t) * (kDecLutMax + kDecWaves * kSegWinWords) + sizeof(SegShared) + sizeof(int32_t) * 2 * kLdsTrieNodes
                    + sizeof(FastTables);
     if (lds_d < sizeof(uint32_t) * (kDecLutMax + kWinWords)) lds_d = sizeof(uint32_t) * (kDecLutMax + kWinWords);
     if (lds_d > 48 * 1024)
         CGIC_HIP_TRY(hipFuncSetAttribute((const void *)decode_streams_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_d));
-    hipLaunchKernelGGL(decode_streams_kernel, dim3(3, (unsigned)B), dim3(kDecThreads), lds_d, s, d);
-    rc = launch_check("decode_streams_kernel");
+    if (d.parts > 1) {
+        if (lds_d > 48 * 1024) {
+            CGIC_HIP_TRY(hipFuncSetAttribute((const void *)decode_functions_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_d));
+            CGIC_HIP_TRY(hipFuncSetAttribute((const void *)decode_parts_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_d));
+        }
+        hipLaunchKernelGGL(decode_functions_kernel, dim3(3 * d.parts, (unsigned)B), dim3(kDecThreads), lds_d, s, d);
+        rc = launch_check("decode_functions_kernel");
+        if (rc) return rc;
+        hipLaunchKernelGGL(decode_parts_kernel, dim3(3 * d.parts, (unsigned)B), dim3(kDecThreads), lds_d, s, d);
+        rc = launch_check("decode_parts_kernel");
+    } else {
+        hipLaunchKernelGGL(decode_streams_kernel, dim3(3, (unsigned)B), dim3(kDecThreads), lds_d, s, d);
+        rc = launch_check("decode_streams_kernel");
+    }
     if (rc) return rc;
     MergeArgs m;
     m.in = in; m.slot = slot; m.nbytes = nbytes; m.h = h; m.w = w; m.mode = mode;
