@@ -523,14 +523,23 @@ __device__ __forceinline__ void vq_filter_body(const VqArgs &a, unsigned char *s
     // ---- stage: fp32 rows, then the split A operands built from them
     if (tid < 2) s_max[tid] = 0;
     if (tid == 0) s_next = NW;              // groups 0..NW-1 of the workgroup's range are the waves' first ones
-    for (int i = tid; i < K; i += NT) cbs[i] = reinterpret_cast<const float4 *>(a.cb)[i];
-    __syncthreads();
     {
+        // every (tile, lane) element reads its codebook row straight from global (L2): all loads of a thread are in
+        // flight together and no barrier sits between the fp32 copy and the operand build (one round trip, not two)
         float emax = 0.f, eemax = 0.f;
-#pragma unroll 4
-        for (int i = tid; i < ntile * 64; i += NT) {
+        constexpr int kPerThread = kVqfMaxK * 4 / NT;             // 8 elements per thread at K = 1024
+        float4 rows[kPerThread];
+#pragma unroll
+        for (int q = 0; q < kPerThread; ++q) {
+            const int i = tid + q * NT;
+            rows[q] = i < ntile * 64 ? reinterpret_cast<const float4 *>(a.cb)[((i >> 6) << 4) + (i & 15)] : float4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int q = 0; q < kPerThread; ++q) {
+            const int i = tid + q * NT;
+            if (i >= ntile * 64) break;
             const int l = i & 63, gg = l >> 4;
-            const float4 e = cbs[((i >> 6) << 4) + (l & 15)];
+            const float4 e = rows[q];
             const float ee = sumsq4(e.x, e.y, e.z, e.w);
             const float ec = gg == 0 ? e.x : gg == 1 ? e.y : gg == 2 ? e.z : e.w;
             unsigned int wh, wm, wl, eh, em, el;
@@ -538,7 +547,7 @@ __device__ __forceinline__ void vq_filter_body(const VqArgs &a, unsigned char *s
             split3(ee, eh, em, el);
             const unsigned int ep = gg == 0 ? eh : gg == 1 ? em : gg == 2 ? el : 0u;
             ldsA[i] = make_uint4(wh | (wm << 16), wl | (ep << 16), wh | (wm << 16), wh | (wm << 16));
-            if (gg == 0) ees[((i >> 6) << 4) + (l & 15)] = ee;
+            if (gg == 0) { ees[((i >> 6) << 4) + (l & 15)] = ee; cbs[((i >> 6) << 4) + (l & 15)] = e; }
             emax = fmaxf(emax, fabsf(ec));
             eemax = fmaxf(eemax, ee);
         }
