@@ -203,6 +203,11 @@ __global__ __launch_bounds__(kEncThreads) void compress_streams_kernel(CompressA
     const int64_t b = blockIdx.y;
     CGIC_STAMP2(0);
     CGIC_SPAN_BEGIN();
+#ifdef CGIC_PHASE_CLOCKS      // dev: per-workgroup (start, end) for tools/probe_compress_blocks.py
+    const unsigned int dbg_lin = blockIdx.y * gridDim.x + blockIdx.x;
+    if (threadIdx.x == 0 && dbg_lin < 4096) g_blk_t[2 * dbg_lin] = wall_clock64();
+    struct DbgEnd { unsigned int lin; __device__ ~DbgEnd() { if (threadIdx.x == 0 && lin < 4096) g_blk_t[2 * lin + 1] = wall_clock64(); } } dbg_end{dbg_lin};
+#endif
     if (s == CGIC_NUM_STREAMS) {
         // job 5: usage histogram of this image's indices (quantize.py:79-81) -- LDS histogram, then
         // at most one global atomic per non-empty bin per image
