@@ -199,12 +199,16 @@ __global__ __launch_bounds__(kEncThreads) void compress_streams_kernel(CompressA
     __shared__ uint16_t lds_sym[kLdsPos];
     __shared__ int32_t lds_len[kLdsTable];
     __shared__ uint32_t lds_code[kLdsTable];
-    const int s = blockIdx.x;
-    const int64_t b = blockIdx.y;
+    // grid (B, jobs): workgroups are dispatched image-fastest, the LONG jobs first (fine, medium, coarse indices,
+    // then the two mask streams, then the histogram).  1024-thread workgroups are handed out at ~100 per us: with the
+    // job as the fast index the fine stream of the last image started 5 us late and ended the launch.
+    const int kJobOrder[6] = {2, 1, 0, 4, 3, 5};
+    const int s = kJobOrder[blockIdx.y];
+    const int64_t b = blockIdx.x;
     CGIC_STAMP2(0);
     CGIC_SPAN_BEGIN();
 #ifdef CGIC_PHASE_CLOCKS      // dev: per-workgroup (start, end) for tools/probe_compress_blocks.py
-    const unsigned int dbg_lin = blockIdx.y * gridDim.x + blockIdx.x;
+    const unsigned int dbg_lin = blockIdx.x * 6 + s;      // (image, job) like the probe expects
     if (threadIdx.x == 0 && dbg_lin < 4096) g_blk_t[2 * dbg_lin] = wall_clock64();
     struct DbgEnd { unsigned int lin; __device__ ~DbgEnd() { if (threadIdx.x == 0 && lin < 4096) g_blk_t[2 * lin + 1] = wall_clock64(); } } dbg_end{dbg_lin};
 #endif
@@ -848,8 +852,9 @@ __global__ __launch_bounds__(kDecThreads) void decode_streams_kernel(DecodeArgs 
     uint32_t *win = lut + kDecLutMax;                   // [16][kSegWinWords] (slow mode: 1 x kWinWords)
     SegShared *seg = reinterpret_cast<SegShared *>(win + kDecWaves * kSegWinWords);
     const int tid = threadIdx.x, lane = lane_id(), wave = tid >> 6;
-    const int s = blockIdx.x;
-    const int64_t b = blockIdx.y;
+    // grid (B, 3), image-fastest, the usually longest stream first (medium, fine, coarse): see compress_streams_kernel
+    const int s = blockIdx.y == 0 ? 1 : blockIdx.y == 1 ? 2 : 0;
+    const int64_t b = blockIdx.x;
     const int64_t n_c = (a.h >> 2) * (a.w >> 2), n_m = (a.h >> 1) * (a.w >> 1), n_f = a.h * a.w;
     const int64_t off = s == 0 ? 0 : (s == 1 ? n_c : n_c + n_m);
     const int cap = (int)(s == 0 ? n_c : (s == 1 ? n_m : n_f));
@@ -1383,7 +1388,7 @@ extern "C" int cgic_compress_streams(const cgic_table *t, const int64_t *ind, co
     a.ws_stride = (int64_t)ws_stride(h, w);
     a.ws_end = (uint32_t *)workspace;
     a.ws_sym = workspace ? (uint16_t *)((char *)workspace + (size_t)B * 3 * ws_stride(h, w) * sizeof(uint32_t)) : nullptr;
-    hipLaunchKernelGGL(compress_streams_kernel, dim3(CGIC_NUM_STREAMS + (hist ? 1 : 0), (unsigned)B), dim3(kEncThreads), 0,
+    hipLaunchKernelGGL(compress_streams_kernel, dim3((unsigned)B, CGIC_NUM_STREAMS + (hist ? 1 : 0)), dim3(kEncThreads), 0,
                        (hipStream_t)stream, a);
     return launch_check("compress_streams_kernel");
 }
@@ -1478,7 +1483,7 @@ extern "C" int cgic_decompress_streams(const cgic_table *t, const uint8_t *in, i
         hipLaunchKernelGGL(decode_parts_kernel, dim3(3 * d.parts, (unsigned)B), dim3(kDecThreads), lds_d, s, d);
         rc = launch_check("decode_parts_kernel");
     } else {
-        hipLaunchKernelGGL(decode_streams_kernel, dim3(3, (unsigned)B), dim3(kDecThreads), lds_d, s, d);
+        hipLaunchKernelGGL(decode_streams_kernel, dim3((unsigned)B, 3), dim3(kDecThreads), lds_d, s, d);
         rc = launch_check("decode_streams_kernel");
     }
     if (rc) return rc;

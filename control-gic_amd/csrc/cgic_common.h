@@ -77,10 +77,10 @@ extern __device__ long long g_blk_t[2 * 4096];   // per-workgroup (start, end) o
 // [30]/[31] = start/end of the workgroup that ended last (as block id pair packed)
 #define CGIC_SPAN_BEGIN() long long _span_t0 = 0; do { if (threadIdx.x == 0) { _span_t0 = wall_clock64(); atomicMin((unsigned long long *)&g_phase_clk[28], (unsigned long long)_span_t0); } } while (0)
 #define CGIC_SPAN_END() do { if (threadIdx.x == 0) { long long _t1 = wall_clock64(); unsigned long long _old = atomicMax((unsigned long long *)&g_phase_clk[29], (unsigned long long)_t1); if ((unsigned long long)_t1 > _old) { g_phase_clk[30] = _t1 - _span_t0; g_phase_clk[31] = blockIdx.x + 1000 * blockIdx.y; } } } while (0)
-// STAMP3: the medium-stream workgroup of image 0 in the (3, B) decode grid, wave 0
-#define CGIC_STAMP3(i) do { if (blockIdx.x == 1 && blockIdx.y == 0 && threadIdx.x == 0) g_phase_clk[i] = clock64(); } while (0)
-// STAMP2: the fine-stream workgroup of image 0 in grid (5, B) kernels
-#define CGIC_STAMP2(i) do { if (blockIdx.x == 2 && blockIdx.y == 0 && threadIdx.x == 0) g_phase_clk[i] = clock64(); } while (0)
+// STAMP3: the medium-stream workgroup of image 0 in the (B, 3) decode grid (medium = row 0), wave 0
+#define CGIC_STAMP3(i) do { if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) g_phase_clk[i] = clock64(); } while (0)
+// STAMP2: the fine-stream workgroup of image 0 in the (B, jobs) compress grid (fine = row 0)
+#define CGIC_STAMP2(i) do { if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) g_phase_clk[i] = clock64(); } while (0)
 #else
 #define CGIC_STAMP(i) do {} while (0)
 #define CGIC_STAMP2(i) do {} while (0)
