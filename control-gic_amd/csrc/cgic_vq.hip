@@ -1024,7 +1024,8 @@ static int launch_filter(const float *z, int64_t hw, int64_t N, const float *cb,
     bool router_first = false;
     if (late > 0 && late < nblk && !split_off) {
         const int64_t delta = (int64_t)(0.0021 * (double)hw * (4.0 / ZT) + 0.5);
-        for (int64_t ge = (per / 4 + 1) * 4; ge <= per + 12; ge += 4) {
+        static const int force_ge = getenv("CGIC_VQ_GE") ? atoi(getenv("CGIC_VQ_GE")) : 0;     // dev: tuning
+        for (int64_t ge = force_ge ? force_ge : (per / 4 + 1) * 4; ge <= per + 12; ge += 4) {
             const int64_t rest = ngroups - (nblk - late) * ge;
             const int64_t gl = rest > 0 ? (rest + late - 1) / late : 0;
             // (gl == 0: the router outlasts the whole VQ -- the early workgroups simply take everything)
