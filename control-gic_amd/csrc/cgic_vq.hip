@@ -355,6 +355,7 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 constexpr int kVqfThreads = 512;               // 8 waves, one workgroup per CU (84 KB of LDS at K = 1024)
 constexpr int kVqfWaves = kVqfThreads / 64;
 constexpr int kVqfMaxK = 1024;
+constexpr int kVqfTbFloats = 1024 + 64;        // per wave: 4 fields x 64 vectors x 4 row groups, + 64 results
 constexpr int kVqfBulk = 12;                   // more flagged vectors than this in a 64-vector group: rerun it exactly on the MFMA
 
 // x == h + m + l exactly, three bf16 by truncation (|m| < 2^-7 |x|, |l| < 2^-14 |x|)
@@ -443,6 +444,7 @@ template <int ZT>
 __device__ __forceinline__ void vq_filter_body(const VqArgs &a, unsigned char *smem, const unsigned int vblk)
 {
     constexpr int NT = kVqfThreads, NW = kVqfWaves;
+    static_assert(ZT <= 4, "the decide step maps one lane to each of the group's 16 * ZT vectors");
     const float *__restrict__ z = a.z;
     const int64_t hw = a.hw, N = a.N;
     const int K = a.K, ntile = K >> 4, np = K >> 5;
@@ -454,7 +456,8 @@ __device__ __forceinline__ void vq_filter_body(const VqArgs &a, unsigned char *s
     uint4 *ldsA = reinterpret_cast<uint4 *>(smem);                         // [K/16][64]
     float4 *cbs = reinterpret_cast<float4 *>(smem + (size_t)K * 64);       // [K] fp32 rows
     float *ees = reinterpret_cast<float *>(smem + (size_t)K * 80);         // [K] their squared norms
-    double *gsum = reinterpret_cast<double *>(smem + (size_t)K * 84);      // [groups of this workgroup] loss partials
+    float *tbuf = reinterpret_cast<float *>(smem + (size_t)K * 84);        // [NW][kVqfTbFloats] per-wave transpose buffers
+    double *gsum = reinterpret_cast<double *>(smem + (size_t)K * 84 + (size_t)NW * kVqfTbFloats * 4);      // [groups of this workgroup] loss partials
     __shared__ unsigned int s_max[2];
     __shared__ unsigned int s_next;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -630,117 +633,78 @@ __device__ __forceinline__ void vq_filter_body(const VqArgs &a, unsigned char *s
         }
         CGIC_STAMP(3);
 
-        // ---- decide
-        float z0[ZT], z1[ZT], z2[ZT], z3[ZT], zz[ZT];
-        int win[ZT];
-        unsigned int flagged[ZT];
-        int nflag = 0;
+        // ---- decide: ONE LANE PER VECTOR.  The scan leaves (smallest, second, where) per (vector, row group) in the
+        // MFMA's lane layout; a transpose through a wave-private LDS buffer gives lane t*16+j all four row groups of
+        // its vector, and the whole decision -- margin, hot row group, the 16 exact distances -- is lane-local: no
+        // cross-lane reductions (they were a third of the kernel's VALU instructions).
+        int win[ZT];                                   // result per tile in the (column j, row group g) layout
+        {
+            float *tb = tbuf + wave * kVqfTbFloats;
 #pragma unroll
-        for (int t = 0; t < ZT; ++t) {
-            {   // all four components of column j in every lane: three swaps
-                const uint2 eo = rows16(__float_as_uint(zv[t]));         // (z0,z0,z2,z2) / (z1,z1,z3,z3)
-                const uint2 e = rows32(eo.x), o = rows32(eo.y);
-                z0[t] = __uint_as_float(e.x); z2[t] = __uint_as_float(e.y);
-                z1[t] = __uint_as_float(o.x); z3[t] = __uint_as_float(o.y);
+            for (int t = 0; t < ZT; ++t) {
+                const int o = (t * 16 + j) * 4 + g;
+                tb[o] = m1[t];
+                tb[256 + o] = m2[t];
+                tb[512 + o] = __int_as_float(bt[t]);
+                tb[768 + o] = zv[t];
             }
-            zz[t] = sumsq4(z0[t], z1[t], z2[t], z3[t]);
-            const float mt = colmin(m1[t]);
+            const float4 a1 = reinterpret_cast<const float4 *>(tb)[lane];            // m1 of row groups 0..3
+            const float4 a2 = reinterpret_cast<const float4 *>(tb)[64 + lane];       // m2
+            const float4 ab = reinterpret_cast<const float4 *>(tb)[128 + lane];      // bt (bits)
+            const float4 az = reinterpret_cast<const float4 *>(tb)[192 + lane];      // z0..z3
+            const bool valid = lane < 16 * ZT;
+            const float y0 = az.x, y1 = az.y, y2 = az.z, y3 = az.w;
+            const float yy = sumsq4(y0, y1, y2, y3);
+            const float mt = __builtin_fminf(__builtin_fminf(a1.x, a1.y), __builtin_fminf(a1.z, a1.w));
             // S bounds ee_k + 2 sum|z_j e_kj| for every code that can matter: by the codebook maxima, and -- the winner
             // and every code that can beat it lie within sqrt(D) of z, D = zz + f_min + slack -- by
             // (|z| + sqrt D)^2 + 2 |z| (|z| + sqrt D); the smaller of the two (v_sqrt_f32 is good to 1 ulp: x 1.001)
-            const float S0 = EEmax + 2.0f * Emax * (((fabsf(z0[t]) + fabsf(z1[t])) + fabsf(z2[t])) + fabsf(z3[t]));
-            const float M0 = 1.2e-5f * S0 + 2.5e-7f * zz[t] + 1e-30f;
-            const float D = fmaxf(zz[t] * 1.0001f + mt + 2.0f * M0, 0.f);
-            const float nz = __builtin_amdgcn_sqrtf(zz[t]) * 1.001f, sd = __builtin_amdgcn_sqrtf(D) * 1.001f;
+            const float S0 = EEmax + 2.0f * Emax * (((fabsf(y0) + fabsf(y1)) + fabsf(y2)) + fabsf(y3));
+            const float M0 = 1.2e-5f * S0 + 2.5e-7f * yy + 1e-30f;
+            const float D = fmaxf(yy * 1.0001f + mt + 2.0f * M0, 0.f);
+            const float nz = __builtin_amdgcn_sqrtf(yy) * 1.001f, sd = __builtin_amdgcn_sqrtf(D) * 1.001f;
             const float S1 = (nz + sd) * (3.0f * nz + sd);
             const float S = S1 < S0 ? S1 : S0;                  // (a NaN S1 keeps S0)
-            const float M = 1.2e-5f * S + 2.5e-7f * zz[t] + 1e-30f;
+            const float M = 1.2e-5f * S + 2.5e-7f * yy + 1e-30f;
             float thr = mt + M;
             thr += fabsf(thr) * 2.4e-7f;
             // anything not comparable (NaN / Inf anywhere above) must count as "flagged": test the negation
-            const bool hot = !(m1[t] > thr);                // this lane's best quad holds a candidate
-            const bool more = !(m2[t] > thr);               // ... and so does another quad of this lane
-            // settled iff exactly one hot row group and no second quad anywhere in the column
-            const bool flag = colsum((hot ? 1 : 0) + (more ? 4 : 0)) != 1;
-            flagged[t] = (unsigned int)(__ballot(flag) & 0xFFFFull);          // per vector, wave-uniform
-            nflag += __builtin_popcount(flagged[t]);
-            // exact fp32 on the 16 codes of the winning (quad, row group): four per lane, lowest index wins ties
-            int key = colmax(hot ? ((bt[t] << 2) | g) : -1);
-            key = key < 0 ? 0 : key;                        // no hot lane at all (then the column is flagged anyway)
-            const int bq = key >> 2, gw = key & 3;
+            const bool h0 = !(a1.x > thr), h1 = !(a1.y > thr), h2 = !(a1.z > thr), h3 = !(a1.w > thr);   // best quad holds a candidate
+            const bool more = !(a2.x > thr) || !(a2.y > thr) || !(a2.z > thr) || !(a2.w > thr);        // ... and so does another quad
+            // settled iff exactly one hot row group and no second quad anywhere
+            const bool flag = valid && (((int)h0 + (int)h1 + (int)h2 + (int)h3) != 1 || more);
+            const int gw = h0 ? 0 : h1 ? 1 : h2 ? 2 : 3;
+            int bq = __float_as_int(gw == 0 ? ab.x : gw == 1 ? ab.y : gw == 2 ? ab.z : ab.w);
+            bq = valid && bq >= 0 && bq < (K >> 6) ? bq : 0;       // (idle lanes of the ZT < 4 instantiations read stale LDS)
+            // exact fp32 on the 16 codes of the winning (quad, row group); descending, the lowest index wins ties
             float d = __builtin_inff();
-            int i = 0;
+            int wi = 0;
 #pragma unroll
-            for (int r = 3; r >= 0; --r) {
-                const int c = 64 * bq + 16 * g + 4 * gw + r;
-                const float dd = dist_row(z0[t], z1[t], z2[t], z3[t], zz[t], cbs[c], ees[c]);
+            for (int q = 15; q >= 0; --q) {
+                const int c = 64 * bq + 16 * (q >> 2) + 4 * gw + (q & 3);
+                const float dd = dist_row(y0, y1, y2, y3, yy, cbs[c], ees[c]);
                 const bool take = dd <= d;
                 d = take ? dd : d;
-                i = take ? c : i;
+                wi = take ? c : wi;
             }
-            colargmin(d, i);
-            win[t] = i;
-        }
-        nflag = __builtin_amdgcn_readfirstlane(nflag);
-
-        if (nflag > kVqfBulk) {
-            // many near-ties (degenerate codebooks, zz >> ee, non-finite input): the exact fp32-MFMA scan of
-            // vq_mfma_body for the whole group, operands from the fp32 rows in LDS
-            float best[ZT];
-            int bt2[ZT];
-#pragma unroll
-            for (int t = 0; t < ZT; ++t) { best[t] = __builtin_inff(); bt2[t] = 0; }
-            for (int ct = 0; ct < ntile; ++ct) {
-                const float av = reinterpret_cast<const float *>(cbs)[(16 * ct + j) * 4 + g];
-                const f32x4 e4 = *reinterpret_cast<const f32x4 *>(&ees[16 * ct + 4 * g]);
-#pragma unroll
-                for (int t = 0; t < ZT; ++t) {
-                    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av, zv[t], acc, 0, 0, 0);
-                    const float d0 = __builtin_fmaf(-2.0f, acc[0], zz[t] + e4[0]);
-                    const float d1 = __builtin_fmaf(-2.0f, acc[1], zz[t] + e4[1]);
-                    const float d2 = __builtin_fmaf(-2.0f, acc[2], zz[t] + e4[2]);
-                    const float d3 = __builtin_fmaf(-2.0f, acc[3], zz[t] + e4[3]);
-                    const float q1 = __builtin_fminf(__builtin_fminf(best[t], d0), d1);
-                    const float q2 = __builtin_fminf(__builtin_fminf(q1, d2), d3);
-                    bt2[t] = q2 < best[t] ? ct : bt2[t];
-                    best[t] = q2;
-                }
-            }
-#pragma unroll
-            for (int t = 0; t < ZT; ++t) {
-                const int c0 = 16 * bt2[t] + 4 * g;
-                float d = best[t];
-                int i = c0;
-#pragma unroll
-                for (int r = 3; r >= 0; --r)
-                    i = dist_row(z0[t], z1[t], z2[t], z3[t], zz[t], cbs[c0 + r], ees[c0 + r]) == d ? c0 + r : i;
-#pragma unroll
-                for (int off = 16; off < 64; off <<= 1) {
-                    const float od = __shfl_xor(d, off, kWave);
-                    const int oi = __shfl_xor(i, off, kWave);
-                    const bool take = od < d || (od == d && oi < i);
-                    d = take ? od : d;
-                    i = take ? oi : i;
-                }
-                win[t] = i;
-            }
-        } else if (nflag) {
-            // a few near-ties: the whole wave scans all K codes exactly for each such vector
-#pragma unroll
-            for (int t = 0; t < ZT; ++t) {
-                unsigned int todo = __builtin_amdgcn_readfirstlane(flagged[t]);
+            const unsigned long long fmask = __ballot(flag);               // one bit per vector, wave-uniform
+            const int nflag = __builtin_popcountll(fmask);
+            if (nflag <= kVqfBulk) {
+                // a few near-ties: the whole wave scans all K codes exactly for each such vector
+                unsigned long long todo = fmask;
                 while (todo) {
-                    const int vj = __builtin_ctz(todo);
+                    const int v = __builtin_ctzll(todo);
                     todo &= todo - 1;
-                    const float y0 = __shfl(zv[t], vj, kWave), y1 = __shfl(zv[t], 16 + vj, kWave);
-                    const float y2 = __shfl(zv[t], 32 + vj, kWave), y3 = __shfl(zv[t], 48 + vj, kWave);
-                    const float yy = sumsq4(y0, y1, y2, y3);
+                    const float s0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(y0), v));
+                    const float s1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(y1), v));
+                    const float s2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(y2), v));
+                    const float s3 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(y3), v));
+                    const float ss = sumsq4(s0, s1, s2, s3);
                     float bd = __builtin_inff();
                     int bi = 0;
 #pragma unroll 4
                     for (int c = K - 64 + lane; c >= 0; c -= 64) {       // descending: the lowest index wins ties
-                        const float dd = dist_row(y0, y1, y2, y3, yy, cbs[c], ees[c]);
+                        const float dd = dist_row(s0, s1, s2, s3, ss, cbs[c], ees[c]);
                         const bool take = dd <= bd;
                         bd = take ? dd : bd;
                         bi = take ? c : bi;
@@ -753,7 +717,55 @@ __device__ __forceinline__ void vq_filter_body(const VqArgs &a, unsigned char *s
                         bd = take ? od : bd;
                         bi = take ? oi : bi;
                     }
-                    win[t] = j == vj ? bi : win[t];
+                    wi = lane == v ? bi : wi;
+                }
+                // back to the (column, row group) layout of the outputs
+                int *tw = reinterpret_cast<int *>(tb + 1024);
+                tw[lane] = wi;
+#pragma unroll
+                for (int t = 0; t < ZT; ++t) win[t] = tw[t * 16 + j];
+            } else {
+                // many near-ties (degenerate codebooks, zz >> ee, non-finite input): the exact fp32-MFMA scan of
+                // vq_mfma_body for the whole group, operands from the fp32 rows in LDS
+                float z0[ZT], z1[ZT], z2[ZT], z3[ZT], zz[ZT], best[ZT];
+                int bt2[ZT];
+#pragma unroll
+                for (int t = 0; t < ZT; ++t) {
+                    const uint2 eo = rows16(__float_as_uint(zv[t]));         // (z0,z0,z2,z2) / (z1,z1,z3,z3)
+                    const uint2 e = rows32(eo.x), o = rows32(eo.y);
+                    z0[t] = __uint_as_float(e.x); z2[t] = __uint_as_float(e.y);
+                    z1[t] = __uint_as_float(o.x); z3[t] = __uint_as_float(o.y);
+                    zz[t] = sumsq4(z0[t], z1[t], z2[t], z3[t]);
+                    best[t] = __builtin_inff();
+                    bt2[t] = 0;
+                }
+                for (int ct = 0; ct < ntile; ++ct) {
+                    const float av = reinterpret_cast<const float *>(cbs)[(16 * ct + j) * 4 + g];
+                    const f32x4 e4 = *reinterpret_cast<const f32x4 *>(&ees[16 * ct + 4 * g]);
+#pragma unroll
+                    for (int t = 0; t < ZT; ++t) {
+                        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+                        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av, zv[t], acc, 0, 0, 0);
+                        const float d0 = __builtin_fmaf(-2.0f, acc[0], zz[t] + e4[0]);
+                        const float d1 = __builtin_fmaf(-2.0f, acc[1], zz[t] + e4[1]);
+                        const float d2 = __builtin_fmaf(-2.0f, acc[2], zz[t] + e4[2]);
+                        const float d3 = __builtin_fmaf(-2.0f, acc[3], zz[t] + e4[3]);
+                        const float q1 = __builtin_fminf(__builtin_fminf(best[t], d0), d1);
+                        const float q2 = __builtin_fminf(__builtin_fminf(q1, d2), d3);
+                        bt2[t] = q2 < best[t] ? ct : bt2[t];
+                        best[t] = q2;
+                    }
+                }
+#pragma unroll
+                for (int t = 0; t < ZT; ++t) {
+                    const int c0 = 16 * bt2[t] + 4 * g;
+                    float dq = best[t];
+                    int i = c0;
+#pragma unroll
+                    for (int r = 3; r >= 0; --r)
+                        i = dist_row(z0[t], z1[t], z2[t], z3[t], zz[t], cbs[c0 + r], ees[c0 + r]) == dq ? c0 + r : i;
+                    colargmin(dq, i);
+                    win[t] = i;
                 }
             }
         }
@@ -1034,7 +1046,7 @@ static int launch_filter(const float *z, int64_t hw, int64_t N, const float *cb,
     }
     a.n_early = (unsigned int)n_early; a.g_early = (unsigned int)g_early; a.g_late = (unsigned int)g_late;
     const int64_t gmax = g_early > g_late ? g_early : g_late;
-    size_t lds = (size_t)K * 84 + (loss ? 8 * (size_t)gmax : 0);
+    size_t lds = (size_t)K * 84 + (size_t)kVqfWaves * kVqfTbFloats * 4 + (loss ? 8 * (size_t)gmax : 0);
     if (!router) {
         CGIC_HIP_TRY(hipFuncSetAttribute((const void *)vq_filter_kernel<ZT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL(vq_filter_kernel<ZT>, dim3(a.nblk), dim3(kVqfThreads), lds, s, a);
@@ -1062,7 +1074,6 @@ static int vq_dispatch(const float *z, int64_t hw, int64_t N, const float *codeb
     static const int exact_only = getenv("CGIC_VQ_EXACT") ? atoi(getenv("CGIC_VQ_EXACT")) : 0;   // dev: A/B against the exact loop
     if (!exact_only && K % 64 == 0 && K <= kVqfMaxK) {
 #define CGIC_VQF_LAUNCH(ZT) launch_filter<ZT>(z, hw, N, codebook, K, indices, z_q, ws, beta, legacy, loss, s, router, router_blocks, router_lds)
-        if (force_zt == 8) return CGIC_VQF_LAUNCH(8);
         if (force_zt == 2) return CGIC_VQF_LAUNCH(2);
         if (force_zt == 1) return CGIC_VQF_LAUNCH(1);
         if (force_zt == 4 || N >= (int64_t)128 * 1024) return CGIC_VQF_LAUNCH(4);
