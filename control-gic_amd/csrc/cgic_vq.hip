@@ -338,10 +338,11 @@ __global__ __launch_bounds__(kVqThreads, ZT <= 4 ? 4 : 2) void vq_router_kernel(
 //    (8+8+8 significand bits, by truncation); the 32 K-slots carry, per dimension, the six products
 //    zh.wh zh.wm zm.wh zh.wl zl.wh zm.wm, plus ee's three pieces against 1.0.  Dropped terms and fp32
 //    accumulation leave |f - F| <= 2^-17.6 S, S = max ee + 2 max|e| sum|z_j| (measured: ~2^-22 S).
-//  * per lane, a running (smallest, second smallest, where) over QUADS of tiles (64 codes): 8 v_min3 + cmp +
-//    cndmask + med3 + min for 4 MFMAs -- 3 VALU per tile instead of 12, and an 8 ns MFMA instead of 14.5.
+//  * per lane, a running (smallest, second smallest) over QUADS of tiles (64 codes), the quad's index packed into the
+//    low mantissa bits of its minimum: 8 v_min3 + and_or + med3 + min for 4 MFMAs -- 2.75 VALU per tile instead
+//    of 12, and an 8 ns MFMA instead of 14.5.
 //  * every code whose reference distance could be minimal has f <= f_min + M,
-//    M = 2 (|f - F| + |d_ref - zz - F|) <= 1.2e-5 S + 2.5e-7 zz  (d_ref's own rounding: 2^-23 zz + 2^-21 S).
+//    M = 2 (|f - F| + |d_ref - zz - F|) + packing <= 1.6e-5 S + 2.5e-7 zz  (d_ref's own rounding: 2^-23 zz + 2^-21 S).
 //    S is the smaller of the codebook-maxima bound and (|z| + sqrt D)(3|z| + sqrt D), D = zz + f_min + slack (the
 //    winner and whatever can beat it lie within sqrt D of z).
 //    If the winner's quad is the only place holding such codes (second-smallest quad value of every
@@ -571,7 +572,6 @@ __device__ __forceinline__ void vq_filter_body(const VqArgs &a, unsigned char *s
         const int64_t base = grp * (16 * ZT);
         const int64_t gb = cb0, gp = cp0;
         float zv[ZT], m1[ZT], m2[ZT];
-        int bt[ZT];
         bf16x8 bop[ZT];
 #pragma unroll
         for (int t = 0; t < ZT; ++t) {
@@ -586,7 +586,6 @@ __device__ __forceinline__ void vq_filter_body(const VqArgs &a, unsigned char *s
             bop[t] = __builtin_bit_cast(bf16x8, bb);
             m1[t] = __builtin_inff();
             m2[t] = __builtin_inff();
-            bt[t] = 0;
         }
         // reserve the next group now: its latents are in flight during this group's scan
         cur = grab();
@@ -625,8 +624,9 @@ __device__ __forceinline__ void vq_filter_body(const VqArgs &a, unsigned char *s
             issue(p + 2, X0, X1);      // the last one is a harmless repeat of the final pair
 #pragma unroll
             for (int t = 0; t < ZT; ++t) {
-                const float u = chain(uq[t], Y0[t], Y1[t]);
-                bt[t] = u < m1[t] ? (p >> 1) : bt[t];
+                // the quad's index rides in the low 4 mantissa bits of its minimum (one v_and_or_b32 instead of a
+                // compare + select per quad); the 2^-19 relative perturbation is part of the margin
+                const float u = __uint_as_float((__float_as_uint(chain(uq[t], Y0[t], Y1[t])) & ~15u) | (unsigned int)(p >> 1));
                 m2[t] = __builtin_amdgcn_fmed3f(m1[t], m2[t], u);     // second smallest quad value
                 m1[t] = __builtin_fminf(m1[t], u);
             }
@@ -645,12 +645,10 @@ __device__ __forceinline__ void vq_filter_body(const VqArgs &a, unsigned char *s
                 const int o = (t * 16 + j) * 4 + g;
                 tb[o] = m1[t];
                 tb[256 + o] = m2[t];
-                tb[512 + o] = __int_as_float(bt[t]);
                 tb[768 + o] = zv[t];
             }
             const float4 a1 = reinterpret_cast<const float4 *>(tb)[lane];            // m1 of row groups 0..3
             const float4 a2 = reinterpret_cast<const float4 *>(tb)[64 + lane];       // m2
-            const float4 ab = reinterpret_cast<const float4 *>(tb)[128 + lane];      // bt (bits)
             const float4 az = reinterpret_cast<const float4 *>(tb)[192 + lane];      // z0..z3
             const bool valid = lane < 16 * ZT;
             const float y0 = az.x, y1 = az.y, y2 = az.z, y3 = az.w;
@@ -660,12 +658,12 @@ __device__ __forceinline__ void vq_filter_body(const VqArgs &a, unsigned char *s
             // and every code that can beat it lie within sqrt(D) of z, D = zz + f_min + slack -- by
             // (|z| + sqrt D)^2 + 2 |z| (|z| + sqrt D); the smaller of the two (v_sqrt_f32 is good to 1 ulp: x 1.001)
             const float S0 = EEmax + 2.0f * Emax * (((fabsf(y0) + fabsf(y1)) + fabsf(y2)) + fabsf(y3));
-            const float M0 = 1.2e-5f * S0 + 2.5e-7f * yy + 1e-30f;
+            const float M0 = 1.6e-5f * S0 + 2.5e-7f * yy + 1e-30f;
             const float D = fmaxf(yy * 1.0001f + mt + 2.0f * M0, 0.f);
             const float nz = __builtin_amdgcn_sqrtf(yy) * 1.001f, sd = __builtin_amdgcn_sqrtf(D) * 1.001f;
             const float S1 = (nz + sd) * (3.0f * nz + sd);
             const float S = S1 < S0 ? S1 : S0;                  // (a NaN S1 keeps S0)
-            const float M = 1.2e-5f * S + 2.5e-7f * yy + 1e-30f;
+            const float M = 1.6e-5f * S + 2.5e-7f * yy + 1e-30f;     // 1.2e-5: filter + reference rounding; 0.4e-5: the packed index
             float thr = mt + M;
             thr += fabsf(thr) * 2.4e-7f;
             // anything not comparable (NaN / Inf anywhere above) must count as "flagged": test the negation
@@ -674,7 +672,7 @@ __device__ __forceinline__ void vq_filter_body(const VqArgs &a, unsigned char *s
             // settled iff exactly one hot row group and no second quad anywhere
             const bool flag = valid && (((int)h0 + (int)h1 + (int)h2 + (int)h3) != 1 || more);
             const int gw = h0 ? 0 : h1 ? 1 : h2 ? 2 : 3;
-            int bq = __float_as_int(gw == 0 ? ab.x : gw == 1 ? ab.y : gw == 2 ? ab.z : ab.w);
+            int bq = __float_as_int(gw == 0 ? a1.x : gw == 1 ? a1.y : gw == 2 ? a1.z : a1.w) & 15;     // the quad index packed by the scan
             bq = valid && bq >= 0 && bq < (K >> 6) ? bq : 0;       // (idle lanes of the ZT < 4 instantiations read stale LDS)
             // exact fp32 on the 16 codes of the winning (quad, row group); descending, the lowest index wins ties
             float d = __builtin_inff();

@@ -115,6 +115,9 @@ def _vq_filter_cases():
         "K256": (big, cb[:256].clone()),
         "K48_exact_loop": (big, cb[:48].clone()),                  # K % 64 != 0 -> fp32 MFMA loop
         "K2048_exact_loop": (big, torch.randn(2048, 4, generator=g)),
+        # a zero row far from quad 0 wins with score exactly 0 (index bits packed into a zero must survive)
+        "zero_row_wins": (big * 1.0e-3, torch.cat([cb[:700] + 3.0, torch.zeros(1, 4), cb[701:] + 3.0])),
+        "denormal_scores": (big * 1.0e-22, torch.cat([cb[:700] * 1.0e-3 + 3.0, torch.full((1, 4), 1.0e-22), cb[701:] * 1.0e-3 + 3.0])),
     }
 
 
