@@ -6,7 +6,8 @@ import control_gic_amd as cg
 from control_gic_amd import _lib
 from bench import HotPath, make_inputs, time_events
 dev = torch.device("cuda")
-x, z, cb = make_inputs(64, 256, 256, 1000)
+B_, S_ = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (64, 256)
+x, z, cb = make_inputs(B_, S_, S_, 1000)
 hp = HotPath(dev, x, z, cb, (0.1, 0.8))
 e8, e16, mask, mode, zq, ind, comp = hp.encode()
 torch.cuda.synchronize()
