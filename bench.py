@@ -9,10 +9,16 @@ Workload = BASELINE.json configs[1]: batch 64 of 256x256, codebook 1024x4, ratio
 The conv encoder/decoder of the codec are out of scope: `z` is a
 synthetic N(0,1) latent standing in for the encoder output.
 
+The K timed steps are K successive, DISTINCT batches: the inputs rotate through enough slots to exceed the
+256 MiB Infinity Cache, so the image bytes of every step come from HBM.  Steps are software-pipelined over two
+HIP streams (control_gic_amd.pipeline.BatchStream: encode side of batch i+1 next to the decode side of batch i;
+`--schedule sequential` runs one batch after the other on one stream instead).  `value` = all pixels of the K
+steps / wall time between two barrier + synchronize brackets, max over ranks.
+
   python bench.py [--gpus N] [--steps K] [--warmup W]
-For N > 1 launch under torch.distributed.run (one rank per GPU); images shard across ranks with
-no data-path collective, plus ONE RCCL all-reduce of the int64[1024] usage histogram per run.
-Rank 0 prints one JSON line.
+N > 1: one rank per GPU.  Under torch.distributed.run the ranks come from the environment; launched plainly
+(`python bench.py --gpus N`) the script spawns the N ranks itself.  Images shard across ranks with no data-path
+collective; ONE RCCL all-reduce of the int64[1024] usage histogram per run.  Rank 0 prints one JSON line.
 """
 import argparse
 import json
@@ -28,6 +34,9 @@ sys.path.insert(0, ROOT)
 
 PEAK_F32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: fp32-input MFMA == fp32 vector peak
 PEAK_HBM_GBS = 8000.0
+IC_BYTES = 256 << 20             # Infinity Cache: the rotating inputs must exceed it
+RATIO_SWEEP = [(0.0, 0.0), (0.0, 0.5), (0.0, 1.0), (0.25, 0.25), (0.1, 0.8), (0.5, 0.0), (0.5, 0.5), (0.7, 0.3),
+               (0.3, 0.7), (1.0, 0.0)]          # all seven modes
 
 
 def log(*a):
@@ -61,39 +70,47 @@ def make_inputs(B, H, W, seed):
     return x, z, cb
 
 
-class HotPath:
-    """pre-built modules + one step() that only enqueues work (graph-capturable)"""
+def make_quantizer(dev, cb):
+    import control_gic_amd as cg
+    vq = cg.VectorQuantizer(1024, 4, beta=0.25).to(dev).eval()
+    vq.embedding.weight.data.copy_(torch.from_numpy(cb))
+    vq.usage_counter.copy_(torch.from_numpy(zipf_freq().astype(np.float32)))
+    return vq
 
-    def __init__(self, dev, x, z, cb, ratio, chunks=1, fork_vq=False):
+
+class HotPath:
+    """one batch: pre-built modules + a step() that only enqueues work (graph-capturable)"""
+
+    def __init__(self, dev, x, z, cb, ratio, vq=None, codec=None):
         import control_gic_amd as cg
         self.cg = cg
-        self.x = torch.from_numpy(x).to(dev)
-        self.z = torch.from_numpy(z).to(dev)
-        self.vq = cg.VectorQuantizer(1024, 4, beta=0.25).to(dev).eval()
-        self.vq.embedding.weight.data.copy_(torch.from_numpy(cb))
-        self.vq.usage_counter.copy_(torch.from_numpy(zipf_freq().astype(np.float32)))
-        self.codec = cg.GrainCodec(self.vq.embedding_counter, self.vq.embedding.weight)
+        self.x = torch.from_numpy(x).to(dev) if isinstance(x, np.ndarray) else x
+        self.z = torch.from_numpy(z).to(dev) if isinstance(z, np.ndarray) else z
+        self.vq = vq if vq is not None else make_quantizer(dev, cb)
+        self.codec = codec if codec is not None else cg.GrainCodec(self.vq.embedding_counter, self.vq.embedding.weight)
         self.router = cg.TripleGrainFixedEntropyRouter(ratio[0], ratio[1], per_image=True)
         self.hist = torch.zeros(1024, dtype=torch.int64, device=dev)
         self.out = None
-        self.pipe = cg.pipeline.HotPathPipeline(self.vq, ratio[0], ratio[1], chunks=chunks, frequency=self.codec.huffman, fork_vq=fork_vq)
-
-    def encode(self):
-        from control_gic_amd.quantize import vq_forward_route
-        e8, e16 = self.cg.entropy_maps(self.x)
-        zq, loss, ind, mask, _, mode = vq_forward_route(self.z, self.vq.embedding.weight, 0.25, True, e16, e8,
-                                                        self.router.coarse_grain_ratio, self.router.medium_grain_ratio)
-        comp = self.codec.compress(ind, mask, mode, hist=self.hist)
-        return e8, e16, mask, mode, zq, ind, comp
-
-    def decode(self, comp):
-        return self.codec.decompress(comp)
+        self.pipe = cg.pipeline.HotPathPipeline(self.vq, ratio[0], ratio[1], frequency=self.codec.huffman)
 
     def step(self):
-        # the batch as `chunks` concurrent chains (entropy -> router -> VQ(+hist) -> compress -> decompress)
-        self.res = self.pipe.run(self.x, self.z, self.hist, decode=True)
-        r = self.res[0]
+        r = self.pipe.run(self.x, self.z, self.hist, decode=True)[0]
         self.out = (r["e8"], r["e16"], r["mask"], r["mode"], r["z_q"], r["ind"], r["comp"], *r["dec"])
+
+    def capture(self):
+        for _ in range(2):
+            self.step()
+        torch.cuda.synchronize()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            self.step()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=side):
+                self.step()
+        torch.cuda.current_stream().wait_stream(side)
+        self.graph = g
+        return g
 
 
 def time_events(fn, iters):
@@ -106,25 +123,48 @@ def time_events(fn, iters):
     return s.elapsed_time(e) * 1e3 / iters      # microseconds per call
 
 
-def stage_breakdown(hp, iters=30):
-    """per-stage device time with HIP events on the launch stream (torch's current stream)"""
-    from control_gic_amd.quantize import _vq_forward
+def graph_kernel_time(fn, per_graph=20, reps=5):
+    """average device time of one launch of fn's kernel(s): `per_graph` back-to-back launches captured in a hipGraph
+    (no host-bound gaps), HIP events around the replay on the stream it runs on"""
+    for _ in range(2):
+        fn()
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=side):
+            for _ in range(per_graph):
+                fn()
+        g.replay()
+        side.synchronize()
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record(side)
+        for _ in range(reps):
+            g.replay()
+        e.record(side)
+        e.synchronize()
+    torch.cuda.current_stream().wait_stream(side)
+    return s.elapsed_time(e) * 1e3 / (per_graph * reps)
+
+
+def stage_breakdown(hp):
+    """per-stage device time, microseconds per launch (each stage alone, graph-timed on its launch stream)"""
+    from control_gic_amd.quantize import _vq_forward, vq_forward_route
     cg = hp.cg
     e8, e16 = cg.entropy_maps(hp.x)
     mask, _, _, mode = hp.router(e16, e8, want_gate=False)
-    _, _, ind = _vq_forward(hp.z, hp.vq.embedding.weight, 0.25, True, hp.hist)
+    _, _, ind = _vq_forward(hp.z, hp.vq.embedding.weight, 0.25, True, None)
     comp = hp.codec.compress(ind, mask, mode)
     st = {}
-    st["entropy_maps"] = time_events(lambda: cg.entropy_maps(hp.x), iters)
-    st["router_alone"] = time_events(lambda: hp.router(e16, e8, want_gate=False), iters)
-    from control_gic_amd.quantize import vq_forward_route
-    st["vq+router_fused_launch"] = time_events(lambda: vq_forward_route(hp.z, hp.vq.embedding.weight, 0.25, True, e16, e8,
-                                                                         hp.router.coarse_grain_ratio, hp.router.medium_grain_ratio), iters)
-    # the dominant kernel on its own (one launch per call: indices + z_q + loss, no histogram pass)
-    st["vq_kernel"] = time_events(lambda: _vq_forward(hp.z, hp.vq.embedding.weight, 0.25, True, None), max(iters, 100))
-    st["vq_kernel_indices_only"] = time_events(lambda: hp.vq.indices(hp.z), iters)
-    st["compress_streams+hist"] = time_events(lambda: hp.codec.compress(ind, mask, mode, hist=hp.hist), iters)
-    st["decompress_streams"] = time_events(lambda: hp.codec.decompress(comp), iters)
+    st["entropy_maps"] = graph_kernel_time(lambda: cg.entropy_maps(hp.x))
+    st["router_alone"] = graph_kernel_time(lambda: hp.router(e16, e8, want_gate=False))
+    st["vq+router_fused_launch"] = graph_kernel_time(lambda: vq_forward_route(
+        hp.z, hp.vq.embedding.weight, 0.25, True, e16, e8, hp.router.coarse_grain_ratio, hp.router.medium_grain_ratio))
+    st["vq_kernel_alone"] = graph_kernel_time(lambda: _vq_forward(hp.z, hp.vq.embedding.weight, 0.25, True, None))
+    st["vq_kernel_indices_only"] = graph_kernel_time(lambda: hp.vq.indices(hp.z))
+    st["compress_streams+hist"] = graph_kernel_time(lambda: hp.codec.compress(ind, mask, mode, hist=hp.hist))
+    st["decompress_streams"] = graph_kernel_time(lambda: hp.codec.decompress(comp))
     return {k: round(v, 2) for k, v in st.items()}
 
 
@@ -158,43 +198,142 @@ def cpu_baseline(x, z, cb, ratio, budget_s=12.0):
                       f"path, oracle/cgic_oracle.c on one thread, {dt:.1f} s; host has {os.cpu_count()} logical cores"}
 
 
-def check_against_oracle(hp, x, z, cb, ratio):
-    """bpp / bitstream match on one image of the timed workload (outside the timed region)"""
+def check_against_oracle(out, x, z, cb, ratio, images=None):
+    """bitstream / index / mask parity of a finished step with the oracle, on EVERY image of the batch (outside the
+    timed region).  Masks are checked given the GPU's own entropy maps (the bit-exact contract of SURVEY.md section 7);
+    pixels -> masks is the `mask_mismatch` report.  Returns (all equal, list of per-image bpp)."""
     from oracle import cgic_oracle as orc
-    e8, e16, mask, mode, zq, ind, comp, dind, dmask, dq, status = hp.out
+    e8, e16, mask, mode, zq, ind, comp, dind, dmask, dq, status = out
     torch.cuda.synchronize()
-    b = 0
     H, W = x.shape[2], x.shape[3]
     h, w = H // 4, W // 4
-    _, _, oidx = orc.vq(z[b:b + 1], cb)
-    ok = bool(np.array_equal(ind.view(-1, h, w)[b].cpu().numpy(), oidx.reshape(h, w)))
-    mk = [m[b, 0].cpu().numpy() for m in mask]
-    ref = orc.compress_image(oidx.reshape(h, w), mk[0], mk[1], mk[2], mode, orc.HuffmanTable(zipf_freq()))
-    host = comp.to_host()[b]
-    ok = ok and host == ref and int(status.abs().max()) == 0
-    omc, omm, omf, _, _ = orc.router(e16[b:b + 1].cpu().numpy(), e8[b:b + 1].cpu().numpy(), ratio[0], ratio[1])
-    ok = ok and np.array_equal(mk[0], omc[0, 0]) and np.array_equal(mk[1], omm[0, 0]) and np.array_equal(mk[2], omf[0, 0])
-    bpp = sum(len(v) for v in host.values()) * 8 / (H * W)
-    return ok, bpp
+    B = x.shape[0]
+    images = range(B) if images is None else images
+    htab = orc.HuffmanTable(zipf_freq())
+    host = comp.to_host()
+    ind_h = ind.view(-1, h, w).cpu().numpy()
+    dind_h = dind.cpu().numpy()
+    dq_h = dq.cpu().numpy()
+    mk = [m.cpu().numpy() for m in mask]
+    e8_h, e16_h = e8.cpu().numpy(), e16.cpu().numpy()
+    ok = int(status.abs().max()) == 0
+    bpp = []
+    for b in images:
+        _, _, oidx = orc.vq(z[b:b + 1], cb)
+        oidx = oidx.reshape(h, w)
+        ok = ok and bool(np.array_equal(ind_h[b], oidx))
+        omc, omm, omf, _, omode = orc.router(e16_h[b:b + 1], e8_h[b:b + 1], ratio[0], ratio[1])
+        ok = ok and omode == mode and all(np.array_equal(mk[g][b, 0], o[0, 0]) for g, o in enumerate((omc, omm, omf)))
+        ref = orc.compress_image(oidx, omc[0, 0], omm[0, 0], omf[0, 0], mode, htab)
+        ok = ok and host[b] == ref
+        oind, _, _, _ = orc.decompress_image(ref, mode, h, w, htab)
+        ok = ok and bool(np.array_equal(dind_h[b], oind)) and bool(np.array_equal(dq_h[b], orc.gather(oind, cb)[0]))
+        bpp.append(sum(len(v) for v in host[b].values()) * 8 / (H * W))
+    return bool(ok), bpp
 
 
-def extra_workload(dev, B, S, steps=60):
-    """a second, untimed-by-the-driver data point: DIV2K-resolution tiles (inference_high_resolution.py cuts a 2K image
-    into 768x768 tiles); same hot path, same graph replay, rank 0 only"""
-    x, z, cb = make_inputs(B, S, S, seed=77)
-    hp = HotPath(dev, x, z, cb, (0.1, 0.8))
-    for _ in range(3):
-        hp.step()
+# ------------------------------------------------------------------------------------------------ extras (rank 0, N=1)
+def mask_mismatch(hp, x, z, cb, ratio):
+    """pixels -> masks -> bytes on the GPU against the CPU oracle from the SAME pixels: the GPU's
+    entropy maps differ from the CPU's by ~1e-6 (exp/log implementations), thresholds are k-th smallest values, so a
+    near-tie can flip a mask element and with it every byte behind it."""
+    from oracle import cgic_oracle as orc
+    e8, e16, mask, mode, zq, ind, comp = hp.out[:7]
     torch.cuda.synchronize()
-    side = torch.cuda.Stream()
-    side.wait_stream(torch.cuda.current_stream())
-    with torch.cuda.stream(side):
-        hp.step()
-        g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g, stream=side):
-            hp.step()
-    torch.cuda.current_stream().wait_stream(side)
-    for _ in range(5):
+    B, H, W = x.shape[0], x.shape[2], x.shape[3]
+    h, w = H // 4, W // 4
+    htab = orc.HuffmanTable(zipf_freq())
+    host = comp.to_host()
+    mk = [m.cpu().numpy() for m in mask]
+    ind_h = ind.view(-1, h, w).cpu().numpy()
+    diff_elems = diff_images = diff_files = files = 0
+    max_de = 0.0
+    for b in range(B):
+        o8, o16 = orc.entropy(x[b:b + 1], 8), orc.entropy(x[b:b + 1], 16)
+        max_de = max(max_de, float(np.abs(o8 - e8[b:b + 1].cpu().numpy()).max()), float(np.abs(o16 - e16[b:b + 1].cpu().numpy()).max()))
+        omc, omm, omf, _, omode = orc.router(o16, o8, ratio[0], ratio[1])
+        d = sum(int((mk[g][b, 0] != o[0, 0]).sum()) for g, o in enumerate((omc, omm, omf)))
+        diff_elems += d
+        diff_images += d > 0
+        ref = orc.compress_image(ind_h[b], omc[0, 0], omm[0, 0], omf[0, 0], omode, htab)
+        files += len(ref)
+        diff_files += sum(host[b].get(k) != v for k, v in ref.items())
+    n_elems = B * (h * w + h * w // 4 + h * w // 16)
+    return {"images": B, "mask_elements": n_elems, "differing_mask_elements": diff_elems, "images_with_a_difference": int(diff_images),
+            "bin_files": files, "differing_bin_files": int(diff_files), "max_abs_entropy_diff": max_de,
+            "note": "GPU entropy -> GPU router vs oracle entropy -> oracle router on the same pixels; given equal masks every byte is identical (bpp_match)"}
+
+
+def ratio_sweep(dev, x, z, cb, vq, codec, steps=30):
+    out = []
+    B, H, W = x.shape[0], x.shape[2], x.shape[3]
+    xd, zd = torch.from_numpy(x).to(dev), torch.from_numpy(z).to(dev)
+    for r in RATIO_SWEEP:
+        hp = HotPath(dev, xd, zd, cb, r, vq=vq, codec=codec)
+        g = hp.capture()
+        for _ in range(3):
+            g.replay()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            g.replay()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        ok, bpp = check_against_oracle(hp.out, x, z, cb, r, images=range(0, B, 16))
+        out.append({"ratio": [r[0], r[1], round(1 - r[0] - r[1], 6)], "mode": int(hp.out[3]), "MPixels/s": round(steps * B * H * W / dt / 1e6, 1),
+                    "ms_per_step": round(dt / steps * 1e3, 5), "bpp_mean": round(float(np.mean(hp.out[6].bpp(H * W))), 6), "bpp_match": ok})
+    return out
+
+
+def div2k_image(dev, cb, vq, codec, iters=8):
+    """one 2040x1356 image (DIV2K-typical) through the tiling driver of inference_high_resolution.py: zero-pad to x16,
+    768-px grid (6 tiles in 4 shape groups), per-tile routing, same-shape tiles batched, pad / stack copies included;
+    eager launches (shapes differ per group)"""
+    from control_gic_amd import highres
+    from control_gic_amd.quantize import vq_forward_route
+    H, W = 1356, 2040
+    rng = np.random.default_rng(4)
+    x = torch.from_numpy(rng.random((1, 3, H, W), dtype=np.float32)).to(dev)
+    zs = {}
+
+    def encode(tiles):
+        import control_gic_amd as cg
+        T, _, th, tw = tiles.shape
+        key = (T, th, tw)
+        if key not in zs:
+            zs[key] = torch.from_numpy(np.random.default_rng(th * 7 + tw).standard_normal((T, 4, th // 4, tw // 4), dtype=np.float32)).to(dev)
+        e8, e16 = cg.entropy_maps(tiles)
+        _, _, ind, mask, _, mode = vq_forward_route(zs[key], vq.embedding.weight, 0.25, True, e16, e8, 0.1, 0.8, per_image=True)
+        return ind, mask, mode
+
+    def once():
+        tiled = highres.compress_tiled(x, encode, codec)
+        per_tile, _ = highres.decompress_tiled(tiled, codec)
+        return tiled, per_tile
+
+    tiled, per_tile = once()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        tiled, per_tile = once()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / iters
+    # round trip: every tile's masks come back exactly, indices wherever the fine grain kept them
+    ok = True
+    for idxs, _, (ind0, masks0, _) in tiled.groups:
+        T = len(idxs)
+        fine = masks0[2].reshape(T, -1).bool()
+        got = torch.cat([per_tile[t][0].reshape(1, -1) for t in idxs])
+        ok = ok and bool(torch.equal(got[fine], ind0.reshape(T, -1)[fine]))
+    return {"workload": f"one {W}x{H} image via highres.compress_tiled + decompress_tiled ({len(tiled.tiles)} tiles, {len(tiled.groups)} shape groups), eager, incl. pad/stack and the host sync of decompress_tiled",
+            "MPixels/s": round(H * W / dt / 1e6, 1), "ms_per_image": round(dt * 1e3, 4), "bpp": round(tiled.bpp(), 6), "round_trip_ok": ok}
+
+
+def tiles_768(dev, cb, vq, codec, B, steps):
+    x, z, _ = make_inputs(B, 768, 768, seed=77)
+    hp = HotPath(dev, x, z, cb, (0.1, 0.8), vq=vq, codec=codec)
+    g = hp.capture()
+    for _ in range(3):
         g.replay()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -202,140 +341,309 @@ def extra_workload(dev, B, S, steps=60):
         g.replay()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    ok, bpp = check_against_oracle(hp, x, z, cb, (0.1, 0.8))
-    return {"workload": f"{B} tiles of {S}x{S} (the tile size of the 2K path), ratio (0.1,0.8,0.1), encode+decode, hipGraph replay",
-            "value": round(steps * B * S * S / dt / 1e6, 2), "unit": "MPixels/s", "ms_per_step": round(dt / steps * 1e3, 5),
-            "bpp_match": bool(ok)}
+    ok, _ = check_against_oracle(hp.out, x, z, cb, (0.1, 0.8), images=[0, B - 1])
+    return {"workload": f"{B} tiles of 768x768 (the tile size of the 2K path), ratio (0.1,0.8,0.1), encode+decode, one batch after the other, hipGraph replay",
+            "value": round(steps * B * 768 * 768 / dt / 1e6, 2), "unit": "MPixels/s", "ms_per_step": round(dt / steps * 1e3, 5), "bpp_match": bool(ok)}
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--batch", type=int, default=64)
-    ap.add_argument("--size", type=int, default=256)
-    ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a hipGraph")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-extra", action="store_true", help="skip the DIV2K-tile data points (clean kernel profiles of the headline workload)")
-    ap.add_argument("--chunks", type=int, default=1, help="process the batch as this many concurrent stream chains")
-    ap.add_argument("--fork-vq", type=int, nargs="?", const=1, default=0, help="1: VQ on a side stream next to entropy -> router; 2: router on a side stream next to VQ")
-    a = ap.parse_args()
+def b1_latency(dev, cb, vq, codec):
+    """one 256x256 image (the only batch size the reference's compress() accepts): encode+decode latency"""
+    x, z, _ = make_inputs(1, 256, 256, seed=5)
+    hp = HotPath(dev, x, z, cb, (0.1, 0.8), vq=vq, codec=codec)
+    g = hp.capture()
+    for _ in range(5):
+        g.replay()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    n = 200
+    for _ in range(n):
+        g.replay()
+    torch.cuda.synchronize()
+    t_graph = (time.perf_counter() - t0) / n
+    t0 = time.perf_counter()
+    for _ in range(50):
+        hp.step()
+    torch.cuda.synchronize()
+    t_eager = (time.perf_counter() - t0) / 50
+    ok, _ = check_against_oracle(hp.out, x, z, cb, (0.1, 0.8))
+    return {"graph_replay_us": round(t_graph * 1e6, 2), "eager_us": round(t_eager * 1e6, 2), "bpp_match": ok,
+            "note": "B=1, 256x256, encode+decode, back-to-back replays (throughput of B=1 calls); eager includes Python + ctypes + allocation per call"}
 
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != a.gpus:
-        log(f"warning: WORLD_SIZE={world} but --gpus {a.gpus}; using WORLD_SIZE")
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
+
+# ------------------------------------------------------------------------------------------------ one rank
+class StubStream:
+    """CPU stand-in for BatchStream (tests of the launcher / reduction logic only; never used on a GPU box)"""
+
+    def __init__(self, B, h, w):
+        self.hist = torch.zeros(1024, dtype=torch.int64)
+        self.n = B * h * w
+
+    def submit(self, n=1):
+        for _ in range(n):
+            self.hist[7] += self.n
+
+    def join(self):
+        pass
+
+
+def run_rank(a, rank, world, local):
+    stub = bool(a.stub)
     dist = None
+    if stub:
+        dev = torch.device("cpu")
+    else:
+        if torch.cuda.device_count() <= local:
+            raise SystemExit(f"bench.py: rank {rank} needs GPU {local} but only {torch.cuda.device_count()} are visible")
+        torch.cuda.set_device(local)
+        dev = torch.device("cuda", local)
+    ranks_seen = 1
     if world > 1 or "RANK" in os.environ:                   # under torch.distributed.run also with one rank
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
-        os.environ.setdefault("RANK", "0")
-        os.environ.setdefault("WORLD_SIZE", str(world))
         with stdout_to_stderr():
-            dist.init_process_group("nccl", device_id=dev)  # "nccl" is RCCL on ROCm
-            warm = torch.zeros(1024, dtype=torch.int64, device=dev)
-            dist.all_reduce(warm)                           # creates the communicator (and its banner) now
+            if stub:
+                dist.init_process_group("gloo", rank=rank, world_size=world)
+            else:
+                dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)  # "nccl" is RCCL on ROCm
+            one = torch.ones(1, dtype=torch.int64, device=dev)
+            dist.all_reduce(one)                            # creates the communicator (and its banner) now
+            ranks_seen = int(one.item())                    # read back from the communicator: how many ranks really joined
+        if ranks_seen != a.gpus:
+            raise SystemExit(f"bench.py: --gpus {a.gpus} but the communicator has {ranks_seen} ranks")
+
+    def sync():
+        if not stub:
             torch.cuda.synchronize()
+
+    def barrier():
+        sync()
+        if dist is not None:
+            dist.barrier()
+        sync()
 
     B, H, W = a.batch, a.size, a.size
     ratio = (0.1, 0.8)
-    x, z, cb = make_inputs(B, H, W, seed=1000 + rank)       # each rank owns its own shard of images
-    hp = HotPath(dev, x, z, cb, ratio, chunks=a.chunks, fork_vq=a.fork_vq)
-
-    # warm-up (also uploads tables / sets function attributes -- nothing synchronous is left for capture)
-    for _ in range(max(2, min(a.warmup, 5))):
-        hp.step()
-    torch.cuda.synchronize()
-    graph = None
-    if not a.no_graph:
-        side = torch.cuda.Stream()
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):
-            hp.step()
-            graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph, stream=side):
-                hp.step()
-        torch.cuda.current_stream().wait_stream(side)
-    run = graph.replay if graph is not None else hp.step
-    for _ in range(a.warmup):
-        run()
-    hp.hist.zero_()
-
-    def barrier():
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
+    h, w = H // 4, W // 4
+    if stub:
+        stream, slots_np, n_slots = StubStream(B, h, w), [], 2
+        hist = stream.hist
+    else:
+        import control_gic_amd as cg
+        per_slot = B * H * W * 13                            # image 12 B/pixel + latent 1 B/pixel
+        n_slots = a.slots if a.slots > 0 else max(2, -(-int(IC_BYTES * 1.15) // per_slot))
+        n_slots = max(2, min(n_slots, 64))
+        slots_np = [make_inputs(B, H, W, seed=1000 + 97 * rank + s) for s in range(n_slots)]   # each rank owns its own images
+        cb = slots_np[0][2]
+        vq = make_quantizer(dev, cb)
+        codec = cg.GrainCodec(vq.embedding_counter, vq.embedding.weight)
+        hist = torch.zeros(1024, dtype=torch.int64, device=dev)
+        slots_dev = [(torch.from_numpy(x).to(dev), torch.from_numpy(z).to(dev)) for x, z, _ in slots_np]
+        if a.schedule == "pipelined" and not a.no_graph:
+            stream = cg.pipeline.BatchStream(vq, ratio[0], ratio[1], slots_dev, frequency=codec.huffman, hist=hist)
+            stream.capture()
+        else:
+            stream = SequentialStream(dev, slots_dev, cb, ratio, vq, codec, hist, graph=not a.no_graph)
+        stream.submit(a.warmup)
+        stream.join()
+        sync()
+        hist.zero_()
 
     barrier()
     t0 = time.perf_counter()
-    for _ in range(a.steps):
-        run()
+    stream.submit(a.steps)                                  # exactly K steps
+    stream.join()
     if dist is not None:
         # the path's only exchange: global usage histogram (int64, exact) -- once per stream of batches
-        dist.all_reduce(hp.hist, op=dist.ReduceOp.SUM)
+        dist.all_reduce(hist, op=dist.ReduceOp.SUM)
     barrier()
     dt = time.perf_counter() - t0
     if dist is not None:
         tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
-    hist_total = int(hp.hist.sum().item())
-    assert hist_total == world * a.steps * B * (H // 4) * (W // 4), "usage histogram lost counts"
+    hist_total = int(hist.sum().item())
+    if hist_total != world * a.steps * B * h * w:
+        raise SystemExit(f"bench.py: usage histogram lost counts ({hist_total} != {world * a.steps * B * h * w})")
 
     if rank == 0:
-        ok, bpp = check_against_oracle(hp, x, z, cb, ratio)
-        stages = stage_breakdown(hp)
-        dom = "vq_kernel"
-        t_dom = stages[dom] * 1e-6
-        N = B * (H // 4) * (W // 4)
-        flops = 2.0 * N * 1024 * 4                        # 2*N*K*D per launch (0.512 kFLOP/pixel)
-        achieved = flops / t_dom / 1e12
-        traffic = None
-        pmc = os.path.join(ROOT, "profiles", "pmc_vq.json")
-        if os.path.exists(pmc):
-            try:
-                traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
         res = {
             "metric": "encode+decode MPixels/s at fixed granularity ratio; bpp match vs reference",
             "value": round(world * a.steps * B * H * W / dt / 1e6, 2),
             "unit": "MPixels/s",
-            "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "n_gpus": world, "rccl_ranks": ranks_seen, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(dt / a.steps * 1e3, 5),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"batch {B} of {H}x{W} per GPU, codebook 1024x4, ratio (0.1,0.8,0.1), "
+            "config": {"workload": f"batch {B} of {H}x{W} per GPU per step, codebook 1024x4, ratio (0.1,0.8,0.1), "
                                    "hot path only (entropy maps + router + VQ + Huffman/mask coder, encode+decode); "
                                    "conv encoder/decoder out of scope, latent synthetic",
-                       "launch": ("eager" if graph is None else "hipGraph replay") + f", {a.chunks} concurrent chunk streams",
+                       "launch": "stub" if stub else (
+                           f"{a.schedule}: " + ("encode-side and decode-side hipGraphs of successive batches on two HIP streams"
+                                                if a.schedule == "pipelined" and not a.no_graph else
+                                                ("one hipGraph per batch, one stream" if not a.no_graph else "eager, one stream"))),
+                       "inputs": f"{n_slots} distinct resident batches in rotation ({n_slots * B * H * W * 13 / 2**20:.0f} MiB > 256 MiB Infinity Cache)",
                        "sharding": "images round-robin over ranks; one RCCL all-reduce of the int64[1024] histogram per run"},
-            "bpp": round(bpp, 6), "bpp_match": bool(ok),
-            "stages_us": stages,
-            "roofline": {"kernel": "vq_filter_kernel<4> (runs as vq_filter_router_kernel<4> with the router workgroups appended in the timed step)", "bound": "mfma", "achieved": round(achieved, 3),
-                         "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4),
-                         "traffic": traffic,
-                         "note": "algorithmic flops = 2*N*K*D of the fp32 distance contraction per launch / HIP-event "
-                                 "average launch duration, priced against the dense fp32 MFMA peak (results are bit-identical "
-                                 "to the fp32 sequence); the kernel itself issues bf16 MFMAs (32 K-slots per 4-dim contraction, "
-                                 f"{2.0 * N * 1024 * 32 / 1e9:.1f} GFLOP per launch = {2.0 * N * 1024 * 32 / t_dom / 2.5e15:.2f} of the 2.5 PFLOP/s bf16 peak) "
-                                 "and is bound by VALU + MFMA issue, see DESIGN.md 4.1"},
         }
-        if world == 1 and (B, H) == (64, 256) and not a.no_extra:
-            res["div2k_tiles"] = [extra_workload(dev, 8, 768), extra_workload(dev, 32, 768, steps=30)]
-        if not a.no_cpu_baseline and world == 1:             # the CPU port is timed at N=1 only (rank 0's host cores)
-            res["cpu_baseline"] = cpu_baseline(x, z, cb, ratio)
-        if not ok:
-            log("ERROR: bitstream / masks / indices differ from the oracle")
+        if not stub:
+            res.update(report(a, dev, world, stream, slots_np, vq, codec, ratio))
         print(json.dumps(res), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+class SequentialStream:
+    """the same K distinct batches, one after the other on one stream (one hipGraph per slot, or eager)"""
+
+    def __init__(self, dev, slots_dev, cb, ratio, vq, codec, hist, graph=True):
+        self.hps = []
+        for x, z in slots_dev:
+            hp = HotPath(dev, x, z, cb, ratio, vq=vq, codec=codec)
+            hp.hist = hist
+            if graph:
+                hp.capture()
+            self.hps.append(hp)
+        self.graph = graph
+        self._next = 0
+
+    def submit(self, n=1):
+        for _ in range(n):
+            hp = self.hps[self._next]
+            self._next = (self._next + 1) % len(self.hps)
+            hp.graph.replay() if self.graph else hp.step()
+
+    def join(self):
+        pass
+
+    def last_out(self, k):
+        return self.hps[k].out
+
+
+def slot_out(stream, k):
+    if isinstance(stream, SequentialStream):
+        return stream.last_out(k)
+    s = stream.slots[k]
+    e = s.enc
+    return (e["e8"], e["e16"], e["mask"], e["mode"], e["z_q"], e["ind"], e["comp"], *s.dec)
+
+
+def report(a, dev, world, stream, slots_np, vq, codec, ratio):
+    """everything next to the headline value (outside the timed region)"""
+    B, H, W = a.batch, a.size, a.size
+    x, z, cb = slots_np[0]
+    res = {}
+    # parity of the timed work itself: ALL images of slot 0 and of the last slot, as left behind by the timed steps
+    torch.cuda.synchronize()
+    ok0, bpp = check_against_oracle(slot_out(stream, 0), x, z, cb, ratio)
+    kl = len(slots_np) - 1
+    okl, _ = check_against_oracle(slot_out(stream, kl), slots_np[kl][0], slots_np[kl][1], cb, ratio, images=range(0, B, 8))
+    res["bpp"] = round(float(np.mean(bpp)), 6)
+    res["bpp_match"] = bool(ok0 and okl)
+    if not res["bpp_match"]:
+        log("ERROR: bitstream / masks / indices differ from the oracle")
+
+    hp = HotPath(dev, x, z, cb, ratio, vq=vq, codec=codec)
+    g = hp.capture()
+    for _ in range(3):
+        g.replay()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(50):
+        g.replay()
+    torch.cuda.synchronize()
+    res["single_batch"] = {"ms_per_step": round((time.perf_counter() - t0) / 50 * 1e3, 5),
+                           "note": "the SAME batch replayed back to back on one stream (round-1 headline configuration: inputs "
+                                   "cache-resident, no overlap between batches) = latency of one batch through all five launches"}
+    res["single_batch"]["MPixels/s"] = round(B * H * W / res["single_batch"]["ms_per_step"] / 1e3, 1)
+    stages = stage_breakdown(hp)
+    res["stages_us"] = stages
+    # roofline of the dominant kernel: the launch the timed step really makes (VQ + router workgroups in one grid)
+    N = B * (H // 4) * (W // 4)
+    flops = 2.0 * N * 1024 * 4                        # SURVEY 8(d): 2*N*K*D per launch (0.512 kFLOP/pixel)
+    t_dom = stages["vq+router_fused_launch"] * 1e-6
+    achieved = flops / t_dom / 1e12
+    traffic = None
+    pmc = os.path.join(ROOT, "profiles", "pmc_vq.json")
+    if os.path.exists(pmc):
+        try:
+            traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+    res["roofline"] = {
+        "kernel": "vq_filter_router_kernel<4> (VQ forward + the per-image router workgroups, the launch of the timed step)",
+        "bound": "mfma", "achieved": round(achieved, 3), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+        "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic,
+        "vq_alone_frac": round(flops / (stages["vq_kernel_alone"] * 1e-6) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
+        "note": "algorithmic flops = 2*N*K*D of the fp32 distance contraction per launch / average launch duration (20 launches "
+                "in a hipGraph, HIP events on the launch stream), priced against the dense fp32 MFMA peak (results are "
+                "bit-identical to the fp32 sequence); the kernel issues bf16 MFMAs with 32 K-slots per 4-dim contraction "
+                f"({2.0 * N * 1024 * 32 / 1e9:.1f} GFLOP per launch = {2.0 * N * 1024 * 32 / t_dom / 2.5e15:.2f} of the 2.5 PFLOP/s bf16 peak); see DESIGN.md 4.1"}
+    if world == 1 and (B, H) == (64, 256) and not a.no_extra:
+        hp.step()
+        res["mask_mismatch"] = mask_mismatch(hp, x, z, cb, ratio)
+        res["ratio_sweep"] = ratio_sweep(dev, x, z, cb, vq, codec)
+        res["b1_latency"] = b1_latency(dev, cb, vq, codec)
+        res["div2k_image"] = div2k_image(dev, cb, vq, codec)
+        res["div2k_tiles"] = [tiles_768(dev, cb, vq, codec, 8, 60), tiles_768(dev, cb, vq, codec, 32, 30)]
+    if not a.no_cpu_baseline and world == 1:             # the CPU port is timed at N=1 only (rank 0's host cores)
+        res["cpu_baseline"] = cpu_baseline(x, z, cb, ratio)
+    return res
+
+
+# ------------------------------------------------------------------------------------------------ launcher
+def _spawned(local_rank, a, port):
+    os.environ["RANK"] = os.environ["LOCAL_RANK"] = str(local_rank)
+    os.environ["WORLD_SIZE"] = str(a.gpus)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    run_rank(a, local_rank, a.gpus, local_rank)
+
+
+def free_port():
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--batch", type=int, default=64)
+    ap.add_argument("--size", type=int, default=256)
+    ap.add_argument("--schedule", choices=["pipelined", "sequential"], default="pipelined")
+    ap.add_argument("--slots", type=int, default=0, help="distinct resident input batches in rotation (0: enough to exceed the Infinity Cache)")
+    ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying hipGraphs (sequential schedule)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip the extra data points (mask mismatch, ratio sweep, DIV2K, B=1)")
+    ap.add_argument("--stub", action="store_true", help=argparse.SUPPRESS)      # CPU test of the launcher only (gloo, no kernels)
+    return ap.parse_args(argv)
+
+
+def main(argv=None):
+    a = parse_args(argv)
+    if a.gpus < 1:
+        raise SystemExit("bench.py: --gpus must be >= 1")
+    if "RANK" in os.environ:                                # launched by torch.distributed.run: one process per GPU already
+        rank = int(os.environ["RANK"])
+        world = int(os.environ.get("WORLD_SIZE", "1"))
+        local = int(os.environ.get("LOCAL_RANK", str(rank)))
+        if world != a.gpus:
+            raise SystemExit(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={world}; refusing to report a {a.gpus}-GPU number")
+        run_rank(a, rank, world, local)
+        return
+    if a.gpus == 1:
+        run_rank(a, 0, 1, 0)
+        return
+    # plain `python bench.py --gpus N`: start the N ranks here, one per GPU
+    if not a.stub and torch.cuda.device_count() < a.gpus:
+        raise SystemExit(f"bench.py: --gpus {a.gpus} but only {torch.cuda.device_count()} GPUs are visible")
+    import torch.multiprocessing as mp
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    mp.spawn(_spawned, args=(a, free_port()), nprocs=a.gpus, join=True)      # raises (non-zero exit) if any rank fails
 
 
 if __name__ == "__main__":

@@ -20,6 +20,7 @@
 
 #include <map>
 #include <mutex>
+#include <utility>
 
 namespace cgic {
 
@@ -84,8 +85,8 @@ __device__ __forceinline__ void finish_loss(double block_sum, double *sq_partial
     }
     __syncthreads();
     if (!s_last) return;
-    if (tid == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    __syncthreads();
+    // no acquire fence: every partial was stored write-through (sc1) and is read below with sc1 loads, which are served by
+    // L2 / memory, never by this CU's L1 (8-byte agent-scope atomics on both sides; an L1 invalidate costs ~1.7 us here)
     double a = 0.0;
     for (unsigned int i = tid; i < nblk; i += NT)
         a += __hip_atomic_load(&sq_partial[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -102,6 +103,46 @@ __device__ __forceinline__ void finish_loss(double block_sum, double *sq_partial
     }
 }
 
+// Cross-row-group exchanges on the VALU (gfx950 v_permlane16_swap / v_permlane32_swap) -- no LDS round trip.
+//   rows16(x): .x = x of the 16-lane rows (0,0,2,2), .y = x of rows (1,1,3,3)
+//   rows32(x): .x = x of the lower 32 lanes in both halves, .y = the upper 32 lanes' in both halves
+__device__ __forceinline__ uint2 rows16(unsigned int x)
+{
+    unsigned int a = x, b = x;
+    swap16(a, b);
+    return make_uint2(a, b);
+}
+__device__ __forceinline__ uint2 rows32(unsigned int x)
+{
+    unsigned int a = x, b = x;
+    swap32(a, b);
+    return make_uint2(a, b);
+}
+// sum over the 64 lanes in a fixed association (xor 1, 2, 4, 8 on DPP operands, then the 16- and 32-lane swaps):
+// every lane gets the total; no LDS crossbar (a shuffle of a double is two ds_bpermute)
+template <int CTRL>
+__device__ __forceinline__ double dpp_add_f64(double v)
+{
+    const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
+    const unsigned int lo = (unsigned int)__builtin_amdgcn_update_dpp(0, (int)(unsigned int)u, CTRL, 0xF, 0xF, true);
+    const unsigned int hi = (unsigned int)__builtin_amdgcn_update_dpp(0, (int)(unsigned int)(u >> 32), CTRL, 0xF, 0xF, true);
+    return v + __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+}
+__device__ __forceinline__ double wave_sum_f64(double v)
+{
+    v = dpp_add_f64<0xB1>(v);        // quad_perm [1,0,3,2]: xor 1
+    v = dpp_add_f64<0x4E>(v);        // quad_perm [2,3,0,1]: xor 2
+    v = dpp_add_f64<0x141>(v);       // row_half_mirror: xor 4 for quad-uniform values
+    v = dpp_add_f64<0x140>(v);       // row_mirror: xor 8 for values uniform over 8 lanes
+    unsigned long long u = __builtin_bit_cast(unsigned long long, v);
+    uint2 a = rows16((unsigned int)u), b = rows16((unsigned int)(u >> 32));
+    v = __builtin_bit_cast(double, ((unsigned long long)b.x << 32) | a.x) + __builtin_bit_cast(double, ((unsigned long long)b.y << 32) | a.y);
+    u = __builtin_bit_cast(unsigned long long, v);
+    a = rows32((unsigned int)u);
+    b = rows32((unsigned int)(u >> 32));
+    return __builtin_bit_cast(double, ((unsigned long long)b.x << 32) | a.x) + __builtin_bit_cast(double, ((unsigned long long)b.y << 32) | a.y);
+}
+
 // Variant for the filter path, executed by ONE wave: lane 0 publishes the workgroup's partial (write-through
 // store, drained, then the ticket); the wave of the last workgroup sums all partials in a fixed order.
 __device__ __forceinline__ void finish_loss_wave(double block_sum, double *sq_partial, unsigned int *ticket, double count,
@@ -116,12 +157,11 @@ __device__ __forceinline__ void finish_loss_wave(double block_sum, double *sq_pa
     }
     last = __builtin_amdgcn_readfirstlane(last);
     if (!last) return;
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    // (no acquire fence: sc1 stores on the producers' side, sc1 loads here -- see finish_loss)
     double a = 0.0;
     for (unsigned int i = lane; i < nblk; i += kWave)
         a += __hip_atomic_load(&sq_partial[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) a += __shfl_down(a, off, kWave);
+    a = wave_sum_f64(a);
     if (lane == 0) {
         const float m = (float)(a / count);
         *loss = legacy ? (m + beta * m) : (beta * m + m);
@@ -328,88 +368,70 @@ __global__ __launch_bounds__(kVqThreads, ZT <= 4 ? 4 : 2) void vq_router_kernel(
 }
 
 // =====================================================================================================
-// Filter path (K % 64 == 0, K <= 1024; the reference's codebook is 1024 x 4): the bf16 matrix cores find
-// the candidates, fp32 decides.  The exact loop above costs ~7 issue slots per (16 codes x 16 vectors)
-// tile, 4 of them the fp32 MFMA (which does not overlap VALU work on gfx950); it cannot be made cheaper
-// and still deliver every distance.  But argmin only needs the distances that can win:
+// Filter path (K % 64 == 0, K <= 1024; the reference's codebook is 1024 x 4): the fp16 matrix cores find
+// the candidates, fp32 decides.  The exact loop above delivers every distance at the fp32 MFMA rate (1/16 of
+// the 16-bit rate) plus ~3 VALU instructions per output pair; argmin only needs the distances that can win:
 //
-//  * score  f(k) = ee_k - 2 z.e_k  (the distance minus zz, which does not change the argmin) comes out of
-//    ONE v_mfma_f32_16x16x32_bf16 per tile: z_j, -2 e_kj and ee_k are each split exactly into three bf16
-//    (8+8+8 significand bits, by truncation); the 32 K-slots carry, per dimension, the six products
-//    zh.wh zh.wm zm.wh zh.wl zl.wh zm.wm, plus ee's three pieces against 1.0.  Dropped terms and fp32
-//    accumulation leave |f - F| <= 2^-17.6 S, S = max ee + 2 max|e| sum|z_j| (measured: ~2^-22 S).
-//  * per lane, a running (smallest, second smallest) over QUADS of tiles (64 codes), the quad's index packed into the
-//    low mantissa bits of its minimum: 8 v_min3 + and_or + med3 + min for 4 MFMAs -- 2.75 VALU per tile instead
-//    of 12, and an 8 ns MFMA instead of 14.5.
+//  * score  f(k) = ee_k - 2 z.e_k  (the distance minus zz, which does not change the argmin) comes out of ONE
+//    v_mfma_f32_32x32x16_f16 per (32 codes x 32 vectors): z_j and w_kj = -2 e_kj are each split into two fp16
+//    pieces by round-to-nearest (11 + 11 significand bits) after an exact power-of-two scaling into fp16's range
+//    (2^b for the codebook, 2^a per latent vector), ee_k into three pieces.  The 16 K-slots carry, per dimension,
+//    zh.wh, zh.wm, zm.wh (12 slots), and ee's three pieces against 2^s, s = a + b - be (3 slots).  Every product
+//    is exact in fp32; the dropped zm.wm terms and the fp32 accumulation leave |f - F| <= 1.8e-6 T_k,
+//    T_k = ee_k + 2 sum|z_j e_kj|, plus an ABSOLUTE floor for pieces that fall into fp16's subnormal range
+//    (<= 2^-7 in scaled units, where the scaled scores of a group are ~2^26; it only matters for a code whose own
+//    T_k is tiny next to the codebook's scale, and then sends the vector to the exact path).
+//    (Round 1 used three bf16 pieces by truncation and v_mfma_f32_16x16x32_bf16: 32 K-slots for the same
+//    precision, i.e. twice the matrix-core time per (code, vector) pair.)
+//  * per lane a running (smallest, second smallest) over TILES of 32 codes (the lane holds 16 of them), the tile's
+//    index packed into the low 5 mantissa bits of its minimum: 8 v_min3 + and_or + med3 + min per MFMA.
 //  * every code whose reference distance could be minimal has f <= f_min + M,
-//    M = 2 (|f - F| + |d_ref - zz - F|) + packing <= 1.6e-5 S + 2.5e-7 zz  (d_ref's own rounding: 2^-23 zz + 2^-21 S).
-//    S is the smaller of the codebook-maxima bound and (|z| + sqrt D)(3|z| + sqrt D), D = zz + f_min + slack (the
-//    winner and whatever can beat it lie within sqrt D of z).
-//    If the winner's quad is the only place holding such codes (second-smallest quad value of every
-//    row group above the threshold, one hot row group), its 16 codes are evaluated with the exact fp32
-//    sequence and the lowest-index minimum is the reference's argmin.  Otherwise (0.1-0.5 % of N(0,1)
-//    vectors) the wave scans all K codes exactly for that vector; a group with many such vectors reruns
-//    the exact fp32-MFMA loop.  Results are bit-identical to the exact kernels for every finite input.
+//    M = 2 (|f - F| + |d_ref - zz - F|) + packing <= 1.3e-5 S + 2.5e-7 zz + floor  (d_ref's own rounding:
+//    2^-23 zz + 2^-21 S; packing 2^-18 |f| twice).  S is the smaller of the codebook-maxima bound and
+//    (|z| + sqrt D)(3|z| + sqrt D), D = zz + f_min + slack (the winner and whatever can beat it lie within sqrt D
+//    of z).  A vector's two 16-code sets (rows 4h..4h+3 mod 8 of each tile, h = lane >> 5) each contribute their
+//    best and second-best tile.  If no second-best is under the threshold, the candidates are the best tile of one
+//    or both halves: those 16 or 32 codes get the exact fp32 sequence, lane-local, and the lowest-index minimum is
+//    the reference's argmin.  Otherwise (a third tile may hide behind the second: ~0.1 % of N(0,1) vectors) the
+//    wave scans all K codes exactly for that vector; a group with many such vectors reruns the exact fp32-MFMA
+//    loop.  Results are bit-identical to the exact kernels for every finite input.
 // =====================================================================================================
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int kVqfThreads = 512;               // 8 waves, one workgroup per CU (84 KB of LDS at K = 1024)
-constexpr int kVqfWaves = kVqfThreads / 64;
 constexpr int kVqfMaxK = 1024;
-constexpr int kVqfTbFloats = 1024 + 64;        // per wave: 4 fields x 64 vectors x 4 row groups, + 64 results
 constexpr int kVqfBulk = 12;                   // more flagged vectors than this in a 64-vector group: rerun it exactly on the MFMA
+constexpr int kVqfGroup = 64;                  // vectors per group: two tiles of 32 (one lane per vector in the decide step)
 
-// x == h + m + l exactly, three bf16 by truncation (|m| < 2^-7 |x|, |l| < 2^-14 |x|)
-__device__ __forceinline__ void split3(float x, unsigned int &h, unsigned int &m, unsigned int &l)
+__device__ __forceinline__ unsigned int h16(float x)
 {
-    const unsigned int xb = __float_as_uint(x);
-    h = xb >> 16;
-    const float r1 = x - __uint_as_float(xb & 0xFFFF0000u);
-    const unsigned int rb = __float_as_uint(r1);
-    m = rb >> 16;
-    const float r2 = r1 - __uint_as_float(rb & 0xFFFF0000u);
-    l = __float_as_uint(r2) >> 16;
+    return (unsigned int)__builtin_bit_cast(unsigned short, (_Float16)x);
+}
+// x ~ h + m (+ l), fp16 pieces by round-to-nearest; the residuals x - h, x - h - m are exact in fp32
+__device__ __forceinline__ void split2h(float x, unsigned int &h, unsigned int &m)
+{
+    const _Float16 hh = (_Float16)x;
+    const float r = x - (float)hh;
+    h = (unsigned int)__builtin_bit_cast(unsigned short, hh);
+    m = h16(r);
+}
+__device__ __forceinline__ void split3h(float x, unsigned int &h, unsigned int &m, unsigned int &l)
+{
+    const _Float16 hh = (_Float16)x;
+    const float r = x - (float)hh;
+    const _Float16 mm = (_Float16)r;
+    h = (unsigned int)__builtin_bit_cast(unsigned short, hh);
+    m = (unsigned int)__builtin_bit_cast(unsigned short, mm);
+    l = h16(r - (float)mm);
+}
+// floor(log2 |x|) of a finite x (-126 for zero / subnormals); 128 for Inf / NaN
+__device__ __forceinline__ int exponent_of(float x)
+{
+    const int e = (int)((__float_as_uint(x) >> 23) & 255u);
+    return e == 0 ? -126 : e - 127;
 }
 
-// Cross-row-group exchanges on the VALU (gfx950 v_permlane16_swap / v_permlane32_swap) -- no LDS round trip.
-// Lane = (column j = lane & 15, row group g = lane >> 4).
-//   rows16(x): .x = x of row groups (0,0,2,2), .y = x of row groups (1,1,3,3)
-//   rows32(x): .x = x of the lower 32 lanes in both halves, .y = the upper 32 lanes' in both halves
-__device__ __forceinline__ uint2 rows16(unsigned int x)
-{
-    unsigned int a = x, b = x;
-    swap16(a, b);
-    return make_uint2(a, b);
-}
-__device__ __forceinline__ uint2 rows32(unsigned int x)
-{
-    unsigned int a = x, b = x;
-    swap32(a, b);
-    return make_uint2(a, b);
-}
-// reduce over the 4 row groups of each column; every lane of the column gets the result
-__device__ __forceinline__ float colmin(float x)
-{
-    uint2 a = rows16(__float_as_uint(x));
-    x = __builtin_fminf(__uint_as_float(a.x), __uint_as_float(a.y));
-    a = rows32(__float_as_uint(x));
-    return __builtin_fminf(__uint_as_float(a.x), __uint_as_float(a.y));
-}
-__device__ __forceinline__ int colmax(int x)
-{
-    uint2 a = rows16((unsigned int)x);
-    x = (int)a.x > (int)a.y ? (int)a.x : (int)a.y;
-    a = rows32((unsigned int)x);
-    return (int)a.x > (int)a.y ? (int)a.x : (int)a.y;
-}
-__device__ __forceinline__ int colsum(int x)
-{
-    uint2 a = rows16((unsigned int)x);
-    x = (int)(a.x + a.y);
-    a = rows32((unsigned int)x);
-    return (int)(a.x + a.y);
-}
-// lexicographic (d, i) minimum over the 4 row groups of each column
+// lexicographic (d, i) minimum over the 4 row groups (lane >> 4) of each column (lane & 15)
 __device__ __forceinline__ void colargmin(float &d, int &i)
 {
     uint2 dd = rows16(__float_as_uint(d)), ii = rows16((unsigned int)i);
@@ -430,7 +452,6 @@ __device__ __forceinline__ void colargmin(float &d, int &i)
         i = take ? ib : ia;
     }
 }
-
 // the reference's rounding sequence for one codebook row
 __device__ __forceinline__ float dist_row(float z0, float z1, float z2, float z3, float zz, const float4 e, float ee)
 {
@@ -441,36 +462,43 @@ __device__ __forceinline__ float dist_row(float z0, float z1, float z2, float z3
     return __builtin_fmaf(-2.0f, mm, zz + ee);
 }
 
-template <int ZT>
+// Where code c's fp32 row / squared norm sits in LDS.  The decide step reads, in every lane, row 32 T + 4 h + 8 q + r of
+// a lane-specific tile T: unpadded, all lanes of a row half would hit the same four banks (16-way conflicts; 67 % of the
+// kernel's LDS cycles).  One extra row per tile (and four extra norms) rotate the bank with the tile.
+__device__ __forceinline__ int rowpos(int c) { return c + (c >> 5); }
+__device__ __forceinline__ int eepos(int c) { return c + 4 * (c >> 5); }
+// LDS of the filter path: [K/32][64] x 16 B split A operands, [K + K/32] fp32 rows, [K + K/8] row norms
+__host__ __device__ constexpr size_t vqf_rows_off(int K) { return (size_t)K * 32; }
+__host__ __device__ constexpr size_t vqf_ees_off(int K) { return vqf_rows_off(K) + (size_t)(K + K / 32) * 16; }
+__host__ __device__ constexpr size_t vqf_lds_bytes(int K) { return vqf_ees_off(K) + (size_t)(K + K / 8) * 4; }
+
+// ALIGNED: hw % 64 == 0 -- a group of 64 consecutive vectors never straddles two images, so (image, position) of a
+// group is wave-uniform and every address is a scalar base plus a per-lane offset that is computed once.
+template <int NT, bool ALIGNED>
 __device__ __forceinline__ void vq_filter_body(const VqArgs &a, unsigned char *smem, const unsigned int vblk)
 {
-    constexpr int NT = kVqfThreads, NW = kVqfWaves;
-    static_assert(ZT <= 4, "the decide step maps one lane to each of the group's 16 * ZT vectors");
+    constexpr int NW = NT / 64, G = kVqfGroup;
     const float *__restrict__ z = a.z;
     const int64_t hw = a.hw, N = a.N;
-    const int K = a.K, ntile = K >> 4, np = K >> 5;
+    const int K = a.K, ntile = K >> 5;
     int64_t *__restrict__ idx_out = a.idx_out;
     float *__restrict__ zq_out = a.zq_out;
-    // A operands, 16 bytes per (tile, lane): {u0, u1, u0, u0} with u0 = wh | wm << 16, u1 = wl | ee piece << 16,
-    // against B = {zh|zh, zh|1.0, zm|zm, zl|0}: slots wh.zh wm.zh | wl.zh ee.1 | wh.zm wm.zm | wh.zl 0.
-    // (8 bytes per lane + two v_mov per tile was measured 1 us slower; LDS size is not what limits residency.)
-    uint4 *ldsA = reinterpret_cast<uint4 *>(smem);                         // [K/16][64]
-    float4 *cbs = reinterpret_cast<float4 *>(smem + (size_t)K * 64);       // [K] fp32 rows
-    float *ees = reinterpret_cast<float *>(smem + (size_t)K * 80);         // [K] their squared norms
-    float *tbuf = reinterpret_cast<float *>(smem + (size_t)K * 84);        // [NW][kVqfTbFloats] per-wave transpose buffers
-    double *gsum = reinterpret_cast<double *>(smem + (size_t)K * 84 + (size_t)NW * kVqfTbFloats * 4);      // [groups of this workgroup] loss partials
+    uint4 *ldsA = reinterpret_cast<uint4 *>(smem);                                  // [K/32][64]
+    float4 *cbs = reinterpret_cast<float4 *>(smem + vqf_rows_off(K));               // fp32 rows, at rowpos()
+    float *ees = reinterpret_cast<float *>(smem + vqf_ees_off(K));                  // their squared norms, at eepos()
     __shared__ unsigned int s_max[2];
-    __shared__ unsigned int s_next;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int j = lane & 15;   // column: which latent vector of the tile
-    const int g = lane >> 4;   // K-slot group of the operands (= dimension) / row group of the result
+    __shared__ double s_wsum[NT / 64];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int j = lane & 31;    // column of the MFMA: which latent vector of the 32-vector tile
+    const int hf = lane >> 5;   // K-slot half of the operands / row half of the result
 
     CGIC_STAMP(0);
     CGIC_BLK_BEGIN();
-    // ---- groups of 16*ZT vectors: the workgroup owns a contiguous range, its waves take groups from a shared
-    // counter.  (Static shares leave the SIMD's younger wave behind: VALU issue is arbitrated by age, the older
-    // wave finishes early and the younger one then runs alone at half the issue rate.)
-    const int64_t ngroups = (N + 16 * ZT - 1) / (16 * ZT);
+    // ---- groups of 64 vectors: the workgroup owns a contiguous range, wave w takes groups w, w + NW, ... of it.
+    // (A shared counter balanced the waves no better -- a SIMD's total work is what it is -- and cost an LDS atomic and a
+    // cross-lane loss reduction per group: with fixed shares a wave's loss partial is a fixed sum.)
+    const int64_t ngroups = (N + G - 1) / G;
     int64_t blk_lo, blk_hi;
     if (vblk < a.n_early) {
         blk_lo = (int64_t)vblk * a.g_early;
@@ -481,213 +509,276 @@ __device__ __forceinline__ void vq_filter_body(const VqArgs &a, unsigned char *s
     }
     blk_lo = blk_lo < ngroups ? blk_lo : ngroups;
     blk_hi = blk_hi < ngroups ? blk_hi : ngroups;
-    auto grab = [&]() -> int64_t {
-        int v = 0;
-        if (lane == 0) v = (int)atomicAdd(&s_next, 1u);
-        return blk_lo + __builtin_amdgcn_readfirstlane(v);
-    };
-    // (image, position) of a group's first vector
-    auto origin = [&](int64_t grp, int64_t *b, int64_t *p) {
-        const int64_t n0 = grp * (16 * ZT);
-        if (((n0 | hw) >> 32) == 0) {
-            const unsigned int q = (unsigned int)n0 / (unsigned int)hw;
-            *b = q; *p = (int64_t)((unsigned int)n0 - q * (unsigned int)hw);
+    // (image, position) of a vector
+    auto divmod = [&](int64_t n, int64_t *b, int64_t *p) {
+        if (((n | hw) >> 32) == 0) {
+            const unsigned int q = (unsigned int)n / (unsigned int)hw;
+            *b = q; *p = (int64_t)((unsigned int)n - q * (unsigned int)hw);
         } else {
-            *b = n0 / hw; *p = n0 - *b * hw;
+            *b = n / hw; *p = n - *b * hw;
         }
     };
-    auto locate = [&](int64_t bb, int64_t pp, int t, int64_t *b, int64_t *p) {
-        pp += 16 * t + j;
+    // ALIGNED: (image, position) of the workgroup's first group by ONE division; a group's own follows by adding and
+    // carrying on the scalar unit (there is no scalar divide, and a vector one costs ~20 instructions per group)
+    int64_t wg_b = 0, wg_p = 0;
+    if (ALIGNED) divmod(blk_lo * G, &wg_b, &wg_p);
+    auto origin = [&](int64_t grp, int64_t *b, int64_t *p0) {
+        int64_t bb = wg_b, pp = wg_p + (grp - blk_lo) * G;
         while (pp >= hw) { pp -= hw; ++bb; }
-        *b = bb; *p = pp;
+        *b = bb; *p0 = pp;
     };
-    auto load_group = [&](int64_t grp, int64_t bb, int64_t pp, float (&out)[ZT]) {
+    const int64_t lane_off = j;                                    // per-lane element offsets inside the group's image
+    const int64_t out_off = (int64_t)(2 * hf) * hw + j;
+    auto load_group = [&](int64_t grp, float (&out)[2][4]) {
+        const int64_t n0 = grp * G;
+        if (ALIGNED) {
+            int64_t b, p0;
+            origin(grp, &b, &p0);                      // wave-uniform
+            const float *zb = z + b * 4 * hw + p0;
 #pragma unroll
-        for (int t = 0; t < ZT; ++t) {
-            const int64_t n = grp * (16 * ZT) + 16 * t + j;
-            float v = 0.f;
-            if (n < N) {
-                int64_t b, p;
-                locate(bb, pp, t, &b, &p);
-                v = z[(b * 4 + g) * hw + p];
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) out[t][c] = zb[c * hw + 32 * t + lane_off];
+        } else {
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const int64_t n = n0 + 32 * t + j;
+                int64_t b = 0, p = 0;
+                const bool ok = n < N;
+                if (ok) divmod(n, &b, &p);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) out[t][c] = ok ? z[(b * 4 + c) * hw + p] : 0.f;
             }
-            out[t] = v;
         }
     };
 
     // the first group's latents are requested before the codebook is staged: their HBM latency hides behind it
-    float zn[ZT];
-    int64_t cur = blk_lo + wave, cb0 = 0, cp0 = 0;
-    if (cur < blk_hi) {
-        origin(cur, &cb0, &cp0);
-        load_group(cur, cb0, cp0, zn);
-    }
+    float zn[2][4];
+    int64_t cur = blk_lo + wave;
+    if (cur < blk_hi) load_group(cur, zn);
 
-
-    // ---- stage: fp32 rows, then the split A operands built from them
+    // ---- stage.  Phase 1: fp32 rows, row norms and the codebook maxima (they fix the fp16 scaling).
     if (tid < 2) s_max[tid] = 0;
-    if (tid == 0) s_next = NW;              // groups 0..NW-1 of the workgroup's range are the waves' first ones
+    constexpr int kRows = (kVqfMaxK + NT - 1) / NT;          // rows per thread (2 at 512 threads)
+    float4 rows[kRows];
+    float rowee[kRows];
     {
-        // every (tile, lane) element reads its codebook row straight from global (L2): all loads of a thread are in
-        // flight together and no barrier sits between the fp32 copy and the operand build (one round trip, not two)
         float emax = 0.f, eemax = 0.f;
-        constexpr int kPerThread = kVqfMaxK * 4 / NT;             // 8 elements per thread at K = 1024
-        float4 rows[kPerThread];
 #pragma unroll
-        for (int q = 0; q < kPerThread; ++q) {
-            const int i = tid + q * NT;
-            rows[q] = i < ntile * 64 ? reinterpret_cast<const float4 *>(a.cb)[((i >> 6) << 4) + (i & 15)] : float4{0.f, 0.f, 0.f, 0.f};
+        for (int q = 0; q < kRows; ++q) {
+            const int k = tid + q * NT;
+            rows[q] = k < K ? reinterpret_cast<const float4 *>(a.cb)[k] : float4{0.f, 0.f, 0.f, 0.f};
         }
+        __syncthreads();                    // s_max is zero
 #pragma unroll
-        for (int q = 0; q < kPerThread; ++q) {
-            const int i = tid + q * NT;
-            if (i >= ntile * 64) break;
-            const int l = i & 63, gg = l >> 4;
+        for (int q = 0; q < kRows; ++q) {
+            const int k = tid + q * NT;
             const float4 e = rows[q];
-            const float ee = sumsq4(e.x, e.y, e.z, e.w);
-            const float ec = gg == 0 ? e.x : gg == 1 ? e.y : gg == 2 ? e.z : e.w;
-            unsigned int wh, wm, wl, eh, em, el;
-            split3(-2.0f * ec, wh, wm, wl);
-            split3(ee, eh, em, el);
-            const unsigned int ep = gg == 0 ? eh : gg == 1 ? em : gg == 2 ? el : 0u;
-            ldsA[i] = make_uint4(wh | (wm << 16), wl | (ep << 16), wh | (wm << 16), wh | (wm << 16));
-            if (gg == 0) { ees[((i >> 6) << 4) + (l & 15)] = ee; cbs[((i >> 6) << 4) + (l & 15)] = e; }
-            emax = fmaxf(emax, fabsf(ec));
-            eemax = fmaxf(eemax, ee);
+            rowee[q] = sumsq4(e.x, e.y, e.z, e.w);
+            if (k < K) { cbs[rowpos(k)] = e; ees[eepos(k)] = rowee[q]; }
+            emax = fmaxf(emax, fmaxf(fmaxf(fabsf(e.x), fabsf(e.y)), fmaxf(fabsf(e.z), fabsf(e.w))));
+            eemax = fmaxf(eemax, rowee[q]);
+            // fmaxf drops NaNs: route them into the maxima by hand (a NaN anywhere in the codebook disables the filter)
+            if (!(rowee[q] == rowee[q])) eemax = rowee[q];
         }
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) {
-            emax = fmaxf(emax, __shfl_xor(emax, off, kWave));
-            eemax = fmaxf(eemax, __shfl_xor(eemax, off, kWave));
+            const float oe = __shfl_xor(emax, off, kWave), oee = __shfl_xor(eemax, off, kWave);
+            emax = fmaxf(emax, oe);
+            eemax = (oee != oee || eemax != eemax) ? __builtin_nanf("") : fmaxf(eemax, oee);
         }
         // non-negative floats order like their bit patterns; a NaN lands above every finite value
         if (lane == 0) { atomicMax(&s_max[0], __float_as_uint(emax)); atomicMax(&s_max[1], __float_as_uint(eemax)); }
     }
     __syncthreads();
     const float Emax = __uint_as_float(s_max[0]), EEmax = __uint_as_float(s_max[1]);
+    // the filter needs a finite, non-zero codebook (an all-zero one ties everywhere: exact path)
+    const bool filter_ok = Emax > 0.f && EEmax > 0.f && EEmax < __builtin_inff() && Emax < __builtin_inff();
+    // 2 Emax 2^b and EEmax 2^be in [2^13, 2^14)
+    const int sb = 13 - (exponent_of(Emax) + 1), sbe = 13 - exponent_of(EEmax);
+    // Phase 2: the split A operands.  Row k = 32 T + i feeds lanes i (K-slots 0..7) and 32 + i (K-slots 8..15) of tile T:
+    //   slots 0..7  : wh0 wm0 wh0 | wh1 wm1 wh1 | wh2 wm2        against  zh0 zh0 zm0 | zh1 zh1 zm1 | zh2 zh2
+    //   slots 8..15 : wh2 | wh3 wm3 wh3 | eh em el | 0          against  zm2 | zh3 zh3 zm3 | 2^s 2^s 2^s | 0
+#pragma unroll
+    for (int q = 0; q < kRows; ++q) {
+        const int k = tid + q * NT;
+        if (k < K) {
+            const float4 e = rows[q];
+            unsigned int wh0, wm0, wh1, wm1, wh2, wm2, wh3, wm3, eh, em, el;
+            split2h(ldexpf(-2.0f * e.x, sb), wh0, wm0);
+            split2h(ldexpf(-2.0f * e.y, sb), wh1, wm1);
+            split2h(ldexpf(-2.0f * e.z, sb), wh2, wm2);
+            split2h(ldexpf(-2.0f * e.w, sb), wh3, wm3);
+            split3h(ldexpf(rowee[q], sbe), eh, em, el);
+            uint4 *dst = ldsA + (k >> 5) * 64 + (k & 31);
+            dst[0] = make_uint4(wh0 | (wm0 << 16), wh0 | (wh1 << 16), wm1 | (wh1 << 16), wh2 | (wm2 << 16));
+            dst[32] = make_uint4(wh2 | (wh3 << 16), wm3 | (wh3 << 16), eh | (em << 16), el);
+        }
+    }
+    __syncthreads();
     CGIC_STAMP(1);
+    // exponent window of the per-vector scale 2^a: 2^s, s = a + sb - sbe, must be a normal fp16
+    const int a_cap = 15 + sbe - sb, a_min = -14 + sbe - sb;
 
+    double sq = 0.0;                    // this lane's share of the loss, over all groups of the wave
     while (cur < blk_hi) {
         const int64_t grp = cur;
-        const int64_t base = grp * (16 * ZT);
-        const int64_t gb = cb0, gp = cp0;
-        float zv[ZT], m1[ZT], m2[ZT];
-        bf16x8 bop[ZT];
+        const int64_t base = grp * G;
+        float zv[2][4];
+        f16x8 bop[2];
+        int qs[2];                      // scaled score = 2^qs x score
+        bool unscalable[2];             // no exponent fits (or no usable codebook): exact path for that vector
 #pragma unroll
-        for (int t = 0; t < ZT; ++t) {
-            zv[t] = zn[t];
-            unsigned int h, m, l;
-            split3(zv[t], h, m, l);
+        for (int t = 0; t < 2; ++t) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) zv[t][c] = zn[t][c];
+            const float zmax = fmaxf(fmaxf(fabsf(zv[t][0]), fabsf(zv[t][1])), fmaxf(fabsf(zv[t][2]), fabsf(zv[t][3])));
+            const int ez = exponent_of(zmax);
+            int sa = 13 - ez;
+            sa = sa < a_cap ? sa : a_cap;       // z small next to the codebook: keep 2^s <= 2^15 (z's pieces only lose bits that do not matter)
+            // z huge next to the codebook (or not finite): no exponent fits -- exact path
+            unscalable[t] = !filter_ok || sa < a_min || ez > 127 || !(zv[t][0] == zv[t][0] && zv[t][1] == zv[t][1] && zv[t][2] == zv[t][2] && zv[t][3] == zv[t][3]);
+            sa = sa < a_min ? a_min : sa;
+            qs[t] = sa + sb;
+            const unsigned int sig = (unsigned int)(sa + sb - sbe + 15) << 10;      // fp16 bits of 2^s
+            // slots 0..7 (hf 0): zh0 zh0 | zm0 zh1 | zh1 zm1 | zh2 zh2      slots 8..15 (hf 1): zm2 zh3 | zh3 zm3 | 2^s 2^s | 2^s 0
+            // with (a, b) = (z0, z1) resp. (z2, z3) both halves hold P = am | bh << 16 and Q = bh | bm << 16
+            unsigned int ah, am, bh, bm;
+            split2h(ldexpf(hf ? zv[t][2] : zv[t][0], sa), ah, am);
+            split2h(ldexpf(hf ? zv[t][3] : zv[t][1], sa), bh, bm);
+            const unsigned int ch = h16(ldexpf(zv[t][2], sa));
+            const unsigned int P = am | (bh << 16), Q = bh | (bm << 16);
             uint4 bb;
-            bb.x = h | (h << 16);
-            bb.y = h | (0x3F80u << 16);           // 1.0 against ee's piece
-            bb.z = m | (m << 16);
-            bb.w = l;                             // slot 7 = 0
-            bop[t] = __builtin_bit_cast(bf16x8, bb);
-            m1[t] = __builtin_inff();
-            m2[t] = __builtin_inff();
+            bb.x = hf ? P : ah | (ah << 16);
+            bb.y = hf ? Q : P;
+            bb.z = hf ? sig | (sig << 16) : Q;
+            bb.w = hf ? sig : ch | (ch << 16);
+            bop[t] = __builtin_bit_cast(f16x8, bb);
         }
-        // reserve the next group now: its latents are in flight during this group's scan
-        cur = grab();
-        if (cur < blk_hi) {
-            origin(cur, &cb0, &cp0);
-            load_group(cur, cb0, cp0, zn);
-        }
+        // the next group's latents are in flight during this group's scan
+        cur += NW;
+        if (cur < blk_hi) load_group(cur, zn);
         CGIC_STAMP(2);
 
-        // ---- scan: QUADS of code tiles (64 codes), as two ping-pong pairs -- the MFMAs of one pair run while the
-        // VALU digests the other.  One running-minimum chain per quad, one (smallest, second, where) update per quad.
-        f32x4 X0[ZT], X1[ZT], Y0[ZT], Y1[ZT];
-        float uq[ZT];
-        const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
-        auto issue = [&](int p, f32x4 (&A0)[ZT], f32x4 (&A1)[ZT]) {
-            const int pp = p < np ? p : np - 1;
-            const bf16x8 a0 = __builtin_bit_cast(bf16x8, ldsA[(2 * pp) * 64 + lane]);
-            const bf16x8 a1 = __builtin_bit_cast(bf16x8, ldsA[(2 * pp + 1) * 64 + lane]);
+        // ---- scan: tiles of 32 codes, ping-pong -- the MFMAs of one tile run while the VALU digests the other.
+        float m1[2], m2[2];
+        m1[0] = m1[1] = m2[0] = m2[1] = __builtin_inff();
+        {
+            f32x16 X[2], Y[2];
+            f32x16 zero16;
 #pragma unroll
-            for (int t = 0; t < ZT; ++t) {
-                A0[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, bop[t], zero4, 0, 0, 0);
-                A1[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, bop[t], zero4, 0, 0, 0);
-            }
-        };
-        auto chain = [&](float u, const f32x4 &A0, const f32x4 &A1) -> float {
-            u = __builtin_fminf(__builtin_fminf(u, A0[0]), A0[1]);       // v_min3_f32 on the raw MFMA outputs
-            u = __builtin_fminf(__builtin_fminf(u, A0[2]), A0[3]);
-            u = __builtin_fminf(__builtin_fminf(u, A1[0]), A1[1]);
-            return __builtin_fminf(__builtin_fminf(u, A1[2]), A1[3]);
-        };
-        issue(0, X0, X1);
-        for (int p = 0; p < np; p += 2) {
-            issue(p + 1, Y0, Y1);
+            for (int r = 0; r < 16; ++r) zero16[r] = 0.f;
+            auto issue = [&](int T, f32x16 (&D)[2]) {
+                const int TT = T < ntile ? T : ntile - 1;      // the last one is a harmless repeat of the final tile
+                const f16x8 av = __builtin_bit_cast(f16x8, ldsA[TT * 64 + lane]);
+                D[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, bop[0], zero16, 0, 0, 0);
+                D[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, bop[1], zero16, 0, 0, 0);
+            };
+            auto digest = [&](int T, const f32x16 (&D)[2]) {
 #pragma unroll
-            for (int t = 0; t < ZT; ++t) uq[t] = chain(__builtin_inff(), X0[t], X1[t]);    // seeded with a constant: no canonicalising v_max
-            issue(p + 2, X0, X1);      // the last one is a harmless repeat of the final pair
+                for (int t = 0; t < 2; ++t) {
+                    float u = __builtin_inff();        // seeded with a constant: a two-operand fminf() canonicalises both operands first
 #pragma unroll
-            for (int t = 0; t < ZT; ++t) {
-                // the quad's index rides in the low 4 mantissa bits of its minimum (one v_and_or_b32 instead of a
-                // compare + select per quad); the 2^-19 relative perturbation is part of the margin
-                const float u = __uint_as_float((__float_as_uint(chain(uq[t], Y0[t], Y1[t])) & ~15u) | (unsigned int)(p >> 1));
-                m2[t] = __builtin_amdgcn_fmed3f(m1[t], m2[t], u);     // second smallest quad value
-                m1[t] = __builtin_fminf(m1[t], u);
+                    for (int r = 0; r < 16; r += 2) u = __builtin_fminf(__builtin_fminf(u, D[t][r]), D[t][r + 1]);     // v_min3_f32 on the raw MFMA outputs
+                    // the tile's index rides in the low 5 mantissa bits of its minimum (one v_and_or_b32 instead of a
+                    // compare + select per tile); the 2^-18 relative perturbation is part of the margin
+                    u = __uint_as_float((__float_as_uint(u) & ~31u) | (unsigned int)T);
+                    m2[t] = __builtin_amdgcn_fmed3f(m1[t], m2[t], u);     // second smallest tile value
+                    // raw v_min_f32: fminf() adds two canonicalising v_max per call here
+                    asm("v_min_f32 %0, %1, %2" : "=v"(m1[t]) : "v"(m1[t]), "v"(u));
+                }
+            };
+            // (pinning this order with sched_barrier was measured slower: 26.1 vs 25.5 us)
+            issue(0, X);
+            for (int T = 0; T < ntile; T += 2) {
+                issue(T + 1, Y);
+                digest(T, X);
+                issue(T + 2, X);
+                digest(T + 1, Y);
             }
         }
         CGIC_STAMP(3);
 
-        // ---- decide: ONE LANE PER VECTOR.  The scan leaves (smallest, second, where) per (vector, row group) in the
-        // MFMA's lane layout; a transpose through a wave-private LDS buffer gives lane t*16+j all four row groups of
-        // its vector, and the whole decision -- margin, hot row group, the 16 exact distances -- is lane-local: no
-        // cross-lane reductions (they were a third of the kernel's VALU instructions).
-        int win[ZT];                                   // result per tile in the (column j, row group g) layout
+        // ---- decide: ONE LANE PER VECTOR.  Lane L = 32 t + j takes vector (tile t, column j): its own scaled
+        // (smallest, second) of the row half it scanned, the other half's from lane L ^ 32 (v_permlane32_swap), and its
+        // four latent components, which it loaded itself.  Margin, candidate sets and the exact distances are lane-local.
+        int wi = 0;
         {
-            float *tb = tbuf + wave * kVqfTbFloats;
-#pragma unroll
-            for (int t = 0; t < ZT; ++t) {
-                const int o = (t * 16 + j) * 4 + g;
-                tb[o] = m1[t];
-                tb[256 + o] = m2[t];
-                tb[768 + o] = zv[t];
-            }
-            const float4 a1 = reinterpret_cast<const float4 *>(tb)[lane];            // m1 of row groups 0..3
-            const float4 a2 = reinterpret_cast<const float4 *>(tb)[64 + lane];       // m2
-            const float4 az = reinterpret_cast<const float4 *>(tb)[192 + lane];      // z0..z3
-            const bool valid = lane < 16 * ZT;
-            const float y0 = az.x, y1 = az.y, y2 = az.z, y3 = az.w;
+            const uint2 s1a = rows32(__float_as_uint(m1[0])), s2a = rows32(__float_as_uint(m2[0]));     // tile 0: .x row half 0, .y row half 1
+            const uint2 s1b = rows32(__float_as_uint(m1[1])), s2b = rows32(__float_as_uint(m2[1]));     // tile 1
+            const float A1 = __uint_as_float(hf ? s1b.x : s1a.x), B1 = __uint_as_float(hf ? s1b.y : s1a.y);
+            const float A2 = __uint_as_float(hf ? s2b.x : s2a.x), B2 = __uint_as_float(hf ? s2b.y : s2a.y);
+            const float y0 = hf ? zv[1][0] : zv[0][0], y1 = hf ? zv[1][1] : zv[0][1];
+            const float y2 = hf ? zv[1][2] : zv[0][2], y3 = hf ? zv[1][3] : zv[0][3];
+            const int q = hf ? qs[1] : qs[0];
+            const bool valid = base + lane < N;
             const float yy = sumsq4(y0, y1, y2, y3);
-            const float mt = __builtin_fminf(__builtin_fminf(a1.x, a1.y), __builtin_fminf(a1.z, a1.w));
+            const float mts = __builtin_fminf(A1, B1);                      // scaled
+            const float mt = ldexpf(mts, -q);
             // S bounds ee_k + 2 sum|z_j e_kj| for every code that can matter: by the codebook maxima, and -- the winner
             // and every code that can beat it lie within sqrt(D) of z, D = zz + f_min + slack -- by
             // (|z| + sqrt D)^2 + 2 |z| (|z| + sqrt D); the smaller of the two (v_sqrt_f32 is good to 1 ulp: x 1.001)
             const float S0 = EEmax + 2.0f * Emax * (((fabsf(y0) + fabsf(y1)) + fabsf(y2)) + fabsf(y3));
-            const float M0 = 1.6e-5f * S0 + 2.5e-7f * yy + 1e-30f;
+            const float M0 = 1.3e-5f * S0 + 2.5e-7f * yy + 1e-30f;
             const float D = fmaxf(yy * 1.0001f + mt + 2.0f * M0, 0.f);
             const float nz = __builtin_amdgcn_sqrtf(yy) * 1.001f, sd = __builtin_amdgcn_sqrtf(D) * 1.001f;
             const float S1 = (nz + sd) * (3.0f * nz + sd);
             const float S = S1 < S0 ? S1 : S0;                  // (a NaN S1 keeps S0)
-            const float M = 1.6e-5f * S + 2.5e-7f * yy + 1e-30f;     // 1.2e-5: filter + reference rounding; 0.4e-5: the packed index
-            float thr = mt + M;
+            const float M = 1.3e-5f * S + 2.5e-7f * yy + 1e-30f;
+            // + 0.02 scaled units: pieces in fp16's subnormal range (5 x 2^-10 per score, both sides)
+            float thr = ldexpf(mt + M, q) + 0.02f;
             thr += fabsf(thr) * 2.4e-7f;
-            // anything not comparable (NaN / Inf anywhere above) must count as "flagged": test the negation
-            const bool h0 = !(a1.x > thr), h1 = !(a1.y > thr), h2 = !(a1.z > thr), h3 = !(a1.w > thr);   // best quad holds a candidate
-            const bool more = !(a2.x > thr) || !(a2.y > thr) || !(a2.z > thr) || !(a2.w > thr);        // ... and so does another quad
-            // settled iff exactly one hot row group and no second quad anywhere
-            const bool flag = valid && (((int)h0 + (int)h1 + (int)h2 + (int)h3) != 1 || more);
-            const int gw = h0 ? 0 : h1 ? 1 : h2 ? 2 : 3;
-            int bq = __float_as_int(gw == 0 ? a1.x : gw == 1 ? a1.y : gw == 2 ? a1.z : a1.w) & 15;     // the quad index packed by the scan
-            bq = valid && bq >= 0 && bq < (K >> 6) ? bq : 0;       // (idle lanes of the ZT < 4 instantiations read stale LDS)
-            // exact fp32 on the 16 codes of the winning (quad, row group); descending, the lowest index wins ties
+            // anything not comparable (NaN / Inf anywhere above) must count as a candidate: test the negation
+            const bool cA1 = !(A1 > thr), cB1 = !(B1 > thr);
+            const bool deep = !(A2 > thr) || !(B2 > thr);       // a second tile of one half is a candidate: a third may be too
+            const bool other = !(B1 < A1) ? cB1 : cA1;           // the half that does not hold the minimum has one as well
+            const bool flag = valid && (deep || (hf ? unscalable[1] : unscalable[0]) || !(cA1 || cB1));
+            const bool firstB = B1 < A1;                        // which half holds the minimum
+            auto tile_of = [&](float v) -> int {
+                int T = __float_as_int(v) & 31;
+                return T < ntile ? T : 0;
+            };
+            // exact fp32 on the 16 codes of the best (tile, row half); descending, the lowest index wins ties
             float d = __builtin_inff();
-            int wi = 0;
+            {
+                const int cb0 = 32 * tile_of(firstB ? B1 : A1) + (firstB ? 4 : 0);
+                const float4 *rb = cbs + rowpos(cb0);          // (a set stays inside one tile: same padding for all 16)
+                const float *eb = ees + eepos(cb0);
 #pragma unroll
-            for (int q = 15; q >= 0; --q) {
-                const int c = 64 * bq + 16 * (q >> 2) + 4 * gw + (q & 3);
-                const float dd = dist_row(y0, y1, y2, y3, yy, cbs[c], ees[c]);
-                const bool take = dd <= d;
-                d = take ? dd : d;
-                wi = take ? c : wi;
+                for (int r4 = 3; r4 >= 0; --r4) {
+                    const float4 en = *reinterpret_cast<const float4 *>(&eb[8 * r4]);
+#pragma unroll
+                    for (int r = 3; r >= 0; --r) {
+                        const int c = cb0 + 8 * r4 + r;
+                        const float dd = dist_row(y0, y1, y2, y3, yy, rb[8 * r4 + r], r == 0 ? en.x : r == 1 ? en.y : r == 2 ? en.z : en.w);
+                        const bool take = dd <= d;
+                        d = take ? dd : d;
+                        wi = take ? c : wi;
+                    }
+                }
+            }
+            // ... and on the other half's best tile where it is a candidate too (lexicographic merge)
+            if (__ballot(valid && other && !flag)) {
+                const int cb1 = 32 * tile_of(firstB ? A1 : B1) + (firstB ? 0 : 4);
+                const float4 *rb = cbs + rowpos(cb1);
+                const float *eb = ees + eepos(cb1);
+                const bool doit = other;
+#pragma unroll
+                for (int r4 = 3; r4 >= 0; --r4) {
+                    const float4 en = *reinterpret_cast<const float4 *>(&eb[8 * r4]);
+#pragma unroll
+                    for (int r = 3; r >= 0; --r) {
+                        const int c = cb1 + 8 * r4 + r;
+                        const float dd = dist_row(y0, y1, y2, y3, yy, rb[8 * r4 + r], r == 0 ? en.x : r == 1 ? en.y : r == 2 ? en.z : en.w);
+                        const bool take = doit && (dd < d || (dd == d && c < wi));
+                        d = take ? dd : d;
+                        wi = take ? c : wi;
+                    }
+                }
             }
             const unsigned long long fmask = __ballot(flag);               // one bit per vector, wave-uniform
             const int nflag = __builtin_popcountll(fmask);
-            if (nflag <= kVqfBulk) {
+            if (nflag != 0 && nflag <= kVqfBulk) {
                 // a few near-ties: the whole wave scans all K codes exactly for each such vector
                 unsigned long long todo = fmask;
                 while (todo) {
@@ -702,7 +793,7 @@ __device__ __forceinline__ void vq_filter_body(const VqArgs &a, unsigned char *s
                     int bi = 0;
 #pragma unroll 4
                     for (int c = K - 64 + lane; c >= 0; c -= 64) {       // descending: the lowest index wins ties
-                        const float dd = dist_row(s0, s1, s2, s3, ss, cbs[c], ees[c]);
+                        const float dd = dist_row(s0, s1, s2, s3, ss, cbs[rowpos(c)], ees[eepos(c)]);
                         const bool take = dd <= bd;
                         bd = take ? dd : bd;
                         bi = take ? c : bi;
@@ -717,83 +808,89 @@ __device__ __forceinline__ void vq_filter_body(const VqArgs &a, unsigned char *s
                     }
                     wi = lane == v ? bi : wi;
                 }
-                // back to the (column, row group) layout of the outputs
-                int *tw = reinterpret_cast<int *>(tb + 1024);
-                tw[lane] = wi;
-#pragma unroll
-                for (int t = 0; t < ZT; ++t) win[t] = tw[t * 16 + j];
-            } else {
+            } else if (nflag != 0) {
                 // many near-ties (degenerate codebooks, zz >> ee, non-finite input): the exact fp32-MFMA scan of
-                // vq_mfma_body for the whole group, operands from the fp32 rows in LDS
-                float z0[ZT], z1[ZT], z2[ZT], z3[ZT], zz[ZT], best[ZT];
-                int bt2[ZT];
+                // vq_mfma_body for the whole group.  Vector 16 tt + col of the group sits in lane 16 tt + col;
+                // the 16x16x4 MFMA wants z[vector 16 tt + (lane & 15)][k = lane >> 4] as its B operand.
+                const int col = lane & 15, g4 = lane >> 4;
+                float zb4[4], z0[4], z1[4], z2[4], z3[4], zz[4], best[4];
+                int bt2[4];
 #pragma unroll
-                for (int t = 0; t < ZT; ++t) {
-                    const uint2 eo = rows16(__float_as_uint(zv[t]));         // (z0,z0,z2,z2) / (z1,z1,z3,z3)
-                    const uint2 e = rows32(eo.x), o = rows32(eo.y);
-                    z0[t] = __uint_as_float(e.x); z2[t] = __uint_as_float(e.y);
-                    z1[t] = __uint_as_float(o.x); z3[t] = __uint_as_float(o.y);
-                    zz[t] = sumsq4(z0[t], z1[t], z2[t], z3[t]);
-                    best[t] = __builtin_inff();
-                    bt2[t] = 0;
+                for (int tt = 0; tt < 4; ++tt) {
+                    const int src = 16 * tt + col;
+                    z0[tt] = __shfl(y0, src, kWave); z1[tt] = __shfl(y1, src, kWave);
+                    z2[tt] = __shfl(y2, src, kWave); z3[tt] = __shfl(y3, src, kWave);
+                    zb4[tt] = g4 == 0 ? z0[tt] : g4 == 1 ? z1[tt] : g4 == 2 ? z2[tt] : z3[tt];
+                    zz[tt] = sumsq4(z0[tt], z1[tt], z2[tt], z3[tt]);
+                    best[tt] = __builtin_inff();
+                    bt2[tt] = 0;
                 }
-                for (int ct = 0; ct < ntile; ++ct) {
-                    const float av = reinterpret_cast<const float *>(cbs)[(16 * ct + j) * 4 + g];
-                    const f32x4 e4 = *reinterpret_cast<const f32x4 *>(&ees[16 * ct + 4 * g]);
+                for (int ct = 0; ct < (K >> 4); ++ct) {
+                    const float av = reinterpret_cast<const float *>(cbs)[rowpos(16 * ct + col) * 4 + g4];
+                    const f32x4 e4 = *reinterpret_cast<const f32x4 *>(&ees[eepos(16 * ct + 4 * g4)]);
 #pragma unroll
-                    for (int t = 0; t < ZT; ++t) {
+                    for (int tt = 0; tt < 4; ++tt) {
                         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-                        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av, zv[t], acc, 0, 0, 0);
-                        const float d0 = __builtin_fmaf(-2.0f, acc[0], zz[t] + e4[0]);
-                        const float d1 = __builtin_fmaf(-2.0f, acc[1], zz[t] + e4[1]);
-                        const float d2 = __builtin_fmaf(-2.0f, acc[2], zz[t] + e4[2]);
-                        const float d3 = __builtin_fmaf(-2.0f, acc[3], zz[t] + e4[3]);
-                        const float q1 = __builtin_fminf(__builtin_fminf(best[t], d0), d1);
+                        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av, zb4[tt], acc, 0, 0, 0);
+                        const float d0 = __builtin_fmaf(-2.0f, acc[0], zz[tt] + e4[0]);
+                        const float d1 = __builtin_fmaf(-2.0f, acc[1], zz[tt] + e4[1]);
+                        const float d2 = __builtin_fmaf(-2.0f, acc[2], zz[tt] + e4[2]);
+                        const float d3 = __builtin_fmaf(-2.0f, acc[3], zz[tt] + e4[3]);
+                        const float q1 = __builtin_fminf(__builtin_fminf(best[tt], d0), d1);
                         const float q2 = __builtin_fminf(__builtin_fminf(q1, d2), d3);
-                        bt2[t] = q2 < best[t] ? ct : bt2[t];
-                        best[t] = q2;
+                        bt2[tt] = q2 < best[tt] ? ct : bt2[tt];
+                        best[tt] = q2;
                     }
                 }
+                int w16[4];
 #pragma unroll
-                for (int t = 0; t < ZT; ++t) {
-                    const int c0 = 16 * bt2[t] + 4 * g;
-                    float dq = best[t];
+                for (int tt = 0; tt < 4; ++tt) {
+                    const int c0 = 16 * bt2[tt] + 4 * g4;
+                    float dq = best[tt];
                     int i = c0;
 #pragma unroll
                     for (int r = 3; r >= 0; --r)
-                        i = dist_row(z0[t], z1[t], z2[t], z3[t], zz[t], cbs[c0 + r], ees[c0 + r]) == dq ? c0 + r : i;
+                        i = dist_row(z0[tt], z1[tt], z2[tt], z3[tt], zz[tt], cbs[rowpos(c0 + r)], ees[eepos(c0 + r)]) == dq ? c0 + r : i;
                     colargmin(dq, i);
-                    win[t] = i;
+                    w16[tt] = i;
                 }
+                // lane 16 tt + col holds all four tiles' results for its own column: pick its tile
+                wi = g4 == 0 ? w16[0] : g4 == 1 ? w16[1] : g4 == 2 ? w16[2] : w16[3];
             }
         }
         CGIC_STAMP(4);
 
-        // ---- outputs: this lane owns channel g of vector n
-        double sq = 0.0;
+        // ---- outputs: lane (column j, half hf) owns channels 2 hf, 2 hf + 1 of vector (tile t, column j); lane L the
+        // index of vector L
+        if (idx_out && base + lane < N) idx_out[base + lane] = (int64_t)wi;
+        if (zq_out || a.sq_partial) {
+            const uint2 wt = rows32((unsigned int)wi);           // .x: tile 0's winners (lanes 0..31), .y: tile 1's
+            int64_t gb = 0, gp0 = 0;
+            if (ALIGNED) origin(grp, &gb, &gp0);
 #pragma unroll
-        for (int t = 0; t < ZT; ++t) {
-            const int64_t n = base + 16 * t + j;
-            if (n < N) {
-                if (zq_out || a.sq_partial) {
-                    const float e = reinterpret_cast<const float *>(cbs)[win[t] * 4 + g];
-                    const float diff = e - zv[t];
+            for (int t = 0; t < 2; ++t) {
+                const int w = (int)(t ? wt.y : wt.x);
+                const float2 e = *reinterpret_cast<const float2 *>(reinterpret_cast<const float *>(cbs) + rowpos(w) * 4 + 2 * hf);
+                const float za = hf ? zv[t][2] : zv[t][0], zb = hf ? zv[t][3] : zv[t][1];
+                const float da = e.x - za, db = e.y - zb;
+                const int64_t n = base + 32 * t + j;
+                if (ALIGNED || n < N) {
                     if (zq_out) {
-                        int64_t b, p;
-                        locate(gb, gp, t, &b, &p);
-                        zq_out[(b * 4 + g) * hw + p] = zv[t] + diff;
+                        if (ALIGNED) {
+                            float *qb = zq_out + (gb * 4 * hw + gp0 + 32 * t) + out_off;
+                            qb[0] = za + da;
+                            qb[hw] = zb + db;
+                        } else {
+                            int64_t b, p;
+                            divmod(n, &b, &p);
+                            zq_out[(b * 4 + 2 * hf) * hw + p] = za + da;
+                            zq_out[(b * 4 + 2 * hf + 1) * hw + p] = zb + db;
+                        }
                     }
-                    sq += (double)diff * (double)diff;
+                    sq += (double)da * (double)da;
+                    sq += (double)db * (double)db;
                 }
-                if (g == 0 && idx_out) idx_out[n] = (int64_t)win[t];
             }
-        }
-        if (a.sq_partial) {
-            // one partial per GROUP (not per wave), parked in LDS: whichever wave took the group, the workgroup's sum
-            // has the same operands in the same order.  Fixed shuffle tree.
-#pragma unroll
-            for (int off = 32; off > 0; off >>= 1) sq += __shfl_down(sq, off, kWave);
-            if (lane == 0) gsum[grp - blk_lo] = sq;
         }
     }
 
@@ -802,13 +899,13 @@ __device__ __forceinline__ void vq_filter_body(const VqArgs &a, unsigned char *s
         // Only wave 0 stays for the hand-off: the other waves leave at the barrier WITHOUT draining their z_q /
         // index stores (an s_waitcnt vmcnt(0) in every wave before the barrier cost ~4 us at the end of every
         // workgroup); wave 0's own stores are long complete by the time it has waited for the others.
+        sq = wave_sum_f64(sq);              // fixed association, on the VALU
+        if (lane == 0) s_wsum[wave] = sq;
         __syncthreads();
         if (wave == 0) {
-            const int ng = (int)(blk_hi - blk_lo);
             double bs = 0.0;
-            for (int i = lane; i < ng; i += kWave) bs += gsum[i];
 #pragma unroll
-            for (int off = 32; off > 0; off >>= 1) bs += __shfl_down(bs, off, kWave);
+            for (int w = 0; w < NW; ++w) bs += s_wsum[w];
             finish_loss_wave(bs, a.sq_partial, a.ticket, (double)N * 4.0, a.beta, a.legacy, a.loss, vblk, a.nblk);
         }
     }
@@ -816,42 +913,44 @@ __device__ __forceinline__ void vq_filter_body(const VqArgs &a, unsigned char *s
     CGIC_BLK_END();
 }
 
-template <int ZT>
-__global__ __launch_bounds__(kVqfThreads, 1) void vq_filter_kernel(VqArgs a)
+#ifndef CGIC_VQF_THREADS
+#define CGIC_VQF_THREADS 768
+#endif
+constexpr int kVqfThreads = CGIC_VQF_THREADS;      // one workgroup per CU, 3 waves per SIMD (measured at B=64 x 64x64 latents: 512 threads 23.7 us, 768 22.8, 1024 22.9)
+#define CGIC_VQF_BOUNDS __launch_bounds__(kVqfThreads, kVqfThreads / 256 > 1 ? kVqfThreads / 256 : 1)
+
+template <bool ALIGNED>
+__global__ CGIC_VQF_BOUNDS void vq_filter_kernel(VqArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_f[];
-    vq_filter_body<ZT>(a, smem_f, blockIdx.x);
+    vq_filter_body<kVqfThreads, ALIGNED>(a, smem_f, blockIdx.x);
 }
 
-// The fused launch of the filter path (see vq_router_kernel).  A VQ workgroup takes the CU's LDS (84 KB) and
-// 2 x 166 VGPRs per SIMD, and dynamic LDS / the VGPR budget are per launch, so a router workgroup cannot share a CU
-// with one: behind the VQ workgroups it only starts when the VQ is over (30.4 + ~11 us).  The router workgroups
-// therefore come FIRST (`nrouter` of them, one CU each for ~11 us); the VQ workgroups that have to wait for those
-// CUs own fewer groups, the others more -- in steps of 4 groups, the unit in which a workgroup's time grows (8
-// waves, 2 per SIMD).  Measured alternatives at B=64: an evenly balanced uneven split (18 / 11 groups) 43.2 us,
-// 8-byte A operands + a 128-VGPR build so that both kinds share a CU 47.6 (two VQ workgroups then also share
-// CUs), a device-wide chunk queue 46.3, the router on a forked graph branch +9 us per step.
-template <int ZT>
-__global__ __launch_bounds__(kVqfThreads, 1) void vq_filter_router_kernel(VqArgs a, RouterArgs r, unsigned int nrouter)
+// The fused launch of the filter path (see vq_router_kernel).  A VQ workgroup takes most of a CU's register file, and
+// dynamic LDS / the VGPR budget are per launch, so a router workgroup does not share a CU with one: behind the VQ
+// workgroups it only starts when the VQ is over.  The router workgroups therefore come FIRST (`nrouter` of them, one CU
+// each for ~11 us); the VQ workgroups that have to wait for those CUs own fewer groups, the others more.
+template <bool ALIGNED>
+__global__ CGIC_VQF_BOUNDS void vq_filter_router_kernel(VqArgs a, RouterArgs r, unsigned int nrouter)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_f[];
     if (blockIdx.x < nrouter) {
         router_body<kVqfThreads>(r, (int64_t)blockIdx.x, smem_f);
         return;
     }
-    vq_filter_body<ZT>(a, smem_f, blockIdx.x - nrouter);
+    vq_filter_body<kVqfThreads, ALIGNED>(a, smem_f, blockIdx.x - nrouter);
 }
 
 // the same with the router workgroups BEHIND the VQ workgroups (when every VQ workgroup gets a CU at once anyway)
-template <int ZT>
-__global__ __launch_bounds__(kVqfThreads, 1) void vq_filter_router_behind_kernel(VqArgs a, RouterArgs r)
+template <bool ALIGNED>
+__global__ CGIC_VQF_BOUNDS void vq_filter_router_behind_kernel(VqArgs a, RouterArgs r)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_f[];
     if (blockIdx.x >= a.nblk) {
         router_body<kVqfThreads>(r, (int64_t)(blockIdx.x - a.nblk), smem_f);
         return;
     }
-    vq_filter_body<ZT>(a, smem_f, blockIdx.x);
+    vq_filter_body<kVqfThreads, ALIGNED>(a, smem_f, blockIdx.x);
 }
 
 // Plain-VALU restatement: one latent vector per thread, codebook broadcast from
@@ -957,6 +1056,8 @@ static int vq_check(const float *z, int64_t B, int64_t hw, const float *cb, int 
     return CGIC_OK;
 }
 
+static int ensure_dynamic_lds(const void *fn, size_t bytes);
+
 struct VqWs {
     unsigned int *ticket;   // library-owned, self-resetting
     double *partial;        // caller's workspace: double partial[nblk]
@@ -982,12 +1083,14 @@ static int launch_mfma(const float *z, int64_t hw, int64_t N, const float *cb, i
     a.nblk = (unsigned int)((N + per_block - 1) / per_block);
     size_t lds = sizeof(float) * (size_t)K * 5;
     if (!router) {
+        int rc = ensure_dynamic_lds((const void *)vq_mfma_kernel<ZT>, lds);
+        if (rc) return rc;
         hipLaunchKernelGGL(vq_mfma_kernel<ZT>, dim3(a.nblk), dim3(kVqThreads), lds, s, a);
         return launch_check("vq_mfma_kernel");
     }
     if (router_lds > lds) lds = router_lds;
-    if (lds > 64 * 1024)
-        CGIC_HIP_TRY(hipFuncSetAttribute((const void *)vq_router_kernel<ZT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    int rc = ensure_dynamic_lds((const void *)vq_router_kernel<ZT>, lds);
+    if (rc) return rc;
     hipLaunchKernelGGL(vq_router_kernel<ZT>, dim3(a.nblk + (unsigned int)router_blocks), dim3(kVqThreads), lds, s, a, *router);
     return launch_check("vq_router_kernel");
 }
@@ -1009,7 +1112,29 @@ static int device_cu_count(int *out)
     return CGIC_OK;
 }
 
-template <int ZT>
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per (function, device) and size -- not on every launch
+static int ensure_dynamic_lds(const void *fn, size_t bytes)
+{
+    static std::mutex mu;
+    static std::map<std::pair<const void *, int>, size_t> done;
+    int dev = 0;
+    CGIC_HIP_TRY(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lock(mu);
+    size_t &have = done[std::make_pair(fn, dev)];
+    if (bytes > have) {
+        CGIC_HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+        have = bytes;
+    }
+    return CGIC_OK;
+}
+
+#ifdef CGIC_DEV_KNOBS
+static int dev_knob(const char *name) { const char *v = getenv(name); return v ? atoi(v) : 0; }
+#else
+static int dev_knob(const char *) { return 0; }      // the environment knobs exist in `make dbg` builds only
+#endif
+
+template <bool ALIGNED>
 static int launch_filter(const float *z, int64_t hw, int64_t N, const float *cb, int K, int64_t *idx, float *zq,
                          VqWs ws, float beta, int legacy, float *loss, hipStream_t s, const RouterArgs *router,
                          int64_t router_blocks, size_t router_lds)
@@ -1017,24 +1142,22 @@ static int launch_filter(const float *z, int64_t hw, int64_t N, const float *cb,
     int cus = 0;
     int rc = device_cu_count(&cus);
     if (rc) return rc;
-    const int64_t ngroups = (N + 16 * ZT - 1) / (16 * ZT);
-    int64_t nblk = (ngroups + kVqfWaves - 1) / kVqfWaves;
-    if (nblk > cus) nblk = cus;                      // one resident workgroup per CU; waves take groups from a counter
-    const int64_t kMaxGroups = 6144;                 // per workgroup: 8 bytes of LDS each for the loss partials
-    if ((ngroups + nblk - 1) / nblk > kMaxGroups) nblk = (ngroups + kMaxGroups - 1) / kMaxGroups;
+    const int64_t ngroups = (N + kVqfGroup - 1) / kVqfGroup;
+    // one resident workgroup per CU; its waves take groups from a counter.  Fewer groups than CUs x waves: spread them
+    // over the CUs first (a small batch then costs one staging + one group per CU, whatever the waves per workgroup)
+    int64_t nblk = ngroups < cus ? ngroups : cus;
     VqArgs a;
     a.z = z; a.hw = hw; a.N = N; a.cb = cb; a.K = K; a.idx_out = idx; a.zq_out = zq;
     a.sq_partial = loss ? ws.partial : nullptr; a.ticket = ws.ticket; a.beta = beta; a.legacy = legacy; a.loss = loss;
     a.nblk = (unsigned int)nblk;
     // groups per workgroup.  Router workgroups in front: the `late` VQ workgroups that must wait for a router's CU
-    // (~11 us at 256x256, ~0.0021 * hw groups of VQ work) own `g_late` groups, the others `g_early`, a multiple of 4
+    // (~11 us at 256x256, ~`delta` groups of VQ work) own `g_late` groups, the others `g_early`, a multiple of 4
     int64_t per = (ngroups + nblk - 1) / nblk, g_early = per, g_late = per, n_early = nblk;
-    static const int split_off = getenv("CGIC_VQ_NOSPLIT") ? atoi(getenv("CGIC_VQ_NOSPLIT")) : 0;    // dev: A/B
     const int64_t late = router ? nblk + router_blocks - cus : 0;
     bool router_first = false;
-    if (late > 0 && late < nblk && !split_off) {
-        const int64_t delta = (int64_t)(0.0021 * (double)hw * (4.0 / ZT) + 0.5);
-        static const int force_ge = getenv("CGIC_VQ_GE") ? atoi(getenv("CGIC_VQ_GE")) : 0;     // dev: tuning
+    if (late > 0 && late < nblk && !dev_knob("CGIC_VQ_NOSPLIT")) {
+        const int64_t delta = (int64_t)(0.0021 * (double)hw + 0.5);
+        const int force_ge = dev_knob("CGIC_VQ_GE");
         for (int64_t ge = force_ge ? force_ge : (per / 4 + 1) * 4; ge <= per + 12; ge += 4) {
             const int64_t rest = ngroups - (nblk - late) * ge;
             const int64_t gl = rest > 0 ? (rest + late - 1) / late : 0;
@@ -1043,21 +1166,23 @@ static int launch_filter(const float *z, int64_t hw, int64_t N, const float *cb,
         }
     }
     a.n_early = (unsigned int)n_early; a.g_early = (unsigned int)g_early; a.g_late = (unsigned int)g_late;
-    const int64_t gmax = g_early > g_late ? g_early : g_late;
-    size_t lds = (size_t)K * 84 + (size_t)kVqfWaves * kVqfTbFloats * 4 + (loss ? 8 * (size_t)gmax : 0);
+    size_t lds = vqf_lds_bytes(K);
     if (!router) {
-        CGIC_HIP_TRY(hipFuncSetAttribute((const void *)vq_filter_kernel<ZT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(vq_filter_kernel<ZT>, dim3(a.nblk), dim3(kVqfThreads), lds, s, a);
+        rc = ensure_dynamic_lds((const void *)vq_filter_kernel<ALIGNED>, lds);
+        if (rc) return rc;
+        hipLaunchKernelGGL(vq_filter_kernel<ALIGNED>, dim3(a.nblk), dim3(kVqfThreads), lds, s, a);
         return launch_check("vq_filter_kernel");
     }
     if (router_lds > lds) lds = router_lds;
-    CGIC_HIP_TRY(hipFuncSetAttribute((const void *)vq_filter_router_kernel<ZT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     if (router_first) {
-        hipLaunchKernelGGL(vq_filter_router_kernel<ZT>, dim3(a.nblk + (unsigned int)router_blocks), dim3(kVqfThreads), lds, s, a, *router,
+        rc = ensure_dynamic_lds((const void *)vq_filter_router_kernel<ALIGNED>, lds);
+        if (rc) return rc;
+        hipLaunchKernelGGL(vq_filter_router_kernel<ALIGNED>, dim3(a.nblk + (unsigned int)router_blocks), dim3(kVqfThreads), lds, s, a, *router,
                            (unsigned int)router_blocks);
     } else {
-        CGIC_HIP_TRY(hipFuncSetAttribute((const void *)vq_filter_router_behind_kernel<ZT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(vq_filter_router_behind_kernel<ZT>, dim3(a.nblk + (unsigned int)router_blocks), dim3(kVqfThreads), lds, s, a, *router);
+        rc = ensure_dynamic_lds((const void *)vq_filter_router_behind_kernel<ALIGNED>, lds);
+        if (rc) return rc;
+        hipLaunchKernelGGL(vq_filter_router_behind_kernel<ALIGNED>, dim3(a.nblk + (unsigned int)router_blocks), dim3(kVqfThreads), lds, s, a, *router);
     }
     return launch_check("vq_filter_router_kernel");
 }
@@ -1066,19 +1191,14 @@ static int vq_dispatch(const float *z, int64_t hw, int64_t N, const float *codeb
                        VqWs ws, float beta, int legacy, float *loss, hipStream_t s, const RouterArgs *router,
                        int64_t router_blocks, size_t router_lds)
 {
-    // per-wave tile: measured on MI355X (tools/probe_vq.hip) ZT=4 at 4 waves/SIMD is the fastest
-    // for large N; smaller N shrinks the tile so that all 256 CUs get work
-    static const int force_zt = getenv("CGIC_VQ_ZT") ? atoi(getenv("CGIC_VQ_ZT")) : 0;     // tuning knob (dev)
-    static const int exact_only = getenv("CGIC_VQ_EXACT") ? atoi(getenv("CGIC_VQ_EXACT")) : 0;   // dev: A/B against the exact loop
-    if (!exact_only && K % 64 == 0 && K <= kVqfMaxK) {
-#define CGIC_VQF_LAUNCH(ZT) launch_filter<ZT>(z, hw, N, codebook, K, indices, z_q, ws, beta, legacy, loss, s, router, router_blocks, router_lds)
-        if (force_zt == 2) return CGIC_VQF_LAUNCH(2);
-        if (force_zt == 1) return CGIC_VQF_LAUNCH(1);
-        if (force_zt == 4 || N >= (int64_t)128 * 1024) return CGIC_VQF_LAUNCH(4);
-        if (N >= (int64_t)64 * 1024) return CGIC_VQF_LAUNCH(2);
-        return CGIC_VQF_LAUNCH(1);
-#undef CGIC_VQF_LAUNCH
+    const int force_zt = dev_knob("CGIC_VQ_ZT");          // dev: tile count of the exact loop
+    if (!dev_knob("CGIC_VQ_EXACT") && K % 64 == 0 && K <= kVqfMaxK) {
+        if (hw % kVqfGroup == 0)
+            return launch_filter<true>(z, hw, N, codebook, K, indices, z_q, ws, beta, legacy, loss, s, router, router_blocks, router_lds);
+        return launch_filter<false>(z, hw, N, codebook, K, indices, z_q, ws, beta, legacy, loss, s, router, router_blocks, router_lds);
     }
+    // exact loop; per-wave tile: measured on MI355X (tools/probe_vq.hip) ZT=4 at 4 waves/SIMD is the fastest
+    // for large N; smaller N shrinks the tile so that all 256 CUs get work
 #define CGIC_VQ_LAUNCH(ZT) launch_mfma<ZT>(z, hw, N, codebook, K, indices, z_q, ws, beta, legacy, loss, s, router, router_blocks, router_lds)
     if (force_zt == 8) return CGIC_VQ_LAUNCH(8);
     if (force_zt == 4) return CGIC_VQ_LAUNCH(4);
@@ -1156,6 +1276,8 @@ extern "C" int cgic_vq_forward_valu_f32(const float *z, int64_t B, int64_t hw, c
     if (rc) return rc;
     int nblk = (int)((N + kVqThreads - 1) / kVqThreads);
     size_t lds = sizeof(float) * (size_t)K * 5;
+    rc = ensure_dynamic_lds((const void *)vq_valu_kernel, lds);
+    if (rc) return rc;
     hipLaunchKernelGGL(vq_valu_kernel, dim3(nblk), dim3(kVqThreads), lds, s, z, hw, N, codebook, K, indices, z_q,
                        loss ? ws.partial : nullptr, ws.ticket, beta, legacy, loss);
     rc = launch_check("vq_valu_kernel");
