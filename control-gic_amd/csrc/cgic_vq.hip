@@ -976,8 +976,11 @@ __global__ __launch_bounds__(kVqThreads) void vq_valu_kernel(
         const float *zp = z + b * 4 * hw + p;
         float z0 = zp[0], z1 = zp[hw], z2 = zp[2 * hw], z3 = zp[3 * hw];
         float zz = sumsq4(z0, z1, z2, z3);
-        float best = 0.f;
+        // lowest index among the minimal distances; a NaN distance never wins (index 0 if every distance is NaN) -- the
+        // same rule as the exact scans of the filter path (torch.argmin would return the first NaN: see cgic_hip.h)
+        float best = __builtin_inff();
         int bi = 0;
+        bool any = false;
         for (int k = 0; k < K; ++k) {
             float4 e = cbs[k];
             float mm = z0 * e.x;
@@ -986,7 +989,8 @@ __global__ __launch_bounds__(kVqThreads) void vq_valu_kernel(
             mm = __builtin_fmaf(z3, e.w, mm);
             float s = zz + ee[k];
             float d = __builtin_fmaf(-2.0f, mm, s);
-            bool take = k == 0 || d < best;
+            bool take = d == d && (!any || d < best);
+            any = any || d == d;
             best = take ? d : best;
             bi = take ? k : bi;
         }

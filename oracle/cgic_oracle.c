@@ -102,6 +102,25 @@ int cgic_oracle_vq(const float *z, long B, int C, long hw, const float *cb, int 
     return 0;
 }
 
+/* The distance row of ONE latent vector against the whole codebook, same rounding sequence as
+ * cgic_oracle_vq (quantize.py:73-75).  Test infrastructure for the adversarial near-tie tests: lets a
+ * test search codebook perturbations whose reference distances differ by exactly 0, 1, 2 ulp. */
+int cgic_oracle_vq_distances(const float *zvec, int C, const float *cb, int K, float *d_out)
+{
+    if (K <= 0 || K > CGIC_K_MAX || C <= 0) return -1;
+    float zz = sumsq_row(zvec, C, 1);
+    for (int k = 0; k < K; ++k) {
+        const float *e = cb + (long)k * C;
+        float ee = sumsq_row(e, C, 1);
+        float mm = zvec[0] * e[0];
+        for (int c = 1; c < C; ++c) mm = fmaf(zvec[c], e[c], mm);
+        float a = zz + ee;
+        float t = 2.0f * mm;
+        d_out[k] = a - t;
+    }
+    return 0;
+}
+
 /* ------------------------------------------------------------------------- *
  * C'. Entropy maps: CGIC/models/model.py:433-483
  *   gray = 0.2989 R + 0.5870 G + 0.1140 B                      (:471)

@@ -59,6 +59,17 @@ def vq(z, codebook, beta=0.25, legacy=True, hist=None):
     return zq, np.float32(loss.value), idx
 
 
+def vq_distances(zvec, codebook):
+    """reference distance row d[k] of one latent vector [C] against codebook [K,C] (quantize.py:73-75 rounding sequence)"""
+    zv = np.ascontiguousarray(zvec, np.float32)
+    cb = np.ascontiguousarray(codebook, np.float32)
+    d = np.empty(cb.shape[0], np.float32)
+    rc = lib().cgic_oracle_vq_distances(_p(zv, C.c_float), C.c_int(cb.shape[1]), _p(cb, C.c_float), C.c_int(cb.shape[0]), _p(d, C.c_float))
+    if rc:
+        raise RuntimeError(f"cgic_oracle_vq_distances rc={rc}")
+    return d
+
+
 def linspace_bins():
     """torch.linspace(-1, 1, 32) fp32 values (model.py:480), restated:
     step=(end-start)/(steps-1) in fp32; first half start+i*step, second half end-(steps-1-i)*step."""
