@@ -113,6 +113,30 @@ __global__ __launch_bounds__(256) void decoder_blend_kernel(
     }
 }
 
+// medium blend for widths that are even but not multiples of 4 (a 272-px tile column of the 2K path gives a
+// 34-wide medium grid): one thread = 2 consecutive x = one coarse-mask element
+__global__ __launch_bounds__(256) void decoder_blend_medium2_kernel(
+    const float *__restrict__ hin, const float *__restrict__ own, const int32_t *__restrict__ m0,
+    const int32_t *__restrict__ m1, int64_t B, int C, int64_t h, int64_t w, float *__restrict__ out)
+{
+    const int64_t wh = w >> 1;
+    const int64_t total = B * C * h * wh;
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t xh = t % wh, r = t / wh;
+        const int64_t y = r % h, bc = r / h;
+        const int64_t b = bc / C;
+        const int64_t x = xh << 1;
+        const float2 hv = *reinterpret_cast<const float2 *>(&hin[(bc * h + y) * w + x]);
+        const float2 ov = *reinterpret_cast<const float2 *>(&own[(bc * h + y) * w + x]);
+        const float q0 = (float)m0[(b * (h >> 1) + (y >> 1)) * wh + xh];
+        const int2 q1 = *reinterpret_cast<const int2 *>(&m1[(b * h + y) * w + x]);
+        float2 o;
+        o.x = hv.x * q0 + ov.x * (float)q1.x;
+        o.y = hv.y * q0 + ov.y * (float)q1.y;
+        *reinterpret_cast<float2 *>(&out[(bc * h + y) * w + x]) = o;
+    }
+}
+
 }  // namespace cgic
 
 using namespace cgic;
@@ -156,8 +180,15 @@ extern "C" int cgic_decoder_blend_medium_f32(const float *h, const float *h_medi
                                              int64_t B, int C, int64_t hh, int64_t ww, float *out, cgic_stream_t stream)
 {
     CGIC_REQUIRE(h && h_medium && mask_c && mask_m && out, CGIC_ERR_INVALID, "decoder_blend_medium: NULL tensor");
-    CGIC_REQUIRE(B >= 0 && C > 0 && hh > 0 && ww > 0 && hh % 2 == 0 && ww % 4 == 0, CGIC_ERR_INVALID,
-                 "decoder_blend_medium: medium grid %lldx%lld (need even height, width %% 4 == 0)", (long long)hh, (long long)ww);
+    CGIC_REQUIRE(B >= 0 && C > 0 && hh > 0 && ww > 0 && hh % 2 == 0 && ww % 2 == 0, CGIC_ERR_INVALID,
+                 "decoder_blend_medium: medium grid %lldx%lld (need even height and width)", (long long)hh, (long long)ww);
+    if (ww % 4 != 0) {
+        const int64_t total2 = B * C * hh * (ww >> 1);
+        if (total2 == 0) return CGIC_OK;
+        hipLaunchKernelGGL(decoder_blend_medium2_kernel, dim3(stream_grid(total2)), dim3(256), 0, (hipStream_t)stream, h, h_medium,
+                           mask_c, mask_m, B, C, hh, ww, out);
+        return launch_check("decoder_blend_medium2_kernel");
+    }
     const int64_t total = B * C * hh * (ww >> 2);
     if (total == 0) return CGIC_OK;
     hipLaunchKernelGGL(decoder_blend_kernel<false>, dim3(stream_grid(total)), dim3(256), 0, (hipStream_t)stream, h, h_medium, mask_c,

@@ -89,10 +89,24 @@ def _codec_for(model, h_indices=None):
 
 def compress_batch(model, input, h_indices=None, decode=True):
     """batched CGIC.compress (model.py:206-401): -> (dec [B,3,H,W] or None, bpp list[B], CompressedBatch).
-    Every image is routed on its own thresholds (install() configures the router that way)."""
+    Every image is routed on its own thresholds (what B independent B=1 calls of the reference give)."""
     assert len(input.shape) == 4                                         # model.py:207
     codec = _codec_for(model, h_indices)
-    quant, diff, grain_indices, grain_mask, ind, _, mode = model.encode(input)
+    # "B independent B=1 calls": every image routed on its own thresholds, whatever the router's batch semantics
+    # for encode()/forward() are (the reference flattens the batch, RouterTriple.py:21-31)
+    rc = getattr(model.encoder, "router_config", None)
+    params = rc.get("params") if isinstance(rc, dict) or hasattr(rc, "get") else None
+    saved = params.get("per_image", None) if params is not None else None
+    if params is not None:
+        params["per_image"] = True
+    try:
+        quant, diff, grain_indices, grain_mask, ind, _, mode = model.encode(input)
+    finally:
+        if params is not None:
+            if saved is None:
+                params.pop("per_image", None)
+            else:
+                params["per_image"] = saved
     comp = codec.compress(ind, grain_mask, mode)
     bpp = comp.bpp(input.shape[2] * input.shape[3])                      # model.py:223,233
     dec = None
@@ -117,8 +131,10 @@ def compress(self, input, path, h_indices=None, h_mask=None, save_img=False):
     return dec, bpp[0], None
 
 
-def install(model, per_image=True):
-    """swap VectorQuantize2 / Entropy / router target / compress of a reference CGIC instance in place"""
+def install(model, per_image=False):
+    """swap VectorQuantize2 / Entropy / router target / compress of a reference CGIC instance in place.
+    per_image=False keeps the reference's routing for encode() / forward() / training (thresholds over the flattened
+    batch, RouterTriple.py:21-31); compress_batch / compress / the tiling driver always route per image."""
     old = model.quantize
     dev = old.embedding.weight.device
     q = VectorQuantize2(old.n_e, old.e_dim, beta=old.beta, legacy=getattr(old, "legacy", True))

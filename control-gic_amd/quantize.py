@@ -183,6 +183,8 @@ class VectorQuantize2(nn.Module):
             self.usage_hist.zero_()
 
     def forward(self, z):
+        if z.dtype != torch.float32:
+            z = z.float()                   # (autocast regions hand over fp16 / bf16: the reference quantises in fp32)
         hist = self.usage_hist if self.training else None
         if torch.is_grad_enabled() and (z.requires_grad or self.embedding.weight.requires_grad):
             z_q, loss, idx = _VQFunction.apply(z, self.embedding.weight, self.beta, self.legacy, hist)

@@ -4,7 +4,8 @@ synthetic images, sharded round-robin over the ranks of one node, ONE RCCL all-r
 histogram at the end and a 2-scalar reduction for the dataset-average bpp.
 
     python examples/mixed_stream.py                       # 1 GPU
-    python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 examples/mixed_stream.py
+    python examples/mixed_stream.py --gpus 8              # spawns the 8 ranks itself (one per GPU, RCCL)
+    python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 examples/mixed_stream.py --gpus 8
 
 The conv encoder of the codec is out of scope: `encode()` below stands in for it with a cheap deterministic
 latent (average-pooled image channels), then runs the real hot path: entropy maps -> [VQ + per-tile router]
@@ -23,15 +24,20 @@ from control_gic_amd import container, dist as cdist, highres                   
 from control_gic_amd.quantize import vq_forward_route                              # noqa: E402
 
 
-def main():
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
+def run(rank, world, expect_world=None):
+    local = int(os.environ.get("LOCAL_RANK", str(rank)))
+    if torch.cuda.device_count() <= local:
+        raise SystemExit(f"mixed_stream: rank {rank} needs GPU {local}, {torch.cuda.device_count()} visible")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if "RANK" in os.environ:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.distributed.init_process_group("nccl", device_id=dev)
+        os.environ.setdefault("MASTER_PORT", "29511")
+        torch.distributed.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        joined = torch.ones(1, dtype=torch.int64, device=dev)
+        torch.distributed.all_reduce(joined)
+        if int(joined.item()) != world:
+            raise SystemExit(f"mixed_stream: {int(joined.item())} ranks joined the communicator, expected {world}")
 
     sizes = [(512, 768)] * 6 + [(1356, 2040)] * 2 + [(512, 768)] * 6 + [(1356, 2040)] * 2      # (H, W) stream order
     vq = cg.VectorQuantizer(1024, 4, beta=0.25).to(dev).eval()
@@ -48,7 +54,7 @@ def main():
         cg._lib.call("cgic_index_histogram", ind.data_ptr(), ind.numel(), 1024, hist.data_ptr(), cg._lib.current_stream(dev))
         return ind, mask, mode
 
-    bits = pixels = 0
+    bpps = []
     blobs = []
     for i in cdist.shard(len(sizes), rank, world):
         H, W = sizes[i]
@@ -57,8 +63,7 @@ def main():
         tiled = highres.compress_tiled(x, encode, codec)
         entries = container.entries_from_tiled(tiled, image_id=i)
         blobs.append(container.pack(entries))
-        bits += sum(len(v) for e in entries for v in e["streams"].values()) * 8
-        pixels += x.shape[-1] * x.shape[-2]
+        bpps.append(tiled.bpp())                              # per image, the reference's accounting (unpadded pixels)
         # decode side on the same rank: every tile must come back (masks exactly; indices wherever the fine grain kept them)
         per_tile, _ = highres.decompress_tiled(tiled, codec)
         for idxs, _, (ind0, masks0, _) in tiled.groups:
@@ -69,7 +74,7 @@ def main():
             for g in range(3):
                 assert torch.equal(torch.cat([per_tile[t][1][g] for t in idxs]).reshape(T, -1), masks0[g].reshape(T, -1))
     cdist.all_reduce_histogram(hist)                       # the path's only collective
-    bpp = cdist.average_bpp(bits, pixels, device=dev)
+    bpp = cdist.average_bpp(bpps, device=dev)              # unweighted mean over images, like inference.py:168-171
     if rank == 0:
         total = int(hist.sum())
         want = sum(((h + 15) // 16 * 4) * ((w + 15) // 16 * 4) if (h > 768 or w > 768) else (h // 16 * 4) * (w // 16 * 4) for h, w in sizes)
@@ -79,6 +84,24 @@ def main():
     if torch.distributed.is_initialized():
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
+
+
+def main():
+    import argparse
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=None, help="ranks (one per GPU); default: WORLD_SIZE or 1")
+    a = ap.parse_args()
+    if "RANK" in os.environ:                                   # under torch.distributed.run
+        world = int(os.environ.get("WORLD_SIZE", "1"))
+        if a.gpus is not None and a.gpus != world:
+            raise SystemExit(f"mixed_stream: --gpus {a.gpus} but WORLD_SIZE={world}")
+        run(int(os.environ["RANK"]), world)
+    elif a.gpus in (None, 1):
+        run(0, 1)
+    else:
+        if torch.cuda.device_count() < a.gpus:
+            raise SystemExit(f"mixed_stream: --gpus {a.gpus} but only {torch.cuda.device_count()} GPUs are visible")
+        cdist.spawn_ranks(run, a.gpus)
 
 
 if __name__ == "__main__":

@@ -28,19 +28,23 @@ def _worker(rank, world, port, n_images, out_dir):
     # deterministic synthetic "indices" per image; every rank can regenerate any image
     hist = torch.zeros(1024, dtype=torch.int64)
     bits = pixels = 0
+    bpps = []
     for i in mine:
         rng = np.random.default_rng(1000 + i)
         idx = rng.integers(0, 1024, 4096)
         idx[:50] = 7                                  # a hot bin
         hist += torch.from_numpy(np.bincount(idx, minlength=1024))
-        bits += int(rng.integers(10_000, 20_000))
-        pixels += 65536
+        b, px = int(rng.integers(10_000, 20_000)), 65536 * (1 + i % 3)     # images of different sizes
+        bits += b
+        pixels += px
+        bpps.append(b / px)
     big = torch.zeros(1024, dtype=torch.int64)
     big[3] = 2 ** 40 + rank                           # beyond fp32's exact range: must stay exact
     cdist.all_reduce_histogram(hist)
     cdist.all_reduce_histogram(big)
-    bpp = cdist.average_bpp(bits, pixels)
-    torch.save({"mine": mine, "hist": hist, "big": big, "bpp": bpp}, os.path.join(out_dir, f"r{rank}.pt"))
+    bpp = cdist.average_bpp(bpps)
+    wbpp = cdist.pixel_weighted_bpp(bits, pixels)
+    torch.save({"mine": mine, "hist": hist, "big": big, "bpp": bpp, "wbpp": wbpp}, os.path.join(out_dir, f"r{rank}.pt"))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -53,17 +57,23 @@ def test_shard_histogram_and_bpp_world2(tmp_path):
     assert owned == list(range(n_images))                       # every image exactly once
     ref = np.zeros(1024, np.int64)
     bits = pixels = 0
+    bpps = []
     for i in range(n_images):
         rng = np.random.default_rng(1000 + i)
         idx = rng.integers(0, 1024, 4096)
         idx[:50] = 7
         ref += np.bincount(idx, minlength=1024)
-        bits += int(rng.integers(10_000, 20_000))
-        pixels += 65536
+        b, px = int(rng.integers(10_000, 20_000)), 65536 * (1 + i % 3)
+        bits += b
+        pixels += px
+        bpps.append(b / px)
     for r in res:
         assert np.array_equal(r["hist"].numpy(), ref)           # identical, exact, on every rank
         assert int(r["big"][3]) == 2 * 2 ** 40 + 1
-        assert abs(r["bpp"] - bits / pixels) < 1e-15
+        # the reference's dataset average: unweighted mean of per-image bpp (inference.py:168-171) ...
+        assert abs(r["bpp"] - sum(bpps) / len(bpps)) < 1e-12
+        # ... which is NOT total bits / total pixels when sizes differ
+        assert abs(r["wbpp"] - bits / pixels) < 1e-15 and abs(r["bpp"] - r["wbpp"]) > 1e-3
 
 
 def test_single_process_is_a_noop():
@@ -72,4 +82,57 @@ def test_single_process_is_a_noop():
     assert cdist.shard(5) == [0, 1, 2, 3, 4]
     h = torch.arange(1024)
     assert cdist.all_reduce_histogram(h) is None and int(h[5]) == 5
-    assert cdist.average_bpp(100, 50) == 2.0
+    assert cdist.average_bpp([2.0, 4.0]) == 3.0 and cdist.pixel_weighted_bpp(100, 50) == 2.0
+
+
+def _spawn_target(rank, world, out_dir):
+    import sys
+    sys.path.insert(0, ROOT)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    t = torch.ones(1, dtype=torch.int64)
+    dist.all_reduce(t)
+    with open(os.path.join(out_dir, f"spawned{rank}.txt"), "w") as f:
+        f.write(f"{os.environ['RANK']} {os.environ['LOCAL_RANK']} {os.environ['WORLD_SIZE']} {int(t)}")
+    dist.destroy_process_group()
+
+
+def test_spawn_ranks_helper(tmp_path):
+    """dist.spawn_ranks: what `python examples/mixed_stream.py --gpus N` uses when it is not under torch.distributed.run"""
+    from control_gic_amd import dist as cdist
+    cdist.spawn_ranks(_spawn_target, 2, args=(str(tmp_path),))
+    for r in range(2):
+        assert open(tmp_path / f"spawned{r}.txt").read() == f"{r} {r} 2 2"
+
+
+def _bench(args, env_extra=None, timeout=300):
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(env_extra or {})
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, capture_output=True, text=True, timeout=timeout, env=env)
+
+
+def test_bench_spawns_its_own_ranks():
+    """`python bench.py --gpus 2` without torch.distributed.run starts 2 ranks itself (here: the CPU stub of the hot
+    path over gloo), rank 0 prints ONE JSON line with n_gpus == rccl_ranks == 2 and the whole-job value"""
+    import json
+    r = _bench(["--gpus", "2", "--stub", "--steps", "3", "--warmup", "1"])
+    assert r.returncode == 0, r.stdout + r.stderr
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["rccl_ranks"] == 2 and d["steps"] == 3 and d["scaling"] == "weak"
+    assert abs(d["value"] - 2 * 3 * 64 * 256 * 256 / (d["ms_per_step"] * 3 * 1e-3) / 1e6) / d["value"] < 1e-3
+    one = json.loads(_bench(["--gpus", "1", "--stub", "--steps", "3", "--warmup", "1"]).stdout.strip())
+    assert one["n_gpus"] == 1 and one["rccl_ranks"] == 1
+
+
+def test_bench_refuses_a_mismatched_world():
+    """under a launcher whose WORLD_SIZE differs from --gpus, or without enough GPUs, bench.py exits non-zero instead of
+    silently benchmarking fewer GPUs than it reports"""
+    r = _bench(["--gpus", "2", "--stub", "--steps", "2"], {"RANK": "0", "WORLD_SIZE": "1", "LOCAL_RANK": "0"})
+    assert r.returncode != 0 and "WORLD_SIZE=1" in r.stderr + r.stdout
+    import torch as _t
+    if not _t.cuda.is_available():
+        r = _bench(["--gpus", "2", "--steps", "2"])
+        assert r.returncode != 0 and "GPUs are visible" in r.stderr + r.stdout

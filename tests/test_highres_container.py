@@ -178,6 +178,13 @@ def test_decoder_blends_and_avgpool_bit_exact():
         assert torch.equal(out_f.view(torch.int32), ref_f.float().view(torch.int32))
         buf = hf_in.clone()
         assert cg.decoder_blend_fine(buf, hf_own, mask, out=buf) is buf and torch.equal(buf, out_f)      # in place
+    # a ragged tile of the 2K path: 272 px wide -> fine grid 68, medium grid 34 (even, not a multiple of 4)
+    g2 = torch.Generator().manual_seed(5)
+    e16r, e8r = torch.rand(2, 4, 17, generator=g2).cuda(), torch.rand(2, 8, 34, generator=g2).cuda()
+    maskr, _, _, _ = cg.TripleGrainFixedEntropyRouter(0.3, 0.4, per_image=True)(e16r, e8r)
+    hin, own = torch.randn(2, 5, 8, 34, generator=g2).cuda(), torch.randn(2, 5, 8, 34, generator=g2).cuda()
+    refr = hin * up2(maskr[0].float()) + own * maskr[1]
+    assert torch.equal(cg.decoder_blend_medium(hin, own, maskr).view(torch.int32), refr.float().view(torch.int32))
 
 
 @pytest.mark.gpu
@@ -244,9 +251,19 @@ def test_install_and_compress_on_a_cgic_shaped_model(tmp_path, orc):
     assert {n: (tmp_path / (n + ".bin")).read_bytes() for n in cg.STREAM_NAMES} == comp.to_host()[2]
     with pytest.raises(IndexError):
         model.compress(x, str(tmp_path))
-    # the streams are what the oracle writes for the same indices / masks
+    # install() keeps the reference's batch-global routing for encode() / forward() ...
+    assert model.encoder.router_config["params"]["per_image"] is False
+    with torch.no_grad():
+        _, _, _, mask_g, _, _, _ = model.encode(x)
+        e8, e16 = cg.entropy_maps(x)
+        ref_g = cg.TripleGrainFixedEntropyRouter(0.1, 0.8, per_image=False)(e16, e8)[0]
+    assert all(torch.equal(a, b) for a, b in zip(mask_g, ref_g))
+    # ... while compress_batch routed every image on its own thresholds (and restored the setting):
+    # the streams are what the oracle writes for the same indices / per-image masks
+    model.encoder.router_config["params"]["per_image"] = True
     with torch.no_grad():
         _, _, _, mask, ind, _, mode = model.encode(x)
+    model.encoder.router_config["params"]["per_image"] = False
     htab = orc.HuffmanTable(np.arange(1024, 0, -1, dtype=np.int64))
     for b in range(3):
         ref = orc.compress_image(ind.view(3, 16, 24)[b].cpu().numpy(), *(m[b, 0].cpu().numpy() for m in mask), mode, htab)
