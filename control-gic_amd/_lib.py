@@ -24,16 +24,25 @@ class CgicError(RuntimeError):
 
 _vp, _i64, _i32, _int, _f32, _f64, _sz = C.c_void_p, C.c_int64, C.c_int32, C.c_int, C.c_float, C.c_double, C.c_size_t
 
+
+class Conv1x1(C.Structure):
+    """struct cgic_conv1x1 (include/cgic_hip.h): a Conv2d(4, 4, 1) fused into a kernel"""
+    _fields_ = [("weight", _vp), ("bias", _vp), ("bias_first", _int)]
+
+
+_cv = C.POINTER(Conv1x1)
+
 # name -> (restype, argtypes); every function include/cgic_hip.h declares
 PROTOTYPES = {
     "cgic_last_error": (C.c_char_p, []),
     "cgic_abi_version": (_int, []),
     "cgic_device_count": (_int, []),
     "cgic_vq_workspace_bytes": (_sz, [_i64]),
-    "cgic_vq_forward_f32": (_int, [_vp, _i64, _i64, _vp, _int, _int, _f32, _int, _vp, _vp, _vp, _vp, _vp, _vp]),
-    "cgic_vq_forward_valu_f32": (_int, [_vp, _i64, _i64, _vp, _int, _int, _f32, _int, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "cgic_conv1x1_rows_f32": (_int, [_vp, _i64, _cv, _vp, _vp]),
+    "cgic_vq_forward_f32": (_int, [_vp, _i64, _i64, _vp, _int, _int, _f32, _int, _vp, _vp, _vp, _vp, _vp, _cv, _vp]),
+    "cgic_vq_forward_valu_f32": (_int, [_vp, _i64, _i64, _vp, _int, _int, _f32, _int, _vp, _vp, _vp, _vp, _vp, _cv, _vp]),
     "cgic_vq_forward_route_f32": (_int, [_vp, _i64, _i64, _vp, _int, _int, _f32, _int, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64,
-                                         _f64, _f64, _int, _vp, _vp, _vp, _vp, C.POINTER(_int), _vp]),
+                                         _f64, _f64, _int, _vp, _vp, _vp, _vp, C.POINTER(_int), _cv, _vp]),
     "cgic_index_histogram": (_int, [_vp, _i64, _int, _vp, _vp]),
     "cgic_entropy_maps_f32": (_int, [_vp, _i64, _i64, _i64, C.POINTER(_f32), _int, _f32, _vp, _vp, _vp]),
     "cgic_router_mode": (_int, [_f64, _f64]),
@@ -55,7 +64,7 @@ PROTOTYPES = {
     "cgic_compress_streams": (_int, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _int, _vp, _i64, _vp, _vp, _vp, _vp]),
     "cgic_decompress_workspace_bytes": (_sz, [_i64, _i64, _i64]),
     "cgic_decompress_streams": (_int, [_vp, _vp, _i64, _vp, _i64, _i64, _i64, _int, _vp, _vp, _vp, _vp, _vp, _int,
-                                       _int, _vp, _vp, _vp, _vp]),
+                                       _int, _vp, _vp, _vp, _vp, _vp, _vp]),
     "cgic_grain_merge_f32": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _int, _i64, _i64, _vp, _vp]),
     "cgic_avgpool_f32": (_int, [_vp, _i64, _i64, _i64, _int, _vp, _vp]),
     "cgic_decoder_blend_medium_f32": (_int, [_vp, _vp, _vp, _vp, _i64, _int, _i64, _i64, _vp, _vp]),
@@ -97,6 +106,22 @@ def call(name, *args):
 def ptr(t):
     """device/host pointer of a torch tensor (None -> NULL)"""
     return None if t is None else t.data_ptr()
+
+
+def conv_arg(conv, bias_first=False):
+    """(ctypes pointer or None, keep-alive tuple) for a fused 1x1 convolution.  conv: None, a torch.nn.Conv2d(4, 4, 1) or a
+    (weight, bias) pair; the tensors must stay alive until the call has been enqueued (the returned tuple holds them)."""
+    if conv is None:
+        return None, ()
+    import torch
+    weight, bias = (conv.weight, conv.bias) if hasattr(conv, "weight") else conv
+    w = weight.detach().reshape(weight.shape[0], -1).contiguous().float()
+    if tuple(w.shape) != (4, 4):
+        raise NotImplementedError(f"fused 1x1 convolution: weight {tuple(weight.shape)}; Control-GIC's quant_conv / post_quant_conv are 4 -> 4 (model.py:51-52)")
+    b = None if bias is None else bias.detach().contiguous().float()
+    require_device(w, b)
+    st = Conv1x1(w.data_ptr(), None if b is None else b.data_ptr(), int(bool(bias_first)))
+    return C.byref(st), (st, w, b)
 
 
 def current_stream(device=None):

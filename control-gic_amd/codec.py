@@ -134,9 +134,21 @@ class GrainCodec:
                       _lib.ptr(ws), _lib.current_stream(dev))
         return CompressedBatch(data, nbytes, mode, h, w)
 
-    def decompress(self, cb, want_masks=True, want_zq=True):
+    def post_conv_table(self, post_quant_conv, bias_first=False):
+        """post_quant_conv applied to the codebook rows (model.py:52,115): gathering from it == convolving the gathered latent"""
+        cbk = self.codebook.detach().contiguous()
+        out = torch.empty_like(cbk)
+        qc, keep = _lib.conv_arg(post_quant_conv, bias_first)
+        with torch.cuda.device(cbk.device):
+            _lib.call("cgic_conv1x1_rows_f32", _lib.ptr(cbk), cbk.shape[0], qc, _lib.ptr(out), _lib.current_stream(cbk.device))
+        del keep
+        return out
+
+    def decompress(self, cb, want_masks=True, want_zq=True, post_quant_conv=None, conv_bias_first=False):
         """CompressedBatch -> (ind [B,h,w] int64, [mask_c, mask_m, mask_f] int32 [B,1,.,.] or None,
-        z_q [B,4,h,w] fp32 or None, status [B] int32 on the device (0 = ok))"""
+        z_q [B,4,h,w] fp32 or None, status [B] int32 on the device (0 = ok)).
+        With post_quant_conv (a Conv2d(4, 4, 1) or (weight, bias)) the third element is the pair
+        (z_q, post_quant_conv(z_q)) -- what CGIC.decode feeds the decoder (model.py:114-116) -- from the same pass."""
         B, h, w, dev = cb.batch, cb.h, cb.w, cb.data.device
         l = _lib.lib()
         ind = torch.empty((B, h, w), dtype=torch.int64, device=dev)
@@ -152,6 +164,12 @@ class GrainCodec:
                 raise ValueError("GrainCodec was built without a codebook")
             cbk = self.codebook.detach().contiguous()
             zq = torch.empty((B, cbk.shape[1], h, w), dtype=torch.float32, device=dev)
+        cbk2 = zq2 = None
+        if post_quant_conv is not None:
+            if not want_zq:
+                raise ValueError("post_quant_conv needs want_zq")
+            cbk2 = self.post_conv_table(post_quant_conv, conv_bias_first)
+            zq2 = torch.empty_like(zq)
         status = torch.empty(B, dtype=torch.int32, device=dev)
         ws = torch.empty(l.cgic_decompress_workspace_bytes(B, h, w), dtype=torch.uint8, device=dev)
         with torch.cuda.device(dev):
@@ -160,5 +178,5 @@ class GrainCodec:
                       _lib.ptr(masks[0]) if masks else None, _lib.ptr(masks[1]) if masks else None,
                       _lib.ptr(masks[2]) if masks else None, _lib.ptr(cbk),
                       cbk.shape[0] if cbk is not None else 0, cbk.shape[1] if cbk is not None else 0,
-                      _lib.ptr(zq), _lib.ptr(status), _lib.ptr(ws), _lib.current_stream(dev))
-        return ind, masks, zq, status
+                      _lib.ptr(zq), _lib.ptr(cbk2), _lib.ptr(zq2), _lib.ptr(status), _lib.ptr(ws), _lib.current_stream(dev))
+        return ind, masks, (zq, zq2) if post_quant_conv is not None else zq, status

@@ -1022,6 +1022,8 @@ struct MergeArgs {
     const float *codebook;
     int K;
     float *zq;
+    const float *codebook2;    // second table gathered with the same indices (post_quant_conv(codebook)), or NULL
+    float *zq2;
     int32_t *status;
     int stage_sym, stage_cb;   // keep the image's decoded symbols / the codebook in LDS
 };
@@ -1223,6 +1225,7 @@ __global__ __launch_bounds__(kMergeThreads) void merge_kernel(MergeArgs a)
 
     int64_t *ind_out = a.ind_out ? a.ind_out + b * n_f : nullptr;
     float *zq = a.zq ? a.zq + b * 4 * n_f : nullptr;
+    float *zq2 = a.zq2 ? a.zq2 + b * 4 * n_f : nullptr;
     uint32_t fcarry = fbase;
     int bad_index = 0;
     for (int64_t base = r0 * w; base < r1 * w; base += (int64_t)kMergeThreads * kMergeItems) {
@@ -1263,6 +1266,11 @@ __global__ __launch_bounds__(kMergeThreads) void merge_kernel(MergeArgs a)
                 if (v < 0 || v >= a.K) { bad_index = 1; v = 0; }
                 const float4 e = a.stage_cb ? cbk[v] : reinterpret_cast<const float4 *>(a.codebook)[v];   // exact rows (:391-392)
                 zq[i] = e.x; zq[n_f + i] = e.y; zq[2 * n_f + i] = e.z; zq[3 * n_f + i] = e.w;
+            }
+            if (zq2) {
+                if (v < 0 || v >= a.K) { bad_index = 1; v = 0; }
+                const float4 e = reinterpret_cast<const float4 *>(a.codebook2)[v];       // 16 KB table: L1 / L2 hits
+                zq2[i] = e.x; zq2[n_f + i] = e.y; zq2[2 * n_f + i] = e.z; zq2[3 * n_f + i] = e.w;
             }
         }
         fcarry += ftotal;
@@ -1442,7 +1450,8 @@ extern "C" size_t cgic_decompress_workspace_bytes(int64_t B, int64_t h, int64_t 
 extern "C" int cgic_decompress_streams(const cgic_table *t, const uint8_t *in, int64_t slot, const int32_t *nbytes,
                                        int64_t B, int64_t h, int64_t w, int mode, int64_t *ind_out,
                                        int32_t *mask_c_out, int32_t *mask_m_out, int32_t *mask_f_out,
-                                       const float *codebook, int K, int e_dim, float *z_q, int32_t *status,
+                                       const float *codebook, int K, int e_dim, float *z_q, const float *codebook2,
+                                       float *z_q2, int32_t *status,
                                        void *workspace, cgic_stream_t stream)
 {
     int rc = check_grid(B, h, w, mode);
@@ -1452,6 +1461,8 @@ extern "C" int cgic_decompress_streams(const cgic_table *t, const uint8_t *in, i
                  "decompress_streams: slot must be a multiple of 16 below 2^28");
     CGIC_REQUIRE(!z_q || (codebook && e_dim == 4 && K > 0), CGIC_ERR_UNSUPPORTED,
                  "decompress_streams: fused gather needs a [K,4] codebook");
+    CGIC_REQUIRE(!z_q2 || (codebook2 && e_dim == 4 && K > 0), CGIC_ERR_UNSUPPORTED,
+                 "decompress_streams: the second gather needs a [K,4] table");
     CGIC_REQUIRE(cgic_table_num_symbols(t) <= 65536, CGIC_ERR_UNSUPPORTED, "table too large");
     if (B == 0) return CGIC_OK;
     const size_t per = (size_t)((h / 4) * (w / 4) + (h / 2) * (w / 2) + h * w);
@@ -1491,7 +1502,7 @@ extern "C" int cgic_decompress_streams(const cgic_table *t, const uint8_t *in, i
     m.in = in; m.slot = slot; m.nbytes = nbytes; m.h = h; m.w = w; m.mode = mode;
     m.dsym = d.dsym; m.dcount = d.dcount; m.ind_out = ind_out;
     m.mc_out = mask_c_out; m.mm_out = mask_m_out; m.mf_out = mask_f_out;
-    m.codebook = codebook; m.K = K; m.zq = z_q; m.status = status;
+    m.codebook = codebook; m.K = K; m.zq = z_q; m.codebook2 = codebook2; m.zq2 = z_q2; m.status = status;
     const size_t wc = (size_t)(((h / 4) * (w / 4) + 31) / 32), wm = (size_t)(((h / 2) * (w / 2) + 31) / 32);
     size_t lds_m = (3 * (wc + wm) + 4) * sizeof(uint32_t);
     CGIC_REQUIRE(lds_m <= kLdsBudget, CGIC_ERR_UNSUPPORTED, "decompress_streams: grid too large for the mask bitsets");

@@ -195,6 +195,40 @@ struct VqArgs {
     // filter path: groups per workgroup.  Workgroups [0, n_early) own `g_early` groups each, the rest `g_late`
     // (router workgroups in front of a fused launch delay the VQ workgroups that have to wait for their CUs)
     unsigned int n_early, g_early, g_late;
+    // quant_conv fused in front of the quantiser (model.py:51,110): z = W h (+ b), 4 -> 4, or NULL
+    const float *conv_w, *conv_b;
+    int conv_bias_first;
+};
+
+// The reference's quant_conv is a torch.nn.Conv2d(4, 4, 1) on the CPU.  Its fp32 rounding sequence is an fma chain over
+// the input channels in order, with the bias either seeding the accumulator or added at the end -- oneDNN picks one or
+// the other by shape and thread count (measured: one thread, or a 64x64 latent, adds the bias last; 8 threads and a
+// 192x192 latent seed with it).  Both orders are implemented; the caller says which one to reproduce.
+struct Conv1x1 {
+    float w[16], b[4];
+    int bias_first, has_bias;
+    __device__ __forceinline__ void load(const float *cw, const float *cb, int bf)
+    {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) w[i] = cw[i];            // wave-uniform addresses: scalar loads
+#pragma unroll
+        for (int i = 0; i < 4; ++i) b[i] = cb ? cb[i] : 0.f;
+        bias_first = bf;
+        has_bias = cb != nullptr;
+    }
+    __device__ __forceinline__ void apply(float (&v)[4]) const
+    {
+        const float h0 = v[0], h1 = v[1], h2 = v[2], h3 = v[3];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            float first = w[4 * c] * h0, seeded = __builtin_fmaf(w[4 * c], h0, b[c]);
+            float acc = (bias_first && has_bias) ? seeded : first;
+            acc = __builtin_fmaf(w[4 * c + 1], h1, acc);
+            acc = __builtin_fmaf(w[4 * c + 2], h2, acc);
+            acc = __builtin_fmaf(w[4 * c + 3], h3, acc);
+            v[c] = (!bias_first && has_bias) ? acc + b[c] : acc;
+        }
+    }
 };
 
 template <int ZT>
@@ -474,7 +508,7 @@ __host__ __device__ constexpr size_t vqf_lds_bytes(int K) { return vqf_ees_off(K
 
 // ALIGNED: hw % 64 == 0 -- a group of 64 consecutive vectors never straddles two images, so (image, position) of a
 // group is wave-uniform and every address is a scalar base plus a per-lane offset that is computed once.
-template <int NT, bool ALIGNED>
+template <int NT, bool ALIGNED, bool CONV>
 __device__ __forceinline__ void vq_filter_body(const VqArgs &a, unsigned char *smem, const unsigned int vblk)
 {
     constexpr int NW = NT / 64, G = kVqfGroup;
@@ -552,6 +586,8 @@ __device__ __forceinline__ void vq_filter_body(const VqArgs &a, unsigned char *s
         }
     };
 
+    Conv1x1 conv;
+    if (CONV) conv.load(a.conv_w, a.conv_b, a.conv_bias_first);
     // the first group's latents are requested before the codebook is staged: their HBM latency hides behind it
     float zn[2][4];
     int64_t cur = blk_lo + wave;
@@ -632,6 +668,7 @@ __device__ __forceinline__ void vq_filter_body(const VqArgs &a, unsigned char *s
         for (int t = 0; t < 2; ++t) {
 #pragma unroll
             for (int c = 0; c < 4; ++c) zv[t][c] = zn[t][c];
+            if (CONV) conv.apply(zv[t]);                // quant_conv on the four channels this lane holds anyway
             const float zmax = fmaxf(fmaxf(fabsf(zv[t][0]), fabsf(zv[t][1])), fmaxf(fabsf(zv[t][2]), fabsf(zv[t][3])));
             const int ez = exponent_of(zmax);
             int sa = 13 - ez;
@@ -919,18 +956,18 @@ __device__ __forceinline__ void vq_filter_body(const VqArgs &a, unsigned char *s
 constexpr int kVqfThreads = CGIC_VQF_THREADS;      // one workgroup per CU, 3 waves per SIMD (measured at B=64 x 64x64 latents: 512 threads 23.7 us, 768 22.8, 1024 22.9)
 #define CGIC_VQF_BOUNDS __launch_bounds__(kVqfThreads, kVqfThreads / 256 > 1 ? kVqfThreads / 256 : 1)
 
-template <bool ALIGNED>
+template <bool ALIGNED, bool CONV>
 __global__ CGIC_VQF_BOUNDS void vq_filter_kernel(VqArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_f[];
-    vq_filter_body<kVqfThreads, ALIGNED>(a, smem_f, blockIdx.x);
+    vq_filter_body<kVqfThreads, ALIGNED, CONV>(a, smem_f, blockIdx.x);
 }
 
 // The fused launch of the filter path (see vq_router_kernel).  A VQ workgroup takes most of a CU's register file, and
 // dynamic LDS / the VGPR budget are per launch, so a router workgroup does not share a CU with one: behind the VQ
 // workgroups it only starts when the VQ is over.  The router workgroups therefore come FIRST (`nrouter` of them, one CU
 // each for ~11 us); the VQ workgroups that have to wait for those CUs own fewer groups, the others more.
-template <bool ALIGNED>
+template <bool ALIGNED, bool CONV>
 __global__ CGIC_VQF_BOUNDS void vq_filter_router_kernel(VqArgs a, RouterArgs r, unsigned int nrouter)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_f[];
@@ -938,11 +975,11 @@ __global__ CGIC_VQF_BOUNDS void vq_filter_router_kernel(VqArgs a, RouterArgs r, 
         router_body<kVqfThreads>(r, (int64_t)blockIdx.x, smem_f);
         return;
     }
-    vq_filter_body<kVqfThreads, ALIGNED>(a, smem_f, blockIdx.x - nrouter);
+    vq_filter_body<kVqfThreads, ALIGNED, CONV>(a, smem_f, blockIdx.x - nrouter);
 }
 
 // the same with the router workgroups BEHIND the VQ workgroups (when every VQ workgroup gets a CU at once anyway)
-template <bool ALIGNED>
+template <bool ALIGNED, bool CONV>
 __global__ CGIC_VQF_BOUNDS void vq_filter_router_behind_kernel(VqArgs a, RouterArgs r)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_f[];
@@ -950,7 +987,7 @@ __global__ CGIC_VQF_BOUNDS void vq_filter_router_behind_kernel(VqArgs a, RouterA
         router_body<kVqfThreads>(r, (int64_t)(blockIdx.x - a.nblk), smem_f);
         return;
     }
-    vq_filter_body<kVqfThreads, ALIGNED>(a, smem_f, blockIdx.x);
+    vq_filter_body<kVqfThreads, ALIGNED, CONV>(a, smem_f, blockIdx.x);
 }
 
 // Plain-VALU restatement: one latent vector per thread, codebook broadcast from
@@ -958,7 +995,8 @@ __global__ CGIC_VQF_BOUNDS void vq_filter_router_behind_kernel(VqArgs a, RouterA
 __global__ __launch_bounds__(kVqThreads) void vq_valu_kernel(
     const float *__restrict__ z, int64_t hw, int64_t N, const float *__restrict__ cb, int K,
     int64_t *__restrict__ idx_out, float *__restrict__ zq_out, double *__restrict__ sq_partial,
-    unsigned int *__restrict__ ticket, float beta, int legacy, float *__restrict__ loss)
+    unsigned int *__restrict__ ticket, float beta, int legacy, float *__restrict__ loss,
+    const float *__restrict__ conv_w, const float *__restrict__ conv_b, int conv_bias_first)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float4 *cbs = reinterpret_cast<float4 *>(smem);  // [K]
@@ -975,6 +1013,13 @@ __global__ __launch_bounds__(kVqThreads) void vq_valu_kernel(
         int64_t b = n / hw, p = n - b * hw;
         const float *zp = z + b * 4 * hw + p;
         float z0 = zp[0], z1 = zp[hw], z2 = zp[2 * hw], z3 = zp[3 * hw];
+        if (conv_w) {
+            Conv1x1 conv;
+            conv.load(conv_w, conv_b, conv_bias_first);
+            float v[4] = {z0, z1, z2, z3};
+            conv.apply(v);
+            z0 = v[0]; z1 = v[1]; z2 = v[2]; z3 = v[3];
+        }
         float zz = sumsq4(z0, z1, z2, z3);
         // lowest index among the minimal distances; a NaN distance never wins (index 0 if every distance is NaN) -- the
         // same rule as the exact scans of the filter path (torch.argmin would return the first NaN: see cgic_hip.h)
@@ -1060,6 +1105,12 @@ static int vq_check(const float *z, int64_t B, int64_t hw, const float *cb, int 
     return CGIC_OK;
 }
 
+static int conv_check(const cgic_conv1x1 *qc)
+{
+    CGIC_REQUIRE(!qc || qc->weight, CGIC_ERR_INVALID, "vq: quant_conv without a weight");
+    return CGIC_OK;
+}
+
 static int ensure_dynamic_lds(const void *fn, size_t bytes);
 
 struct VqWs {
@@ -1138,10 +1189,10 @@ static int dev_knob(const char *name) { const char *v = getenv(name); return v ?
 static int dev_knob(const char *) { return 0; }      // the environment knobs exist in `make dbg` builds only
 #endif
 
-template <bool ALIGNED>
+template <bool ALIGNED, bool CONV>
 static int launch_filter(const float *z, int64_t hw, int64_t N, const float *cb, int K, int64_t *idx, float *zq,
                          VqWs ws, float beta, int legacy, float *loss, hipStream_t s, const RouterArgs *router,
-                         int64_t router_blocks, size_t router_lds)
+                         int64_t router_blocks, size_t router_lds, const cgic_conv1x1 *qc)
 {
     int cus = 0;
     int rc = device_cu_count(&cus);
@@ -1154,6 +1205,7 @@ static int launch_filter(const float *z, int64_t hw, int64_t N, const float *cb,
     a.z = z; a.hw = hw; a.N = N; a.cb = cb; a.K = K; a.idx_out = idx; a.zq_out = zq;
     a.sq_partial = loss ? ws.partial : nullptr; a.ticket = ws.ticket; a.beta = beta; a.legacy = legacy; a.loss = loss;
     a.nblk = (unsigned int)nblk;
+    a.conv_w = CONV ? qc->weight : nullptr; a.conv_b = CONV ? qc->bias : nullptr; a.conv_bias_first = CONV ? qc->bias_first : 0;
     // groups per workgroup.  Router workgroups in front: the `late` VQ workgroups that must wait for a router's CU
     // (~11 us at 256x256, ~`delta` groups of VQ work) own `g_late` groups, the others `g_early`, a multiple of 4
     int64_t per = (ngroups + nblk - 1) / nblk, g_early = per, g_late = per, n_early = nblk;
@@ -1172,35 +1224,37 @@ static int launch_filter(const float *z, int64_t hw, int64_t N, const float *cb,
     a.n_early = (unsigned int)n_early; a.g_early = (unsigned int)g_early; a.g_late = (unsigned int)g_late;
     size_t lds = vqf_lds_bytes(K);
     if (!router) {
-        rc = ensure_dynamic_lds((const void *)vq_filter_kernel<ALIGNED>, lds);
+        rc = ensure_dynamic_lds((const void *)vq_filter_kernel<ALIGNED, CONV>, lds);
         if (rc) return rc;
-        hipLaunchKernelGGL(vq_filter_kernel<ALIGNED>, dim3(a.nblk), dim3(kVqfThreads), lds, s, a);
+        hipLaunchKernelGGL((vq_filter_kernel<ALIGNED, CONV>), dim3(a.nblk), dim3(kVqfThreads), lds, s, a);
         return launch_check("vq_filter_kernel");
     }
     if (router_lds > lds) lds = router_lds;
     if (router_first) {
-        rc = ensure_dynamic_lds((const void *)vq_filter_router_kernel<ALIGNED>, lds);
+        rc = ensure_dynamic_lds((const void *)vq_filter_router_kernel<ALIGNED, CONV>, lds);
         if (rc) return rc;
-        hipLaunchKernelGGL(vq_filter_router_kernel<ALIGNED>, dim3(a.nblk + (unsigned int)router_blocks), dim3(kVqfThreads), lds, s, a, *router,
+        hipLaunchKernelGGL((vq_filter_router_kernel<ALIGNED, CONV>), dim3(a.nblk + (unsigned int)router_blocks), dim3(kVqfThreads), lds, s, a, *router,
                            (unsigned int)router_blocks);
     } else {
-        rc = ensure_dynamic_lds((const void *)vq_filter_router_behind_kernel<ALIGNED>, lds);
+        rc = ensure_dynamic_lds((const void *)vq_filter_router_behind_kernel<ALIGNED, CONV>, lds);
         if (rc) return rc;
-        hipLaunchKernelGGL(vq_filter_router_behind_kernel<ALIGNED>, dim3(a.nblk + (unsigned int)router_blocks), dim3(kVqfThreads), lds, s, a, *router);
+        hipLaunchKernelGGL((vq_filter_router_behind_kernel<ALIGNED, CONV>), dim3(a.nblk + (unsigned int)router_blocks), dim3(kVqfThreads), lds, s, a, *router);
     }
     return launch_check("vq_filter_router_kernel");
 }
 
 static int vq_dispatch(const float *z, int64_t hw, int64_t N, const float *codebook, int K, int64_t *indices, float *z_q,
                        VqWs ws, float beta, int legacy, float *loss, hipStream_t s, const RouterArgs *router,
-                       int64_t router_blocks, size_t router_lds)
+                       int64_t router_blocks, size_t router_lds, const cgic_conv1x1 *qc)
 {
     const int force_zt = dev_knob("CGIC_VQ_ZT");          // dev: tile count of the exact loop
     if (!dev_knob("CGIC_VQ_EXACT") && K % 64 == 0 && K <= kVqfMaxK) {
-        if (hw % kVqfGroup == 0)
-            return launch_filter<true>(z, hw, N, codebook, K, indices, z_q, ws, beta, legacy, loss, s, router, router_blocks, router_lds);
-        return launch_filter<false>(z, hw, N, codebook, K, indices, z_q, ws, beta, legacy, loss, s, router, router_blocks, router_lds);
+#define CGIC_VQF_LAUNCH(AL, CV) launch_filter<AL, CV>(z, hw, N, codebook, K, indices, z_q, ws, beta, legacy, loss, s, router, router_blocks, router_lds, qc)
+        if (hw % kVqfGroup == 0) return qc ? CGIC_VQF_LAUNCH(true, true) : CGIC_VQF_LAUNCH(true, false);
+        return qc ? CGIC_VQF_LAUNCH(false, true) : CGIC_VQF_LAUNCH(false, false);
+#undef CGIC_VQF_LAUNCH
     }
+    CGIC_REQUIRE(!qc, CGIC_ERR_UNSUPPORTED, "vq: the fused quant_conv needs K %% 64 == 0 and K <= %d (K=%d): apply the 1x1 convolution separately", kVqfMaxK, K);
     // exact loop; per-wave tile: measured on MI355X (tools/probe_vq.hip) ZT=4 at 4 waves/SIMD is the fastest
     // for large N; smaller N shrinks the tile so that all 256 CUs get work
 #define CGIC_VQ_LAUNCH(ZT) launch_mfma<ZT>(z, hw, N, codebook, K, indices, z_q, ws, beta, legacy, loss, s, router, router_blocks, router_lds)
@@ -1227,9 +1281,12 @@ extern "C" size_t cgic_vq_workspace_bytes(int64_t n_vectors)
 
 extern "C" int cgic_vq_forward_f32(const float *z, int64_t B, int64_t hw, const float *codebook, int K,
                                    int e_dim, float beta, int legacy, int64_t *indices, float *z_q,
-                                   float *loss, int64_t *hist, void *workspace, cgic_stream_t stream)
+                                   float *loss, int64_t *hist, void *workspace, const cgic_conv1x1 *quant_conv,
+                                   cgic_stream_t stream)
 {
     int rc = vq_check(z, B, hw, codebook, K, e_dim, loss, workspace, hist && !indices);
+    if (rc) return rc;
+    rc = conv_check(quant_conv);
     if (rc) return rc;
     const int64_t N = B * hw;
     if (N == 0) return CGIC_OK;
@@ -1237,7 +1294,7 @@ extern "C" int cgic_vq_forward_f32(const float *z, int64_t B, int64_t hw, const 
     VqWs ws;
     rc = vq_ws(loss ? workspace : nullptr, s, &ws);
     if (rc) return rc;
-    rc = vq_dispatch(z, hw, N, codebook, K, indices, z_q, ws, beta, legacy, loss, s, nullptr, 0, 0);
+    rc = vq_dispatch(z, hw, N, codebook, K, indices, z_q, ws, beta, legacy, loss, s, nullptr, 0, 0, quant_conv);
     if (rc == CGIC_OK && hist) rc = launch_hist(indices, N, K, hist, s);
     return rc;
 }
@@ -1247,9 +1304,11 @@ extern "C" int cgic_vq_forward_route_f32(const float *z, int64_t B, int64_t hw, 
                                          void *workspace, const float *e16, const float *e8, int64_t h16, int64_t w16,
                                          double coarse_ratio, double medium_ratio, int per_image, int32_t *mask_c,
                                          int32_t *mask_m, int32_t *mask_f, float *gate, int *mode_out,
-                                         cgic_stream_t stream)
+                                         const cgic_conv1x1 *quant_conv, cgic_stream_t stream)
 {
     int rc = vq_check(z, B, hw, codebook, K, e_dim, loss, workspace, false);
+    if (rc) return rc;
+    rc = conv_check(quant_conv);
     if (rc) return rc;
     if (mode_out) *mode_out = cgic_router_mode(coarse_ratio, medium_ratio);
     const int64_t N = B * hw;
@@ -1263,14 +1322,17 @@ extern "C" int cgic_vq_forward_route_f32(const float *z, int64_t B, int64_t hw, 
     VqWs ws;
     rc = vq_ws(loss ? workspace : nullptr, s, &ws);
     if (rc) return rc;
-    return vq_dispatch(z, hw, N, codebook, K, indices, z_q, ws, beta, legacy, loss, s, &r, nseg, rlds);
+    return vq_dispatch(z, hw, N, codebook, K, indices, z_q, ws, beta, legacy, loss, s, &r, nseg, rlds, quant_conv);
 }
 
 extern "C" int cgic_vq_forward_valu_f32(const float *z, int64_t B, int64_t hw, const float *codebook, int K,
                                         int e_dim, float beta, int legacy, int64_t *indices, float *z_q,
-                                        float *loss, int64_t *hist, void *workspace, cgic_stream_t stream)
+                                        float *loss, int64_t *hist, void *workspace, const cgic_conv1x1 *quant_conv,
+                                        cgic_stream_t stream)
 {
     int rc = vq_check(z, B, hw, codebook, K, e_dim, loss, workspace, hist && !indices);
+    if (rc) return rc;
+    rc = conv_check(quant_conv);
     if (rc) return rc;
     const int64_t N = B * hw;
     if (N == 0) return CGIC_OK;
@@ -1283,10 +1345,38 @@ extern "C" int cgic_vq_forward_valu_f32(const float *z, int64_t B, int64_t hw, c
     rc = ensure_dynamic_lds((const void *)vq_valu_kernel, lds);
     if (rc) return rc;
     hipLaunchKernelGGL(vq_valu_kernel, dim3(nblk), dim3(kVqThreads), lds, s, z, hw, N, codebook, K, indices, z_q,
-                       loss ? ws.partial : nullptr, ws.ticket, beta, legacy, loss);
+                       loss ? ws.partial : nullptr, ws.ticket, beta, legacy, loss,
+                       quant_conv ? quant_conv->weight : (const float *)nullptr, quant_conv ? quant_conv->bias : (const float *)nullptr,
+                       quant_conv ? quant_conv->bias_first : 0);
     rc = launch_check("vq_valu_kernel");
     if (rc == CGIC_OK && hist) rc = launch_hist(indices, N, K, hist, s);
     return rc;
+}
+
+// y[n] = W x[n] (+ b) for n rows of 4 floats: post_quant_conv applied to the codebook (model.py:52,115) -- gathering rows
+// of the transformed codebook is bit-identical to convolving the gathered latent, at 1024 rows instead of B*h*w
+__global__ __launch_bounds__(256) void conv_rows_kernel(const float4 *__restrict__ x, int64_t n, const float *__restrict__ cw,
+                                                        const float *__restrict__ cb, int bias_first, float4 *__restrict__ y)
+{
+    Conv1x1 conv;
+    conv.load(cw, cb, bias_first);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float4 r = x[i];
+        float v[4] = {r.x, r.y, r.z, r.w};
+        conv.apply(v);
+        y[i] = make_float4(v[0], v[1], v[2], v[3]);
+    }
+}
+
+extern "C" int cgic_conv1x1_rows_f32(const float *rows, int64_t n, const cgic_conv1x1 *conv, float *out, cgic_stream_t stream)
+{
+    CGIC_REQUIRE(rows && out && conv && conv->weight && n >= 0, CGIC_ERR_INVALID, "conv1x1_rows: NULL argument");
+    if (n == 0) return CGIC_OK;
+    int64_t nblk = (n + 255) / 256;
+    if (nblk > 4096) nblk = 4096;
+    hipLaunchKernelGGL(conv_rows_kernel, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, (const float4 *)rows, n, conv->weight,
+                       conv->bias, conv->bias_first, (float4 *)out);
+    return launch_check("conv_rows_kernel");
 }
 
 extern "C" int cgic_index_histogram(const int64_t *indices, int64_t n, int K, int64_t *hist, cgic_stream_t stream)

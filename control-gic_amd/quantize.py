@@ -75,7 +75,9 @@ class _VQFunction(torch.autograd.Function):
         return gz, gw, None, None, None
 
 
-def _vq_forward(z, weight, beta, legacy, hist, want_zq=True, want_loss=True, kernel="mfma"):
+def _vq_forward(z, weight, beta, legacy, hist, want_zq=True, want_loss=True, kernel="mfma", quant_conv=None, conv_bias_first=False):
+    """quant_conv: optional Conv2d(4, 4, 1) (or (weight, bias)) applied to z inside the kernel -- CGIC.quant_conv
+    (model.py:51,110); conv_bias_first selects which of the CPU reference's two rounding sequences to reproduce"""
     _lib.require_device(z, weight)
     if z.dtype != torch.float32 or weight.dtype != torch.float32:
         raise TypeError("VectorQuantizer computes in fp32 like the reference; got "
@@ -91,15 +93,17 @@ def _vq_forward(z, weight, beta, legacy, hist, want_zq=True, want_loss=True, ker
     if want_loss:
         ws = torch.empty(_lib.lib().cgic_vq_workspace_bytes(N), dtype=torch.uint8, device=z.device)
     fn = "cgic_vq_forward_f32" if kernel == "mfma" else "cgic_vq_forward_valu_f32"
+    qc, keep = _lib.conv_arg(quant_conv, conv_bias_first)
     with torch.cuda.device(z.device):
         _lib.call(fn, _lib.ptr(z), B, h * w, _lib.ptr(weight), weight.shape[0], C, float(beta), int(bool(legacy)),
-                  _lib.ptr(idx), _lib.ptr(z_q), _lib.ptr(loss), _lib.ptr(hist), _lib.ptr(ws),
+                  _lib.ptr(idx), _lib.ptr(z_q), _lib.ptr(loss), _lib.ptr(hist), _lib.ptr(ws), qc,
                   _lib.current_stream(z.device))
+    del keep
     return z_q, loss, idx
 
 
 def vq_forward_route(z, weight, beta, legacy, e16, e8, coarse_ratio, medium_ratio, per_image=True, want_gate=False,
-                     want_zq=True, want_loss=True):
+                     want_zq=True, want_loss=True, quant_conv=None, conv_bias_first=False):
     """VectorQuantize2.forward and TripleGrainFixedEntropyRouter.forward in ONE launch (the router's per-image
     workgroups ride behind the VQ workgroups; see cgic_vq_forward_route_f32).  Returns
     (z_q, loss, indices, [mask_c, mask_m, mask_f], gate, mode) -- identical to the two separate calls."""
@@ -124,12 +128,37 @@ def vq_forward_route(z, weight, beta, legacy, e16, e8, coarse_ratio, medium_rati
     mf = torch.empty((B, 1, 4 * h16, 4 * w16), dtype=torch.int32, device=dev)
     gate = torch.empty((B, 1, 4 * h16, 12 * w16), dtype=torch.float32, device=dev) if want_gate else None
     mode = ctypes.c_int(0)
+    qc, keep = _lib.conv_arg(quant_conv, conv_bias_first)
     with torch.cuda.device(dev):
         _lib.call("cgic_vq_forward_route_f32", _lib.ptr(z), B, h * w, _lib.ptr(weight), weight.shape[0], C, float(beta),
                   int(bool(legacy)), _lib.ptr(idx), _lib.ptr(z_q), _lib.ptr(loss), _lib.ptr(ws), _lib.ptr(e16), _lib.ptr(e8),
                   h16, w16, float(coarse_ratio), float(medium_ratio), int(bool(per_image)), _lib.ptr(mc), _lib.ptr(mm),
-                  _lib.ptr(mf), _lib.ptr(gate), ctypes.byref(mode), _lib.current_stream(dev))
+                  _lib.ptr(mf), _lib.ptr(gate), ctypes.byref(mode), qc, _lib.current_stream(dev))
+    del keep
     return z_q, loss, idx, [mc, mm, mf], gate, mode.value
+
+
+class FusedQuantConv(nn.Conv2d):
+    """CGIC.quant_conv (model.py:51) with its work moved into the quantiser's kernel: under no_grad it returns its input
+    unchanged and VectorQuantize2 applies the convolution to the four channel values each lane already holds (one HBM
+    round trip of the latent less).  With autograd on it is a plain Conv2d again.  Same parameters, same state_dict keys."""
+
+    bias_first = False      # which of the CPU reference's two rounding sequences the fused kernel reproduces (cgic_hip.h)
+
+    @classmethod
+    def adopt(cls, conv):
+        if tuple(conv.weight.shape) != (4, 4, 1, 1):
+            raise NotImplementedError("FusedQuantConv: Control-GIC's quant_conv is Conv2d(4, 4, 1)")
+        m = cls(4, 4, 1, bias=conv.bias is not None)
+        m.weight, m.bias = conv.weight, conv.bias
+        m.train(conv.training)
+        return m
+
+    def passes_through(self):
+        return not torch.is_grad_enabled() and self.weight.is_cuda
+
+    def forward(self, x):
+        return x if self.passes_through() else super().forward(x)
 
 
 class VectorQuantize2(nn.Module):
@@ -186,10 +215,13 @@ class VectorQuantize2(nn.Module):
         if z.dtype != torch.float32:
             z = z.float()                   # (autocast regions hand over fp16 / bf16: the reference quantises in fp32)
         hist = self.usage_hist if self.training else None
+        fused = getattr(self, "_fused_quant_conv", None)      # model.install(): quant_conv handed its input through
+        conv = fused if fused is not None and fused.passes_through() else None
         if torch.is_grad_enabled() and (z.requires_grad or self.embedding.weight.requires_grad):
             z_q, loss, idx = _VQFunction.apply(z, self.embedding.weight, self.beta, self.legacy, hist)
         else:
-            z_q, loss, idx = _vq_forward(z, self.embedding.weight, self.beta, self.legacy, hist)
+            z_q, loss, idx = _vq_forward(z, self.embedding.weight, self.beta, self.legacy, hist, quant_conv=conv,
+                                         conv_bias_first=conv.bias_first if conv is not None else False)
         if self.training:
             self.fold_usage_hist()
         return z_q, loss, idx

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define CGIC_ABI_VERSION 1
+#define CGIC_ABI_VERSION 2
 
 #define CGIC_OK 0
 #define CGIC_ERR_INVALID (-1)     /* bad argument (shape, ratio, NULL pointer ...) */
@@ -65,15 +65,31 @@ int cgic_device_count(void);
  *   hist     device [K]         int64 or NULL  += occurrences of each index
  *            (the usage counter of quantize.py:28,79-81, exact integers)
  *   workspace device, cgic_vq_workspace_bytes(B*hw) bytes, or NULL iff loss==NULL
+ *   quant_conv NULL, or the 1x1 convolution in front of the quantiser (CGIC.quant_conv, model.py:51,110) to apply to
+ *            every latent vector first: then `z` is the encoder output h and everything above refers to W h + b
  * Two implementations behind the same contract, bit-identical results: for K % 64 == 0, K <= 1024 (the reference's
- * 1024 x 4 codebook) a bf16-MFMA candidate filter with an exact fp32 resolve, otherwise (or with CGIC_VQ_EXACT=1
- * in the environment) the fp32-MFMA loop over every code.  NaN / Inf in z or the codebook are outside the
- * contract (a valid index comes back, not necessarily torch.argmin's).
+ * 1024 x 4 codebook) an fp16-MFMA candidate filter with an exact fp32 resolve, otherwise the fp32-MFMA loop over
+ * every code (no fused quant_conv there: CGIC_ERR_UNSUPPORTED).
+ * Non-finite values: torch.argmin returns the first NaN; here a NaN distance never wins (lowest index among the
+ * minimal non-NaN distances, 0 if all are NaN).  The deviation is confined to vectors whose own distance row
+ * contains a non-finite value (tests/test_gpu_stress.py).
  * ------------------------------------------------------------------------- */
+/* torch.nn.Conv2d(4, 4, 1) as the CPU reference computes it: per output channel an fma chain over the input
+ * channels in order.  oneDNN seeds the accumulator with the bias or adds it at the end depending on shape and
+ * thread count (measured with torch 2.10: 1 thread, or a 64x64 latent -> bias last; 8 threads and >= 96x96 ->
+ * bias first); `bias_first` selects which of the two sequences to reproduce. */
+typedef struct cgic_conv1x1 {
+    const float *weight;   /* device [4, 4] fp32 = Conv2d.weight[:, :, 0, 0], row = output channel */
+    const float *bias;     /* device [4] fp32 or NULL */
+    int bias_first;
+} cgic_conv1x1;
+/* out[n] = conv(rows[n]) for n rows of 4 floats (post_quant_conv applied to the codebook, model.py:52,115) */
+int cgic_conv1x1_rows_f32(const float *rows, int64_t n, const cgic_conv1x1 *conv, float *out, cgic_stream_t stream);
+
 size_t cgic_vq_workspace_bytes(int64_t n_vectors);
 int cgic_vq_forward_f32(const float *z, int64_t B, int64_t hw, const float *codebook, int K, int e_dim,
                         float beta, int legacy, int64_t *indices, float *z_q, float *loss,
-                        int64_t *hist, void *workspace, cgic_stream_t stream);
+                        int64_t *hist, void *workspace, const cgic_conv1x1 *quant_conv, cgic_stream_t stream);
 /* cgic_vq_forward_f32 and cgic_router_f32 in ONE launch: the router's per-image workgroups share the grid with
  * the VQ workgroups (neither needs the other's output; both need what precedes them, i.e. the latent and
  * the entropy maps).  Same contracts as the two separate calls. */
@@ -82,12 +98,13 @@ int cgic_vq_forward_route_f32(const float *z, int64_t B, int64_t hw, const float
                               void *workspace, const float *e16, const float *e8, int64_t h16, int64_t w16,
                               double coarse_ratio, double medium_ratio, int per_image, int32_t *mask_c,
                               int32_t *mask_m, int32_t *mask_f, float *gate, int *mode_out,
-                              cgic_stream_t stream);
+                              const cgic_conv1x1 *quant_conv, cgic_stream_t stream);
 /* same contract, plain-VALU kernel (no MFMA); kept as an independent
  * implementation for cross-checking the MFMA kernel's rounding */
 int cgic_vq_forward_valu_f32(const float *z, int64_t B, int64_t hw, const float *codebook, int K,
                              int e_dim, float beta, int legacy, int64_t *indices, float *z_q,
-                             float *loss, int64_t *hist, void *workspace, cgic_stream_t stream);
+                             float *loss, int64_t *hist, void *workspace, const cgic_conv1x1 *quant_conv,
+                             cgic_stream_t stream);
 
 /* usage histogram of an index tensor (quantize.py:79-81): hist[idx[i]] += 1 */
 int cgic_index_histogram(const int64_t *indices, int64_t n, int K, int64_t *hist, cgic_stream_t stream);
@@ -207,6 +224,9 @@ int cgic_decode_stream(const cgic_table *t, const uint8_t *in, int64_t nbytes, i
  *   ind_out device [B, h, w] int64; mask_*_out device int32 (any may be NULL)
  *   codebook device [K, 4] + z_q device [B, 4, h, w] fp32: optional fused
  *           embedding gather (model.py:391-392), exact codebook rows
+ *   codebook2 device [K, 4] + z_q2 device [B, 4, h, w] fp32: optional second gather of the same
+ *           indices from another table -- post_quant_conv(codebook) gives post_quant_conv(quant)
+ *           (CGIC.decode needs both, model.py:114-116) without a pass over the latent
  *   status  device [B] int32: 0, or CGIC_ERR_INVALID when a stream's symbol
  *           count does not match its mask / a mask stream has the wrong length
  *           / an index is outside the codebook (the reference raises there)
@@ -222,8 +242,8 @@ size_t cgic_decompress_workspace_bytes(int64_t B, int64_t h, int64_t w);
 int cgic_decompress_streams(const cgic_table *t, const uint8_t *in, int64_t slot, const int32_t *nbytes,
                             int64_t B, int64_t h, int64_t w, int mode, int64_t *ind_out,
                             int32_t *mask_c_out, int32_t *mask_m_out, int32_t *mask_f_out,
-                            const float *codebook, int K, int e_dim, float *z_q, int32_t *status,
-                            void *workspace, cgic_stream_t stream);
+                            const float *codebook, int K, int e_dim, float *z_q, const float *codebook2,
+                            float *z_q2, int32_t *status, void *workspace, cgic_stream_t stream);
 
 /* ---------------------------------------------------------------------------
  * Three-grain latent merge in front of the quantiser --

@@ -465,3 +465,93 @@ def test_mixed_stream_example_runs():
                        timeout=600, env=env)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "histogram total 991232" in r.stdout
+
+
+# ---------------------------------------------------------------------------- f2. quant_conv / post_quant_conv fused
+def _conv_seq(x, W, b, bias_first):
+    """the two fp32 rounding sequences torch's CPU Conv2d(4, 4, 1) uses (include/cgic_hip.h): fma chain over the input
+    channels in order, bias seeding the accumulator or added last.  x [N,4] -> [N,4], exact (fma emulated in float64:
+    a*b is exact there and the sum of a 48-bit product and a float rounds once to double, then to float -- a double
+    rounding in ~1e-9 of the cases, none on these inputs, checked against torch below)."""
+    def fma(a, xv, c):
+        return (np.float64(a) * xv.astype(np.float64) + c.astype(np.float64)).astype(np.float32)
+    out = np.empty_like(x)
+    for c in range(4):
+        if bias_first:
+            acc = np.full(x.shape[0], b[c], np.float32)
+            for k in range(4):
+                acc = fma(W[c, k], x[:, k], acc)
+        else:
+            acc = (W[c, 0] * x[:, 0]).astype(np.float32)
+            for k in range(1, 4):
+                acc = fma(W[c, k], x[:, k], acc)
+            acc = (acc + b[c]).astype(np.float32)
+        out[:, c] = acc
+    return out
+
+
+@pytest.mark.parametrize("shape", [(1, 4, 64, 64), (2, 4, 48, 40), (1, 4, 20, 36)])
+def test_fused_quant_conv_matches_the_cpu_convolution(orc, shape):
+    """VQ with quant_conv fused == VQ of torch's own CPU Conv2d output, indices and z_q bit for bit, for whichever of
+    the two accumulation orders the CPU convolution took on this host for this shape (it depends on shape and threads)"""
+    from control_gic_amd.quantize import _vq_forward
+    torch.manual_seed(3)
+    conv = torch.nn.Conv2d(4, 4, 1)
+    h = torch.randn(shape)
+    cb = torch.randn(1024, 4)
+    with torch.no_grad():
+        z_cpu = conv(h)                                              # the reference's quant_conv on the CPU
+    hf = h.permute(0, 2, 3, 1).reshape(-1, 4).numpy()
+    zf = z_cpu.permute(0, 2, 3, 1).reshape(-1, 4).numpy()
+    W, b = conv.weight.detach().numpy().reshape(4, 4), conv.bias.detach().numpy()
+    orders = [bf for bf in (False, True) if np.array_equal(_conv_seq(hf, W, b, bf), zf)]
+    assert len(orders) >= 1, "torch's CPU conv matches neither documented sequence"
+    ozq, oloss, oidx = orc.vq(z_cpu.numpy(), cb.numpy())
+    convd = conv.to(DEV)
+    for kernel in ("mfma", "valu"):
+        zq, loss, idx = _vq_forward(h.to(DEV), cb.to(DEV), 0.25, True, None, kernel=kernel, quant_conv=convd, conv_bias_first=orders[0])
+        assert np.array_equal(idx.cpu().numpy(), oidx)               # bit-exact
+        assert np.array_equal(zq.cpu().numpy(), ozq)                 # bit-exact: z_q = z + (e - z) on the convolved latent
+        assert abs(float(loss) - float(oloss)) <= 1e-6 * abs(float(oloss))
+    # the other order is the other documented sequence, not noise: it reproduces _conv_seq(..., not order) exactly
+    other = not orders[0]
+    z_other = _conv_seq(hf, W, b, other).reshape(shape[0], shape[2], shape[3], 4).transpose(0, 3, 1, 2)
+    _, _, oidx2 = orc.vq(np.ascontiguousarray(z_other), cb.numpy())
+    _, _, idx2 = _vq_forward(h.to(DEV), cb.to(DEV), 0.25, True, None, quant_conv=convd, conv_bias_first=other)
+    assert np.array_equal(idx2.cpu().numpy(), oidx2)
+    # no bias
+    conv_nb = torch.nn.Conv2d(4, 4, 1, bias=False)
+    with torch.no_grad():
+        z_nb = conv_nb(h)
+    _, _, oidx3 = orc.vq(z_nb.numpy(), cb.numpy())
+    _, _, idx3 = _vq_forward(h.to(DEV), cb.to(DEV), 0.25, True, None, quant_conv=conv_nb.to(DEV))
+    assert np.array_equal(idx3.cpu().numpy(), oidx3)
+
+
+def test_fused_post_quant_conv_is_a_second_gather(orc):
+    """decompress(..., post_quant_conv) returns (quant, post_quant_conv(quant)): the second one bit-identical to the
+    documented sequence applied to the gathered rows, i.e. to the CPU Conv2d (same two-order caveat)"""
+    torch.manual_seed(5)
+    g = torch.Generator().manual_seed(5)
+    B, h, w = 3, 32, 48
+    cbk = torch.randn(1024, 4, generator=g)
+    vq = _make_vq(cbk.numpy())
+    vq.usage_counter.copy_(torch.arange(1024, 0, -1, dtype=torch.float32))
+    codec = cg.GrainCodec(vq.embedding_counter, vq.embedding.weight)
+    e16 = (torch.rand(B, h // 4, w // 4, generator=g) * 2.6).to(DEV)
+    e8 = (torch.rand(B, h // 2, w // 2, generator=g) * 2.6).to(DEV)
+    mask, _, _, mode = cg.TripleGrainFixedEntropyRouter(0.1, 0.8, per_image=True)(e16, e8)
+    ind = torch.randint(0, 1024, (B, h, w), generator=g).to(DEV)
+    comp = codec.compress(ind, mask, mode)
+    conv = torch.nn.Conv2d(4, 4, 1)
+    ind_d, mask_d, (quant, quant2), status = codec.decompress(comp, post_quant_conv=conv.to(DEV))
+    ind_p, _, quant_p, _ = codec.decompress(comp)
+    assert int(status.abs().max()) == 0 and torch.equal(ind_d, ind_p) and torch.equal(quant, quant_p)
+    qf = quant.permute(0, 2, 3, 1).reshape(-1, 4).cpu().numpy()
+    W, b = conv.weight.detach().cpu().numpy().reshape(4, 4), conv.bias.detach().cpu().numpy()
+    assert np.array_equal(quant2.permute(0, 2, 3, 1).reshape(-1, 4).cpu().numpy(), _conv_seq(qf, W, b, False))
+    with torch.no_grad():
+        ref = conv.cpu()(quant.cpu())
+    # torch's CPU result is one of the two sequences; both are within an ulp or two of each other
+    assert torch.equal(ref, quant2.cpu()) or np.array_equal(ref.permute(0, 2, 3, 1).reshape(-1, 4).numpy(), _conv_seq(qf, W, b, True))
+    assert (ref - quant2.cpu()).abs().max() <= 1e-6

@@ -228,8 +228,11 @@ def test_install_and_compress_on_a_cgic_shaped_model(tmp_path, orc):
             quant, emb_loss, ind = self.quantize(self.quant_conv(d["h"]))
             return quant, emb_loss, d["indices"], d["mask"], ind, d["fine_ratio"], d["compression_mode"]
 
+        def decoder(self, quant2, quant, mask):    # decoder.py:340 signature: (post_quant_conv(quant), quant, mask)
+            return self.dec(quant2) + 0.0 * quant.mean()
+
         def decode(self, quant, mask):             # model.py:114-117
-            return self.dec(self.post_quant_conv(quant))
+            return self.decoder(self.post_quant_conv(quant), quant, mask)
 
     torch.manual_seed(0)
     model = StubCGIC().to(dev).eval()
@@ -246,6 +249,18 @@ def test_install_and_compress_on_a_cgic_shaped_model(tmp_path, orc):
     assert tuple(dec_b.shape) == (3, 3, 64, 96)
     for b, (dec, bpp, pmap) in enumerate(outs):
         assert pmap is None and bpp == bpp_b[b] and torch.equal(dec[0], dec_b[b])
+    # quant_conv ran inside the VQ kernel, post_quant_conv inside the decode-side gather: same result as the plain modules
+    assert isinstance(model.quant_conv, cg.quantize.FusedQuantConv) and model.quantize._fused_quant_conv is model.quant_conv
+    with torch.no_grad():
+        h_lat = model.encoder(x, *(cg.entropy_maps(x)[::-1]))["h"]
+        assert model.quant_conv(h_lat) is h_lat                                        # handed through under no_grad
+        z_plain = torch.nn.functional.conv2d(h_lat, model.quant_conv.weight, model.quant_conv.bias)
+        zq_plain, _, ind_plain = cg.quantize._vq_forward(z_plain, model.quantize.embedding.weight, 0.25, True, None)
+        zq_fused, _, ind_fused = model.quantize(h_lat)
+    # (the GPU's own Conv2d may round differently from the fused fma chain by an ulp: indices agree except at near-ties)
+    assert (ind_plain != ind_fused).float().mean() < 1e-3 and (zq_plain - zq_fused).abs().max() < 1e-5
+    with torch.enable_grad():
+        assert model.quant_conv(h_lat.clone().requires_grad_()).grad_fn is not None   # autograd sees a real Conv2d
     files = sorted(p.name for p in tmp_path.iterdir())
     assert files == sorted(n + ".bin" for n in cg.STREAM_NAMES)                     # the reference's five files
     assert {n: (tmp_path / (n + ".bin")).read_bytes() for n in cg.STREAM_NAMES} == comp.to_host()[2]
