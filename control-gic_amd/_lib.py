@@ -43,6 +43,8 @@ PROTOTYPES = {
     "cgic_vq_forward_valu_f32": (_int, [_vp, _i64, _i64, _vp, _int, _int, _f32, _int, _vp, _vp, _vp, _vp, _vp, _cv, _vp]),
     "cgic_vq_forward_route_f32": (_int, [_vp, _i64, _i64, _vp, _int, _int, _f32, _int, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64,
                                          _f64, _f64, _int, _vp, _vp, _vp, _vp, C.POINTER(_int), _cv, _vp]),
+    "cgic_vq_backward_workspace_bytes": (_sz, [_i64, _int]),
+    "cgic_vq_backward_f32": (_int, [_vp, _i64, _i64, _vp, _int, _int, _vp, _vp, _vp, _f32, _int, _vp, _vp, _vp, _vp]),
     "cgic_index_histogram": (_int, [_vp, _i64, _int, _vp, _vp]),
     "cgic_entropy_maps_f32": (_int, [_vp, _i64, _i64, _i64, C.POINTER(_f32), _int, _f32, _vp, _vp, _vp]),
     "cgic_router_mode": (_int, [_f64, _f64]),

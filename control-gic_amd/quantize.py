@@ -50,9 +50,10 @@ class _CounterView(MutableMapping):
 
 
 class _VQFunction(torch.autograd.Function):
-    """Forward = the HIP kernel.  Backward restates quantize.py:85-93 analytically:
+    """Forward = the HIP kernel.  Backward = csrc/cgic_vq_bwd.hip, restating quantize.py:85-93 analytically:
     z_q = z + (e - z).detach()  => dz += g_zq;  loss = m1 + beta*m2 (legacy) with
-    m1 = mean((e.detach() - z)^2), m2 = mean((e - z.detach())^2)."""
+    m1 = mean((e.detach() - z)^2), m2 = mean((e - z.detach())^2)  => dz += g_loss * (-2/n * w_z) * (e - z) and a
+    deterministic scatter-add of g_loss * (2/n * w_e) * (e - z) into the codebook rows."""
 
     @staticmethod
     def forward(ctx, z, weight, beta, legacy, hist):
@@ -65,14 +66,29 @@ class _VQFunction(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_zq, g_loss, _):
         z, weight, idx = ctx.saved_tensors
-        B, C, h, w = z.shape
-        zf = z.permute(0, 2, 3, 1).reshape(-1, C)
-        diff = weight.detach()[idx] - zf                      # e - z, [N, C]
-        scale = 2.0 / diff.numel()
-        w_z, w_e = (1.0, ctx.beta) if ctx.legacy else (ctx.beta, 1.0)
-        gz = g_zq + (g_loss * (-scale * w_z) * diff).view(B, h, w, C).permute(0, 3, 1, 2)
-        gw = torch.zeros_like(weight).index_add_(0, idx, g_loss * (scale * w_e) * diff)
+        gz, gw = vq_backward(z, weight, idx, g_zq, g_loss, ctx.beta, ctx.legacy,
+                             want_gz=ctx.needs_input_grad[0], want_gw=ctx.needs_input_grad[1])
         return gz, gw, None, None, None
+
+
+def vq_backward(z, weight, idx, g_zq, g_loss, beta, legacy, want_gz=True, want_gw=True):
+    """(g_z [B,C,h,w] or None, g_codebook [K,C] or None) -- cgic_vq_backward_f32"""
+    _lib.require_device(z, weight, idx, g_zq, g_loss)
+    B, C, h, w = z.shape
+    z = z.contiguous()
+    wt = weight.detach().contiguous()
+    dev = z.device
+    g_zq = None if g_zq is None else g_zq.contiguous().float()
+    g_loss = None if g_loss is None else g_loss.reshape(1).contiguous().float()
+    gz = torch.empty_like(z) if want_gz else None
+    gw = torch.empty_like(wt) if want_gw else None
+    N = B * h * w
+    ws = torch.empty(_lib.lib().cgic_vq_backward_workspace_bytes(N, wt.shape[0]), dtype=torch.uint8, device=dev) if want_gw else None
+    with torch.cuda.device(dev):
+        _lib.call("cgic_vq_backward_f32", _lib.ptr(z), B, h * w, _lib.ptr(wt), wt.shape[0], C, _lib.ptr(idx.contiguous()),
+                  _lib.ptr(g_zq), _lib.ptr(g_loss), float(beta), int(bool(legacy)), _lib.ptr(gz), _lib.ptr(gw), _lib.ptr(ws),
+                  _lib.current_stream(dev))
+    return gz, gw
 
 
 def _vq_forward(z, weight, beta, legacy, hist, want_zq=True, want_loss=True, kernel="mfma", quant_conv=None, conv_bias_first=False):
@@ -203,11 +219,21 @@ class VectorQuantize2(nn.Module):
     def embedding_counter(self):
         return _CounterView(self)
 
+    #: under torch.distributed (DDP training, config_train.yaml:9-15) sum the step's histogram over all ranks before it is
+    #: folded in, so that every rank's counter -- the Huffman frequency table that ends up in the checkpoint -- counts the
+    #: whole batch.  (The reference's counters are requires_grad=False Parameters that DDP never reduces: each rank counts
+    #: its own shard and rank 0's partial counts are what gets saved; set False to reproduce that.)
+    sync_usage_counter = True
+
     def fold_usage_hist(self):
-        """Add the kernel's exact int64 histogram into the fp32 counters and clear it.
+        """Add the kernel's exact int64 histogram into the fp32 counters and clear it; with a process group, all-reduce it
+        first (one 8 KB int64 all-reduce: RCCL on the GPUs, exact).
         The reference adds 1.0 per vector in fp32 (quantize.py:79-81), which stops
         counting at 2**24; below that both give the same integers."""
         with torch.no_grad():
+            if self.sync_usage_counter:
+                from . import dist as cdist
+                cdist.all_reduce_histogram(self.usage_hist)          # no-op without a process group / with one rank
             self.usage_counter += self.usage_hist.to(self.usage_counter.dtype)
             self.usage_hist.zero_()
 

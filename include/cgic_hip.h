@@ -106,6 +106,20 @@ int cgic_vq_forward_valu_f32(const float *z, int64_t B, int64_t hw, const float 
                              float *loss, int64_t *hist, void *workspace, const cgic_conv1x1 *quant_conv,
                              cgic_stream_t stream);
 
+/* Backward of cgic_vq_forward_f32 for training (quantize.py:85-93 under autograd, CGIC.training_step model.py:155-174):
+ *   g_zq   device [B, 4, hw] fp32 or NULL   gradient arriving at z_q (straight-through: passes to z)
+ *   g_loss device [1] fp32 or NULL          gradient arriving at loss
+ *   g_z    device [B, 4, hw] fp32 or NULL   = g_zq + g_loss * (-2/n * w_z) * (e[idx] - z)      (bit-identical to that expression)
+ *   g_codebook device [K, 4] fp32 or NULL   = g_loss * (2/n * w_e) * sum_{idx[n] = k} (e[idx] - z_n); n = B*hw*4,
+ *          (w_z, w_e) = (1, beta) if legacy else (beta, 1).  Deterministic (fixed-point LDS accumulation per workgroup,
+ *          workgroup tables added in a fixed order), unlike torch.index_add_'s fp32 atomics; accurate to ~1e-9 relative
+ *          of the largest |e - z| per term.
+ *   workspace device, cgic_vq_backward_workspace_bytes(B*hw, K) bytes, or NULL iff g_codebook == NULL */
+size_t cgic_vq_backward_workspace_bytes(int64_t n_vectors, int K);
+int cgic_vq_backward_f32(const float *z, int64_t B, int64_t hw, const float *codebook, int K, int e_dim,
+                         const int64_t *indices, const float *g_zq, const float *g_loss, float beta, int legacy,
+                         float *g_z, float *g_codebook, void *workspace, cgic_stream_t stream);
+
 /* usage histogram of an index tensor (quantize.py:79-81): hist[idx[i]] += 1 */
 int cgic_index_histogram(const int64_t *indices, int64_t n, int K, int64_t *hist, cgic_stream_t stream);
 

@@ -136,3 +136,42 @@ def test_bench_refuses_a_mismatched_world():
     if not _t.cuda.is_available():
         r = _bench(["--gpus", "2", "--steps", "2"])
         assert r.returncode != 0 and "GPUs are visible" in r.stderr + r.stdout
+
+
+def _counter_worker(rank, world, port, out_dir):
+    import sys
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import control_gic_amd as cg
+    vq = cg.VectorQuantizer(1024, 4, beta=0.25).train()          # CPU module: no kernel is launched below
+    rng = np.random.default_rng(50 + rank)
+    total = np.zeros(1024, np.int64)
+    for step in range(3):                                          # what forward() does after the kernel filled usage_hist
+        h = np.bincount(rng.integers(0, 1024, 4096), minlength=1024)
+        vq.usage_hist += torch.from_numpy(h)
+        vq.fold_usage_hist()
+        total += h
+    local = cg.VectorQuantizer(1024, 4, beta=0.25).train()
+    local.sync_usage_counter = False                               # the reference's behaviour: every rank counts its own shard
+    local.usage_hist += torch.from_numpy(total)
+    local.fold_usage_hist()
+    torch.save({"synced": vq.usage_counter.clone(), "local": local.usage_counter.clone(), "mine": torch.from_numpy(total),
+                "hist_left": int(vq.usage_hist.abs().sum()), "key3": float(vq.embedding_counter["3"].item())},
+               os.path.join(out_dir, f"c{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_training_usage_counter_is_reduced_over_ranks(tmp_path):
+    """VectorQuantize2 in training mode under a process group: every rank's embedding_counter counts the WHOLE batch
+    (sum over ranks, exact), identically on all ranks; sync_usage_counter=False keeps the reference's per-rank counts"""
+    world = 2
+    mp.spawn(_counter_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    res = [torch.load(tmp_path / f"c{r}.pt") for r in range(world)]
+    want = (res[0]["mine"] + res[1]["mine"]).float()
+    for r in res:
+        assert torch.equal(r["synced"], want) and r["hist_left"] == 0 and r["key3"] == float(want[3])
+        assert torch.equal(r["local"], r["mine"].float())
+    assert not torch.equal(res[0]["local"], res[1]["local"])

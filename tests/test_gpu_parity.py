@@ -555,3 +555,55 @@ def test_fused_post_quant_conv_is_a_second_gather(orc):
     # torch's CPU result is one of the two sequences; both are within an ulp or two of each other
     assert torch.equal(ref, quant2.cpu()) or np.array_equal(ref.permute(0, 2, 3, 1).reshape(-1, 4).numpy(), _conv_seq(qf, W, b, True))
     assert (ref - quant2.cpu()).abs().max() <= 1e-6
+
+
+# ---------------------------------------------------------------------------- f4. training: backward kernel
+@pytest.mark.parametrize("legacy", [True, False])
+def test_vq_backward_kernel_vs_formula(legacy):
+    """csrc/cgic_vq_bwd.hip against quantize.py:85-93 differentiated by torch autograd on the same tensors: dz bit-identical
+    to the analytic expression, the codebook gradient within 2e-6 relative of an fp64 scatter-add (torch's own fp32
+    index_add_ is itself order-dependent), and identical from run to run"""
+    g = torch.Generator().manual_seed(11)
+    B, h, w, K = 4, 24, 40, 1024
+    z = torch.randn(B, 4, h, w, generator=g).to(DEV).requires_grad_()
+    vq = cg.VectorQuantizer(K, 4, beta=0.25, legacy=legacy).to(DEV).train()
+    vq.embedding.weight.data.copy_(torch.randn(K, 4, generator=g))
+    zq, loss, idx = vq(z)
+    gq = torch.randn(B, 4, h, w, generator=g).to(DEV)
+    (zq * gq).sum().add(3.0 * loss).backward()
+    gz, gw = z.grad.clone(), vq.embedding.weight.grad.clone()
+    # reference expressions (quantize.py:83-93) on the GPU through torch autograd
+    z2 = z.detach().clone().requires_grad_()
+    wt = vq.embedding.weight.detach().clone().requires_grad_()
+    zf = z2.permute(0, 2, 3, 1).reshape(-1, 4)
+    e = wt[idx]
+    if legacy:
+        l2 = torch.mean((e.detach() - zf) ** 2) + 0.25 * torch.mean((e - zf.detach()) ** 2)
+    else:
+        l2 = 0.25 * torch.mean((e.detach() - zf) ** 2) + torch.mean((e - zf.detach()) ** 2)
+    q2 = (zf + (e - zf).detach()).view(B, h, w, 4).permute(0, 3, 1, 2)
+    (q2 * gq).sum().add(3.0 * l2).backward()
+    assert torch.allclose(gz, z2.grad, rtol=1e-5, atol=1e-8)                     # autograd's own op order differs by an ulp
+    # the kernel's documented expression, exactly: g_zq + (g_loss * (-2/n * w_z)) * (e - z)
+    n = float(z.numel())
+    w_z, w_e = (1.0, 0.25) if legacy else (0.25, 1.0)
+    diff = (vq.embedding.weight.detach()[idx] - z.detach().permute(0, 2, 3, 1).reshape(-1, 4))
+    cz = torch.tensor(3.0, device=DEV) * (-(2.0 / n) * w_z)
+    want_gz = gq + (cz * diff).view(B, h, w, 4).permute(0, 3, 1, 2)
+    assert torch.equal(gz, want_gz)                                              # bit-exact
+    want_gw = torch.zeros(K, 4, dtype=torch.float64, device=DEV).index_add_(0, idx, diff.double()) * (3.0 * (2.0 / n) * w_e)
+    assert torch.allclose(gw.double(), want_gw, rtol=2e-6, atol=1e-12)
+    assert torch.allclose(gw, wt.grad, rtol=1e-4, atol=1e-9)                     # torch's fp32 atomics
+    # deterministic: a second backward gives the same bits
+    z.grad = None; vq.embedding.weight.grad = None
+    zq, loss, idx = vq(z)
+    (zq * gq).sum().add(3.0 * loss).backward()
+    assert torch.equal(vq.embedding.weight.grad, gw) and torch.equal(z.grad, gz)
+    # only one of the two gradients wanted
+    z3 = z.detach().clone().requires_grad_()
+    with torch.no_grad():
+        pass
+    vq.embedding.weight.requires_grad_(False)
+    zq, loss, _ = vq(z3)
+    (zq * gq).sum().add(3.0 * loss).backward()
+    assert torch.equal(z3.grad, gz)
