@@ -22,6 +22,8 @@
 // torch.mean's summation tree); it is held to 2e-5 absolute, and measures ~1e-6.
 #include "cgic_common.h"
 
+#include <stdlib.h>
+
 namespace cgic {
 
 constexpr int kEntThreads = 256;
@@ -233,6 +235,15 @@ extern "C" int cgic_entropy_maps_f32(const float *x, int64_t B, int64_t H, int64
     dim3 grid((unsigned)(((W + 63) / 64 + kEntStrips - 1) / kEntStrips), (unsigned)(H / 16), (unsigned)B);
     // exp(-0.5 (r/sigma)^2) = exp2(c r^2), c = -0.5 log2(e) / sigma^2 (float64 on the host, rounded once)
     const float exp2_scale = (float)(-0.5 * 1.4426950408889634 / ((double)sigma * (double)sigma));
+#ifdef CGIC_DEV_KNOBS
+    // dev: pad the workgroup's LDS so that fewer of them fit a CU (co-residency experiments)
+    static const int pad = getenv("CGIC_ENT_PAD") ? atoi(getenv("CGIC_ENT_PAD")) : 0;
+    if (pad > 0) {
+        CGIC_HIP_TRY(hipFuncSetAttribute((const void *)entropy_maps_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, pad));
+        hipLaunchKernelGGL(entropy_maps_kernel, grid, dim3(kEntThreads), (size_t)pad, s, x, H, W, exp2_scale, e8, e16, ba);
+        return launch_check("entropy_maps_kernel");
+    }
+#endif
     hipLaunchKernelGGL(entropy_maps_kernel, grid, dim3(kEntThreads), 0, s, x, H, W, exp2_scale, e8, e16, ba);
     return launch_check("entropy_maps_kernel");
 }

@@ -47,8 +47,17 @@ int router_prepare(const float *e16, const float *e8, int64_t B, int64_t h16, in
     a.rank_c = (unsigned int)(k_c != 0 ? k_c - 1 : 0);      // sorted[k-1 if k != 0 else k]
     a.rank_m = (unsigned int)(k_m != 0 ? k_m - 1 : 0);
     const size_t lds = router_lds_bytes(N16, N8, &a.stage);
+    // large per-image segments: several workgroups per image share the mask writing (every one repeats the selects, which
+    // costs nothing while most CUs are idle): up to 8, while the launch stays within ~a quarter of the chip
+    a.bands = 1;
+    if (per_image && h16 * w16 >= 32 * 32) {
+        int64_t nb = 64 / nseg;
+        if (nb > 8) nb = 8;
+        if (nb > h16) nb = h16;
+        a.bands = nb >= 2 ? (int)nb : 1;
+    }
     CGIC_REQUIRE(lds <= 150 * 1024, CGIC_ERR_UNSUPPORTED, "router: segment of %lld coarse patches exceeds LDS", (long long)N16);
-    *out = a; *nseg_out = nseg; *lds_out = lds;
+    *out = a; *nseg_out = nseg * a.bands; *lds_out = lds;       // workgroups of the launch
     return CGIC_OK;
 }
 

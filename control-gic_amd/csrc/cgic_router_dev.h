@@ -44,12 +44,22 @@ __device__ float radix_select(F val, int64_t n, unsigned int rank0, RouterShared
 #pragma unroll 1
     for (int shift = 24; shift >= 0; shift -= 8, ++pass) {
         unsigned int *h = sh->hist[pass % 3];
-        // (a wave-aggregated variant -- one ballot per distinct digit per wave -- was measured 2x
-        // SLOWER than plain LDS atomics here, even though entropy values crowd into 2-3 bins of the
-        // first pass)
-        for (int64_t i = tid; i < n; i += NT) {
-            uint32_t key = f2key(val(i));
-            if ((key & himask) == prefix) atomicAdd(&h[(key >> shift) & 0xFF], 1u);
+        // Same-address LDS atomics serialise across the whole workgroup, and entropy values crowd into 2-3 bins of a pass
+        // (all of them in the exponent byte): at 9216 values per 768x768 tile a pass spent ~4 us incrementing ONE
+        // counter.  Every lane therefore merges equal digits of its own consecutive slots before it touches LDS: a
+        // hot pass costs one or two atomics per lane instead of n / NT, a spread-out pass the same as before.
+        // (Ballot-based wave aggregation was measured no faster: its ~25 extra instructions per slot cost what it saved.)
+        {
+            unsigned int run_d = 0, run_n = 0;
+            for (int64_t i = tid; i < n; i += NT) {
+                const uint32_t key = f2key(val(i));
+                if ((key & himask) != prefix) continue;
+                const unsigned int digit = (key >> shift) & 0xFF;
+                if (digit != run_d && run_n) { atomicAdd(&h[run_d], run_n); run_n = 0; }
+                run_d = digit;
+                ++run_n;
+            }
+            if (run_n) atomicAdd(&h[run_d], run_n);
         }
         if (pass >= 1) {
             unsigned int *hz = sh->hist[(pass + 1) % 3];
@@ -87,13 +97,18 @@ struct RouterArgs {
     unsigned int rank_c;   // 0-based rank of the coarse threshold in the segment
     unsigned int rank_m;
     int stage;             // 1: the segment's e16/e8 are copied to LDS once (all select passes read LDS)
+    int bands;             // workgroups per segment (per-image segments only): every one finds the thresholds, each writes
+                           // only its band of rows of the masks (one CU per 768x768 tile spent 10 us writing 200 KB of masks)
 };
 
 // The whole router for segment `seg`, executed by a block of NT threads; `dyn` = dynamic LDS of at least
 // router_lds_bytes() bytes.
 template <int NT>
-__device__ __forceinline__ void router_body(const RouterArgs &a, int64_t seg, unsigned char *dyn)
+__device__ __forceinline__ void router_body(const RouterArgs &a, int64_t blk, unsigned char *dyn)
 {
+    const int nb = a.bands > 1 ? a.bands : 1;
+    const int64_t seg = blk / nb;
+    const int band = (int)(blk - seg * nb);
     RouterShared *sh = reinterpret_cast<RouterShared *>(dyn);
     unsigned long long *gc_bits = reinterpret_cast<unsigned long long *>(dyn + 3072);  // [ceil(N16/64)]
 
@@ -132,18 +147,31 @@ __device__ __forceinline__ void router_body(const RouterArgs &a, int64_t seg, un
         if (i < N16) g = has_thr_c ? (e16[i] < thr_c) : (mode == 4);
         unsigned long long bal = __ballot(g);
         if (lane == 0) gc_bits[i >> 6] = bal;
-        if (i < N16) mc[i] = g ? 1 : 0;
+        if (i < N16 && band == 0) mc[i] = g ? 1 : 0;
     }
     __syncthreads();
     // 32-bit index math throughout (N8 < 2^31 is checked on the host): a 64-bit divide is ~100 instructions
     const int n8i = (int)n8, w8i = (int)w8, n16i = (int)n16, w16i = (int)w16;
-    auto gc_of8 = [&](int64_t i) -> bool {   // coarse gate of the parent of medium element i
+    auto gc_at = [&](int b, int y8, int x8) -> bool {   // coarse gate of the parent of medium element (y8, x8) of image b
+        const int c = b * n16i + (y8 >> 1) * w16i + (x8 >> 1);
+        return (gc_bits[c >> 6] >> (c & 63)) & 1ull;
+    };
+    auto gc_of8 = [&](int64_t i) -> bool {
         const int ii = (int)i;
         const int b = ii / n8i, r = ii - b * n8i;
         const int y = r / w8i, x = r - y * w8i;
-        const int c = b * n16i + (y >> 1) * w16i + (x >> 1);
-        return (gc_bits[c >> 6] >> (c & 63)) & 1ull;
+        return gc_at(b, y, x);
     };
+    // One image per segment (per-image routing: every batched compress): walk rows by wave and columns by lane -- the
+    // flat loops below spend ~4 integer divisions (~25 VALU instructions each) per element, which at 9216 + 36864
+    // elements per 768x768 tile on ONE CU was 11 of the router's 39 us.
+    const bool rows2d = a.per == 1 && (w8 >= 64 || nb > 1);      // (narrow rows leave most lanes of a wave idle: flat loops there)
+    constexpr int NWV = NT / 64;
+    const int wv = tid >> 6;
+    // this workgroup's band of coarse rows [cy0, cy1) (medium rows x2, fine rows x4); bands > 1 only with rows2d
+    const int cper = ((int)h16 + nb - 1) / nb;
+    const int cy0 = band * cper < (int)h16 ? band * cper : (int)h16;
+    const int cy1 = cy0 + cper < (int)h16 ? cy0 + cper : (int)h16;
 
     CGIC_STAMP(3);
     // ---- medium gate
@@ -152,7 +180,12 @@ __device__ __forceinline__ void router_body(const RouterArgs &a, int64_t seg, un
         if (a.stage) {
             // materialise the masked values once (LDS), so the four radix passes are plain LDS sweeps
             float *l8m = const_cast<float *>(e8) + N8;
-            for (int64_t i = tid; i < N8; i += NT) l8m[i] = e8[i] * (1.0f - (gc_of8(i) ? 1.0f : 0.0f));
+            if (rows2d) {
+                for (int y = wv; y < (int)h8; y += NWV)
+                    for (int x = lane; x < w8i; x += 64) l8m[y * w8i + x] = e8[y * w8i + x] * (1.0f - (gc_at(0, y, x) ? 1.0f : 0.0f));
+            } else {
+                for (int64_t i = tid; i < N8; i += NT) l8m[i] = e8[i] * (1.0f - (gc_of8(i) ? 1.0f : 0.0f));
+            }
             __syncthreads();
             thr_m = radix_select<NT>([&](int64_t i) { return l8m[i]; }, N8, a.rank_m, sh);
         } else {
@@ -161,31 +194,37 @@ __device__ __forceinline__ void router_body(const RouterArgs &a, int64_t seg, un
     }
     if (mode == 1)        // :40-43
         thr_m = radix_select<NT>([&](int64_t i) { return e8[i]; }, N8, a.rank_m, sh);
-    auto gm_of8 = [&](int64_t i) -> bool {
+    auto gm_rule = [&](float v, bool gc) -> bool {
         switch (mode) {
-        case 0: return (e8[i] < thr_m) && !gc_of8(i);      // :32
-        case 1: return e8[i] < thr_m;                       // :44
-        case 3: return !gc_of8(i);                          // :68
+        case 0: return (v < thr_m) && !gc;                  // :32
+        case 1: return v < thr_m;                           // :44
+        case 3: return !gc;                                 // :68
         case 5: return true;                                // :81
         default: return false;
         }
     };
+    auto gm_of8 = [&](int64_t i) -> bool { return gm_rule(e8[i], (mode == 0 || mode == 3) ? gc_of8(i) : false); };
     CGIC_STAMP(4);
-    for (int64_t i = tid; i < N8; i += NT) mm[i] = gm_of8(i) ? 1 : 0;
+    if (rows2d) {
+        for (int y = 2 * cy0 + wv; y < 2 * cy1; y += NWV)
+            for (int x = lane; x < w8i; x += 64)
+                mm[y * w8i + x] = gm_rule(e8[y * w8i + x], (mode == 0 || mode == 3) ? gc_at(0, y, x) : false) ? 1 : 0;
+    } else {
+        for (int64_t i = tid; i < N8; i += NT) mm[i] = gm_of8(i) ? 1 : 0;
+    }
     CGIC_STAMP(5);
 
     // ---- fine gate + optional gate tensor (:34,47,58,69,77,83,87,93): 4 consecutive x per thread
     // (w4 is a multiple of 4, so a quad never straddles a row, a medium pair or a coarse cell)
     float *gate = a.gate ? a.gate + seg * N4 * 3 : nullptr;
     const int W4 = (int)w4, W8 = (int)w8, W16 = (int)w16, NQ = (int)(N4 >> 2), n4i = (int)n4, qrow = W4 >> 2;
-    for (int q = tid; q < NQ; q += NT) {
-        const int i = q << 2;
-        const int b = i / n4i, r = i - b * n4i;
-        const int y = r / W4, x = r - y * W4;
+    auto fine_quad = [&](int b, int y, int x) {
+        const int i = b * n4i + y * W4 + x;
         const int64_t c = (int64_t)b * n16 + (y >> 2) * W16 + (x >> 2);
         const bool gc = (gc_bits[c >> 6] >> (c & 63)) & 1ull;
         const int64_t m0 = (int64_t)b * n8 + (y >> 1) * W8 + (x >> 1);
-        const bool gm0 = gm_of8(m0), gm1 = gm_of8(m0 + 1);
+        const bool gcm = (mode == 0 || mode == 3) ? gc : false;          // (the medium pair's coarse parent is this quad's)
+        const bool gm0 = gm_rule(e8[m0], gcm), gm1 = gm_rule(e8[m0 + 1], gcm);
         bool gf0, gf1;
         switch (mode) {
         case 0: gf0 = !gc && !gm0; gf1 = !gc && !gm1; break;
@@ -202,7 +241,17 @@ __device__ __forceinline__ void router_body(const RouterArgs &a, int64_t seg, un
             *reinterpret_cast<float4 *>(row + w4 + x) = make_float4(a0, a0, a1, a1);
             *reinterpret_cast<float4 *>(row + 2 * w4 + x) = make_float4(gf0 ? 1.f : 0.f, gf0 ? 1.f : 0.f, gf1 ? 1.f : 0.f, gf1 ? 1.f : 0.f);
         }
-        (void)qrow;
+    };
+    if (rows2d) {
+        for (int y = 4 * cy0 + wv; y < 4 * cy1; y += NWV)
+            for (int xq = lane; xq < qrow; xq += 64) fine_quad(0, y, xq << 2);
+    } else {
+        for (int q = tid; q < NQ; q += NT) {
+            const int i = q << 2;
+            const int b = i / n4i, r = i - b * n4i;
+            const int y = r / W4, x = r - y * W4;
+            fine_quad(b, y, x);
+        }
     }
     CGIC_STAMP(6);
 }

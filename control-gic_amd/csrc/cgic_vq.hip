@@ -1212,9 +1212,11 @@ static int launch_filter(const float *z, int64_t hw, int64_t N, const float *cb,
     const int64_t late = router ? nblk + router_blocks - cus : 0;
     bool router_first = false;
     if (late > 0 && late < nblk && !dev_knob("CGIC_VQ_NOSPLIT")) {
-        const int64_t delta = (int64_t)(0.0021 * (double)hw + 0.5);
+        // how long a router workgroup holds its CU, in groups of VQ work (~1.05 us each per workgroup): measured 12 us at
+        // 64x64 latents, 21 us at 192x192 (with its row bands)
+        const int64_t delta = (int64_t)((10.9 + 0.000275 * (double)hw) / 1.05 + 0.5);
         const int force_ge = dev_knob("CGIC_VQ_GE");
-        for (int64_t ge = force_ge ? force_ge : (per / 4 + 1) * 4; ge <= per + 12; ge += 4) {
+        for (int64_t ge = force_ge ? force_ge : (per / 4 + 1) * 4; ge <= per + 28; ge += 4) {
             const int64_t rest = ngroups - (nblk - late) * ge;
             const int64_t gl = rest > 0 ? (rest + late - 1) / late : 0;
             // (gl == 0: the router outlasts the whole VQ -- the early workgroups simply take everything)
