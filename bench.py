@@ -571,14 +571,16 @@ def report(a, dev, world, stream, slots_np, vq, codec, ratio):
         except Exception:
             traffic = None
     res["roofline"] = {
-        "kernel": "vq_filter_router_kernel<4> (VQ forward + the per-image router workgroups, the launch of the timed step)",
+        "kernel": "vq_filter_router_kernel (VQ forward + the per-image router workgroups, the launch of the timed step)",
         "bound": "mfma", "achieved": round(achieved, 3), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
         "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic,
         "vq_alone_frac": round(flops / (stages["vq_kernel_alone"] * 1e-6) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
         "note": "algorithmic flops = 2*N*K*D of the fp32 distance contraction per launch / average launch duration (20 launches "
                 "in a hipGraph, HIP events on the launch stream), priced against the dense fp32 MFMA peak (results are "
-                "bit-identical to the fp32 sequence); the kernel issues bf16 MFMAs with 32 K-slots per 4-dim contraction "
-                f"({2.0 * N * 1024 * 32 / 1e9:.1f} GFLOP per launch = {2.0 * N * 1024 * 32 / t_dom / 2.5e15:.2f} of the 2.5 PFLOP/s bf16 peak); see DESIGN.md 4.1"}
+                "bit-identical to the fp32 sequence); the kernel issues fp16 MFMAs with 16 K-slots per 4-dim contraction "
+                f"({2.0 * N * 1024 * 16 / 1e9:.1f} GFLOP per launch = {2.0 * N * 1024 * 16 / t_dom / 2.5e15:.2f} of the 2.5 PFLOP/s fp16 peak) "
+                "and is bound by VALU issue (one half-rate v_min3 per two scores), not by the matrix cores; frac = the fused launch "
+                "(router workgroups hold 64 CUs for ~12 us), vq_alone_frac = the VQ kernel by itself; see DESIGN.md 4.1"}
     if world == 1 and (B, H) == (64, 256) and not a.no_extra:
         hp.step()
         res["mask_mismatch"] = mask_mismatch(hp, x, z, cb, ratio)

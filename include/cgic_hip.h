@@ -47,6 +47,11 @@ typedef void *cgic_stream_t;
  * indices_fine, mask_coarse, mask_medium */
 #define CGIC_NUM_STREAMS 5
 
+/* Launch resources: kernels that hand work to "the last workgroup to arrive" use self-resetting ticket words in
+ * library-owned device memory.  Eager launches take them from a ring; launches being captured into a hipGraph take them
+ * from a pool of 262 144 words per device that is never recycled (the graph may be replayed at any time later), so a
+ * process can capture at most that many ticketed launches (CGIC_ERR_INVALID beyond).  Call each entry point once
+ * eagerly on a device before capturing it (allocations and function attributes are set up on first use). */
 const char *cgic_last_error(void);
 int cgic_abi_version(void);
 /* number of visible HIP devices, or CGIC_ERR_HIP; never throws, never aborts */
