@@ -58,6 +58,8 @@ __device__ __forceinline__ uint32_t code_bits(const TableDev &t, int s, uint32_t
     return (uint32_t)((w << (off & 31)) >> (64 - nb));
 }
 
+__device__ int pack_huffman_stream(const TableDev &t, unsigned long long carry, EncStorage st, uint8_t *out, int64_t cap);
+
 // Phase A + B for one Huffman-coded stream.  sym_at(i, &flag) returns the symbol at linear
 // position i and whether it is selected.  Returns bytes written (0 = empty file) or CGIC_ERR_*.
 template <typename SymAt>
@@ -107,7 +109,13 @@ __device__ int encode_huffman_stream(const TableDev &t, int64_t npos, SymAt sym_
     __syncthreads();   // phase-A stores (LDS or global, same workgroup) visible to phase B
     CGIC_STAMP2(2);
     if (s_err) return s_err;
+    return pack_huffman_stream(t, carry, st, out, cap);
+}
 
+// Phase B: one thread per 32-bit output word gathers the code bits that overlap it (no atomics, any code length).
+__device__ int pack_huffman_stream(const TableDev &t, unsigned long long carry, EncStorage st, uint8_t *out, int64_t cap)
+{
+    const int tid = threadIdx.x;
     const uint32_t count = (uint32_t)(carry >> 32);
     const uint32_t total_bits = (uint32_t)carry;
     if (count == 0) return 0;                                   // `if not text: write b''`  (:116-118)
@@ -144,6 +152,131 @@ __device__ int encode_huffman_stream(const TableDev &t, int64_t npos, SymAt sym_
     }
     CGIC_STAMP2(3);
     return (int)nbytes;
+}
+
+// Phase A for LONG streams (a 768x768 tile's fine grid has 36 864 positions): the round-by-round form above pays one
+// block-wide scan (three barriers) per 4096 positions -- nine in a row for that stream, 22 us on one CU.  Here the
+// (symbol | unselected) entries of ALL positions are first staged in LDS with coalesced loads (2 bytes each), every
+// thread then owns one CONTIGUOUS chunk: it sums its code lengths, ONE block scan turns the sums into start offsets, and a
+// second walk over the same LDS entries writes (end bit, symbol) of the selected ones.  The compacted list goes to the
+// static LDS arrays when it fits (a fine stream keeps ~10 % of its positions), else to the global workspace.
+// dense = non-NULL: the stream covers every position of a contiguous int64 index array with an int32 mask beside it (the fine
+// grid): four positions per thread and trip, 16-byte loads, no index arithmetic
+template <typename SymAt>
+__device__ int encode_huffman_stream_long(const TableDev &t, int64_t npos, SymAt sym_at, uint16_t *stage, EncStorage st_lds,
+                                          EncStorage st_glob, uint8_t *out, int64_t cap, const int64_t *dense_ind = nullptr,
+                                          const int32_t *dense_mask = nullptr)
+{
+    __shared__ unsigned long long scan_smem[kEncThreads / kWave + 1];
+    __shared__ int s_err;
+    const int tid = threadIdx.x;
+    if (tid == 0) s_err = 0;
+    __syncthreads();
+    // eight positions per thread in flight at a time: with one, every trip of the loop waited out its own HBM / L2 round
+    // trip (36 trips x ~0.7 us for a 768x768 tile's fine stream)
+    constexpr int kInFlight = 8;
+    const bool dense = dense_ind != nullptr && (npos & 3) == 0 && ((reinterpret_cast<uintptr_t>(dense_ind) | reinterpret_cast<uintptr_t>(dense_mask)) & 15) == 0;
+    if (dense) {
+        const int64_t nq = npos >> 2;
+        for (int64_t base = 0; base < nq; base += (int64_t)kEncThreads * 2) {
+            int4 m[2];
+            longlong2 a[2], b[2];
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const int64_t q = base + (int64_t)k * kEncThreads + tid;
+                if (q < nq) {
+                    m[k] = reinterpret_cast<const int4 *>(dense_mask)[q];
+                    a[k] = reinterpret_cast<const longlong2 *>(dense_ind)[2 * q];
+                    b[k] = reinterpret_cast<const longlong2 *>(dense_ind)[2 * q + 1];
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const int64_t q = base + (int64_t)k * kEncThreads + tid;
+                if (q < nq) {
+                    const int64_t v[4] = {a[k].x, a[k].y, b[k].x, b[k].y};
+                    const int f[4] = {m[k].x, m[k].y, m[k].z, m[k].w};
+                    uint32_t e[4];
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        e[c] = 0xFFFFu;
+                        if (f[c] == 1) {
+                            if (v[c] < 0 || v[c] >= t.n || v[c] >= 0xFFFF) s_err = CGIC_ERR_INVALID;
+                            else e[c] = (uint32_t)v[c];
+                        }
+                    }
+                    reinterpret_cast<uint2 *>(stage)[q] = make_uint2(e[0] | (e[1] << 16), e[2] | (e[3] << 16));
+                }
+            }
+        }
+    } else
+    for (int64_t base = 0; base < npos; base += (int64_t)kEncThreads * kInFlight) {
+        int64_t sy[kInFlight];
+        bool fl[kInFlight];
+#pragma unroll
+        for (int k = 0; k < kInFlight; ++k) {
+            const int64_t i = base + (int64_t)k * kEncThreads + tid;
+            fl[k] = false;
+            sy[k] = 0;
+            if (i < npos) sy[k] = sym_at(i, &fl[k]);
+        }
+#pragma unroll
+        for (int k = 0; k < kInFlight; ++k) {
+            const int64_t i = base + (int64_t)k * kEncThreads + tid;
+            uint16_t e = 0xFFFFu;
+            if (fl[k]) {
+                if (sy[k] < 0 || sy[k] >= t.n || sy[k] >= 0xFFFF) s_err = CGIC_ERR_INVALID;      // KeyError in the reference
+                else e = (uint16_t)sy[k];
+            }
+            if (i < npos) stage[i] = e;
+        }
+    }
+    __syncthreads();
+    CGIC_STAMP2(1);
+    if (s_err) return s_err;
+    // chunks of a multiple of 4 entries (8-byte LDS reads; `stage` is 16-byte aligned and padded by the caller's sizing)
+    const int64_t chunk = ((npos + kEncThreads - 1) / kEncThreads + 3) & ~(int64_t)3;
+    const int64_t lo = (int64_t)tid * chunk < npos ? (int64_t)tid * chunk : npos;
+    const int64_t hi = lo + chunk < npos ? lo + chunk : npos;
+    uint32_t lcount = 0, lbits = 0;
+    for (int64_t i = lo; i < hi; i += 4) {
+        const uint2 q = *reinterpret_cast<const uint2 *>(stage + i);       // (entries past npos read stale LDS: masked below)
+        const uint32_t e[4] = {q.x & 0xFFFFu, q.x >> 16, q.y & 0xFFFFu, q.y >> 16};
+        uint32_t l[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) l[c] = (uint32_t)t.len[e[c] == 0xFFFFu ? 0 : e[c]];     // four lookups in flight
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const bool on = e[c] != 0xFFFFu && i + c < hi;
+            lcount += on ? 1u : 0u;
+            lbits += on ? l[c] : 0u;
+        }
+    }
+    unsigned long long local = ((unsigned long long)lcount << 32) | lbits;
+    unsigned long long total;
+    unsigned long long excl = block_exclusive_scan(local, scan_smem, &total);
+    const uint32_t count = (uint32_t)(total >> 32);
+    const EncStorage st = count <= (uint32_t)kLdsPos ? st_lds : st_glob;
+    uint32_t ci = (uint32_t)(excl >> 32), bit = (uint32_t)excl;
+    for (int64_t i = lo; i < hi; i += 4) {
+        const uint2 q = *reinterpret_cast<const uint2 *>(stage + i);
+        const uint32_t e[4] = {q.x & 0xFFFFu, q.x >> 16, q.y & 0xFFFFu, q.y >> 16};
+        uint32_t l[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) l[c] = (uint32_t)t.len[e[c] == 0xFFFFu ? 0 : e[c]];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            if (e[c] != 0xFFFFu && i + c < hi) {
+                bit += l[c];
+                st.cend[ci] = bit;
+                st.csym[ci] = (uint16_t)e[c];
+                ++ci;
+            }
+        }
+    }
+    __syncthreads();
+    CGIC_STAMP2(2);
+    return pack_huffman_stream(t, total, st, out, cap);
 }
 
 // 1-bit stream (BinaryCoding): bit_at(i) in {0,1}; other values are a KeyError in the reference
@@ -189,6 +322,7 @@ struct CompressArgs {
     uint16_t *ws_sym;
     int64_t ws_stride;      // positions reserved per (image, stream) in the workspace
     unsigned long long *hist;   // optional [tab.n]: usage histogram of ALL h*w indices (job 5 of each image)
+    int64_t stage_positions;    // entries of the dynamic-LDS staging buffer (0: none)
 };
 
 constexpr int kLdsTable = 1024;          // tables up to this many single-word codes are staged in LDS
@@ -199,6 +333,7 @@ __global__ __launch_bounds__(kEncThreads) void compress_streams_kernel(CompressA
     __shared__ uint16_t lds_sym[kLdsPos];
     __shared__ int32_t lds_len[kLdsTable];
     __shared__ uint32_t lds_code[kLdsTable];
+    extern __shared__ __attribute__((aligned(16))) uint16_t lds_stage[];     // [h*w] for long streams (see encode_huffman_stream_long)
     // grid (B, jobs): workgroups are dispatched image-fastest, the LONG jobs first (fine, medium, coarse indices,
     // then the two mask streams, then the histogram).  1024-thread workgroups are handed out at ~100 per us: with the
     // job as the fast index the fine stream of the last image started 5 us late and ended the launch.
@@ -250,12 +385,10 @@ __global__ __launch_bounds__(kEncThreads) void compress_streams_kernel(CompressA
         const int64_t gh = h >> sh, gw = w >> sh, npos = gh * gw;
         const int32_t *mask = (s == 0 ? a.mc : s == 1 ? a.mm : a.mf) + b * npos;
         const int64_t *ind = a.ind + b * h * w;
-        EncStorage st;
-        if (npos <= kLdsPos) { st.cend = lds_end; st.csym = lds_sym; }
-        else {
-            st.cend = a.ws_end + (b * 3 + s) * a.ws_stride;
-            st.csym = a.ws_sym + (b * 3 + s) * a.ws_stride;
-        }
+        EncStorage st, st_glob;
+        st.cend = lds_end; st.csym = lds_sym;
+        st_glob.cend = a.ws_end + (b * 3 + s) * a.ws_stride;
+        st_glob.csym = a.ws_sym + (b * 3 + s) * a.ws_stride;
         // ind[:, ::4, ::4][mask_c == 1] etc.: row-major over the granularity's own grid (:219-221)
         auto sym_at = [&](int64_t i, bool *flag) -> int64_t {
             // both loads are issued unconditionally so that they share one memory round trip
@@ -265,7 +398,10 @@ __global__ __launch_bounds__(kEncThreads) void compress_streams_kernel(CompressA
             *flag = mask[i] == 1;
             return v;
         };
-        rc = encode_huffman_stream(a.tab, npos, sym_at, st, out, a.slot);
+        if (npos <= kLdsPos) rc = encode_huffman_stream(a.tab, npos, sym_at, st, out, a.slot);
+        else if (a.stage_positions >= npos)
+            rc = encode_huffman_stream_long(a.tab, npos, sym_at, lds_stage, st, st_glob, out, a.slot, sh == 0 ? ind : nullptr, sh == 0 ? mask : nullptr);
+        else rc = encode_huffman_stream(a.tab, npos, sym_at, st_glob, out, a.slot);
     } else {
         const int sh = s == 3 ? 2 : 1;
         const int64_t npos = (h >> sh) * (w >> sh);
@@ -1396,7 +1532,19 @@ extern "C" int cgic_compress_streams(const cgic_table *t, const int64_t *ind, co
     a.ws_stride = (int64_t)ws_stride(h, w);
     a.ws_end = (uint32_t *)workspace;
     a.ws_sym = workspace ? (uint16_t *)((char *)workspace + (size_t)B * 3 * ws_stride(h, w) * sizeof(uint32_t)) : nullptr;
-    hipLaunchKernelGGL(compress_streams_kernel, dim3((unsigned)B, CGIC_NUM_STREAMS + (hist ? 1 : 0)), dim3(kEncThreads), 0,
+    // long streams stage 2 bytes per position in dynamic LDS (static: 57.5 KB) when the fine grid fits
+    size_t dyn = 0;
+    a.stage_positions = 0;
+    if (h * w > kLdsPos && (size_t)(h * w) * 2 <= 96 * 1024) {
+        dyn = (((size_t)(h * w) + 3) / 4 * 4 * 2 + 64 + 15) & ~(size_t)15;       // whole 4-entry groups (+ slack)
+        a.stage_positions = h * w;
+        static size_t have = 0;       // (grows monotonically; a race only repeats the call)
+        if (dyn > have) {
+            CGIC_HIP_TRY(hipFuncSetAttribute((const void *)compress_streams_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
+            have = dyn;
+        }
+    }
+    hipLaunchKernelGGL(compress_streams_kernel, dim3((unsigned)B, CGIC_NUM_STREAMS + (hist ? 1 : 0)), dim3(kEncThreads), dyn,
                        (hipStream_t)stream, a);
     return launch_check("compress_streams_kernel");
 }
