@@ -10,9 +10,9 @@ The conv encoder/decoder of the codec are out of scope (SURVEY.md section 2 rows
 synthetic N(0,1) latent standing in for the encoder output.
 
 The K timed steps are K successive, DISTINCT batches: the inputs rotate through enough slots to exceed the
-256 MiB Infinity Cache, so the image bytes of every step come from HBM.  Steps are software-pipelined over two
-HIP streams (control_gic_amd.pipeline.BatchStream: encode side of batch i+1 next to the decode side of batch i;
-`--schedule sequential` runs one batch after the other on one stream instead).  `value` = all pixels of the K
+256 MiB Infinity Cache, so the image bytes of every step come from HBM.  One hipGraph per batch, one batch after the
+other on one stream (`--schedule pipelined`: control_gic_amd.pipeline.BatchStream, encode side of batch i+1 next to the
+decode side of batch i on two HIP streams -- measured no faster).  `value` = all pixels of the K
 steps / wall time between two barrier + synchronize brackets, max over ranks.
 
   python bench.py [--gpus N] [--steps K] [--warmup W]
@@ -370,6 +370,44 @@ def b1_latency(dev, cb, vq, codec):
             "note": "B=1, 256x256, encode+decode, back-to-back replays (throughput of B=1 calls); eager includes Python + ctypes + allocation per call"}
 
 
+def end_to_end_estimate(dev, hot_ms_per_batch, B, H, W):
+    """SURVEY.md section 8(d) asks for the hot-path number next to the end-to-end one.  The stock conv encoder / decoder are out
+    of scope and the reference cannot travel to the GPU box, so this is an ESTIMATE, labelled as such: the reference's
+    measured FLOP counts per 256x256 image (encode 276.4 GFLOP, decode 824.2 GFLOP, fp32 -- the 1e-5 pixel
+    tolerance excludes 16-bit) divided by the fp32 3x3-convolution throughput torch/MIOpen reaches on this GPU at the
+    reference's channel widths and resolutions (vqvae_blocks.py:303-374, decoder.py:340-398: 128..512 channels, 256^2..16^2)."""
+    import torch.nn.functional as F
+    shapes = [(8, 128, 256, 256), (8, 256, 128, 128), (16, 512, 64, 64), (32, 512, 32, 32)]
+    tf = []
+    for n, c, hh, ww in shapes:
+        xx = torch.randn(n, c, hh, ww, device=dev)
+        wt = torch.randn(c, c, 3, 3, device=dev) * 0.01
+        for _ in range(3):
+            F.conv2d(xx, wt, padding=1)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        it = 8
+        for _ in range(it):
+            F.conv2d(xx, wt, padding=1)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / it
+        tf.append(2.0 * n * c * c * 9 * hh * ww / dt / 1e12)
+        del xx, wt
+    conv_tf = float(np.mean(tf))
+    scale = (H * W) / 65536.0                                     # FLOPs scale with the pixel count
+    enc_ms = 276.4e9 * scale / (conv_tf * 1e12) * 1e3 * B
+    dec_ms = 824.2e9 * scale / (conv_tf * 1e12) * 1e3 * B
+    mp = B * H * W / 1e6
+    return {"kind": "estimate", "conv_fp32_TFLOPs_measured": [round(v, 1) for v in tf], "conv_fp32_TFLOPs_mean": round(conv_tf, 1),
+            "encode_MPixels/s": round(mp / ((enc_ms + hot_ms_per_batch * 0.6) * 1e-3), 3),
+            "encode+decode_MPixels/s": round(mp / ((enc_ms + dec_ms + hot_ms_per_batch) * 1e-3), 3),
+            "hot_path_share_of_encode+decode": round(hot_ms_per_batch / (enc_ms + dec_ms + hot_ms_per_batch), 6),
+            "cpu_reference_encode+decode_MPixels/s": 0.030, "cpu_reference_encode_MPixels/s": 0.085,
+            "note": "stock conv encoder + decoder = 276.4 + 824.2 GFLOP per 256x256 image (SURVEY.md 3.1, torch FlopCounterMode on the "
+                    "reference) at the mean measured fp32 3x3-conv rate of this GPU; the hot path (this repository) is the remainder. "
+                    "CPU figures: the real reference on 8 Xeon cores in the survey container (SURVEY.md 8d), not re-measured here."}
+
+
 # ------------------------------------------------------------------------------------------------ one rank
 class StubStream:
     """CPU stand-in for BatchStream (tests of the launcher / reduction logic only; never used on a GPU box)"""
@@ -588,6 +626,10 @@ def report(a, dev, world, stream, slots_np, vq, codec, ratio):
         res["b1_latency"] = b1_latency(dev, cb, vq, codec)
         res["div2k_image"] = div2k_image(dev, cb, vq, codec)
         res["div2k_tiles"] = [tiles_768(dev, cb, vq, codec, 8, 60), tiles_768(dev, cb, vq, codec, 32, 30)]
+        try:
+            res["end_to_end_estimate"] = end_to_end_estimate(dev, res["single_batch"]["ms_per_step"], B, H, W)
+        except Exception as e:                                   # (MIOpen missing / out of memory: the estimate is optional)
+            res["end_to_end_estimate"] = {"error": str(e)[:200]}
     if not a.no_cpu_baseline and world == 1:             # the CPU port is timed at N=1 only (rank 0's host cores)
         res["cpu_baseline"] = cpu_baseline(x, z, cb, ratio)
     return res
@@ -616,7 +658,8 @@ def parse_args(argv=None):
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--batch", type=int, default=64)
     ap.add_argument("--size", type=int, default=256)
-    ap.add_argument("--schedule", choices=["pipelined", "sequential"], default="pipelined")
+    ap.add_argument("--schedule", choices=["pipelined", "sequential"], default="sequential",
+                    help="sequential: one hipGraph per batch on one stream; pipelined: BatchStream, encode side of batch i+1 next to the decode side of batch i")
     ap.add_argument("--slots", type=int, default=0, help="distinct resident input batches in rotation (0: enough to exceed the Infinity Cache)")
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying hipGraphs (sequential schedule)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
