@@ -1162,6 +1162,7 @@ struct MergeArgs {
     float *zq2;
     int32_t *status;
     int stage_sym, stage_cb;   // keep the image's decoded symbols / the codebook in LDS
+    int64_t band_syms;         // u16 entries reserved for a band's own symbol ranges when stage_sym == 0
 };
 
 __global__ __launch_bounds__(kMergeThreads) void merge_kernel(MergeArgs a)
@@ -1298,6 +1299,18 @@ __global__ __launch_bounds__(kMergeThreads) void merge_kernel(MergeArgs a)
             mmb[i] = v;
         }
         __syncthreads();
+        if (wc <= kMergeThreads && wm <= kMergeThreads) {
+            // both prefixes from ONE block scan of (coarse count << 32 | medium count): three barriers instead of six
+            __shared__ unsigned long long scan64[kMergeThreads / kWave + 1];
+            const unsigned long long c = ((unsigned long long)(tid < wc ? __popc(mcb[tid]) : 0) << 32) | (unsigned long long)(tid < wm ? __popc(mmb[tid]) : 0);
+            unsigned long long tot;
+            const unsigned long long ex = block_exclusive_scan(c, scan64, &tot);
+            if (tid < wc) pcb[tid] = (uint32_t)(ex >> 32);
+            if (tid < wm) pmb[tid] = (uint32_t)ex;
+            cnt_c = (uint32_t)(tot >> 32);
+            cnt_m = (uint32_t)tot;
+            __syncthreads();
+        } else {
         uint32_t carry = 0, total;
         for (int64_t base = 0; base < wc; base += kMergeThreads) {
             const int64_t i = base + tid;
@@ -1317,6 +1330,7 @@ __global__ __launch_bounds__(kMergeThreads) void merge_kernel(MergeArgs a)
         }
         cnt_m = carry;
         __syncthreads();
+        }
     }
     CGIC_STAMP(12);
 
@@ -1336,18 +1350,45 @@ __global__ __launch_bounds__(kMergeThreads) void merge_kernel(MergeArgs a)
     // fine symbols consumed by the rows above this band (exact for any mask bits)
     uint32_t fbase = 0;
     {
+        // the flag is constant over a 2x2 medium cell: walk the medium cells of the rows above (rows by wave, columns by
+        // lane, no divisions) and count 4 per cell.  (The per-position loop cost the LAST band of a 768x768 tile 70 trips of
+        // ~40 instructions -- the merge launch took twice as long as its first band.)
         uint32_t mine = 0;
-        for (int64_t i = tid; i < r0 * w; i += kMergeThreads) {
-            bool bc, bm;
-            const int y = (int)i / (int)w;
-            mine += fine_flag(y, (int)i - y * (int)w, &bc, &bm) ? 1u : 0u;
-        }
+        const int wvm = tid >> 6, lnm = tid & 63;
+        for (int y2 = wvm; y2 < (int)(r0 >> 1); y2 += kMergeThreads / 64)
+            for (int x2 = lnm; x2 < (int)w2; x2 += 64) {
+                bool bc, bm;
+                mine += fine_flag(2 * y2, 2 * x2, &bc, &bm) ? 4u : 0u;
+            }
         (void)block_exclusive_scan(mine, scan_smem, &fbase);
     }
     CGIC_STAMP(13);
 
     const uint16_t *ds_c = a.stage_sym ? lsym : gsym, *ds_m = ds_c + n_c, *ds_f = ds_m + n_m;
     const int64_t dc_c = s_hdr[2], dc_m = s_hdr[3], dc_f = s_hdr[4];
+    // Large images (the symbols of the whole image do not fit LDS): this band only consumes three CONTIGUOUS rank ranges --
+    // the coarse / medium ones of the mask bits inside its rows and the fine ones from fbase on.  One coalesced load of
+    // those (a.band_syms entries reserved behind the prefixes) replaces two or three dependent global loads per position.
+    uint16_t *bsym = reinterpret_cast<uint16_t *>(pmb + wm);
+    int64_t off_c = 0, off_m = 0, off_f = 0;           // global rank of the first staged entry of each range
+    if (!a.stage_sym && a.band_syms > 0) {
+        auto rank_of = [&](const uint32_t *bits, const uint32_t *pre, int64_t j, int64_t nbits, uint32_t total) -> int64_t {
+            if (j >= nbits) return (int64_t)total;
+            return (int64_t)pre[j >> 5] + __popc(bits[j >> 5] & ((1u << (j & 31)) - 1u));
+        };
+        const int64_t c0 = rank_of(mcb, pcb, (r0 >> 2) * w4, n_c, cnt_c), c1 = rank_of(mcb, pcb, (r1 >> 2) * w4, n_c, cnt_c);
+        const int64_t m0 = rank_of(mmb, pmb, (r0 >> 1) * w2, n_m, cnt_m), m1 = rank_of(mmb, pmb, (r1 >> 1) * w2, n_m, cnt_m);
+        const int64_t f0 = fbase, f1 = f0 + (r1 - r0) * w;                    // at most every position of the band
+        const int64_t nc = c1 - c0, nm = m1 - m0, nf = (f1 < n_f ? f1 : n_f) - f0;
+        if (nc >= 0 && nm >= 0 && nf >= 0 && nc + nm + nf + 3 <= a.band_syms) {
+            for (int64_t i = tid; i < nc; i += kMergeThreads) bsym[i] = ds_c[c0 + i];
+            for (int64_t i = tid; i < nm; i += kMergeThreads) bsym[nc + i] = ds_m[m0 + i];
+            for (int64_t i = tid; i < nf; i += kMergeThreads) bsym[nc + nm + i] = ds_f[f0 + i];
+            __syncthreads();
+            off_c = c0; off_m = m0 - nc; off_f = f0 - nc - nm;     // ds_x[rank] == bsym[rank - off_x]
+            ds_c = bsym; ds_m = bsym; ds_f = bsym;
+        }
+    }
     const bool has_c = mode == 0 || mode == 2 || mode == 3 || mode == 4;
     const bool has_m = mode == 0 || mode == 1 || mode == 3 || mode == 5;
     const bool has_f = mode == 0 || mode == 1 || mode == 2 || mode == 6;
@@ -1379,8 +1420,8 @@ __global__ __launch_bounds__(kMergeThreads) void merge_kernel(MergeArgs a)
             const bool bf = fine_flag(y, x, &bc, &bm);
             fl |= (uint32_t)bf << k;
             int64_t v = 0;
-            if (bc && use_c) v += ds_c[pcb[j4 >> 5] + __popc(mcb[j4 >> 5] & ((1u << (j4 & 31)) - 1u))];
-            if (bm && use_m) v += ds_m[pmb[j2 >> 5] + __popc(mmb[j2 >> 5] & ((1u << (j2 & 31)) - 1u))];
+            if (bc && use_c) v += ds_c[(int64_t)pcb[j4 >> 5] + __popc(mcb[j4 >> 5] & ((1u << (j4 & 31)) - 1u)) - off_c];
+            if (bm && use_m) v += ds_m[(int64_t)pmb[j2 >> 5] + __popc(mmb[j2 >> 5] & ((1u << (j2 & 31)) - 1u)) - off_m];
             vals[k] = v;
             if (a.mc_out && (y & 3) == 0 && (x & 3) == 0) a.mc_out[b * n_c + j4] = bc;
             if (a.mm_out && (y & 1) == 0 && (x & 1) == 0) a.mm_out[b * n_m + j2] = bm;
@@ -1394,7 +1435,7 @@ __global__ __launch_bounds__(kMergeThreads) void merge_kernel(MergeArgs a)
             if (i >= r1 * w) continue;
             int64_t v = vals[k];
             if ((fl >> k) & 1u) {
-                if (use_f && (int64_t)frank < dc_f) v += ds_f[frank];           // t[t==1] = decoded (:292)
+                if (use_f && (int64_t)frank < dc_f) v += ds_f[(int64_t)frank - off_f];           // t[t==1] = decoded (:292)
                 ++frank;
             }
             if (ind_out) ind_out[i] = v;                                        // sum of the three grids (:293)
@@ -1660,8 +1701,6 @@ extern "C" int cgic_decompress_streams(const cgic_table *t, const uint8_t *in, i
     if (m.stage_sym) lds_m += ((per + 1) / 2) * 4;
     // mask-stream slots must cover the word-wise staging reads
     CGIC_REQUIRE((size_t)slot >= (wm + 2) * 4, CGIC_ERR_CAPACITY, "decompress_streams: slot smaller than a mask stream");
-    if (lds_m > 48 * 1024)
-        CGIC_HIP_TRY(hipFuncSetAttribute((const void *)merge_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_m));
     // 4 bands per image fill the GPU at B = 64; a few large tiles get more (every band re-derives the mask prefixes,
     // so not more than needed): ~256 workgroups in all, at least 2 coarse rows per band
     int64_t nbands = kMergeBands;
@@ -1669,6 +1708,15 @@ extern "C" int cgic_decompress_streams(const cgic_table *t, const uint8_t *in, i
         const int64_t h4 = h >> 2;
         while (nbands * B < 256 && nbands * 2 <= h4 / 2) nbands *= 2;
     }
+    // the image's symbols do not fit LDS: every band stages its own three rank ranges (at most 21/16 symbols per position)
+    m.band_syms = 0;
+    if (!m.stage_sym) {
+        const int64_t rows_per = (((h >> 2) + nbands - 1) / nbands) * 4;
+        const int64_t need = rows_per * w * 21 / 16 + 8;
+        if (lds_m + (size_t)need * 2 <= 64 * 1024) { m.band_syms = need; lds_m += (size_t)need * 2; }
+    }
+    if (lds_m > 48 * 1024)
+        CGIC_HIP_TRY(hipFuncSetAttribute((const void *)merge_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_m));
     hipLaunchKernelGGL(merge_kernel, dim3((unsigned)nbands, (unsigned)B), dim3(kMergeThreads), lds_m, s, m);
     return launch_check("merge_kernel");
 }
