@@ -13,7 +13,7 @@ from .entropy import Entropy, entropy_maps
 from .indices_coding import HuffmanCoding
 from .mask_coding import BinaryCoding
 from .codec import GrainCodec, CompressedBatch, mode_streams, STREAM_NAMES
-from . import pipeline, highres, container, model
+from . import pipeline, highres, container, model, ops
 from .pipeline import HotPathPipeline
 from .model import install, compress_batch, grain_merge, avg_pool, decoder_blend_medium, decoder_blend_fine
 

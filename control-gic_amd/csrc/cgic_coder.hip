@@ -1579,11 +1579,7 @@ extern "C" int cgic_compress_streams(const cgic_table *t, const int64_t *ind, co
     if (h * w > kLdsPos && (size_t)(h * w) * 2 <= 96 * 1024) {
         dyn = (((size_t)(h * w) + 3) / 4 * 4 * 2 + 64 + 15) & ~(size_t)15;       // whole 4-entry groups (+ slack)
         a.stage_positions = h * w;
-        static size_t have = 0;       // (grows monotonically; a race only repeats the call)
-        if (dyn > have) {
-            CGIC_HIP_TRY(hipFuncSetAttribute((const void *)compress_streams_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
-            have = dyn;
-        }
+        { int rc_ = ensure_dynamic_lds((const void *)compress_streams_kernel, dyn); if (rc_) return rc_; }
     }
     hipLaunchKernelGGL(compress_streams_kernel, dim3((unsigned)B, CGIC_NUM_STREAMS + (hist ? 1 : 0)), dim3(kEncThreads), dyn,
                        (hipStream_t)stream, a);
@@ -1621,7 +1617,7 @@ extern "C" int cgic_decode_stream(const cgic_table *t, const uint8_t *in, int64_
     a.in = in; a.nbytes = nbytes; a.syms = syms; a.cap = cap; a.count = count;
     size_t lds = sizeof(uint32_t) * (kDecLutMax + kDecWaves * kSegWinWords) + sizeof(SegShared) + sizeof(int32_t) * 2 * kLdsTrieNodes;
     if (lds < sizeof(uint32_t) * (kDecLutMax + kWinWords)) lds = sizeof(uint32_t) * (kDecLutMax + kWinWords);
-    CGIC_HIP_TRY(hipFuncSetAttribute((const void *)decode_stream_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    { int rc_ = ensure_dynamic_lds((const void *)decode_stream_kernel, (size_t)lds); if (rc_) return rc_; }
     hipLaunchKernelGGL(decode_stream_kernel, dim3(1), dim3(kDecThreads), lds, (hipStream_t)stream, a);
     return launch_check("decode_stream_kernel");
 }
@@ -1671,11 +1667,11 @@ extern "C" int cgic_decompress_streams(const cgic_table *t, const uint8_t *in, i
                    + sizeof(FastTables);
     if (lds_d < sizeof(uint32_t) * (kDecLutMax + kWinWords)) lds_d = sizeof(uint32_t) * (kDecLutMax + kWinWords);
     if (lds_d > 48 * 1024)
-        CGIC_HIP_TRY(hipFuncSetAttribute((const void *)decode_streams_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_d));
+        { int rc_ = ensure_dynamic_lds((const void *)decode_streams_kernel, (size_t)lds_d); if (rc_) return rc_; }
     if (d.parts > 1) {
         if (lds_d > 48 * 1024) {
-            CGIC_HIP_TRY(hipFuncSetAttribute((const void *)decode_functions_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_d));
-            CGIC_HIP_TRY(hipFuncSetAttribute((const void *)decode_parts_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_d));
+            { int rc_ = ensure_dynamic_lds((const void *)decode_functions_kernel, (size_t)lds_d); if (rc_) return rc_; }
+            { int rc_ = ensure_dynamic_lds((const void *)decode_parts_kernel, (size_t)lds_d); if (rc_) return rc_; }
         }
         hipLaunchKernelGGL(decode_functions_kernel, dim3(3 * d.parts, (unsigned)B), dim3(kDecThreads), lds_d, s, d);
         rc = launch_check("decode_functions_kernel");
@@ -1716,7 +1712,7 @@ extern "C" int cgic_decompress_streams(const cgic_table *t, const uint8_t *in, i
         if (lds_m + (size_t)need * 2 <= 64 * 1024) { m.band_syms = need; lds_m += (size_t)need * 2; }
     }
     if (lds_m > 48 * 1024)
-        CGIC_HIP_TRY(hipFuncSetAttribute((const void *)merge_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_m));
+        { int rc_ = ensure_dynamic_lds((const void *)merge_kernel, (size_t)lds_m); if (rc_) return rc_; }
     hipLaunchKernelGGL(merge_kernel, dim3((unsigned)nbands, (unsigned)B), dim3(kMergeThreads), lds_m, s, m);
     return launch_check("merge_kernel");
 }

@@ -60,6 +60,9 @@ struct TableDev {
 constexpr int kTicketStride = 16;
 int acquire_tickets(hipStream_t stream, int n, unsigned int **ptr);
 
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per (function, device) and size -- not on every launch
+int ensure_dynamic_lds(const void *fn, size_t bytes);
+
 struct Table;  // host object behind cgic_table
 int table_device_view(const cgic_table *t, TableDev *out);  // uploads lazily
 

@@ -89,7 +89,7 @@ extern "C" int cgic_router_f32(const float *e16, const float *e8, int64_t B, int
     int rc = router_prepare(e16, e8, B, h16, w16, c_ratio, m_ratio, per_image, mask_c, mask_m, mask_f, gate, &a, &nseg, &lds);
     if (rc) return rc;
     if (lds > 64 * 1024)
-        CGIC_HIP_TRY(hipFuncSetAttribute((const void *)router_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        { int rc_ = ensure_dynamic_lds((const void *)router_kernel, (size_t)lds); if (rc_) return rc_; }
     hipLaunchKernelGGL(router_kernel, dim3((unsigned)nseg), dim3(kRouterThreads), lds, (hipStream_t)stream, a);
     return launch_check("router_kernel");
 }

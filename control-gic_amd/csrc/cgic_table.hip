@@ -15,6 +15,7 @@
 #include <stdarg.h>
 
 #include <map>
+#include <utility>
 #include <mutex>
 #include <new>
 #include <vector>
@@ -81,6 +82,21 @@ int acquire_tickets(hipStream_t s, int n, unsigned int **ptr)
                      "call once outside stream capture on this device before capturing (or too many captured launches)");
         *ptr = p.chunk + p.chunk_next * kTicketStride;
         p.chunk_next += (size_t)n;
+    }
+    return CGIC_OK;
+}
+
+int ensure_dynamic_lds(const void *fn, size_t bytes)
+{
+    static std::mutex mu;
+    static std::map<std::pair<const void *, int>, size_t> done;
+    int dev = 0;
+    CGIC_HIP_TRY(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lock(mu);
+    size_t &have = done[std::make_pair(fn, dev)];
+    if (bytes > have) {
+        CGIC_HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+        have = bytes;
     }
     return CGIC_OK;
 }

@@ -151,12 +151,22 @@ __device__ __forceinline__ void finish_loss_wave(double block_sum, double *sq_pa
     const int lane = lane_id();
     int last = 0;
     if (lane == 0) {
+#ifdef CGIC_STRICT_HANDOFF
+        // textbook form (make FLAGS+=-DCGIC_STRICT_HANDOFF): plain store, release at the ticket; for A/B runs against the
+        // write-through shortcut below on a new ROCm / GPU
+        sq_partial[blk] = block_sum;
+        last = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT) == nblk - 1;
+#else
         __hip_atomic_store(&sq_partial[blk], block_sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         last = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == nblk - 1;
+#endif
     }
     last = __builtin_amdgcn_readfirstlane(last);
     if (!last) return;
+#ifdef CGIC_STRICT_HANDOFF
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+#endif
     // (no acquire fence: sc1 stores on the producers' side, sc1 loads here -- see finish_loss)
     double a = 0.0;
     for (unsigned int i = lane; i < nblk; i += kWave)
@@ -1111,8 +1121,6 @@ static int conv_check(const cgic_conv1x1 *qc)
     return CGIC_OK;
 }
 
-static int ensure_dynamic_lds(const void *fn, size_t bytes);
-
 struct VqWs {
     unsigned int *ticket;   // library-owned, self-resetting
     double *partial;        // caller's workspace: double partial[nblk]
@@ -1164,22 +1172,6 @@ static int device_cu_count(int *out)
         it = cus.emplace(dev, n > 0 ? n : 256).first;
     }
     *out = it->second;
-    return CGIC_OK;
-}
-
-// hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per (function, device) and size -- not on every launch
-static int ensure_dynamic_lds(const void *fn, size_t bytes)
-{
-    static std::mutex mu;
-    static std::map<std::pair<const void *, int>, size_t> done;
-    int dev = 0;
-    CGIC_HIP_TRY(hipGetDevice(&dev));
-    std::lock_guard<std::mutex> lock(mu);
-    size_t &have = done[std::make_pair(fn, dev)];
-    if (bytes > have) {
-        CGIC_HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
-        have = bytes;
-    }
     return CGIC_OK;
 }
 

@@ -151,7 +151,7 @@ extern "C" int cgic_vq_backward_f32(const float *z, int64_t B, int64_t hw, const
     a.coef_z = (float)(-scale * w_z); a.g_z = g_z; a.partial = g_codebook ? (double *)workspace : nullptr; a.status = nullptr;
     const size_t lds = (size_t)K * 16 + (g_codebook ? (size_t)K * 32 : 0);
     if (lds > 48 * 1024)
-        CGIC_HIP_TRY(hipFuncSetAttribute((const void *)vq_backward_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        { int rc_ = ensure_dynamic_lds((const void *)vq_backward_kernel, (size_t)lds); if (rc_) return rc_; }
     hipLaunchKernelGGL(vq_backward_kernel, dim3(nblk), dim3(kBwdThreads), lds, s, a);
     int rc = launch_check("vq_backward_kernel");
     if (rc || !g_codebook) return rc;

@@ -105,12 +105,15 @@ def decompress_tiled(tiled, codec, decode=None):
     """-> per-tile (ind, masks, z_q) in row-major order; with decode(z_q, masks) -> pixels also the blended,
     clamped, unpadded reconstruction (:248-255; tiles do not overlap, so the weights cancel)"""
     per_tile = [None] * len(tiled.tiles)
+    statuses = []
     for idxs, comp, _ in tiled.groups:
         ind, masks, zq, status = codec.decompress(comp)
-        if int(status.abs().max()) != 0:
-            raise RuntimeError("corrupt tile stream")
+        statuses.append(status)
         for k, i in enumerate(idxs):
             per_tile[i] = (ind[k:k + 1], [m[k:k + 1] for m in masks], zq[k:k + 1])
+    # ONE host synchronisation for the whole image (not one per shape group)
+    if statuses and int(torch.cat(statuses).abs().max()) != 0:
+        raise RuntimeError("corrupt tile stream")
     if decode is None:
         return per_tile, None
     H, W = tiled.image_hw

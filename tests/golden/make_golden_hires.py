@@ -6,7 +6,9 @@ Runs the REAL reference (inference_high_resolution.py helpers + CGIC.compress on
 per-tile compress, bpp accounting.  Build container only (needs /root/reference); the fixture holds
 data: per-tile latents, entropy maps, masks, indices, the .bin bytes and the bpp numbers.
 
-    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden_hires.py
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden_hires.py            # 800 x 1040
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden_hires.py 1356 2040  # the DIV2K-typical size of SURVEY.md 8a-H / 8d:
+                                                                                  # pad to 1360 x 2048, tiles 768/592 x 768/768/512
 """
 import io
 import os
@@ -42,7 +44,8 @@ from oracle import cgic_oracle as orc  # noqa: E402
 from make_golden import freq_tables  # noqa: E402
 
 torch.set_num_threads(8)
-H, W = 800, 1040
+H, W = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (800, 1040)
+OUT = f"hires_{H}x{W}.npz"
 RATIO = (0.1, 0.8)
 
 params = yaml.safe_load(open(os.path.join(REF, "configs/config_inference.yaml")))["model"]["params"]
@@ -118,5 +121,5 @@ for i in range(len(h_list)):
         t += 1
 out["n_tiles"] = np.int32(t)
 out["bpp_image"] = np.float64(bit_sum / W / H)                      # :256 -- over the UNPADDED size
-np.savez_compressed(os.path.join(HERE, "hires_800x1040.npz"), **out)
-print("wrote hires_800x1040.npz", os.path.getsize(os.path.join(HERE, "hires_800x1040.npz")), "bytes; bpp_image", out["bpp_image"])
+np.savez_compressed(os.path.join(HERE, OUT), **out)
+print("wrote", OUT, os.path.getsize(os.path.join(HERE, OUT)), "bytes; bpp_image", out["bpp_image"])

@@ -607,3 +607,31 @@ def test_vq_backward_kernel_vs_formula(legacy):
     zq, loss, _ = vq(z3)
     (zq * gq).sum().add(3.0 * loss).backward()
     assert torch.equal(z3.grad, gz)
+
+
+def test_custom_ops_match_the_module_path():
+    """torch.ops.cgic.* == the module classes (same kernels), and autograd flows through cgic::vq_forward into the backward kernel"""
+    g = torch.Generator().manual_seed(21)
+    z = torch.randn(2, 4, 16, 32, generator=g).to(DEV)
+    cb = torch.randn(1024, 4, generator=g).to(DEV)
+    x = torch.rand(2, 3, 64, 128, generator=g).to(DEV)
+    from control_gic_amd.quantize import _vq_forward
+    zq, loss, idx = torch.ops.cgic.vq_forward(z, cb, 0.25, True)
+    zq2, loss2, idx2 = _vq_forward(z, cb, 0.25, True, None)
+    assert torch.equal(zq, zq2) and torch.equal(idx, idx2) and float(loss) == float(loss2)
+    e8, e16 = torch.ops.cgic.entropy_maps(x)
+    e8b, e16b = cg.entropy_maps(x)
+    assert torch.equal(e8, e8b) and torch.equal(e16, e16b)
+    m = torch.ops.cgic.router(e16, e8, 0.1, 0.8, True)
+    mb, _, _, _ = cg.TripleGrainFixedEntropyRouter(0.1, 0.8, per_image=True)(e16, e8)
+    assert all(torch.equal(a, b) for a, b in zip(m, mb))
+    out = torch.ops.cgic.vq_forward_route(z, cb, 0.25, True, e16, e8, 0.1, 0.8, True)
+    assert torch.equal(out[0], zq) and torch.equal(out[2], idx) and all(torch.equal(a, b) for a, b in zip(out[3:], mb))
+    zr, cr = z.clone().requires_grad_(), cb.clone().requires_grad_()
+    q, l, _ = torch.ops.cgic.vq_forward(zr, cr, 0.25, True)
+    (q.sum() * 0.5 + 2.0 * l).backward()
+    vq = _make_vq(cb.cpu().numpy()).train()
+    zm = z.clone().requires_grad_()
+    q2, l2, _ = vq(zm)
+    (q2.sum() * 0.5 + 2.0 * l2).backward()
+    assert torch.equal(zr.grad, zm.grad) and torch.equal(cr.grad, vq.embedding.weight.grad)

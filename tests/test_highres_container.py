@@ -1,6 +1,7 @@
 """High-resolution tiling (inference_high_resolution.py) and the container format.
 CPU part: grid/padding/bpp accounting + oracle against the reference's per-tile files;
-GPU part: the HIP path on the same golden (BASELINE config 4 in miniature: 800x1040 -> 4 ragged tiles)."""
+GPU part: the HIP path on the same goldens (BASELINE config 4: 800x1040 -> 4 ragged tiles, and the DIV2K-typical
+2040x1356 -> pad 2048x1360 -> 6 tiles in 4 shape groups)."""
 import numpy as np
 import pytest
 import torch
@@ -8,6 +9,9 @@ import torch
 import control_gic_amd as cg
 from control_gic_amd import container, highres
 from conftest import unpack_mask
+
+
+HIRES = ["hires_800x1040", "hires_1356x2040"]
 
 
 def _tiles(g):
@@ -39,8 +43,9 @@ def test_gaussian_weights_shape_and_asymmetry():
     assert not torch.allclose(ys, ys.flip(0))                 # y midpoint h/2: the reference's off-by-half
 
 
-def test_oracle_reproduces_every_tile(orc, golden):
-    g = golden("hires_800x1040")
+@pytest.mark.parametrize("fixture", HIRES)
+def test_oracle_reproduces_every_tile(orc, golden, fixture):
+    g = golden(fixture)
     htab = orc.HuffmanTable(golden("coders")["zipf_freq"])
     c, m = (float(v) for v in g["ratio"])
     bits = 0.0
@@ -86,8 +91,9 @@ class _V:
 
 
 @pytest.mark.gpu
-def test_tiled_compress_matches_reference_files(golden):
-    g = golden("hires_800x1040")
+@pytest.mark.parametrize("fixture", HIRES)
+def test_tiled_compress_matches_reference_files(golden, fixture):
+    g = golden(fixture)
     gc = golden("coders")
     dev = "cuda"
     tiles = _tiles(g)
@@ -97,13 +103,17 @@ def test_tiled_compress_matches_reference_files(golden):
     codec = cg.GrainCodec({str(int(k)): _V(float(gc["zipf_freq"][int(k)])) for k in gc["zipf_order"]}, vq.embedding.weight)
     c, m = (float(v) for v in g["ratio"])
     router = cg.TripleGrainFixedEntropyRouter(c, m, per_image=True)
-    by_shape = {(th, tw): t for t, (_, _, th, tw) in enumerate(tiles)}
+    by_shape = {}
+    for t, (_, _, th, tw) in enumerate(tiles):
+        by_shape.setdefault((th, tw), []).append(t)            # same-shape tiles are batched in row-major order
 
     def encode(batch):
-        # stand-in for the conv encoder: the latent / entropy maps the reference's encoder produced for this tile
-        t = by_shape[(batch.shape[-2], batch.shape[-1])]
-        mask, _, _, mode = router(torch.from_numpy(g[f"t{t}_e16"]).to(dev), torch.from_numpy(g[f"t{t}_e8"]).to(dev))
-        ind = vq.indices(torch.from_numpy(g[f"t{t}_z"]).to(dev))
+        # stand-in for the conv encoder: the latents / entropy maps the reference's encoder produced for these tiles
+        ts = by_shape[(batch.shape[-2], batch.shape[-1])]
+        assert batch.shape[0] == len(ts)
+        cat = lambda key: torch.from_numpy(np.concatenate([g[f"t{t}_{key}"] for t in ts])).to(dev)
+        mask, _, _, mode = router(cat("e16"), cat("e8"))           # per_image: every tile on its own thresholds
+        ind = vq.indices(cat("z"))
         return ind, mask, mode
 
     H, W = (int(v) for v in g["image_hw"])

@@ -136,3 +136,25 @@ def test_slot_and_workspace_sizes():
     assert l.cgic_compress_workspace_bytes(64, 64, 64) == 0                 # 4096 positions fit LDS
     assert l.cgic_compress_workspace_bytes(1, 192, 192) >= 3 * 36864 * 6    # 768^2 tile: global scratch
     assert l.cgic_decompress_workspace_bytes(2, 64, 64) >= 2 * (256 + 1024 + 4096) * 2 + 24   # u16 symbols + counts
+
+
+def test_custom_ops_schema_and_fake_tensor_shapes():
+    """torch.ops.cgic.*: registered with a schema and shape inference (what torch.compile / FakeTensor need); no kernel runs.
+    A CPU tensor has no implementation -- there is no CPU fallback."""
+    import torch
+    from torch._subclasses.fake_tensor import FakeTensorMode
+    assert "Tensor z, Tensor codebook, float beta, bool legacy" in str(torch.ops.cgic.vq_forward.default._schema)
+    with FakeTensorMode():
+        z, cb = torch.empty(2, 4, 16, 24, device="cuda"), torch.empty(1024, 4, device="cuda")
+        zq, loss, idx = torch.ops.cgic.vq_forward(z, cb, 0.25, True)
+        assert tuple(zq.shape) == (2, 4, 16, 24) and loss.shape == () and tuple(idx.shape) == (768,) and idx.dtype == torch.int64
+        e8, e16 = torch.ops.cgic.entropy_maps(torch.empty(2, 3, 64, 96, device="cuda"))
+        assert tuple(e8.shape) == (2, 8, 12) and tuple(e16.shape) == (2, 4, 6)
+        masks = torch.ops.cgic.router(e16, e8, 0.1, 0.8, True)
+        assert [tuple(m.shape) for m in masks] == [(2, 1, 4, 6), (2, 1, 8, 12), (2, 1, 16, 24)] and masks[0].dtype == torch.int32
+        out = torch.ops.cgic.vq_forward_route(z, cb, 0.25, True, torch.empty(2, 4, 6, device="cuda"), torch.empty(2, 8, 12, device="cuda"), 0.1, 0.8, True)
+        assert len(out) == 6 and tuple(out[5].shape) == (2, 1, 16, 24)
+        gz, gw = torch.ops.cgic.vq_backward(z, cb, idx, zq, loss, 0.25, True)
+        assert gz.shape == z.shape and gw.shape == cb.shape
+    with pytest.raises(NotImplementedError):
+        torch.ops.cgic.vq_forward(torch.zeros(1, 4, 4, 4), torch.zeros(1024, 4), 0.25, True)
