@@ -635,3 +635,34 @@ def test_custom_ops_match_the_module_path():
     q2, l2, _ = vq(zm)
     (q2.sum() * 0.5 + 2.0 * l2).backward()
     assert torch.equal(zr.grad, zm.grad) and torch.equal(cr.grad, vq.embedding.weight.grad)
+
+
+def test_batch_stream_two_stream_schedule_is_bit_identical():
+    """pipeline.BatchStream (encode side of batch i+1 next to the decode side of batch i, graphs on two HIP streams, rotating
+    slots) produces exactly what the one-stream order produces: same streams, indices, masks, rows; exact usage histogram"""
+    import control_gic_amd.pipeline as pl
+    g = torch.Generator().manual_seed(31)
+    cbk = torch.randn(1024, 4, generator=g)
+    vq = _make_vq(cbk.numpy())
+    vq.usage_counter.copy_(torch.arange(1024, 0, -1, dtype=torch.float32))
+    slots = [(torch.rand(4, 3, 64, 96, generator=g).to(DEV), torch.randn(4, 4, 16, 24, generator=g).to(DEV)) for _ in range(3)]
+    hist = torch.zeros(1024, dtype=torch.int64, device=DEV)
+    bs = pl.BatchStream(vq, 0.1, 0.8, slots, hist=hist)
+    bs.capture()
+    hist.zero_()
+    bs.submit(7)                      # 7 steps over 3 slots: slots are reused while the other stream still works
+    bs.join()
+    torch.cuda.synchronize()
+    ref_pipe = pl.HotPathPipeline(vq, 0.1, 0.8)
+    hist_ref = torch.zeros(1024, dtype=torch.int64, device=DEV)
+    counts = [3, 2, 2]                # how often each slot ran
+    for k, (x, z) in enumerate(slots):
+        r = ref_pipe.run(x, z, hist_ref, decode=True)[0]
+        for _ in range(counts[k] - 1):
+            ref_pipe.run(x, z, hist_ref, decode=True)
+        s = bs.slots[k]
+        assert s.enc["comp"].to_host() == r["comp"].to_host()
+        assert torch.equal(s.enc["ind"], r["ind"]) and torch.equal(s.enc["z_q"], r["z_q"]) and float(s.enc["loss"]) == float(r["loss"])
+        assert all(torch.equal(a, b) for a, b in zip(s.enc["mask"], r["mask"]))
+        assert torch.equal(s.dec[0], r["dec"][0]) and torch.equal(s.dec[2], r["dec"][2]) and int(s.dec[3].abs().max()) == 0
+    assert torch.equal(hist, hist_ref) and int(hist.sum()) == 7 * 4 * 16 * 24

@@ -4,13 +4,14 @@ import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import control_gic_amd as cg
 from control_gic_amd import _lib
-from bench import HotPath, make_inputs, time_events
+from bench import HotPath, make_inputs
 dev = torch.device("cuda")
 B_, S_ = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (64, 256)
 x, z, cb = make_inputs(B_, S_, S_, 1000)
 hp = HotPath(dev, x, z, cb, (0.1, 0.8))
-e8, e16, mask, mode, zq, ind, comp = hp.encode()
-for _ in range(3): hp.decode(comp)
+hp.step(); torch.cuda.synchronize()
+comp = hp.out[6]
+for _ in range(3): hp.codec.decompress(comp)
 torch.cuda.synchronize()
 l = _lib.lib(); l.cgic_debug_phase_clocks.argtypes = [ctypes.c_void_p]
 c = (ctypes.c_longlong * 32)(); l.cgic_debug_phase_clocks(c); c = list(c)
