@@ -604,7 +604,6 @@ constexpr int kFastChunks = 192;                   // streams up to this many ch
                                                    // lengths / symbols / chunk functions for the lane-per-chunk pass C
 constexpr int kPackBig = 0xFF;                     // packed "past the end" marker (max real next = 63 + 64)
 constexpr int kDecParts = 8;                        // workgroups per stream when streams are split (large grids)
-constexpr int kMergeItems = 2;
 
 struct BitWindow {
     uint32_t *win;           // LDS, kSegWinWords
@@ -1405,49 +1404,79 @@ __global__ __launch_bounds__(kMergeThreads) void merge_kernel(MergeArgs a)
     float *zq2 = a.zq2 ? a.zq2 + b * 4 * n_f : nullptr;
     uint32_t fcarry = fbase;
     int bad_index = 0;
-    for (int64_t base = r0 * w; base < r1 * w; base += (int64_t)kMergeThreads * kMergeItems) {
-        uint32_t fl = 0;       // fine flags of my items
-        const int64_t i0 = base + (int64_t)tid * kMergeItems;
-        int64_t vals[kMergeItems];
-#pragma unroll
-        for (int k = 0; k < kMergeItems; ++k) {
-            const int64_t i = i0 + k;
-            vals[k] = 0;
-            if (i >= r1 * w) continue;
-            const int y = (int)i / (int)w, x = (int)i - y * (int)w;        // 32-bit divide (h*w < 2^26)
-            const int64_t j2 = (int64_t)(y >> 1) * w2 + (x >> 1), j4 = (int64_t)(y >> 2) * w4 + (x >> 2);
-            bool bc, bm;
-            const bool bf = fine_flag(y, x, &bc, &bm);
-            fl |= (uint32_t)bf << k;
-            int64_t v = 0;
-            if (bc && use_c) v += ds_c[(int64_t)pcb[j4 >> 5] + __popc(mcb[j4 >> 5] & ((1u << (j4 & 31)) - 1u)) - off_c];
-            if (bm && use_m) v += ds_m[(int64_t)pmb[j2 >> 5] + __popc(mmb[j2 >> 5] & ((1u << (j2 & 31)) - 1u)) - off_m];
-            vals[k] = v;
-            if (a.mc_out && (y & 3) == 0 && (x & 3) == 0) a.mc_out[b * n_c + j4] = bc;
-            if (a.mm_out && (y & 1) == 0 && (x & 1) == 0) a.mm_out[b * n_m + j2] = bm;
-            if (a.mf_out) a.mf_out[b * n_f + i] = bf;
+    // One thread per QUAD of four consecutive positions of a row (w % 4 == 0): they share their coarse cell and lie in two
+    // medium cells, so a quad costs one coarse and two medium rank lookups instead of four of each, and every output is one
+    // 16-byte store per plane (the per-position form issued 4-byte stores 8 bytes apart).
+    const int w4i = (int)w4;
+    for (int64_t qbase = r0 * w4; qbase < r1 * w4; qbase += kMergeThreads) {
+        const int64_t q = qbase + tid;
+        const bool live = q < r1 * w4;
+        int64_t v[4] = {0, 0, 0, 0};
+        bool bfa = false, bfb = false;
+        int y = 0, xq = 0;
+        if (live) {
+            y = (int)q / w4i; xq = (int)q - y * w4i;                           // 32-bit divide (h*w < 2^26)
+            const int64_t j4 = (int64_t)(y >> 2) * w4 + xq, j2 = (int64_t)(y >> 1) * w2 + 2 * xq;
+            bool bc, bma, bmb, dummy;
+            bfa = fine_flag(y, 4 * xq, &bc, &bma);
+            bfb = fine_flag(y, 4 * xq + 2, &dummy, &bmb);
+            int64_t vc = 0, va = 0, vb = 0;
+            if (bc && use_c) vc = ds_c[(int64_t)pcb[j4 >> 5] + __popc(mcb[j4 >> 5] & ((1u << (j4 & 31)) - 1u)) - off_c];
+            if (use_m) {
+                // j2 is even: both cells sit in the same bitset word
+                const uint32_t word = mmb[j2 >> 5], below = word & ((1u << (j2 & 31)) - 1u);
+                const int64_t rk = (int64_t)pmb[j2 >> 5] + __popc(below) - off_m;
+                if (bma) va = ds_m[rk];
+                if (bmb) vb = ds_m[rk + (bma ? 1 : 0)];
+            }
+            v[0] = v[1] = vc + va;
+            v[2] = v[3] = vc + vb;
+            const int64_t i = (int64_t)y * w + 4 * xq;
+            if (a.mc_out && (y & 3) == 0) a.mc_out[b * n_c + j4] = bc;
+            if (a.mm_out && (y & 1) == 0) *reinterpret_cast<int2 *>(a.mm_out + b * n_m + j2) = make_int2(bma, bmb);
+            if (a.mf_out) *reinterpret_cast<int4 *>(a.mf_out + b * n_f + i) = make_int4(bfa, bfa, bfb, bfb);
         }
         uint32_t ftotal;
-        uint32_t frank = block_exclusive_scan((uint32_t)__popc(fl), scan_smem, &ftotal) + fcarry;
-#pragma unroll
-        for (int k = 0; k < kMergeItems; ++k) {
-            const int64_t i = i0 + k;
-            if (i >= r1 * w) continue;
-            int64_t v = vals[k];
-            if ((fl >> k) & 1u) {
-                if (use_f && (int64_t)frank < dc_f) v += ds_f[(int64_t)frank - off_f];           // t[t==1] = decoded (:292)
-                ++frank;
+        uint32_t frank = block_exclusive_scan((bfa ? 2u : 0u) + (bfb ? 2u : 0u), scan_smem, &ftotal) + fcarry;
+        if (live) {
+            if (bfa) {
+                if (use_f) {                                                    // t[t==1] = decoded (:292)
+                    if ((int64_t)frank < dc_f) v[0] += ds_f[(int64_t)frank - off_f];
+                    if ((int64_t)frank + 1 < dc_f) v[1] += ds_f[(int64_t)frank + 1 - off_f];
+                }
+                frank += 2;
             }
-            if (ind_out) ind_out[i] = v;                                        // sum of the three grids (:293)
+            if (bfb && use_f) {
+                if ((int64_t)frank < dc_f) v[2] += ds_f[(int64_t)frank - off_f];
+                if ((int64_t)frank + 1 < dc_f) v[3] += ds_f[(int64_t)frank + 1 - off_f];
+            }
+            const int64_t i = (int64_t)y * w + 4 * xq;
+            if (ind_out) {                                                      // sum of the three grids (:293)
+                reinterpret_cast<longlong2 *>(ind_out + i)[0] = make_longlong2(v[0], v[1]);
+                reinterpret_cast<longlong2 *>(ind_out + i)[1] = make_longlong2(v[2], v[3]);
+            }
+            if (zq || zq2) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    if (v[k] < 0 || v[k] >= a.K) { bad_index = 1; v[k] = 0; }
+            }
             if (zq) {
-                if (v < 0 || v >= a.K) { bad_index = 1; v = 0; }
-                const float4 e = a.stage_cb ? cbk[v] : reinterpret_cast<const float4 *>(a.codebook)[v];   // exact rows (:391-392)
-                zq[i] = e.x; zq[n_f + i] = e.y; zq[2 * n_f + i] = e.z; zq[3 * n_f + i] = e.w;
+                float4 e[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) e[k] = a.stage_cb ? cbk[v[k]] : reinterpret_cast<const float4 *>(a.codebook)[v[k]];   // exact rows (:391-392)
+                *reinterpret_cast<float4 *>(zq + i) = make_float4(e[0].x, e[1].x, e[2].x, e[3].x);
+                *reinterpret_cast<float4 *>(zq + n_f + i) = make_float4(e[0].y, e[1].y, e[2].y, e[3].y);
+                *reinterpret_cast<float4 *>(zq + 2 * n_f + i) = make_float4(e[0].z, e[1].z, e[2].z, e[3].z);
+                *reinterpret_cast<float4 *>(zq + 3 * n_f + i) = make_float4(e[0].w, e[1].w, e[2].w, e[3].w);
             }
             if (zq2) {
-                if (v < 0 || v >= a.K) { bad_index = 1; v = 0; }
-                const float4 e = reinterpret_cast<const float4 *>(a.codebook2)[v];       // 16 KB table: L1 / L2 hits
-                zq2[i] = e.x; zq2[n_f + i] = e.y; zq2[2 * n_f + i] = e.z; zq2[3 * n_f + i] = e.w;
+                float4 e[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) e[k] = reinterpret_cast<const float4 *>(a.codebook2)[v[k]];       // 16 KB table: L1 / L2 hits
+                *reinterpret_cast<float4 *>(zq2 + i) = make_float4(e[0].x, e[1].x, e[2].x, e[3].x);
+                *reinterpret_cast<float4 *>(zq2 + n_f + i) = make_float4(e[0].y, e[1].y, e[2].y, e[3].y);
+                *reinterpret_cast<float4 *>(zq2 + 2 * n_f + i) = make_float4(e[0].z, e[1].z, e[2].z, e[3].z);
+                *reinterpret_cast<float4 *>(zq2 + 3 * n_f + i) = make_float4(e[0].w, e[1].w, e[2].w, e[3].w);
             }
         }
         fcarry += ftotal;
@@ -1649,6 +1678,10 @@ extern "C" int cgic_decompress_streams(const cgic_table *t, const uint8_t *in, i
     CGIC_REQUIRE(!z_q2 || (codebook2 && e_dim == 4 && K > 0), CGIC_ERR_UNSUPPORTED,
                  "decompress_streams: the second gather needs a [K,4] table");
     CGIC_REQUIRE(cgic_table_num_symbols(t) <= 65536, CGIC_ERR_UNSUPPORTED, "table too large");
+    // the merge writes four positions per store
+    CGIC_REQUIRE(((reinterpret_cast<uintptr_t>(ind_out) | reinterpret_cast<uintptr_t>(z_q) | reinterpret_cast<uintptr_t>(z_q2) |
+                   reinterpret_cast<uintptr_t>(mask_f_out)) & 15) == 0 && (reinterpret_cast<uintptr_t>(mask_m_out) & 7) == 0,
+                 CGIC_ERR_INVALID, "decompress_streams: outputs must be 16-byte aligned");
     if (B == 0) return CGIC_OK;
     const size_t per = (size_t)((h / 4) * (w / 4) + (h / 2) * (w / 2) + h * w);
     hipStream_t s = (hipStream_t)stream;
@@ -1702,7 +1735,13 @@ extern "C" int cgic_decompress_streams(const cgic_table *t, const uint8_t *in, i
     int64_t nbands = kMergeBands;
     {
         const int64_t h4 = h >> 2;
-        while (nbands * B < 256 && nbands * 2 <= h4 / 2) nbands *= 2;
+#ifndef CGIC_MERGE_MINROWS
+#define CGIC_MERGE_MINROWS 1
+#endif
+#ifndef CGIC_MERGE_WGS
+#define CGIC_MERGE_WGS 256
+#endif
+        while (nbands * B < CGIC_MERGE_WGS && nbands * 2 <= h4 / CGIC_MERGE_MINROWS) nbands *= 2;
     }
     // the image's symbols do not fit LDS: every band stages its own three rank ranges (at most 21/16 symbols per position)
     m.band_syms = 0;
