@@ -603,7 +603,7 @@ constexpr int kLdsTrieNodes = 2048;                // decode tries up to this ma
 constexpr int kFastChunks = 192;                   // streams up to this many chunks (1.5 KB) cache per-position
                                                    // lengths / symbols / chunk functions for the lane-per-chunk pass C
 constexpr int kPackBig = 0xFF;                     // packed "past the end" marker (max real next = 63 + 64)
-constexpr int kDecParts = 8;                        // workgroups per stream when streams are split (large grids)
+constexpr int kDecParts = 8;                        // workgroups per stream when streams are split (large grids); <= 8: flags + counter share one ticket slot
 
 struct BitWindow {
     uint32_t *win;           // LDS, kSegWinWords
@@ -703,6 +703,53 @@ struct FastTables {                   // per chunk x bit offset, filled by pass 
     uint16_t fn[kFastChunks * kWave];     // chunk function: low byte exit offset + 64 (0xFF = end), high byte symbols
 };
 
+// ---- split streams in ONE launch: the workgroups of a stream exchange their range functions through global memory
+// (decode_split_kernel).  tick: one zeroed ticket slot per stream -- words 0..parts-2 "function of part g published",
+// word 8 = parts that have read their predecessors; the last reader zeroes the slot again for the next launch.
+struct PartSync {
+    uint32_t *bf;            // [parts][64] range functions of this stream (global)
+    unsigned int *tick;      // [kTicketStride] ticket slot of this stream (global, zero when the launch starts)
+    int *s_entry;            // LDS [2]: the range's true entry offset and the symbols before it
+};
+
+// Wave 0 of a part: publish the range's function (`fn` = lane-th entry) and compose the functions of the parts before.
+// A part only ever waits for parts with smaller workgroup ids, which were dispatched before it.
+__device__ __forceinline__ void part_exchange(int part, int nparts, uint32_t fn, const PartSync &ps)
+{
+    const int lane = lane_id();
+    if (part < nparts - 1) {                                     // nobody reads the last range's function
+        ps.bf[part * kWave + lane] = fn;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        if (lane == 0) __hip_atomic_store(&ps.tick[part], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    int e = 0, n = 0;
+    if (part > 0) {
+        if (lane == 0)
+            for (int g = 0; g < part; ++g)
+                while (__hip_atomic_load(&ps.tick[g], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 1u) __builtin_amdgcn_s_sleep(1);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        uint32_t r[kDecParts - 1];
+#pragma unroll
+        for (int g = 0; g < kDecParts - 1; ++g) r[g] = g < part ? ps.bf[g * kWave + lane] : 0u;
+#pragma unroll
+        for (int g = 0; g < kDecParts - 1; ++g) {
+            if (g < part && e < kWave) {
+                const uint32_t v = (uint32_t)__builtin_amdgcn_readlane((int)r[g], __builtin_amdgcn_readfirstlane(e));
+                n += (int)(v >> 8);
+                e = (v & 0xFF) == 0xFF ? kBig : (int)(v & 0xFF);
+            }
+        }
+        if (lane == 0) {
+            const unsigned int old = __hip_atomic_fetch_add(&ps.tick[8], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (old == (unsigned int)(nparts - 2)) {             // every part after the first has read: reset for the next launch
+                for (int i = 0; i < nparts - 1; ++i) __hip_atomic_store(&ps.tick[i], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(&ps.tick[8], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+    }
+    if (lane == 0) { ps.s_entry[0] = e; ps.s_entry[1] = n; }
+}
+
 // Decode stream bytes `in` with waves [w0, w0+nw) of the block; each participating wave calls
 // this with k = its index inside the stream.  Two block-wide barriers inside (ALL waves of the
 // block must reach them, also waves with nw == 0 work: pass nw=0 and they just sync).
@@ -711,7 +758,7 @@ __device__ __forceinline__ void decode_segmented(const TableDev &t, const uint32
                                                  SegShared *sh, const uint8_t *in, int nbytes, int pad, int w0, int nw,
                                                  int k, int cap, Put put, int *count_out, FastTables *ft = nullptr,
                                                  int part = 0, int nparts = 1, int e_in0 = 0, int n_in0 = 0,
-                                                 uint32_t *bf_out = nullptr)
+                                                 uint32_t *bf_out = nullptr, const PartSync *sync = nullptr)
 {
     // part / nparts: this workgroup handles the part-th of nparts equal chunk ranges of the stream (split streams,
     // see decode_functions_kernel); e_in0 / n_in0: bit offset into the range's first chunk where its first codeword
@@ -819,6 +866,21 @@ __device__ __forceinline__ void decode_segmented(const TableDev &t, const uint32
             bf_out[lane] = ((uint32_t)cnt << 8) | (uint32_t)(cur < kWave ? cur : 0xFF);
         }
         return;
+    }
+    if (sync && sg == 0) {
+        // split stream, one launch: this range's function (same walk as above) goes out, the true entry comes back
+        if (wave == 0) {
+            int cur = lane, cnt = 0;
+            if (active) {
+                for (int v = w0; v < w0 + nw; ++v) {
+                    if (cur < kWave) { cnt += sh->C[v][cur]; cur = sh->F[v][cur]; }
+                }
+            }
+            part_exchange(part, nparts, ((uint32_t)cnt << 8) | (uint32_t)(cur < kWave ? cur : 0xFF), *sync);
+        }
+        __syncthreads();
+        e_in = sync->s_entry[0];
+        n_in = sync->s_entry[1];
     }
     // ---- pass B: true entry offset + output index of this wave's range, and the segment's exit
     int e = e_in, n = n_in;
@@ -977,6 +1039,7 @@ struct DecodeArgs {
     int32_t *status;         // [B] zeroed here for the merge kernel's atomicMin
     int parts;               // workgroups per stream in the split-stream launches (kDecParts), else 1
     uint32_t *bf;            // [B, 3, parts, 64] range functions written by decode_functions_kernel
+    unsigned int *tick;      // [B, 3] ticket slots of decode_split_kernel (NULL: the two-launch form)
 };
 
 __global__ __launch_bounds__(kDecThreads) void decode_streams_kernel(DecodeArgs a)
@@ -1137,6 +1200,60 @@ __global__ __launch_bounds__(kDecThreads) void decode_parts_kernel(DecodeArgs a)
     FastTables *ft = reinterpret_cast<FastTables *>(reinterpret_cast<int32_t *>(seg + 1) + 2 * kLdsTrieNodes);
     decode_segmented<true>(a.tab, lut, win + wave * kSegWinWords, seg, in, nb, s_pad, 0, kDecWaves, wave, cap, put, &s_count, ft,
                            part, a.parts, s_entry[0], s_entry[1]);
+    __syncthreads();
+    if (tid == 0 && part == a.parts - 1) *dc = s_count > cap ? -3 : s_count;      // the last part knows the total
+}
+
+// Both of the above in ONE launch: pass A once, the range functions exchanged between the workgroups of a stream through
+// global memory and a ticket slot (part_exchange) instead of a kernel boundary -- the launch gap, the second staging of the
+// LUT / trie / bit windows and the second pass A go away (8 tiles of 768x768: 14.3 + 19.7 us as two launches).  Ranges
+// longer than the per-position tables (tiles beyond ~800x800) still build their function with a pass of their own.
+__global__ __launch_bounds__(kDecThreads) void decode_split_kernel(DecodeArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t sm[];
+    __shared__ int s_count, s_nb, s_pad;
+    __shared__ uint32_t s_fn[kWave];
+    __shared__ int s_entry[2];
+    uint32_t *lut = sm;
+    uint32_t *win = lut + kDecLutMax;
+    SegShared *seg = reinterpret_cast<SegShared *>(win + kDecWaves * kSegWinWords);
+    const int tid = threadIdx.x, wave = tid >> 6;
+    const int s = blockIdx.x / a.parts, part = blockIdx.x % a.parts;
+    const int64_t b = blockIdx.y;
+    const int64_t n_c = (a.h >> 2) * (a.w >> 2), n_m = (a.h >> 1) * (a.w >> 1), n_f = a.h * a.w;
+    const int64_t off = s == 0 ? 0 : (s == 1 ? n_c : n_c + n_m);
+    const int cap = (int)(s == 0 ? n_c : (s == 1 ? n_m : n_f));
+    if (s == 0 && part == 0 && tid == 0 && a.status) a.status[b] = 0;
+    int32_t *dc = a.dcount + b * 3 + s;
+    const uint8_t *in = a.in + (b * CGIC_NUM_STREAMS + s) * a.slot;
+    if (tid == 0) s_count = 0;
+    decode_part_prologue(a, lut, seg, s, b, in, &s_nb, &s_pad);
+    __syncthreads();
+    const int nb = s_nb;
+    if (nb <= 0) {                                               // the same for every part of the stream: nobody waits
+        if (tid == 0 && part == a.parts - 1) *dc = nb == 0 ? -1 : -2;
+        return;
+    }
+    PartSync ps{a.bf + (b * 3 + s) * a.parts * kWave, a.tick + (b * 3 + s) * kTicketStride, s_entry};
+    uint16_t *dst = a.dsym + b * (n_c + n_m + n_f) + off;
+    auto put = [&](int k, int sym) { dst[k] = (uint16_t)sym; };
+    FastTables *ft = reinterpret_cast<FastTables *>(reinterpret_cast<int32_t *>(seg + 1) + 2 * kLdsTrieNodes);
+    int nbits = s_pad == 0 ? 0 : (nb - 1) * 8 - s_pad;
+    nbits = nbits < 0 ? 0 : nbits;
+    const int nchunks = (nbits + kWave - 1) / kWave, per_part = (nchunks + a.parts - 1) / a.parts;
+    if (per_part <= kFastChunks) {
+        decode_segmented<true>(a.tab, lut, win + wave * kSegWinWords, seg, in, nb, s_pad, 0, kDecWaves, wave, cap, put, &s_count, ft,
+                               part, a.parts, 0, 0, nullptr, &ps);
+    } else {
+        decode_segmented<false>(a.tab, lut, win + wave * kSegWinWords, seg, in, nb, s_pad, 0, kDecWaves, wave, 0,
+                                [](int, int) {}, &s_count, (FastTables *)nullptr, part, a.parts, 0, 0, s_fn);
+        __syncthreads();
+        if (wave == 0) part_exchange(part, a.parts, s_fn[tid], ps);
+        if (tid == 0) s_count = 0;
+        __syncthreads();
+        decode_segmented<true>(a.tab, lut, win + wave * kSegWinWords, seg, in, nb, s_pad, 0, kDecWaves, wave, cap, put, &s_count, ft,
+                               part, a.parts, s_entry[0], s_entry[1]);
+    }
     __syncthreads();
     if (tid == 0 && part == a.parts - 1) *dc = s_count > cap ? -3 : s_count;      // the last part knows the total
 }
@@ -1701,7 +1818,20 @@ extern "C" int cgic_decompress_streams(const cgic_table *t, const uint8_t *in, i
     if (lds_d < sizeof(uint32_t) * (kDecLutMax + kWinWords)) lds_d = sizeof(uint32_t) * (kDecLutMax + kWinWords);
     if (lds_d > 48 * 1024)
         { int rc_ = ensure_dynamic_lds((const void *)decode_streams_kernel, (size_t)lds_d); if (rc_) return rc_; }
-    if (d.parts > 1) {
+    d.tick = nullptr;
+#ifdef CGIC_DEC_TWO_LAUNCH
+    if (false) {
+#else
+    if (d.parts > 1 && B * 3 <= (int64_t)(16384 / 4)) {
+#endif
+        // one launch: the parts of a stream exchange their range functions through a ticket slot per stream
+        rc = acquire_tickets(s, (int)(B * 3), &d.tick);
+        if (rc) return rc;
+        if (lds_d > 48 * 1024)
+            { int rc_ = ensure_dynamic_lds((const void *)decode_split_kernel, (size_t)lds_d); if (rc_) return rc_; }
+        hipLaunchKernelGGL(decode_split_kernel, dim3(3 * d.parts, (unsigned)B), dim3(kDecThreads), lds_d, s, d);
+        rc = launch_check("decode_split_kernel");
+    } else if (d.parts > 1) {
         if (lds_d > 48 * 1024) {
             { int rc_ = ensure_dynamic_lds((const void *)decode_functions_kernel, (size_t)lds_d); if (rc_) return rc_; }
             { int rc_ = ensure_dynamic_lds((const void *)decode_parts_kernel, (size_t)lds_d); if (rc_) return rc_; }
