@@ -154,6 +154,119 @@ __device__ int pack_huffman_stream(const TableDev &t, unsigned long long carry, 
     return (int)nbytes;
 }
 
+// ---- split streams: the positions of a long stream are divided over several workgroups ("parts": contiguous position
+// ranges).  A part compacts and sizes its own range, tells the others (symbols, bits, its first 32 code bits), learns where
+// its bits start from the parts before it, and packs the output words whose FIRST payload bit is its own; the tail of its last
+// word comes from the heads of the parts behind it.  No atomics on the output, no pre-zeroed buffer.
+constexpr int kEncMaxParts = 7;           // descriptors of a stream fit two ticket slots: 4 words per part + the reader count
+constexpr int kEncDoneWord = 4 * kEncMaxParts;
+struct EncExchange {
+    unsigned int *tick;      // 2 ticket slots (zero when the launch starts): [4g..4g+3] = {symbols, bits, head, 1 ok | 2 error}
+    int part, nparts;
+};
+
+__device__ int pack_huffman_part(const TableDev &t, unsigned long long mine, EncStorage st, uint8_t *out, int64_t cap,
+                                 const EncExchange &x, int err)
+{
+    __shared__ uint32_t s_desc[4 * kEncMaxParts];
+    const int tid = threadIdx.x;
+    const uint32_t count = err ? 0u : (uint32_t)(mine >> 32), bits = err ? 0u : (uint32_t)mine;
+    if (tid == 0) {
+        // the first (up to) 32 bits of this part's code bits, left-aligned
+        uint32_t head = 0, pos = 0, start = 0;
+        for (uint32_t c = 0; c < count && pos < 32; ++c) {
+            const uint32_t end = st.cend[c], len = end - start;
+            const uint32_t take = len < 32 - pos ? len : 32 - pos;
+            head |= code_bits(t, st.csym[c], 0, take) << (32 - pos - take);
+            pos += len;
+            start = end;
+        }
+        unsigned int *d = x.tick + 4 * x.part;
+        d[0] = count; d[1] = bits; d[2] = head;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        __hip_atomic_store(&d[3], err ? 2u : 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (tid < x.nparts) {
+        // every part reads every descriptor: the prefix needs the parts before, the last word and the header byte the ones behind
+        unsigned int *d = x.tick + 4 * tid;
+        unsigned int f;
+        while ((f = __hip_atomic_load(&d[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == 0u) __builtin_amdgcn_s_sleep(1);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        s_desc[4 * tid] = d[0]; s_desc[4 * tid + 1] = d[1]; s_desc[4 * tid + 2] = d[2]; s_desc[4 * tid + 3] = f;
+    }
+    __syncthreads();
+    CGIC_STAMP2(4);
+    if (tid == 0) {
+        // the last part to have read zeroes the slots for the next launch
+        const unsigned int old = __hip_atomic_fetch_add(&x.tick[kEncDoneWord], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (old == (unsigned int)(x.nparts - 1)) {
+            // (the data words too: the pool hands the slot to other kernels later, which expect every word zero)
+            for (int g = 0; g < 4 * x.nparts; ++g) __hip_atomic_store(&x.tick[g], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&x.tick[kEncDoneWord], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    uint32_t S = 0, total_bits = 0, total_count = 0;
+    bool any_err = false;
+    for (int g = 0; g < x.nparts; ++g) {
+        if (g < x.part) S += s_desc[4 * g + 1];
+        total_bits += s_desc[4 * g + 1];
+        total_count += s_desc[4 * g];
+        any_err |= s_desc[4 * g + 3] == 2u;
+    }
+    if (any_err) return CGIC_ERR_INVALID;                       // KeyError in the reference
+    if (total_count == 0) return 0;                             // `if not text: write b''`  (:116-118)
+    const uint32_t pad = 8 - (total_bits & 7);                  // 1..8                      (:92)
+    const int64_t nbytes = 1 + (int64_t)((total_bits + pad) >> 3);
+    if (nbytes > cap) return CGIC_ERR_CAPACITY;
+    const int64_t nwords = (nbytes + 3) >> 2;
+    const uint32_t E = S + bits;
+    uint32_t *out32 = reinterpret_cast<uint32_t *>(out);
+    // words whose first payload bit (0 for word 0, else 32 q - 8) lies in [S, E)
+    int64_t q_lo = S == 0 ? 0 : ((int64_t)S + 8 + 31) >> 5, q_hi = bits ? ((int64_t)E + 8 + 31) >> 5 : q_lo;
+    if (bits == 0) q_hi = q_lo = 0;
+    for (int64_t q = q_lo + tid; q < q_hi; q += kEncThreads) {
+        const int64_t lo = 32 * q - 8, hi = lo + 32;
+        uint32_t acc = q == 0 ? (pad << 24) : 0u;               // "{0:08b}".format(extra_padding) (:96)
+        const uint32_t p0 = (lo < 0 ? 0u : (uint32_t)lo) - S;   // relative to this part's first bit
+        const int64_t rhi = hi - (int64_t)S;
+        {
+            uint32_t a = 0, b = count;
+            while (a < b) {
+                uint32_t m = (a + b) >> 1;
+                if (st.cend[m] > p0) b = m; else a = m + 1;
+            }
+            uint32_t c = a;
+            uint32_t start = c ? st.cend[c - 1] : 0u;
+            while (c < count && (int64_t)start < rhi) {
+                const uint32_t end = st.cend[c];
+                const int sy = st.csym[c];
+                const uint32_t from = start > p0 ? start : p0;
+                const uint32_t to = (int64_t)end < rhi ? end : (uint32_t)rhi;
+                if (to > from) acc |= code_bits(t, sy, from - start, to - from) << (uint32_t)(rhi - to);
+                start = end;
+                ++c;
+            }
+        }
+        // the rest of the word: the first bits of the parts behind
+        int64_t pos = E;
+        for (int g = x.part + 1; g < x.nparts && pos < hi; ++g) {
+            const uint32_t bg = s_desc[4 * g + 1];
+            if (bg == 0) continue;
+            const uint32_t have = bg < 32u ? bg : 32u, want = (uint32_t)(hi - pos);
+            const uint32_t take = have < want ? have : want;
+            acc |= (s_desc[4 * g + 2] >> (32 - take)) << (uint32_t)(hi - pos - take);
+            pos += bg;
+        }
+        out32[q] = __builtin_bswap32(acc);                       // MSB-first bytes (:108)
+    }
+    if (x.part == x.nparts - 1) {
+        // words that hold nothing but padding (first payload bit >= total_bits)
+        for (int64_t q = (((int64_t)total_bits + 8 + 31) >> 5) + tid; q < nwords; q += kEncThreads) out32[q] = 0u;
+    }
+    CGIC_STAMP2(3);
+    return (int)nbytes;
+}
+
 // Phase A for LONG streams (a 768x768 tile's fine grid has 36 864 positions): the round-by-round form above pays one
 // block-wide scan (three barriers) per 4096 positions -- nine in a row for that stream, 22 us on one CU.  Here the
 // (symbol | unselected) entries of ALL positions are first staged in LDS with coalesced loads (2 bytes each), every
@@ -165,7 +278,7 @@ __device__ int pack_huffman_stream(const TableDev &t, unsigned long long carry, 
 template <typename SymAt>
 __device__ int encode_huffman_stream_long(const TableDev &t, int64_t npos, SymAt sym_at, uint16_t *stage, EncStorage st_lds,
                                           EncStorage st_glob, uint8_t *out, int64_t cap, const int64_t *dense_ind = nullptr,
-                                          const int32_t *dense_mask = nullptr)
+                                          const int32_t *dense_mask = nullptr, const EncExchange *x = nullptr)
 {
     __shared__ unsigned long long scan_smem[kEncThreads / kWave + 1];
     __shared__ int s_err;
@@ -233,7 +346,7 @@ __device__ int encode_huffman_stream_long(const TableDev &t, int64_t npos, SymAt
     }
     __syncthreads();
     CGIC_STAMP2(1);
-    if (s_err) return s_err;
+    if (s_err) return x ? pack_huffman_part(t, 0ull, st_lds, out, cap, *x, s_err) : s_err;      // (the other parts wait for this one's word)
     // chunks of a multiple of 4 entries (8-byte LDS reads; `stage` is 16-byte aligned and padded by the caller's sizing)
     const int64_t chunk = ((npos + kEncThreads - 1) / kEncThreads + 3) & ~(int64_t)3;
     const int64_t lo = (int64_t)tid * chunk < npos ? (int64_t)tid * chunk : npos;
@@ -276,6 +389,7 @@ __device__ int encode_huffman_stream_long(const TableDev &t, int64_t npos, SymAt
     }
     __syncthreads();
     CGIC_STAMP2(2);
+    if (x) return pack_huffman_part(t, total, st, out, cap, *x, 0);
     return pack_huffman_stream(t, total, st, out, cap);
 }
 
@@ -323,6 +437,8 @@ struct CompressArgs {
     int64_t ws_stride;      // positions reserved per (image, stream) in the workspace
     unsigned long long *hist;   // optional [tab.n]: usage histogram of ALL h*w indices (job 5 of each image)
     int64_t stage_positions;    // entries of the dynamic-LDS staging buffer (0: none)
+    int parts[3];               // workgroups per index stream (coarse, medium, fine); > 1: split streams, see EncExchange
+    unsigned int *tick;         // [B, 3] x 2 ticket slots when any stream is split
 };
 
 constexpr int kLdsTable = 1024;          // tables up to this many single-word codes are staged in LDS
@@ -337,13 +453,23 @@ __global__ __launch_bounds__(kEncThreads) void compress_streams_kernel(CompressA
     // grid (B, jobs): workgroups are dispatched image-fastest, the LONG jobs first (fine, medium, coarse indices,
     // then the two mask streams, then the histogram).  1024-thread workgroups are handed out at ~100 per us: with the
     // job as the fast index the fine stream of the last image started 5 us late and ended the launch.
-    const int kJobOrder[6] = {2, 1, 0, 4, 3, 5};
-    const int s = kJobOrder[blockIdx.y];
-    const int64_t b = blockIdx.x;
+    // (split streams: the parts of the fine stream, then the medium one's, ...)
+    // Split streams wait for each other: their launch is (jobs, B) -- the parts of a stream are neighbours in dispatch order,
+    // so a workgroup never holds a CU waiting for one that is hundreds of workgroups behind it in the queue.
+    const bool jobs_fastest = a.tick != nullptr;
+    int s, part = 0, nparts = 1;
+    {
+        int y = (int)(jobs_fastest ? blockIdx.x : blockIdx.y);
+        if (y < a.parts[2]) { s = 2; part = y; nparts = a.parts[2]; }
+        else if ((y -= a.parts[2]) < a.parts[1]) { s = 1; part = y; nparts = a.parts[1]; }
+        else if ((y -= a.parts[1]) < a.parts[0]) { s = 0; part = y; nparts = a.parts[0]; }
+        else { y -= a.parts[0]; s = y == 0 ? 4 : y == 1 ? 3 : 5; }
+    }
+    const int64_t b = jobs_fastest ? blockIdx.y : blockIdx.x;
     CGIC_STAMP2(0);
     CGIC_SPAN_BEGIN();
 #ifdef CGIC_PHASE_CLOCKS      // dev: per-workgroup (start, end) for tools/probe_compress_blocks.py
-    const unsigned int dbg_lin = blockIdx.x * 6 + s;      // (image, job) like the probe expects
+    const unsigned int dbg_lin = (unsigned int)b * 16 + (jobs_fastest ? blockIdx.x : blockIdx.y);      // (image, job in launch order) like the probe expects
     if (threadIdx.x == 0 && dbg_lin < 4096) g_blk_t[2 * dbg_lin] = wall_clock64();
     struct DbgEnd { unsigned int lin; __device__ ~DbgEnd() { if (threadIdx.x == 0 && lin < 4096) g_blk_t[2 * lin + 1] = wall_clock64(); } } dbg_end{dbg_lin};
 #endif
@@ -367,7 +493,7 @@ __global__ __launch_bounds__(kEncThreads) void compress_streams_kernel(CompressA
     }
     int32_t *nb = a.nbytes + b * CGIC_NUM_STREAMS + s;
     if (!((a.stream_mask >> s) & 1)) {
-        if (threadIdx.x == 0) *nb = -1;
+        if (threadIdx.x == 0 && part == nparts - 1) *nb = -1;
         return;
     }
     uint8_t *out = a.out + (b * CGIC_NUM_STREAMS + s) * a.slot;
@@ -385,20 +511,28 @@ __global__ __launch_bounds__(kEncThreads) void compress_streams_kernel(CompressA
         const int64_t gh = h >> sh, gw = w >> sh, npos = gh * gw;
         const int32_t *mask = (s == 0 ? a.mc : s == 1 ? a.mm : a.mf) + b * npos;
         const int64_t *ind = a.ind + b * h * w;
+        // this workgroup's positions: all of them, or the part-th of nparts ranges (whole groups of four)
+        const int64_t per = nparts > 1 ? (((npos + nparts - 1) / nparts) + 3) & ~(int64_t)3 : npos;
+        const int64_t pos0 = (int64_t)part * per < npos ? (int64_t)part * per : npos;
+        const int64_t mypos = pos0 + per < npos ? per : npos - pos0;
         EncStorage st, st_glob;
         st.cend = lds_end; st.csym = lds_sym;
-        st_glob.cend = a.ws_end + (b * 3 + s) * a.ws_stride;
-        st_glob.csym = a.ws_sym + (b * 3 + s) * a.ws_stride;
+        st_glob.cend = a.ws_end + (b * 3 + s) * a.ws_stride + pos0;
+        st_glob.csym = a.ws_sym + (b * 3 + s) * a.ws_stride + pos0;
         // ind[:, ::4, ::4][mask_c == 1] etc.: row-major over the granularity's own grid (:219-221)
         auto sym_at = [&](int64_t i, bool *flag) -> int64_t {
             // both loads are issued unconditionally so that they share one memory round trip
-            const int ii = (int)i, gwi = (int)gw;                       // 32-bit divide (h*w < 2^26)
+            const int ii = (int)(i + pos0), gwi = (int)gw;              // 32-bit divide (h*w < 2^26)
             const int y = ii / gwi, x = ii - y * gwi;
             const int64_t v = ind[((int64_t)(y << sh) * w) + (x << sh)];
-            *flag = mask[i] == 1;
+            *flag = mask[ii] == 1;
             return v;
         };
-        if (npos <= kLdsPos) rc = encode_huffman_stream(a.tab, npos, sym_at, st, out, a.slot);
+        if (nparts > 1) {
+            const EncExchange ex{a.tick + ((b * 3 + s) * 2) * kTicketStride, part, nparts};
+            rc = encode_huffman_stream_long(a.tab, mypos, sym_at, lds_stage, st, st_glob, out, a.slot, sh == 0 ? ind + pos0 : nullptr,
+                                            sh == 0 ? mask + pos0 : nullptr, &ex);
+        } else if (npos <= kLdsPos) rc = encode_huffman_stream(a.tab, npos, sym_at, st, out, a.slot);
         else if (a.stage_positions >= npos)
             rc = encode_huffman_stream_long(a.tab, npos, sym_at, lds_stage, st, st_glob, out, a.slot, sh == 0 ? ind : nullptr, sh == 0 ? mask : nullptr);
         else rc = encode_huffman_stream(a.tab, npos, sym_at, st_glob, out, a.slot);
@@ -408,7 +542,7 @@ __global__ __launch_bounds__(kEncThreads) void compress_streams_kernel(CompressA
         const int32_t *mask = (s == 3 ? a.mc : a.mm) + b * npos;   // grain_mask[k].flatten() (:230-231)
         rc = encode_binary_stream(npos, [&](int64_t i) { return (int)mask[i]; }, out, a.slot);
     }
-    if (threadIdx.x == 0) *nb = rc < 0 ? rc - 10 : rc;     // errors are CGIC_ERR_* - 10 (-1 means "not written")
+    if (threadIdx.x == 0 && part == nparts - 1) *nb = rc < 0 ? rc - 10 : rc;     // errors are CGIC_ERR_* - 10 (-1 means "not written")
     CGIC_SPAN_END();
 }
 
@@ -1719,15 +1853,42 @@ extern "C" int cgic_compress_streams(const cgic_table *t, const int64_t *ind, co
     a.ws_stride = (int64_t)ws_stride(h, w);
     a.ws_end = (uint32_t *)workspace;
     a.ws_sym = workspace ? (uint16_t *)((char *)workspace + (size_t)B * 3 * ws_stride(h, w) * sizeof(uint32_t)) : nullptr;
-    // long streams stage 2 bytes per position in dynamic LDS (static: 57.5 KB) when the fine grid fits
+    // Streams beyond kLdsPos positions are split over workgroups of at most ~kLdsPos positions each (a 768x768 tile: fine
+    // 36 864 positions -> 5 parts, medium 9216 -> 2) when the launch is small enough for the ticket pool; every part stages
+    // 2 bytes per position of its range in dynamic LDS (static: 57.5 KB).
+    a.parts[0] = a.parts[1] = a.parts[2] = 1;
+    a.tick = nullptr;
+    int64_t longest = 0;                  // positions the longest workgroup stages
+    const bool split = B * 6 <= (int64_t)(16384 / 4);
+    for (int g = 0; g < 3; ++g) {
+        const int64_t npos = (h >> (2 - g)) * (w >> (2 - g));
+#ifndef CGIC_ENC_PART_POS
+#define CGIC_ENC_PART_POS 4096       // positions per part: measured 8192 -> 14.1 us, 4096 -> 12.2 us, 3072 -> 12.2 us (8 tiles of 768x768)
+#endif
+        int64_t P = split && npos > kLdsPos ? (npos + CGIC_ENC_PART_POS - 1) / CGIC_ENC_PART_POS : 1;
+        P = P > kEncMaxParts ? kEncMaxParts : P;
+#ifdef CGIC_ENC_PARTS_MAX
+        P = P > CGIC_ENC_PARTS_MAX ? CGIC_ENC_PARTS_MAX : P;
+#endif
+        a.parts[g] = (int)P;
+        const int64_t per = P > 1 ? (((npos + P - 1) / P) + 3) & ~(int64_t)3 : npos;
+        if (npos > kLdsPos && per > longest) longest = per;
+    }
     size_t dyn = 0;
     a.stage_positions = 0;
-    if (h * w > kLdsPos && (size_t)(h * w) * 2 <= 96 * 1024) {
-        dyn = (((size_t)(h * w) + 3) / 4 * 4 * 2 + 64 + 15) & ~(size_t)15;       // whole 4-entry groups (+ slack)
-        a.stage_positions = h * w;
+    if (longest > 0 && (size_t)longest * 2 <= 96 * 1024) {
+        dyn = (((size_t)longest + 3) / 4 * 4 * 2 + 64 + 15) & ~(size_t)15;       // whole 4-entry groups (+ slack)
+        a.stage_positions = longest;
         { int rc_ = ensure_dynamic_lds((const void *)compress_streams_kernel, dyn); if (rc_) return rc_; }
+    } else if (longest > 0) {
+        a.parts[0] = a.parts[1] = a.parts[2] = 1;                 // no staging room: the round-by-round form, unsplit
     }
-    hipLaunchKernelGGL(compress_streams_kernel, dim3((unsigned)B, CGIC_NUM_STREAMS + (hist ? 1 : 0)), dim3(kEncThreads), dyn,
+    if (a.parts[0] + a.parts[1] + a.parts[2] > 3) {
+        rc = acquire_tickets((hipStream_t)stream, (int)(B * 6), &a.tick);
+        if (rc) return rc;
+    }
+    const unsigned jobs = (unsigned)(a.parts[0] + a.parts[1] + a.parts[2]) + 2u + (hist ? 1u : 0u);
+    hipLaunchKernelGGL(compress_streams_kernel, a.tick ? dim3(jobs, (unsigned)B) : dim3((unsigned)B, jobs), dim3(kEncThreads), dyn,
                        (hipStream_t)stream, a);
     return launch_check("compress_streams_kernel");
 }

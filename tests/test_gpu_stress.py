@@ -234,3 +234,40 @@ def test_codec_random_sweep_time_boxed(orc, golden):
         assert all(torch.equal(a, b_) for a, b_ in zip(dmask, mask)), desc
         n += 1
     assert n >= 30, n
+
+
+def test_split_streams_survive_ticket_pool_wrap(orc, golden):
+    """Grids beyond 64x64 split their index streams over several workgroups that talk through library-owned ticket slots
+    (compress: descriptors + flags, decode: flags).  The eager pool is a ring of 16 384 slots shared by every kernel: run
+    enough launches to wrap it several times -- a slot that is not returned all-zero breaks a later launch (bytes differ,
+    or workgroups wait forever: the test is time-limited by pytest-timeout / the driver)."""
+    g = golden("coders")
+    rng = np.random.default_rng(5)
+
+    class _Item:
+        def __init__(self, v): self.v = v
+        def item(self): return self.v
+
+    mapping = {str(int(k)): _Item(float(g["zipf_freq"][int(k)])) for k in g["zipf_order"]}
+    table = orc.HuffmanTable(g["zipf_freq"])
+    cbk = torch.from_numpy(rng.standard_normal((1024, 4)).astype(np.float32)).to(DEV)
+    codec = cg.GrainCodec(mapping, cbk)
+    B, h, w = 3, 92, 208
+    e16 = torch.from_numpy((rng.random((B, h // 4, w // 4)) * 2.6).astype(np.float32)).to(DEV)
+    e8 = torch.from_numpy((rng.random((B, h // 2, w // 2)) * 2.6).astype(np.float32)).to(DEV)
+    ind = rng.integers(0, 1024, (B, h, w))
+    ind_d = torch.from_numpy(ind).to(DEV)
+    mask, _, _, mode = cg.TripleGrainFixedEntropyRouter(0.33, 0.33, per_image=True)(e16, e8)
+    mks = [t.cpu().numpy() for t in mask]
+    first = codec.compress(ind_d, mask, mode).to_host()
+    for b in range(B):
+        assert first[b] == orc.compress_image(ind[b], mks[0][b, 0], mks[1][b, 0], mks[2][b, 0], mode, table)
+    dind0 = codec.decompress(codec.compress(ind_d, mask, mode))[0].clone()
+    # 28 slots per iteration (18 compress + 9 decode + the router/VQ-free rest): 2400 iterations = four times round the ring
+    for it in range(2400):
+        comp = codec.compress(ind_d, mask, mode)
+        dind, _, _, status = codec.decompress(comp)
+        if it % 200 == 199:
+            assert comp.to_host() == first, it
+            assert int(status.abs().max()) == 0 and torch.equal(dind, dind0), it
+    torch.cuda.synchronize()

@@ -13,14 +13,16 @@ hp.step(); torch.cuda.synchronize()
 e8, e16, mask, mode, zq, ind, comp = hp.out[:7]
 for _ in range(3): comp = hp.codec.compress(ind, mask, mode, hist=hp.hist)
 torch.cuda.synchronize()
-l = _lib.lib(); n = T * 6
+l = _lib.lib(); n = T * 16
 buf = (ctypes.c_longlong * (2 * n))(); l.cgic_debug_block_times(buf, n)
 t = np.array(list(buf), dtype=np.int64).reshape(n, 2)
-t0 = t[:, 0].min(); st = (t[:, 0] - t0) / 100.0; en = (t[:, 1] - t0) / 100.0
-names = ["indices_coarse", "indices_medium", "indices_fine", "mask_coarse", "mask_medium", "histogram"]
-for s_ in range(6):
-    sel = np.arange(n) % 6 == s_
-    print(f"job {s_} {names[s_]:15s}: duration median {np.median((en - st)[sel]):6.2f} us, start median {np.median(st[sel]):5.2f}, end max {en[sel].max():6.2f}")
+ok = t[:, 0] > 0
+t0 = t[ok, 0].min(); st = (t[:, 0] - t0) / 100.0; en = (t[:, 1] - t0) / 100.0
+# jobs in launch order: the parts of the fine stream, the medium one's, the coarse one's, mask_medium, mask_coarse, histogram
+for j in range(16):
+    sel = (np.arange(n) % 16 == j) & ok
+    if sel.any():
+        print(f"job {j:2d}: duration median {np.median((en - st)[sel]):6.2f} us, start median {np.median(st[sel]):5.2f}, end max {en[sel].max():6.2f}")
 l.cgic_debug_phase_clocks.argtypes = [ctypes.c_void_p]
 c = (ctypes.c_longlong * 32)(); l.cgic_debug_phase_clocks(c); c = list(c)
-print("fine-stream workgroup of image 0, phases (us @2.1GHz): setup %.2f | phase A %.2f | phase B %.2f" % ((c[1]-c[0])/2.1e3, (c[2]-c[1])/2.1e3, (c[3]-c[2])/2.1e3))
+print("first fine-stream workgroup of image 0, phases (us @2.1GHz): setup %.2f | phase A %.2f | exchange %.2f | pack %.2f" % ((c[1]-c[0])/2.1e3, (c[2]-c[1])/2.1e3, (c[4]-c[2])/2.1e3, (c[3]-c[4])/2.1e3))
