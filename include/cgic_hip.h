@@ -47,11 +47,13 @@ typedef void *cgic_stream_t;
  * indices_fine, mask_coarse, mask_medium */
 #define CGIC_NUM_STREAMS 5
 
-/* Launch resources: kernels that hand work to "the last workgroup to arrive" use self-resetting ticket words in
- * library-owned device memory.  Eager launches take them from a ring; launches being captured into a hipGraph take them
- * from a pool of 262 144 words per device that is never recycled (the graph may be replayed at any time later), so a
- * process can capture at most that many ticketed launches (CGIC_ERR_INVALID beyond).  Call each entry point once
- * eagerly on a device before capturing it (allocations and function attributes are set up on first use). */
+/* Launch resources: kernels whose workgroups hand work to each other (the VQ loss hand-off, the split index streams of
+ * grids beyond 64x64 in compress / decompress) use self-resetting ticket slots in library-owned device memory.  Eager
+ * launches take them from a ring; launches being captured into a hipGraph take them from a pool of 262 144 slots per
+ * device that is never recycled (the graph may be replayed at any time later): a VQ launch takes 1 slot, a split-stream
+ * compress 6 per image, a split-stream decompress 3 per image (CGIC_ERR_INVALID once the pool is used up; batches of
+ * more than 682 / 1365 such images fall back to unsplit streams / two launches).  Call each entry point once eagerly
+ * on a device before capturing it (allocations and function attributes are set up on first use). */
 const char *cgic_last_error(void);
 int cgic_abi_version(void);
 /* number of visible HIP devices, or CGIC_ERR_HIP; never throws, never aborts */
