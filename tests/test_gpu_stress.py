@@ -271,3 +271,103 @@ def test_split_streams_survive_ticket_pool_wrap(orc, golden):
             assert comp.to_host() == first, it
             assert int(status.abs().max()) == 0 and torch.equal(dind, dind0), it
     torch.cuda.synchronize()
+
+
+def _zipf_codec(orc, golden, rng):
+    g = golden("coders")
+
+    class _Item:
+        def __init__(self, v): self.v = v
+        def item(self): return self.v
+
+    mapping = {str(int(k)): _Item(float(g["zipf_freq"][int(k)])) for k in g["zipf_order"]}
+    cbk = torch.from_numpy(rng.standard_normal((1024, 4)).astype(np.float32)).to(DEV)
+    return cg.GrainCodec(mapping, cbk), orc.HuffmanTable(g["zipf_freq"])
+
+
+def _host_streams(comp, b):
+    return comp.to_host()[b]
+
+
+@pytest.mark.parametrize("pattern", ["one_per_part", "last_rows_only", "first_position_only", "none", "dense_medium", "all"])
+def test_split_compress_corner_masks_vs_oracle(orc, golden, pattern):
+    """the split-stream encoder (grids beyond 64x64: parts of <= 4096 positions that exchange symbol counts, bit counts and head
+    bits): parts with no symbol at all, with ONE short codeword each (an output word then spans three and more parts), a stream
+    that only the last / the first part contributes to, an empty stream, and fully selected grids -- bytes == oracle"""
+    rng = np.random.default_rng(11)
+    codec, table = _zipf_codec(orc, golden, rng)
+    B, h, w = 2, 128, 160                       # fine 20480 positions -> 5 parts, medium 5120 -> unsplit short path, coarse 1280
+    if pattern == "dense_medium":
+        h, w = 192, 192                         # medium 9216 -> 3 parts
+    ind = rng.integers(0, 1024, (B, h, w))
+    ind[0, :, :] = np.where(rng.random((h, w)) < 0.5, 0, ind[0])        # many 1-3-bit codewords in image 0
+    mc = np.zeros((B, 1, h // 4, w // 4), np.int32)
+    mm = np.zeros((B, 1, h // 2, w // 2), np.int32)
+    mf = np.zeros((B, 1, h, w), np.int32)
+    if pattern == "one_per_part":
+        flat = mf.reshape(B, -1)
+        for p0 in range(0, h * w, 4096): flat[:, p0 + 7] = 1
+        flat[1, 5000:5003] = 1
+    elif pattern == "last_rows_only":
+        mf[:, :, -3:, :] = 1; mm[:, :, -1:, :] = 1
+    elif pattern == "first_position_only":
+        mf[:, :, 0, 0] = 1; mm[:, :, 0, 0] = 1; mc[:, :, 0, 0] = 1
+    elif pattern == "dense_medium":
+        mm[:] = 1; mf[:, :, ::7, :] = 1
+    elif pattern == "all":
+        mc[:] = 1; mm[:] = 1; mf[:] = 1
+    masks = [torch.from_numpy(m).to(DEV) for m in (mc, mm, mf)]
+    comp = codec.compress(torch.from_numpy(ind).to(DEV), masks, 0)
+    for b in range(B):
+        ref = orc.compress_image(ind[b], mc[b, 0], mm[b, 0], mf[b, 0], 0, table)
+        assert _host_streams(comp, b) == ref, (pattern, b)
+
+
+def test_split_compress_bad_symbol_is_an_error_not_a_hang(orc, golden):
+    """an index outside the code table inside ONE part of a split stream: every part of the stream learns about it through the
+    exchange, the stream reports the reference's KeyError, the other streams and images are unaffected"""
+    rng = np.random.default_rng(12)
+    codec, table = _zipf_codec(orc, golden, rng)
+    B, h, w = 2, 128, 160
+    ind = rng.integers(0, 1024, (B, h, w))
+    mc = (rng.random((B, 1, h // 4, w // 4)) < 0.1).astype(np.int32)
+    mm = (rng.random((B, 1, h // 2, w // 2)) < 0.5).astype(np.int32)
+    mf = (rng.random((B, 1, h, w)) < 0.3).astype(np.int32)
+    mf[1, 0, 70, 3] = 1
+    bad = ind.copy(); bad[1, 70, 3] = 4096                      # third part of image 1's fine stream
+    masks = [torch.from_numpy(m).to(DEV) for m in (mc, mm, mf)]
+    comp = codec.compress(torch.from_numpy(bad).to(DEV), masks, 0)
+    nb = comp.nbytes.cpu().numpy()
+    assert nb[1, 2] == cg._lib.ERR_INVALID - 10 and (nb[0] > 0).all() and (nb[1, [0, 1, 3, 4]] > 0).all()
+    with pytest.raises(KeyError):
+        comp.to_host()
+    good = codec.compress(torch.from_numpy(ind).to(DEV), masks, 0)          # the slots were handed back clean
+    for b in range(B):
+        assert _host_streams(good, b) == orc.compress_image(ind[b], mc[b, 0], mm[b, 0], mf[b, 0], 0, table)
+
+
+@pytest.mark.parametrize("ratio", [(0.001, 0.002), (0.999, 0.0005), (0.0, 0.001), (0.002, 0.0), (0.1, 0.8)])
+@pytest.mark.parametrize("shape", [(128, 160), (192, 192), (68, 244)])
+def test_split_decode_tiny_and_huge_streams_round_trip(orc, golden, ratio, shape):
+    """the one-launch split decoder (grids beyond 64x64: 8 workgroups per stream exchanging range functions): streams of a few
+    codewords (fewer 64-bit chunks than workgroups: most parts are empty and still publish) next to streams of tens of
+    thousands, odd widths; bytes == oracle, decode == merge of the encoded grids, masks round-trip"""
+    rng = np.random.default_rng(13)
+    codec, table = _zipf_codec(orc, golden, rng)
+    B = 3
+    h, w = shape
+    e16 = torch.from_numpy((rng.random((B, h // 4, w // 4)) * 2.6).astype(np.float32)).to(DEV)
+    e8 = torch.from_numpy((rng.random((B, h // 2, w // 2)) * 2.6).astype(np.float32)).to(DEV)
+    ind = rng.integers(0, 1024, (B, h, w))
+    mask, _, _, mode = cg.TripleGrainFixedEntropyRouter(*ratio, per_image=True)(e16, e8)
+    comp = codec.compress(torch.from_numpy(ind).to(DEV), mask, mode)
+    mks = [t.cpu().numpy() for t in mask]
+    for b in range(B):
+        assert _host_streams(comp, b) == orc.compress_image(ind[b], mks[0][b, 0], mks[1][b, 0], mks[2][b, 0], mode, table), (b, mode)
+    dind, dmask, zq, status = codec.decompress(comp)
+    exp = np.where(mks[2][:, 0] == 1, ind, 0)
+    exp = exp + np.repeat(np.repeat(np.where(mks[1][:, 0] == 1, ind[:, ::2, ::2], 0), 2, 1), 2, 2)
+    exp = exp + np.repeat(np.repeat(np.where(mks[0][:, 0] == 1, ind[:, ::4, ::4], 0), 4, 1), 4, 2)
+    assert int(status.abs().max()) == 0 and np.array_equal(dind.cpu().numpy(), exp)
+    assert all(torch.equal(a, b_) for a, b_ in zip(dmask, mask))
+    assert torch.equal(zq, codec.codebook[dind].permute(0, 3, 1, 2))
