@@ -181,9 +181,12 @@ __device__ int pack_huffman_part(const TableDev &t, unsigned long long mine, Enc
             pos += len;
             start = end;
         }
+        // (agent-scope stores, drained, then the flag; agent-scope loads on the other side: no L2-wide fences, see part_exchange)
         unsigned int *d = x.tick + 4 * x.part;
-        d[0] = count; d[1] = bits; d[2] = head;
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        __hip_atomic_store(&d[0], count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&d[1], bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&d[2], head, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __hip_atomic_store(&d[3], err ? 2u : 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     if (tid < x.nparts) {
@@ -191,8 +194,11 @@ __device__ int pack_huffman_part(const TableDev &t, unsigned long long mine, Enc
         unsigned int *d = x.tick + 4 * tid;
         unsigned int f;
         while ((f = __hip_atomic_load(&d[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == 0u) __builtin_amdgcn_s_sleep(1);
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        s_desc[4 * tid] = d[0]; s_desc[4 * tid + 1] = d[1]; s_desc[4 * tid + 2] = d[2]; s_desc[4 * tid + 3] = f;
+        asm volatile("" ::: "memory");
+        s_desc[4 * tid] = __hip_atomic_load(&d[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_desc[4 * tid + 1] = __hip_atomic_load(&d[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_desc[4 * tid + 2] = __hip_atomic_load(&d[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_desc[4 * tid + 3] = f;
     }
     __syncthreads();
     CGIC_STAMP2(4);
@@ -737,7 +743,16 @@ constexpr int kLdsTrieNodes = 2048;                // decode tries up to this ma
 constexpr int kFastChunks = 192;                   // streams up to this many chunks (1.5 KB) cache per-position
                                                    // lengths / symbols / chunk functions for the lane-per-chunk pass C
 constexpr int kPackBig = 0xFF;                     // packed "past the end" marker (max real next = 63 + 64)
-constexpr int kDecParts = 8;                        // workgroups per stream when streams are split (large grids); <= 8: flags + counter share one ticket slot
+constexpr int kDecParts = 8;                        // workgroups per stream in the two-launch split form (decode_functions / decode_parts)
+#ifndef CGIC_DEC_PARTS_MAX
+#define CGIC_DEC_PARTS_MAX 12
+#endif
+constexpr int kDecPartsMax = CGIC_DEC_PARTS_MAX;                    // ... and at most in the one-launch form: flags 0..11 and the reader count (word 15) share one ticket slot
+constexpr int kDecDoneWord = 15;
+#ifndef CGIC_DEC_PART_BYTES
+#define CGIC_DEC_PART_BYTES 1280
+#endif
+constexpr int kDecPartBytes = CGIC_DEC_PART_BYTES;     // stream bytes per part: 160 chunks, one pass-A round of 16 waves x 10 chunks
 
 struct BitWindow {
     uint32_t *win;           // LDS, kSegWinWords
@@ -839,7 +854,7 @@ struct FastTables {                   // per chunk x bit offset, filled by pass 
 
 // ---- split streams in ONE launch: the workgroups of a stream exchange their range functions through global memory
 // (decode_split_kernel).  tick: one zeroed ticket slot per stream -- words 0..parts-2 "function of part g published",
-// word 8 = parts that have read their predecessors; the last reader zeroes the slot again for the next launch.
+// word 15 = parts that have read their predecessors; the last reader zeroes the slot again for the next launch.
 struct PartSync {
     uint32_t *bf;            // [parts][64] range functions of this stream (global)
     unsigned int *tick;      // [kTicketStride] ticket slot of this stream (global, zero when the launch starts)
@@ -851,9 +866,12 @@ struct PartSync {
 __device__ __forceinline__ void part_exchange(int part, int nparts, uint32_t fn, const PartSync &ps)
 {
     const int lane = lane_id();
+    // Hand-off without fences: the 64 words go out as agent-scope (write-through) stores, are drained, then the flag; the
+    // readers use agent-scope loads.  An agent-scope release / acquire pair writes back and invalidates the XCD's whole L2
+    // -- measured +4.6 us on the decode launch of 64 256x256 images with ONE stream split in two.
     if (part < nparts - 1) {                                     // nobody reads the last range's function
-        ps.bf[part * kWave + lane] = fn;
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        __hip_atomic_store(&ps.bf[part * kWave + lane], fn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (lane == 0) __hip_atomic_store(&ps.tick[part], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     int e = 0, n = 0;
@@ -861,12 +879,13 @@ __device__ __forceinline__ void part_exchange(int part, int nparts, uint32_t fn,
         if (lane == 0)
             for (int g = 0; g < part; ++g)
                 while (__hip_atomic_load(&ps.tick[g], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 1u) __builtin_amdgcn_s_sleep(1);
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        uint32_t r[kDecParts - 1];
+        asm volatile("" ::: "memory");
+        uint32_t r[kDecPartsMax - 1];
 #pragma unroll
-        for (int g = 0; g < kDecParts - 1; ++g) r[g] = g < part ? ps.bf[g * kWave + lane] : 0u;
+        for (int g = 0; g < kDecPartsMax - 1; ++g)
+            r[g] = g < part ? __hip_atomic_load(&ps.bf[g * kWave + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
 #pragma unroll
-        for (int g = 0; g < kDecParts - 1; ++g) {
+        for (int g = 0; g < kDecPartsMax - 1; ++g) {
             if (g < part && e < kWave) {
                 const uint32_t v = (uint32_t)__builtin_amdgcn_readlane((int)r[g], __builtin_amdgcn_readfirstlane(e));
                 n += (int)(v >> 8);
@@ -874,10 +893,10 @@ __device__ __forceinline__ void part_exchange(int part, int nparts, uint32_t fn,
             }
         }
         if (lane == 0) {
-            const unsigned int old = __hip_atomic_fetch_add(&ps.tick[8], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned int old = __hip_atomic_fetch_add(&ps.tick[kDecDoneWord], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (old == (unsigned int)(nparts - 2)) {             // every part after the first has read: reset for the next launch
                 for (int i = 0; i < nparts - 1; ++i) __hip_atomic_store(&ps.tick[i], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(&ps.tick[8], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(&ps.tick[kDecDoneWord], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }
     }
@@ -1342,54 +1361,114 @@ __global__ __launch_bounds__(kDecThreads) void decode_parts_kernel(DecodeArgs a)
 // global memory and a ticket slot (part_exchange) instead of a kernel boundary -- the launch gap, the second staging of the
 // LUT / trie / bit windows and the second pass A go away (8 tiles of 768x768: 14.3 + 19.7 us as two launches).  Ranges
 // longer than the per-position tables (tiles beyond ~800x800) still build their function with a pass of their own.
+//
+// The workgroups of an image (gridDim.x of them: 4 for grids up to 64x64, 24 beyond) are dealt to its streams BY STREAM
+// LENGTH, on the device (the byte counts live there): every stream that was sent gets one, the rest go one at a time to the
+// stream with the most bytes per workgroup.  At the usual (0.1, 0.8, 0.1) ratios the medium stream of a 256x256 image is twice
+// the fine one and gets the fourth workgroup (its pass A is bound by one CU's LDS crossbar: two CUs halve it); with only the
+// fine grid sent (ratio (0,0,1): 590 chunks) all four decode that one stream.  Order inside an image: medium parts, fine
+// parts, coarse parts -- a part's predecessors have smaller workgroup ids.
+// (scalars only, no indexed arrays, no loop in the common case: everything here stays on the scalar unit)
+__device__ __forceinline__ void decode_roles(int n0, int n1, int n2, int wgs, int *q0, int *q1, int *q2)
+{
+    // a part per kDecPartBytes of stream (160 chunks: one pass-A round of the 16 waves), at most kDecPartsMax
+    auto want = [](int n) -> int {
+        if (n <= 0) return 0;
+        const int p = (int)(((unsigned)n + (unsigned)kDecPartBytes - 1u) / (unsigned)kDecPartBytes);
+        return p > kDecPartsMax ? kDecPartsMax : p;
+    };
+    int p0 = want(n0), p1 = want(n1), p2 = want(n2);
+    // more than the image has workgroups (long streams on a small grid): take from the stream with the most parts
+    while (p0 + p1 + p2 > wgs) {
+        if (p1 >= p2 && p1 >= p0) --p1;
+        else if (p2 >= p0) --p2;
+        else --p0;
+    }
+    *q0 = p0; *q1 = p1; *q2 = p2;
+}
+
 __global__ __launch_bounds__(kDecThreads) void decode_split_kernel(DecodeArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t sm[];
-    __shared__ int s_count, s_nb, s_pad;
+    __shared__ int s_count;
     __shared__ uint32_t s_fn[kWave];
     __shared__ int s_entry[2];
     uint32_t *lut = sm;
     uint32_t *win = lut + kDecLutMax;
     SegShared *seg = reinterpret_cast<SegShared *>(win + kDecWaves * kSegWinWords);
     const int tid = threadIdx.x, wave = tid >> 6;
-    const int s = blockIdx.x / a.parts, part = blockIdx.x % a.parts;
     const int64_t b = blockIdx.y;
+    // who am I: every workgroup of the image derives the same split from the same three byte counts.  The counts and the
+    // three header bytes are requested first, the LUT / trie staging (the same for every role) runs while they arrive.
+    const uint8_t *in0 = a.in + (b * CGIC_NUM_STREAMS) * a.slot;
+    const int n0 = (a.stream_mask & 1) ? a.nbytes[b * CGIC_NUM_STREAMS] : -2, n1 = (a.stream_mask & 2) ? a.nbytes[b * CGIC_NUM_STREAMS + 1] : -2,
+              n2 = (a.stream_mask & 4) ? a.nbytes[b * CGIC_NUM_STREAMS + 2] : -2;
+    const int pad0 = in0[0], pad1 = in0[a.slot], pad2 = in0[2 * a.slot];       // (slot memory is always readable)
+    if (tid == 0) s_count = 0;
+    load_lut(a.tab, lut);
+    if (a.tab.n_nodes <= kLdsTrieNodes) {
+        int32_t *ltrie = reinterpret_cast<int32_t *>(seg + 1);
+        for (int i = tid; i < 2 * a.tab.n_nodes; i += kDecThreads) ltrie[i] = a.tab.child[i];
+        a.tab.child = ltrie;
+    }
+    int p0, p1, p2;
+    decode_roles(n0, n1, n2, (int)gridDim.x, &p0, &p1, &p2);
+    int s, part = (int)blockIdx.x, nparts;
+    if (part < p1) { s = 1; nparts = p1; }
+    else if ((part -= p1) < p2) { s = 2; nparts = p2; }
+    else if ((part -= p2) < p0) { s = 0; nparts = p0; }
+    else { s = -1; nparts = 0; }
+    if (blockIdx.x == 0 && tid == 0) {
+        if (a.status) a.status[b] = 0;
+        if (n0 <= 0) a.dcount[b * 3] = n0 == 0 ? -1 : -2;          // empty file (None) / not sent
+        if (n1 <= 0) a.dcount[b * 3 + 1] = n1 == 0 ? -1 : -2;
+        if (n2 <= 0) a.dcount[b * 3 + 2] = n2 == 0 ? -1 : -2;
+    }
+    if (s < 0) return;                                            // more workgroups than the streams are worth
     const int64_t n_c = (a.h >> 2) * (a.w >> 2), n_m = (a.h >> 1) * (a.w >> 1), n_f = a.h * a.w;
     const int64_t off = s == 0 ? 0 : (s == 1 ? n_c : n_c + n_m);
     const int cap = (int)(s == 0 ? n_c : (s == 1 ? n_m : n_f));
-    if (s == 0 && part == 0 && tid == 0 && a.status) a.status[b] = 0;
     int32_t *dc = a.dcount + b * 3 + s;
-    const uint8_t *in = a.in + (b * CGIC_NUM_STREAMS + s) * a.slot;
-    if (tid == 0) s_count = 0;
-    decode_part_prologue(a, lut, seg, s, b, in, &s_nb, &s_pad);
+    const uint8_t *in = in0 + s * a.slot;
+    const int nb = s == 0 ? n0 : s == 1 ? n1 : n2;                // > 0: the stream has a workgroup
+    const int s_pad = s == 0 ? pad0 : s == 1 ? pad1 : pad2;
     __syncthreads();
-    const int nb = s_nb;
-    if (nb <= 0) {                                               // the same for every part of the stream: nobody waits
-        if (tid == 0 && part == a.parts - 1) *dc = nb == 0 ? -1 : -2;
-        return;
-    }
-    PartSync ps{a.bf + (b * 3 + s) * a.parts * kWave, a.tick + (b * 3 + s) * kTicketStride, s_entry};
     uint16_t *dst = a.dsym + b * (n_c + n_m + n_f) + off;
     auto put = [&](int k, int sym) { dst[k] = (uint16_t)sym; };
     FastTables *ft = reinterpret_cast<FastTables *>(reinterpret_cast<int32_t *>(seg + 1) + 2 * kLdsTrieNodes);
+    if (nparts == 1) {
+        // the stream is this workgroup's alone (like decode_streams_kernel)
+        int nw = (nb + 15) >> 4;                         // no wave below ~2 chunks
+        nw = nw < 1 ? 1 : (nw > kDecWaves ? kDecWaves : nw);
+        if (nb <= kFastChunks * 8)
+            decode_segmented<false>(a.tab, lut, win + wave * kSegWinWords, seg, in, nb, s_pad, 0, wave < nw ? nw : 0, wave, cap, put,
+                                    &s_count, ft);
+        else
+            decode_segmented<true>(a.tab, lut, win + wave * kSegWinWords, seg, in, nb, s_pad, 0, wave < nw ? nw : 0, wave, cap, put,
+                                   &s_count, ft);
+        __syncthreads();
+        if (tid == 0) *dc = s_count > cap ? -3 : s_count;
+        return;
+    }
+    PartSync ps{a.bf + (b * 3 + s) * kDecPartsMax * kWave, a.tick + (b * 3 + s) * kTicketStride, s_entry};
     int nbits = s_pad == 0 ? 0 : (nb - 1) * 8 - s_pad;
     nbits = nbits < 0 ? 0 : nbits;
-    const int nchunks = (nbits + kWave - 1) / kWave, per_part = (nchunks + a.parts - 1) / a.parts;
+    const int nchunks = (nbits + kWave - 1) / kWave, per_part = (nchunks + nparts - 1) / nparts;
     if (per_part <= kFastChunks) {
         decode_segmented<true>(a.tab, lut, win + wave * kSegWinWords, seg, in, nb, s_pad, 0, kDecWaves, wave, cap, put, &s_count, ft,
-                               part, a.parts, 0, 0, nullptr, &ps);
+                               part, nparts, 0, 0, nullptr, &ps);
     } else {
         decode_segmented<false>(a.tab, lut, win + wave * kSegWinWords, seg, in, nb, s_pad, 0, kDecWaves, wave, 0,
-                                [](int, int) {}, &s_count, (FastTables *)nullptr, part, a.parts, 0, 0, s_fn);
+                                [](int, int) {}, &s_count, (FastTables *)nullptr, part, nparts, 0, 0, s_fn);
         __syncthreads();
-        if (wave == 0) part_exchange(part, a.parts, s_fn[tid], ps);
+        if (wave == 0) part_exchange(part, nparts, s_fn[tid], ps);
         if (tid == 0) s_count = 0;
         __syncthreads();
         decode_segmented<true>(a.tab, lut, win + wave * kSegWinWords, seg, in, nb, s_pad, 0, kDecWaves, wave, cap, put, &s_count, ft,
-                               part, a.parts, s_entry[0], s_entry[1]);
+                               part, nparts, s_entry[0], s_entry[1]);
     }
     __syncthreads();
-    if (tid == 0 && part == a.parts - 1) *dc = s_count > cap ? -3 : s_count;      // the last part knows the total
+    if (tid == 0 && part == nparts - 1) *dc = s_count > cap ? -3 : s_count;      // the last part knows the total
 }
 
 constexpr int kMergeThreads = 512;
@@ -1936,7 +2015,7 @@ extern "C" size_t cgic_decompress_workspace_bytes(int64_t B, int64_t h, int64_t 
     if (B <= 0 || h <= 0 || w <= 0) return 0;
     const size_t per = (size_t)((h / 4) * (w / 4) + (h / 2) * (w / 2) + h * w);
     return align16((size_t)B * per * sizeof(uint16_t)) + align16((size_t)B * 3 * sizeof(int32_t))
-           + align16((size_t)B * 3 * kDecParts * kWave * sizeof(uint32_t));                     // split-stream functions
+           + align16((size_t)B * 3 * kDecPartsMax * kWave * sizeof(uint32_t));                  // split-stream functions
 }
 
 extern "C" int cgic_decompress_streams(const cgic_table *t, const uint8_t *in, int64_t slot, const int32_t *nbytes,
@@ -1970,9 +2049,11 @@ extern "C" int cgic_decompress_streams(const cgic_table *t, const uint8_t *in, i
     d.dsym = (uint16_t *)workspace;
     d.dcount = (int32_t *)((char *)workspace + align16((size_t)B * per * sizeof(uint16_t)));
     d.status = status;
-    // grids beyond a 256x256 image (latent 64x64) have streams of many segments: split each over kDecParts workgroups
-    // (tables with >64-bit codes take the one-wave path of decode_streams_kernel)
-    d.parts = h * w > 64 * 64 && d.tab.max_len <= 64 ? kDecParts : 1;
+    // Streams are split over workgroups that exchange range functions (decode_split_kernel): 4 workgroups per image for grids
+    // up to 64x64 (a 256x256 image), 24 beyond, dealt to the streams by length on the device.  Tables with codes longer than
+    // 64 bits take the one-wave path of decode_streams_kernel; batches beyond the ticket ring keep the older forms.
+    const bool large = h * w > 64 * 64;
+    d.parts = large && d.tab.max_len <= 64 ? kDecParts : 1;
     d.bf = (uint32_t *)((char *)d.dcount + align16((size_t)B * 3 * sizeof(int32_t)));
     size_t lds_d = sizeof(uint32_t) * (kDecLutMax + kDecWaves * kSegWinWords) + sizeof(SegShared) + sizeof(int32_t) * 2 * kLdsTrieNodes
                    + sizeof(FastTables);
@@ -1983,14 +2064,19 @@ extern "C" int cgic_decompress_streams(const cgic_table *t, const uint8_t *in, i
 #ifdef CGIC_DEC_TWO_LAUNCH
     if (false) {
 #else
-    if (d.parts > 1 && B * 3 <= (int64_t)(16384 / 4)) {
+    if (d.tab.max_len <= 64 && B * 3 <= (int64_t)(16384 / 4)) {
 #endif
-        // one launch: the parts of a stream exchange their range functions through a ticket slot per stream
         rc = acquire_tickets(s, (int)(B * 3), &d.tick);
         if (rc) return rc;
         if (lds_d > 48 * 1024)
             { int rc_ = ensure_dynamic_lds((const void *)decode_split_kernel, (size_t)lds_d); if (rc_) return rc_; }
-        hipLaunchKernelGGL(decode_split_kernel, dim3(3 * d.parts, (unsigned)B), dim3(kDecThreads), lds_d, s, d);
+#ifndef CGIC_DEC_WGS_SMALL
+#define CGIC_DEC_WGS_SMALL 4
+#endif
+#ifndef CGIC_DEC_WGS_LARGE
+#define CGIC_DEC_WGS_LARGE 24
+#endif
+        hipLaunchKernelGGL(decode_split_kernel, dim3(large ? CGIC_DEC_WGS_LARGE : CGIC_DEC_WGS_SMALL, (unsigned)B), dim3(kDecThreads), lds_d, s, d);
         rc = launch_check("decode_split_kernel");
     } else if (d.parts > 1) {
         if (lds_d > 48 * 1024) {

@@ -92,6 +92,11 @@ __global__ __launch_bounds__(kEntThreads) void entropy_maps_kernel(
     const int64_t s_hi = s_lo + kEntStrips < nsx ? s_lo + kEntStrips : nsx;
 
     CGIC_STAMP(16);
+#ifdef CGIC_PHASE_CLOCKS      // dev: per-workgroup (start, end) for tools/probe_entropy.py
+    const unsigned int dbg_lin = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+    if (threadIdx.x == 0 && dbg_lin < 4096) g_blk_t[2 * dbg_lin] = wall_clock64();
+    struct DbgEnd { unsigned int lin; __device__ ~DbgEnd() { if (threadIdx.x == 0 && lin < 4096) g_blk_t[2 * lin + 1] = wall_clock64(); } } dbg_end{dbg_lin};
+#endif
     if (tid < kBins) bins[tid] = bins_arg.v[tid];
     for (int i = tid; i < 4 * kBins * kTileStride; i += kEntThreads) (&tile[0][0])[i] = 0.f;
 

@@ -18,3 +18,10 @@ names = {17: "loads done+gray", 18: "lds store", 19: "barrier", 20: "sub-patch 0
 for i in range(17, 25):
     print(f"  {names[i]:16s} +{(c[i]-c[i-1])/2.29e3:6.2f} us  (t={(c[i]-c[16])/2.29e3:6.2f})")
 print("entropy_maps B=64: %.1f us" % time_events(lambda: cg.entropy_maps(xx), 50))
+cg.entropy_maps(xx); torch.cuda.synchronize()
+n = 1024
+buf = (ctypes.c_longlong * (2 * n))(); l.cgic_debug_block_times(buf, n)
+t = np.array(list(buf), dtype=np.int64).reshape(n, 2)
+t0 = t[:, 0].min(); st = (t[:, 0] - t0) / 100.0; en = (t[:, 1] - t0) / 100.0
+print("workgroups: start min/med/p90/max %.2f %.2f %.2f %.2f | end min/med/p90/max %.2f %.2f %.2f %.2f | life med %.2f max %.2f us" % (
+    st.min(), np.median(st), np.percentile(st, 90), st.max(), en.min(), np.median(en), np.percentile(en, 90), en.max(), np.median(en - st), (en - st).max()))
