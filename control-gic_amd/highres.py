@@ -81,9 +81,62 @@ class TiledImage:
         return out
 
 
-def compress_tiled(x, encode, codec, tile=TILE):
+# ---- shape groups side by side.  A 2040x1356 image is 6 tiles in 4 shape groups of one or two tiles: each group's launches
+# keep a handful of CUs busy, so the groups cost what the slowest one costs when they run on parallel streams (forked from
+# and joined back into the caller's stream by events -- which is also what a hipGraph capture of the whole image records).
+_side_streams = {}
+
+
+def _tensors_of(obj):
+    if torch.is_tensor(obj):
+        yield obj
+    elif isinstance(obj, (list, tuple)):
+        for o in obj:
+            yield from _tensors_of(o)
+    elif hasattr(obj, "data") and hasattr(obj, "nbytes") and torch.is_tensor(getattr(obj, "data", None)):
+        yield obj.data
+        yield obj.nbytes
+
+
+class _Fork:
+    """run the bodies of `for k, st in fork.lanes(n)` on n streams: lane 0 is the current stream, the others wait for what was
+    queued on it so far; join() makes the current stream wait for all of them and tells the allocator about the hand-over"""
+
+    def __init__(self, device, enabled):
+        self.cur = torch.cuda.current_stream(device)
+        self.enabled = enabled
+        self.used = []
+        self.device = device
+
+    def lane(self, k):
+        if not self.enabled or k == 0:
+            return self.cur
+        pool = _side_streams.setdefault(torch.device(self.device).index or 0, [])
+        while len(pool) < k:
+            pool.append(torch.cuda.Stream(self.device))
+        st = pool[k - 1]
+        if st not in self.used:
+            ev = torch.cuda.Event()
+            ev.record(self.cur)                      # (recorded when the first side lane starts: everything before the fork)
+            st.wait_event(ev)
+            self.used.append(st)
+        return st
+
+    def join(self, produced=()):
+        for st in self.used:
+            ev = torch.cuda.Event()
+            ev.record(st)
+            self.cur.wait_event(ev)
+        if self.used:
+            for t in _tensors_of(list(produced)):
+                t.record_stream(self.cur)            # allocated on a side stream, consumed (and eventually freed) on this one
+        self.used = []
+
+
+def compress_tiled(x, encode, codec, tile=TILE, concurrent=False):
     """x [1,3,H,W] on the device; encode(tiles [T,3,th,tw]) -> (ind [T*h*w] int64, masks [3 x int32], mode)
-    with per-tile routing (the reference's per-tile B=1 call); codec: GrainCodec.  -> TiledImage"""
+    with per-tile routing (the reference's per-tile B=1 call); codec: GrainCodec.  -> TiledImage.
+    concurrent: the shape groups run on parallel streams (same results; see _Fork)"""
     if x.dim() != 4 or x.shape[0] != 1:
         raise ValueError("compress_tiled takes one image [1,3,H,W] (the reference script uses batch 1)")
     H, W = x.shape[-2:]
@@ -94,23 +147,38 @@ def compress_tiled(x, encode, codec, tile=TILE):
     for i, (_, _, th, tw) in enumerate(tiles):
         by_shape.setdefault((th, tw), []).append(i)
     groups = []
-    for (th, tw), idxs in by_shape.items():
-        batch = torch.stack([xp[0, :, tiles[i][0]:tiles[i][0] + th, tiles[i][1]:tiles[i][1] + tw] for i in idxs])
-        ind, masks, mode = encode(batch)
-        groups.append((idxs, codec.compress(ind, masks, mode), (ind, masks, mode)))
+    fork = _Fork(x.device, concurrent)
+    # the largest group first: it is the long pole, and lane 0 (no fork latency) is its stream
+    order = sorted(by_shape.items(), key=lambda kv: -len(kv[1]) * kv[0][0] * kv[0][1])
+    for lane, ((th, tw), idxs) in enumerate(order):
+        with torch.cuda.stream(fork.lane(lane)):
+            batch = torch.stack([xp[0, :, tiles[i][0]:tiles[i][0] + th, tiles[i][1]:tiles[i][1] + tw] for i in idxs])
+            ind, masks, mode = encode(batch)
+            groups.append((idxs, codec.compress(ind, masks, mode), (ind, masks, mode)))
+    fork.join([(c, e) for _, c, e in groups])
     return TiledImage((H, W), pad, tiles, groups)
 
 
-def decompress_tiled(tiled, codec, decode=None):
+def decompress_tiled(tiled, codec, decode=None, concurrent=False, check=True):
     """-> per-tile (ind, masks, z_q) in row-major order; with decode(z_q, masks) -> pixels also the blended,
-    clamped, unpadded reconstruction (:248-255; tiles do not overlap, so the weights cancel)"""
+    clamped, unpadded reconstruction (:248-255; tiles do not overlap, so the weights cancel).
+    concurrent: shape groups on parallel streams; check=False skips the host synchronisation on the decoder status (for
+    stream capture): the second result is then the [tiles] status tensor to look at later"""
     per_tile = [None] * len(tiled.tiles)
     statuses = []
-    for idxs, comp, _ in tiled.groups:
-        ind, masks, zq, status = codec.decompress(comp)
+    dev = tiled.groups[0][1].data.device if tiled.groups else None
+    fork = _Fork(dev, concurrent and dev is not None)
+    outs = []
+    for lane, (idxs, comp, _) in enumerate(tiled.groups):
+        with torch.cuda.stream(fork.lane(lane)):
+            ind, masks, zq, status = codec.decompress(comp)
+        outs.append((ind, masks, zq, status))
         statuses.append(status)
         for k, i in enumerate(idxs):
             per_tile[i] = (ind[k:k + 1], [m[k:k + 1] for m in masks], zq[k:k + 1])
+    fork.join(outs)
+    if not check:
+        return per_tile, (torch.cat(statuses) if statuses else None)
     # ONE host synchronisation for the whole image (not one per shape group)
     if statuses and int(torch.cat(statuses).abs().max()) != 0:
         raise RuntimeError("corrupt tile stream")

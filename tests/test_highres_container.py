@@ -293,3 +293,42 @@ def test_install_and_compress_on_a_cgic_shaped_model(tmp_path, orc):
     for b in range(3):
         ref = orc.compress_image(ind.view(3, 16, 24)[b].cpu().numpy(), *(m[b, 0].cpu().numpy() for m in mask), mode, htab)
         assert comp.to_host()[b] == ref
+
+
+@pytest.mark.gpu
+def test_tiled_shape_groups_on_parallel_streams_give_the_same_streams():
+    """highres concurrent=True: the shape groups of an image run on parallel streams (forked / joined by events); bytes, decoded
+    indices and masks are those of the sequential driver"""
+    import control_gic_amd as cg
+    from control_gic_amd import highres
+    from control_gic_amd.quantize import vq_forward_route
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(21)
+    H, W = 1000, 1800                                   # 768 + 240 (padded 1008) x 768 + 768 + 272 (padded 1808): 6 tiles, 4 groups
+    x = torch.from_numpy(rng.random((1, 3, H, W), dtype=np.float32)).to(dev)
+    cb = torch.from_numpy(rng.standard_normal((1024, 4)).astype(np.float32)).to(dev)
+    vq = cg.VectorQuantizer(1024, 4, beta=0.25).to(dev)
+    with torch.no_grad():
+        vq.embedding.weight.copy_(cb)
+    vq.usage_counter.copy_(torch.from_numpy(rng.integers(1, 1000, 1024).astype(np.float32)))
+    codec = cg.GrainCodec(vq.embedding_counter, vq.embedding.weight.detach())
+    zs = {}
+
+    def encode(tiles):
+        T, _, th, tw = tiles.shape
+        if (T, th, tw) not in zs:
+            zs[(T, th, tw)] = torch.from_numpy(np.random.default_rng(th + 3 * tw).standard_normal((T, 4, th // 4, tw // 4), dtype=np.float32)).to(dev)
+        e8, e16 = cg.entropy_maps(tiles)
+        _, _, ind, mask, _, mode = vq_forward_route(zs[(T, th, tw)], vq.embedding.weight, 0.25, True, e16, e8, 0.1, 0.8, per_image=True)
+        return ind, mask, mode
+
+    seq = highres.compress_tiled(x, encode, codec)
+    per_seq, _ = highres.decompress_tiled(seq, codec)
+    for _ in range(3):
+        par = highres.compress_tiled(x, encode, codec, concurrent=True)
+        per_par, st = highres.decompress_tiled(par, codec, concurrent=True, check=False)
+        torch.cuda.synchronize()
+        assert len(par.groups) == 4 and int(st.abs().max()) == 0
+        assert par.streams() == seq.streams() and par.bpp() == seq.bpp()
+        for (i0, m0, z0), (i1, m1, z1) in zip(per_seq, per_par):
+            assert torch.equal(i0, i1) and torch.equal(z0, z1) and all(torch.equal(a, b) for a, b in zip(m0, m1))
