@@ -3,23 +3,29 @@
 // CGIC/models/model.py:433-483; CGIC.encode runs it twice, model.py:100-101,
 // each time materialising a [patches, p*p, 32] fp32 temp).
 //
-// Layout: a 256-thread block owns a 16-row x 64-column strip of one image =
-// four 16x16 patches side by side; each wave owns one of them.  The strip is
-// read once with coalesced float4 loads (256 B per row per channel), turned
-// into gray in registers and parked in LDS.  Per 8x8 sub-patch a wave does
-// lane = pixel: only the bins within +-2 of the pixel's own bin can be non-zero
-// in fp32 (exp underflows to exactly 0 beyond 14.42 sigma = 2.24 bin widths,
-// in the reference too) and only +-1 can matter (beyond: < 3e-17 per pixel, see
-// subpatch_sum), so 3 exps per pixel instead of 32; the 64x32 kernel
-// values are deposited in a wave-private LDS tile and summed per bin in a
-// fixed order (lane = bin) -- deterministic, no float atomics.  The four 8x8
-// sums accumulate into the 16x16 patch's histogram.
+// Layout: a wave owns one 16x16 patch at a time (lane = row, 4 consecutive columns: a 64-byte quad of lanes per
+// row, read as float4 per channel) and walks the patches of its 256-thread workgroup's row band; the pixels of the
+// next patch are requested before the current one is computed.  Waves never synchronise with each other.
 //
-// fp32 throughout, denormals kept (epsilon = 1e-40 is an fp32 denormal, model.py:451).
-// The Gaussian is evaluated as exp2(c * r^2) with c = -0.5*log2(e)/sigma^2 folded on the host
-// (one v_exp_f32 instead of an IEEE divide + OCML expf: 3 instructions per bin instead of ~45).
-// This op cannot be bit-exact against the CPU reference anyway (SLEEF vs GPU transcendentals,
-// torch.mean's summation tree); it is held to 2e-5 absolute, and measures ~1e-6.
+// Per pixel only the bins within +-2 of its own bin can be non-zero in fp32 (exp underflows to exactly 0 beyond
+// 14.42 sigma = 2.24 bin widths, in the reference too) and only +-1 can matter (beyond: < 3e-17 per pixel), so
+// 3 exps per pixel instead of 32.  The histogram of an 8x8 sub-patch is the sum of those kernel values per bin.
+// Round 2 (second half): the values are DEPOSITED, not gathered -- each one is converted to fixed point (quantum
+// 2^-28) and added with a return-less 32-bit LDS atomic into a wave-private table [bin][sub-patch][replica]; integer
+// addition is associative, so the result does not depend on the order in which the LDS serves the lanes
+// (deterministic, run to run and across layouts).  Eight replicas per (bin, sub-patch), chosen by the pixel's row,
+// keep same-address collisions at <= 2 lanes per instruction (a smooth patch puts all its pixels into one bin) and a
+// replica's total at <= 8 pixels * 2^28 < 2^32.  Lane = (bin, half-wave) then reads its 8 replicas (two b128
+// loads), converts and adds them in a fixed tree.  Before: every value was written into a [bin][pixel] LDS tile and
+// each bin summed all 64 columns (8 b128 reads + 31 adds per lane and sub-patch for 192 non-zero values):
+// ~420 VALU instructions per patch against ~200 now.
+//
+// fp32 throughout.  The Gaussian is exp2(c * r^2) with c = -0.5*log2(e)/sigma^2 folded on the host (one v_exp_f32
+// instead of an IEEE divide + OCML expf).  The entropy of a histogram only depends on its normalised form, so the
+// mean over pixels (:456) is not materialised.  (Evaluating it as ln S - (sum s ln s)/S, which needs both sums in one
+// lane only, was measured 5x less accurate -- 5.9e-6 against the CPU reference -- because the two terms cancel.)
+// This op cannot be bit-exact against the CPU reference anyway (SLEEF vs GPU transcendentals, torch.mean's
+// summation tree); it is held to 2e-5 absolute, and measures ~1e-6.
 #include "cgic_common.h"
 
 #include <stdlib.h>
@@ -27,69 +33,86 @@
 namespace cgic {
 
 constexpr int kEntThreads = 256;
-constexpr int kEntStrips = 4;     // 64-column strips per workgroup (a 256-wide image row: one workgroup per 16 rows)
+constexpr int kEntWaves = kEntThreads / kWave;
 constexpr int kBins = 32;
-constexpr int kWin = 3;           // bins evaluated per pixel: the nearest one and its two neighbours
-constexpr int kTileStride = 68;  // 64 pixels + 4 pad dwords: conflict-free b128 column reads
+constexpr int kWin = 3;            // bins evaluated per pixel: the nearest one and its two neighbours
+constexpr int kHistStride = 36;    // dwords per bin: 4 sub-patches x 8 replicas + 4 pad (conflict-free b128 rows)
+constexpr float kFixScale = 268435456.f;          // 2^28: a replica collects <= 8 pixels with values <= 1
 
 struct BinsArg { float v[kBins]; };   // passed by value in the kernarg segment
 
-// Butterfly over the 32 bins held by lanes {0..31} (and, mirrored, {32..63}); every lane ends with
-// the same total, summed in the same fixed order => deterministic.  Offsets 1, 2, 4, 8 are DPP operands of
-// the adds (quad_perm / row_half_mirror / row_mirror on values that are already uniform inside the smaller
-// group = xor), offset 16 is a v_permlane16_swap: no LDS round trip (five ds_bpermute + waits cost ~55 ns per
-// sum, six sums per 16x16 patch).  Same association as the ds_bpermute butterfly it replaces, bit for bit.
-// (An earlier DPP + v_readlane variant was measured SLOWER: 48.7 vs 39.6 us at B=64.)
-template <int CTRL>
+template <int CTRL, int ROW_MASK = 0xF>
 __device__ __forceinline__ float dpp_add(float v)
 {
-    return v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+    return v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xF, true));
 }
-__device__ __forceinline__ float sum32(float v)
+// Sum over the 32 lanes of each half-wave; the total is valid in the UPPER row of the half only (lanes 16..31 and
+// 48..63).  Offsets 1, 2, 4, 8 are DPP operands of the adds (quad_perm / row_half_mirror / row_mirror on values that
+// are already uniform inside the smaller group = xor butterfly), then row_bcast:15 hands row 0's total to row 1 and
+// row 2's to row 3.  Fixed association => deterministic.  (The all-lanes form needs a v_permlane16_swap instead of
+// the last step: 4x the issue time of a DPP add, tools/probe_valu2.)
+__device__ __forceinline__ float sum32_upper(float v)
 {
     v = dpp_add<0xB1>(v);        // quad_perm [1,0,3,2]: xor 1
     v = dpp_add<0x4E>(v);        // quad_perm [2,3,0,1]: xor 2
     v = dpp_add<0x141>(v);       // row_half_mirror: xor 4 for quad-uniform values
     v = dpp_add<0x140>(v);       // row_mirror: xor 8 for values uniform over 8 lanes
-    unsigned int a = __float_as_uint(v), b = a;
-    swap16(a, b);
-    return __uint_as_float(a) + __uint_as_float(b);      // xor 16
+    return dpp_add<0x142, 0xA>(v);   // row_bcast:15 into rows 1 and 3
 }
 
-// entropy of one histogram: lane (b = lane&31) holds sum over pixels of bin b.
-// pdf / norm as pdf * v_rcp_f32(norm) and log as v_log_f32 * ln 2 (1 ulp each) instead of the IEEE divide and
-// OCML logf (~30 instructions): this op is held to 2e-5 absolute against the CPU reference and measures ~1e-6
-// either way.  v_log_f32 does not take denormals, and an empty bin is pdf = eps = 1e-40: its term
-// eps * log(eps) = -9e-39 is dropped (contributes < 3e-37 over 32 bins).
-__device__ __forceinline__ float patch_entropy(float s, float inv_npix)
+// Same sum, valid in all 64 lanes: the last step is a ds_swizzle (lane ^ 16 through the LDS crossbar, no memory):
+// one LDS-port instruction instead of a v_permlane16_swap that holds the VALU port for four issue slots.
+__device__ __forceinline__ float sum32_all(float v)
 {
-    const float eps = 1e-40f;
-    float pdf = s * inv_npix;                   // torch.mean over pixels (1/64, 1/256: exact) (:456)
-    float norm = sum32(pdf) + eps;              // sum over bins + epsilon     (:457)
-    pdf = pdf * __builtin_amdgcn_rcpf(norm) + eps;                          // (:458)
-    float t = pdf > 1e-30f ? pdf * (__builtin_amdgcn_logf(pdf) * 0.6931471805599453f) : 0.f;
-    return -sum32(t);                           //                             (:459)
+    v = dpp_add<0xB1>(v);
+    v = dpp_add<0x4E>(v);
+    v = dpp_add<0x141>(v);
+    v = dpp_add<0x140>(v);
+    return v + __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, v), 0x401F));   // xor 0x10
+}
+
+// entropy of the histogram whose bin b total `s` (>= 0, any common scale: the mean over pixels of :456 drops out)
+// sits in lane b of a half-wave; valid in lanes 16..31 / 48..63.  pdf / norm as pdf * v_rcp_f32(norm) and log as
+// v_log_f32 * ln 2 (1 ulp each) instead of the IEEE divide and OCML logf.  An empty bin is p = eps = 1e-40 in the
+// reference: its term eps * log(eps) = -9e-39 is dropped (< 3e-37 over 32 bins; an all-zero histogram gives 0 where
+// the reference gives 2.9e-37).  NaN totals stay NaN.
+__device__ __forceinline__ float hist_entropy(float s)
+{
+    const float S = sum32_all(s);                                   // sum over bins          (:457)
+    const float p = s * __builtin_amdgcn_rcpf(fmaxf(S, 1e-30f));    //                        (:458)
+    const float t = p * __builtin_amdgcn_logf(fmaxf(p, 1e-30f));    // p log2 p, 0 for an empty bin
+    return -0.6931471805599453f * sum32_upper(t);                   //                        (:459)
+}
+
+__device__ __forceinline__ int cvt_floor_i32(float v)
+{
+    int r;
+    asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(r) : "v"(v));      // floor, saturating, NaN -> 0
+    return r;
+}
+__device__ __forceinline__ unsigned int cvt_round_u32(float v)
+{
+    int r;
+    asm("v_cvt_rpi_i32_f32 %0, %1" : "=v"(r) : "v"(v));      // floor(v + 0.5); v in [0, 2^28]; NaN -> 0
+    return (unsigned int)r;
 }
 
 __global__ __launch_bounds__(kEntThreads) void entropy_maps_kernel(
     const float *__restrict__ x, int64_t H, int64_t W, float exp2_scale, float *__restrict__ e8,
-    float *__restrict__ e16, BinsArg bins_arg)
+    float *__restrict__ e16, BinsArg bins_arg, int patches_per_wave)
 {
-    __shared__ __attribute__((aligned(16))) float gray[16][64 + 4];
-    __shared__ __attribute__((aligned(16))) float tile[4][kBins * kTileStride];
-    __shared__ float bins[kBins];
+    __shared__ __attribute__((aligned(16))) unsigned int hist_all[kEntWaves][kBins * kHistStride];
+    __shared__ float bins[kBins + 4];
 
     const int64_t b = blockIdx.z;
     const int64_t row0 = (int64_t)blockIdx.y * 16;
     const int tid = threadIdx.x;
     const int lane = lane_id();
     const int wave = tid >> 6;
-    // A workgroup walks up to kEntStrips consecutive 64-column strips of its 16 rows; the pixels of strip s+1 are
-    // requested (into registers) before strip s is computed.  One strip per workgroup spent half of every
-    // workgroup's life waiting for its 12 KB of HBM (2.2 of 4.3 us, four workgroups per CU): 22.6 us per launch.
-    const int64_t nsx = (W + 63) / 64;
-    const int64_t s_lo = (int64_t)blockIdx.x * kEntStrips;
-    const int64_t s_hi = s_lo + kEntStrips < nsx ? s_lo + kEntStrips : nsx;
+    // the workgroup's band of 16-pixel-wide patches; wave w takes patches w, w + 4, ... of it
+    const int64_t npx = W / 16;
+    const int64_t p_lo = (int64_t)blockIdx.x * (kEntWaves * patches_per_wave);
+    const int64_t p_end = p_lo + kEntWaves * patches_per_wave < npx ? p_lo + kEntWaves * patches_per_wave : npx;
 
     CGIC_STAMP(16);
 #ifdef CGIC_PHASE_CLOCKS      // dev: per-workgroup (start, end) for tools/probe_entropy.py
@@ -97,120 +120,121 @@ __global__ __launch_bounds__(kEntThreads) void entropy_maps_kernel(
     if (threadIdx.x == 0 && dbg_lin < 4096) g_blk_t[2 * dbg_lin] = wall_clock64();
     struct DbgEnd { unsigned int lin; __device__ ~DbgEnd() { if (threadIdx.x == 0 && lin < 4096) g_blk_t[2 * lin + 1] = wall_clock64(); } } dbg_end{dbg_lin};
 #endif
-    if (tid < kBins) bins[tid] = bins_arg.v[tid];
-    for (int i = tid; i < 4 * kBins * kTileStride; i += kEntThreads) (&tile[0][0])[i] = 0.f;
 
-    const int lr = tid >> 4;          // row 0..15 of the strip this thread loads
-    const int lc4 = (tid & 15) * 4;   // column 0..60
+    // pixel role: lane = (row of the patch, 4 consecutive columns)
+    const int prow = lane >> 2;
+    const int pc4 = (lane & 3) * 4;
     const int64_t plane = H * W;
     float4 pR = {0.f, 0.f, 0.f, 0.f}, pG = pR, pB = pR;
-    auto request = [&](int64_t strip) {
-        const int64_t col = strip * 64 + lc4;
-        pR = pG = pB = float4{0.f, 0.f, 0.f, 0.f};
-        if (strip < s_hi && col < W) {   // W % 16 == 0 => a float4 is entirely inside or outside
-            const float *p = x + (b * 3) * plane + (row0 + lr) * W + col;
+    auto request = [&](int64_t patch) {
+        if (patch < p_end) {
+            const float *p = x + (b * 3) * plane + (row0 + prow) * W + patch * 16 + pc4;
             pR = *reinterpret_cast<const float4 *>(p);
             pG = *reinterpret_cast<const float4 *>(p + plane);
             pB = *reinterpret_cast<const float4 *>(p + 2 * plane);
         }
     };
-    request(s_lo);
+    request(p_lo + wave);
 
-    float *T = tile[wave];
+    if (tid < kBins) bins[tid] = bins_arg.v[tid];
+    // sub-patch (sy, sx) of this lane's pixels and its replica: slot = sub * 8 + (row & 7)
+    const int slot = ((lane >> 5) << 4) | (((lane >> 1) & 1) << 3) | (prow & 7);
+    // histogram role: lane = (bin, half); over the two read-back rounds it owns sub-patches `half` and 2 + `half`
     const int bin = lane & 31;
     const int half = lane >> 5;
-    const float inv_step = 15.5f;        // (nbins-1)/2 bins per unit; only picks the candidate window
+    unsigned int *Hw = hist_all[wave];
+    uint4 *own0 = reinterpret_cast<uint4 *>(Hw + bin * kHistStride + half * 8);
+    uint4 *own1 = reinterpret_cast<uint4 *>(Hw + bin * kHistStride + 16 + half * 8);
+    const uint4 zero4 = {0u, 0u, 0u, 0u};
+    own0[0] = zero4; own0[1] = zero4; own1[0] = zero4; own1[1] = zero4;
+    __syncthreads();                                      // bins[]; the only workgroup-wide barrier
+    const float k0 = -bins[0] * 15.5f - 0.5f;             // (g - bins[0]) * 15.5 - 0.5: floor() = nearest bin - 1
 
 #pragma unroll 1
-    for (int64_t strip = s_lo; strip < s_hi; ++strip) {
-    const int64_t col0 = strip * 64;
-    {
+    for (int64_t patch = p_lo + wave; patch < p_end; patch += kEntWaves) {
         // gray = 0.2989 R + 0.5870 G + 0.1140 B  (:471)
-        float4 g4;
-        g4.x = (0.2989f * pR.x + 0.5870f * pG.x) + 0.1140f * pB.x;
-        g4.y = (0.2989f * pR.y + 0.5870f * pG.y) + 0.1140f * pB.y;
-        g4.z = (0.2989f * pR.z + 0.5870f * pG.z) + 0.1140f * pB.z;
-        g4.w = (0.2989f * pR.w + 0.5870f * pG.w) + 0.1140f * pB.w;
+        float g[4];
+        g[0] = (0.2989f * pR.x + 0.5870f * pG.x) + 0.1140f * pB.x;
+        g[1] = (0.2989f * pR.y + 0.5870f * pG.y) + 0.1140f * pB.y;
+        g[2] = (0.2989f * pR.z + 0.5870f * pG.z) + 0.1140f * pB.z;
+        g[3] = (0.2989f * pR.w + 0.5870f * pG.w) + 0.1140f * pB.w;
+        request(patch + kEntWaves);            // in flight during this patch's arithmetic
         CGIC_STAMP(17);
-        *reinterpret_cast<float4 *>(&gray[lr][lc4]) = g4;
-    }
-    CGIC_STAMP(18);
-    __syncthreads();
-    CGIC_STAMP(19);
-    request(strip + 1);                  // in flight during this strip's arithmetic
-    const float bin0 = bins[0];
-    float s16 = 0.f;
 
-    if (col0 + wave * 16 < W) {          // else this wave's 16x16 patch is outside the image (whole wave)
-    // sum over the 64 pixels of 8x8 sub-patch `sp` of every bin's kernel value; every lane returns the
-    // total of bin (lane & 31) (both half-waves hold the same 32 totals)
-    auto subpatch_sum = [&](int sp) -> float {
-        const int sy = sp >> 1, sx = sp & 1;
-        // lane = pixel (row-major inside the 8x8 patch, like nn.Unfold)
-        const int py = lane >> 3, px = lane & 7;
-        const float gv = gray[sy * 8 + py][wave * 16 + sx * 8 + px];
-        // candidate window: nearest bin +-1.  A bin further than 1.5 bin widths holds exp(-0.5 (0.0968/sigma)^2) <= 3e-17
-        // (sigma <= 0.0111; 4.5e-21 at the reference's 0.01): nonzero in fp32 and summed by the reference, but worth
-        // < 1e-15 of entropy -- far below this op's 2e-5 tolerance and its ~1e-6 transcendental noise.
-        float fc = rintf((gv - bin0) * inv_step);
-        fc = fminf(fmaxf(fc, 0.f), 31.f);
-        int jc = (gv == gv) ? (int)fc : 0;
-        int jlo = jc - 1 < 0 ? 0 : jc - 1;
-        jlo = jlo > kBins - kWin ? kBins - kWin : jlo;
+        unsigned long long nan_lanes = 0;      // lanes that hold a NaN pixel (the reference's histogram turns NaN)
+        // candidate window: nearest bin +-1.  A bin further than 1.5 bin widths holds exp(-0.5 (0.0968/sigma)^2)
+        // <= 3e-17 (sigma <= 0.0111; 4.5e-21 at the reference's 0.01): nonzero in fp32 and summed by the reference,
+        // but worth < 1e-15 of entropy.  All twelve bin centres are fetched before the first deposit (the compiler
+        // does not move LDS reads across the atomics).
+        int jlo[4];
+        float bc[4][kWin];
 #pragma unroll
-        for (int q = 0; q < kWin; ++q) {
-            const int jb = jlo + q;
-            const float res = gv - bins[jb];                       // residuals          (:453)
-            const float kv = __builtin_amdgcn_exp2f(exp2_scale * (res * res));   // exp(-0.5 (res/sigma)^2) (:454)
-            T[jb * kTileStride + lane] = kv;
+        for (int i = 0; i < 4; ++i) {
+            nan_lanes |= __ballot(g[i] != g[i]);
+            jlo[i] = min(max(cvt_floor_i32(fmaf(g[i], 15.5f, k0)), 0), kBins - kWin);       // v_med3_i32
+#pragma unroll
+            for (int q = 0; q < kWin; ++q) bc[i][q] = bins[jlo[i] + q];
         }
-        __builtin_amdgcn_wave_barrier();
-        // lane = (bin, half): sum 32 pixels in a fixed order, then the two halves
-        const float4 *row = reinterpret_cast<const float4 *>(&T[bin * kTileStride + half * 32]);
-        float4 a4 = row[0];
 #pragma unroll
-        for (int q = 1; q < 8; ++q) {            // four independent accumulators: 8-deep chains, fixed order
-            const float4 v = row[q];
-            a4.x += v.x; a4.y += v.y; a4.z += v.z; a4.w += v.w;
-        }
-        float s = (a4.x + a4.y) + (a4.z + a4.w);
-        s += __shfl_xor(s, 32, kWave);     // (a v_permlane32_swap here instead was measured 18 us SLOWER per launch)
-        __builtin_amdgcn_wave_barrier();
-        // clear what this pixel deposited, ready for the next sub-patch
+        for (int i = 0; i < 4; ++i) {
+            unsigned int *hp = Hw + jlo[i] * kHistStride + slot;
 #pragma unroll
-        for (int q = 0; q < kWin; ++q) T[(jlo + q) * kTileStride + lane] = 0.f;
-        __builtin_amdgcn_wave_barrier();
-        return s;
-    };
-
-#pragma unroll 1
-    for (int pr = 0; pr < 2; ++pr) {     // sub-patch pairs (0,0)(0,1) then (1,0)(1,1), row-major like nn.Unfold
-        const float sA = subpatch_sum(2 * pr);
-        const float sB = subpatch_sum(2 * pr + 1);
-        s16 += sA;
-        s16 += sB;
-        if (e8) {
-            // finalise BOTH 8x8 patches in one pass: half-wave 0 takes A, half-wave 1 takes B (the
-            // butterfly offsets 1..16 of sum32 stay inside a 32-lane half)
-            const float ent = patch_entropy(half ? sB : sA, 1.0f / 64.0f);
-            if ((lane & 31) == 0) {
-                const int64_t h8 = H / 8, w8 = W / 8;
-                e8[(b * h8 + (row0 / 8 + pr)) * w8 + (col0 / 8 + wave * 2 + half)] = ent;
+            for (int q = 0; q < kWin; ++q) {
+                const float res = g[i] - bc[i][q];                                     // residuals (:453)
+                const float kv = __builtin_amdgcn_exp2f(exp2_scale * (res * res));     // exp(-0.5 (res/sigma)^2) (:454)
+                __hip_atomic_fetch_add(hp + q * kHistStride, cvt_round_u32(kv * kFixScale), __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_WAVEFRONT);
             }
         }
-        CGIC_STAMP(20 + pr);
-    }
-    if (e16) {
-        float ent = patch_entropy(s16, 1.0f / 256.0f);
-        if (lane == 0) {
-            const int64_t h16 = H / 16, w16 = W / 16;
-            e16[(b * h16 + row0 / 16) * w16 + (col0 / 16 + wave)] = ent;
+        __builtin_amdgcn_wave_barrier();       // LDS operations of one wave execute in order
+        CGIC_STAMP(18);
+
+        // read back: round k = sub-patch pair (k,0) | (k,1) in the two half-waves, row-major like nn.Unfold
+        float s8[2];
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            uint4 *own = k ? own1 : own0;
+            const uint4 a = own[0], c = own[1];
+            own[0] = zero4; own[1] = zero4;    // ready for the next patch
+            s8[k] = (((float)a.x + (float)a.y) + ((float)a.z + (float)a.w)) +
+                    (((float)c.x + (float)c.y) + ((float)c.z + (float)c.w));
         }
+        __builtin_amdgcn_wave_barrier();
+        float s16 = s8[0] + s8[1];
+        s16 += __shfl_xor(s16, 32, kWave);     // both halves: (sub 0 + sub 2) + (sub 1 + sub 3), commutative
+        if (nan_lanes) {                       // wave-uniform, never taken on real images
+            const unsigned long long sx0 = 0x3333333333333333ull, lo = 0xFFFFFFFFull;
+            const float qnan = __builtin_nanf("");
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {      // sub-patch (k, half): rows 8k..8k+7 = lanes 32k..32k+31, sx = bit 1 of the lane
+                const unsigned long long rows = k ? nan_lanes >> 32 : nan_lanes & lo;
+                const bool badA = (rows & sx0 & lo) != 0, badB = (rows & ~sx0 & lo) != 0;
+                if (half ? badB : badA) s8[k] = qnan;
+            }
+            s16 = qnan;
+        }
+        CGIC_STAMP(19);
+
+        const int64_t pcol = patch;
+        if (e8) {
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const float ent = hist_entropy(s8[k]);
+                if (bin == 16) {
+                    const int64_t h8 = H / 8, w8 = W / 8;
+                    e8[(b * h8 + (row0 / 8 + k)) * w8 + (pcol * 2 + half)] = ent;
+                }
+            }
+        }
+        if (e16) {
+            const float ent = hist_entropy(s16);
+            if (lane == 16) {
+                const int64_t h16 = H / 16, w16 = W / 16;
+                e16[(b * h16 + row0 / 16) * w16 + pcol] = ent;
+            }
+        }
+        CGIC_STAMP(24);
     }
-    }   // wave inside the image
-    CGIC_STAMP(24);
-    __syncthreads();                     // everybody is done with gray[] before the next strip overwrites it
-    }   // strips
 }
 
 }  // namespace cgic
@@ -237,7 +261,14 @@ extern "C" int cgic_entropy_maps_f32(const float *x, int64_t B, int64_t H, int64
     BinsArg ba;
     memcpy(ba.v, bins, sizeof(ba.v));
     hipStream_t s = (hipStream_t)stream;
-    dim3 grid((unsigned)(((W + 63) / 64 + kEntStrips - 1) / kEntStrips), (unsigned)(H / 16), (unsigned)B);
+    // a wave walks `ppw` patches of its row band: 4 for a 256-wide image (one workgroup per 16 rows)
+#ifdef CGIC_ENT_PPW
+    const int ppw = CGIC_ENT_PPW;       // dev: tools/build_variants.sh
+#else
+    const int ppw = 4;
+#endif
+    const int64_t per_wg = (int64_t)kEntWaves * ppw;
+    dim3 grid((unsigned)((W / 16 + per_wg - 1) / per_wg), (unsigned)(H / 16), (unsigned)B);
     // exp(-0.5 (r/sigma)^2) = exp2(c r^2), c = -0.5 log2(e) / sigma^2 (float64 on the host, rounded once)
     const float exp2_scale = (float)(-0.5 * 1.4426950408889634 / ((double)sigma * (double)sigma));
 #ifdef CGIC_DEV_KNOBS
@@ -245,10 +276,10 @@ extern "C" int cgic_entropy_maps_f32(const float *x, int64_t B, int64_t H, int64
     static const int pad = getenv("CGIC_ENT_PAD") ? atoi(getenv("CGIC_ENT_PAD")) : 0;
     if (pad > 0) {
         CGIC_HIP_TRY(hipFuncSetAttribute((const void *)entropy_maps_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, pad));
-        hipLaunchKernelGGL(entropy_maps_kernel, grid, dim3(kEntThreads), (size_t)pad, s, x, H, W, exp2_scale, e8, e16, ba);
+        hipLaunchKernelGGL(entropy_maps_kernel, grid, dim3(kEntThreads), (size_t)pad, s, x, H, W, exp2_scale, e8, e16, ba, ppw);
         return launch_check("entropy_maps_kernel");
     }
 #endif
-    hipLaunchKernelGGL(entropy_maps_kernel, grid, dim3(kEntThreads), 0, s, x, H, W, exp2_scale, e8, e16, ba);
+    hipLaunchKernelGGL(entropy_maps_kernel, grid, dim3(kEntThreads), 0, s, x, H, W, exp2_scale, e8, e16, ba, ppw);
     return launch_check("entropy_maps_kernel");
 }
