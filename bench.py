@@ -10,8 +10,9 @@ The conv encoder/decoder of the codec are out of scope (SURVEY.md section 2 rows
 synthetic N(0,1) latent standing in for the encoder output.
 
 The K timed steps are K successive, DISTINCT batches: the inputs rotate through enough slots to exceed the
-256 MiB Infinity Cache, so the image bytes of every step come from HBM.  One hipGraph per batch, one batch after the
-other on one stream (`--schedule pipelined`: control_gic_amd.pipeline.BatchStream, encode side of batch i+1 next to the
+256 MiB Infinity Cache, so the image bytes of every step come from HBM.  The whole rotation of batches is captured
+back to back in ONE hipGraph on one stream (successive graph launches are ~7 us apart on the device; `--no-ring`: one
+hipGraph per batch; what is left of K after whole rotations always runs as per-batch graphs) (`--schedule pipelined`: control_gic_amd.pipeline.BatchStream, encode side of batch i+1 next to the
 decode side of batch i on two HIP streams -- measured no faster).  `value` = all pixels of the K
 steps / wall time between two barrier + synchronize brackets, max over ranks.
 
@@ -510,7 +511,7 @@ def run_rank(a, rank, world, local):
             stream = cg.pipeline.BatchStream(vq, ratio[0], ratio[1], slots_dev, frequency=codec.huffman, hist=hist)
             stream.capture()
         else:
-            stream = SequentialStream(dev, slots_dev, cb, ratio, vq, codec, hist, graph=not a.no_graph)
+            stream = SequentialStream(dev, slots_dev, cb, ratio, vq, codec, hist, graph=not a.no_graph, ring=not a.no_ring)
         stream.submit(a.warmup)
         stream.join()
         sync()
@@ -548,7 +549,8 @@ def run_rank(a, rank, world, local):
                        "launch": "stub" if stub else (
                            f"{a.schedule}: " + ("encode-side and decode-side hipGraphs of successive batches on two HIP streams"
                                                 if a.schedule == "pipelined" and not a.no_graph else
-                                                ("one hipGraph per batch, one stream" if not a.no_graph else "eager, one stream"))),
+                                                ("eager, one stream" if a.no_graph else "one hipGraph per batch, one stream" if a.no_ring else
+                                                 f"one hipGraph per rotation of {n_slots} batches (per-batch graphs for the remainder of K), one stream"))),
                        "inputs": f"{n_slots} distinct resident batches in rotation ({n_slots * B * H * W * 13 / 2**20:.0f} MiB > 256 MiB Infinity Cache)",
                        "sharding": "images round-robin over ranks; one RCCL all-reduce of the int64[1024] histogram per run"},
         }
@@ -561,9 +563,12 @@ def run_rank(a, rank, world, local):
 
 
 class SequentialStream:
-    """the same K distinct batches, one after the other on one stream (one hipGraph per slot, or eager)"""
+    """the same K distinct batches, one after the other on one stream: eager, one hipGraph per batch, or (ring) ONE hipGraph
+    that holds the whole rotation of batches back to back -- successive graph launches are ~7 us apart on the device
+    (rocprofv3 kernel trace: merge -> next entropy, profiles/r02s2_gaps.md), kernels inside a graph are not -- plus the
+    per-batch graphs for what is left of K"""
 
-    def __init__(self, dev, slots_dev, cb, ratio, vq, codec, hist, graph=True):
+    def __init__(self, dev, slots_dev, cb, ratio, vq, codec, hist, graph=True, ring=True):
         self.hps = []
         for x, z in slots_dev:
             hp = HotPath(dev, x, z, cb, ratio, vq=vq, codec=codec)
@@ -572,13 +577,30 @@ class SequentialStream:
                 hp.capture()
             self.hps.append(hp)
         self.graph = graph
+        self.ring = None
+        if graph and ring and len(self.hps) > 1:
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, stream=side):
+                    for hp in self.hps:
+                        hp.step()                             # hp.out now names the ring's output buffers
+            torch.cuda.current_stream().wait_stream(side)
+            self.ring = g
         self._next = 0
 
     def submit(self, n=1):
-        for _ in range(n):
+        m = len(self.hps)
+        while n > 0:
+            if self.ring is not None and self._next == 0 and n >= m:
+                self.ring.replay()
+                n -= m
+                continue
             hp = self.hps[self._next]
-            self._next = (self._next + 1) % len(self.hps)
+            self._next = (self._next + 1) % m
             hp.graph.replay() if self.graph else hp.step()
+            n -= 1
 
     def join(self):
         pass
@@ -690,6 +712,7 @@ def parse_args(argv=None):
     ap.add_argument("--schedule", choices=["pipelined", "sequential"], default="sequential",
                     help="sequential: one hipGraph per batch on one stream; pipelined: BatchStream, encode side of batch i+1 next to the decode side of batch i")
     ap.add_argument("--slots", type=int, default=0, help="distinct resident input batches in rotation (0: enough to exceed the Infinity Cache)")
+    ap.add_argument("--no-ring", action="store_true", help="one hipGraph per batch instead of one per rotation of batches (sequential schedule)")
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying hipGraphs (sequential schedule)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the extra data points (mask mismatch, ratio sweep, DIV2K, B=1)")
