@@ -82,7 +82,7 @@ def make_quantizer(dev, cb):
 class HotPath:
     """one batch: pre-built modules + a step() that only enqueues work (graph-capturable)"""
 
-    def __init__(self, dev, x, z, cb, ratio, vq=None, codec=None):
+    def __init__(self, dev, x, z, cb, ratio, vq=None, codec=None, fuse_router=True):
         import control_gic_amd as cg
         self.cg = cg
         self.x = torch.from_numpy(x).to(dev) if isinstance(x, np.ndarray) else x
@@ -92,7 +92,7 @@ class HotPath:
         self.router = cg.TripleGrainFixedEntropyRouter(ratio[0], ratio[1], per_image=True)
         self.hist = torch.zeros(1024, dtype=torch.int64, device=dev)
         self.out = None
-        self.pipe = cg.pipeline.HotPathPipeline(self.vq, ratio[0], ratio[1], frequency=self.codec.huffman)
+        self.pipe = cg.pipeline.HotPathPipeline(self.vq, ratio[0], ratio[1], frequency=self.codec.huffman, fuse_router=fuse_router)
 
     def step(self):
         r = self.pipe.run(self.x, self.z, self.hist, decode=True)[0]
@@ -501,6 +501,8 @@ def run_rank(a, rank, world, local):
         per_slot = B * H * W * 13                            # image 12 B/pixel + latent 1 B/pixel
         n_slots = a.slots if a.slots > 0 else max(2, -(-int(IC_BYTES * 1.15) // per_slot))
         n_slots = max(2, min(n_slots, 64))
+        if a.slots <= 0 and a.schedule == "sequential" and a.lanes > 1:
+            n_slots = a.lanes * -(-n_slots // a.lanes)        # every lane the same number of batches
         slots_np = [make_inputs(B, H, W, seed=1000 + 97 * rank + s) for s in range(n_slots)]   # each rank owns its own images
         cb = slots_np[0][2]
         vq = make_quantizer(dev, cb)
@@ -511,7 +513,7 @@ def run_rank(a, rank, world, local):
             stream = cg.pipeline.BatchStream(vq, ratio[0], ratio[1], slots_dev, frequency=codec.huffman, hist=hist)
             stream.capture()
         else:
-            stream = SequentialStream(dev, slots_dev, cb, ratio, vq, codec, hist, graph=not a.no_graph, ring=not a.no_ring)
+            stream = SequentialStream(dev, slots_dev, cb, ratio, vq, codec, hist, graph=not a.no_graph, ring=not a.no_ring, lanes=a.lanes, fuse_router=not a.split_router)
         stream.submit(a.warmup)
         stream.join()
         sync()
@@ -550,7 +552,8 @@ def run_rank(a, rank, world, local):
                            f"{a.schedule}: " + ("encode-side and decode-side hipGraphs of successive batches on two HIP streams"
                                                 if a.schedule == "pipelined" and not a.no_graph else
                                                 ("eager, one stream" if a.no_graph else "one hipGraph per batch, one stream" if a.no_ring else
-                                                 f"one hipGraph per rotation of {n_slots} batches (per-batch graphs for the remainder of K), one stream"))),
+                                                 f"{a.lanes} independent HIP stream(s), batch t on stream t % {a.lanes}, one hipGraph per stream's rotation of "
+                                                 f"{n_slots // max(1, a.lanes)} batches (per-batch graphs for the remainder of K)"))),
                        "inputs": f"{n_slots} distinct resident batches in rotation ({n_slots * B * H * W * 13 / 2**20:.0f} MiB > 256 MiB Infinity Cache)",
                        "sharding": "images round-robin over ranks; one RCCL all-reduce of the int64[1024] histogram per run"},
         }
@@ -563,50 +566,86 @@ def run_rank(a, rank, world, local):
 
 
 class SequentialStream:
-    """the same K distinct batches, one after the other on one stream: eager, one hipGraph per batch, or (ring) ONE hipGraph
-    that holds the whole rotation of batches back to back -- successive graph launches are ~7 us apart on the device
-    (rocprofv3 kernel trace: merge -> next entropy, profiles/r02s2_gaps.md), kernels inside a graph are not -- plus the
-    per-batch graphs for what is left of K"""
+    """K distinct batches through the five launches of the hot path, batch after batch.  Modes:
+      * eager (graph=False) or one hipGraph per batch (ring=False) on one stream;
+      * ring: ONE hipGraph holds a lane's whole rotation of batches back to back -- successive graph launches are ~7 us
+        apart on the device (rocprofv3 kernel trace: merge -> next entropy), kernels inside a graph are not -- plus the
+        per-batch graphs for what is left of K;
+      * lanes > 1: the rotation is dealt over `lanes` HIP streams (batch t runs on lane t % lanes), each with its own ring
+        graph and NO dependency on the others: two batches are in flight at any time and the GPU runs the
+        one-workgroup-per-image kernels of one (router, coder, decoder: 64-256 workgroups, latency-bound) on the CUs the
+        other's leave idle (tools/probe_overlap2.py: decode+merge next to entropy 31 us instead of 26 + 13).
+    Every batch still goes through the same five launches in order; results are identical (checked afterwards)."""
 
-    def __init__(self, dev, slots_dev, cb, ratio, vq, codec, hist, graph=True, ring=True):
+    def __init__(self, dev, slots_dev, cb, ratio, vq, codec, hist, graph=True, ring=True, lanes=1, fuse_router=True):
         self.hps = []
         for x, z in slots_dev:
-            hp = HotPath(dev, x, z, cb, ratio, vq=vq, codec=codec)
+            hp = HotPath(dev, x, z, cb, ratio, vq=vq, codec=codec, fuse_router=fuse_router)
             hp.hist = hist
             if graph:
                 hp.capture()
             self.hps.append(hp)
         self.graph = graph
-        self.ring = None
-        if graph and ring and len(self.hps) > 1:
-            side = torch.cuda.Stream()
-            side.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(side):
-                g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g, stream=side):
-                    for hp in self.hps:
-                        hp.step()                             # hp.out now names the ring's output buffers
-            torch.cuda.current_stream().wait_stream(side)
-            self.ring = g
-        self._next = 0
+        lanes = max(1, min(int(lanes), len(self.hps)))
+        self.lanes = []
+        for j in range(lanes):
+            lane = {"hps": self.hps[j::lanes], "pos": 0, "ring": None,
+                    "stream": torch.cuda.Stream(dev) if lanes > 1 else None}
+            if graph and ring and len(lane["hps"]) > 1:
+                side = torch.cuda.Stream()
+                side.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(side):
+                    g = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g, stream=side):
+                        for hp in lane["hps"]:
+                            hp.step()                         # hp.out now names the ring's output buffers
+                torch.cuda.current_stream().wait_stream(side)
+                lane["ring"] = g
+            self.lanes.append(lane)
+        self._t = 0
 
     def submit(self, n=1):
-        m = len(self.hps)
-        while n > 0:
-            if self.ring is not None and self._next == 0 and n >= m:
-                self.ring.replay()
-                n -= m
-                continue
-            hp = self.hps[self._next]
-            self._next = (self._next + 1) % m
-            hp.graph.replay() if self.graph else hp.step()
-            n -= 1
+        L = len(self.lanes)
+        todo = [0] * L
+        for t in range(self._t, self._t + n):                  # batch t belongs to lane t % L
+            todo[t % L] += 1
+        self._t += n
+        cur = torch.cuda.current_stream()
+        for lane in self.lanes:
+            if lane["stream"] is not None:
+                lane["stream"].wait_stream(cur)
+        while any(todo):
+            for j, lane in enumerate(self.lanes):              # one graph launch per lane and turn keeps every queue fed
+                if not todo[j]:
+                    continue
+                m = len(lane["hps"])
+                ctx = torch.cuda.stream(lane["stream"]) if lane["stream"] is not None else _nullctx()
+                with ctx:
+                    if lane["ring"] is not None and lane["pos"] == 0 and todo[j] >= m:
+                        lane["ring"].replay()
+                        todo[j] -= m
+                    else:
+                        hp = lane["hps"][lane["pos"]]
+                        lane["pos"] = (lane["pos"] + 1) % m
+                        hp.graph.replay() if self.graph else hp.step()
+                        todo[j] -= 1
 
     def join(self):
-        pass
+        cur = torch.cuda.current_stream()
+        for lane in self.lanes:
+            if lane["stream"] is not None:
+                cur.wait_stream(lane["stream"])
 
     def last_out(self, k):
         return self.hps[k].out
+
+
+class _nullctx:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        return False
 
 
 def slot_out(stream, k):
@@ -712,6 +751,8 @@ def parse_args(argv=None):
     ap.add_argument("--schedule", choices=["pipelined", "sequential"], default="sequential",
                     help="sequential: one hipGraph per batch on one stream; pipelined: BatchStream, encode side of batch i+1 next to the decode side of batch i")
     ap.add_argument("--slots", type=int, default=0, help="distinct resident input batches in rotation (0: enough to exceed the Infinity Cache)")
+    ap.add_argument("--lanes", type=int, default=4, help="independent HIP streams the rotation of batches is dealt over (sequential schedule); 1 = one batch in flight")
+    ap.add_argument("--split-router", action="store_true", help="router as its own launch instead of riding in the VQ launch")
     ap.add_argument("--no-ring", action="store_true", help="one hipGraph per batch instead of one per rotation of batches (sequential schedule)")
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying hipGraphs (sequential schedule)")
     ap.add_argument("--no-cpu-baseline", action="store_true")

@@ -17,13 +17,17 @@ from .router import TripleGrainFixedEntropyRouter
 
 
 class HotPathPipeline:
-    def __init__(self, quantizer, coarse_ratio, medium_ratio, chunks=1, frequency=None, fork_vq=False):
+    def __init__(self, quantizer, coarse_ratio, medium_ratio, chunks=1, frequency=None, fork_vq=False, fuse_router=True):
         self.vq = quantizer
         self.router = TripleGrainFixedEntropyRouter(coarse_ratio, medium_ratio, per_image=True)
         self.codec = GrainCodec(frequency if frequency is not None else quantizer.embedding_counter,
                                 quantizer.embedding.weight)
         self.chunks = max(1, int(chunks))
         self.fork_vq = int(fork_vq)       # 1: VQ(+hist) on a side stream next to entropy -> router; 2: router on a side stream next to VQ
+        # True: the per-image router workgroups ride in the VQ launch (best for ONE batch at a time).  False: a launch
+        # of its own in front of the VQ kernel -- a small-footprint kernel that shares CUs with the kernels of OTHER
+        # batches when several independent streams of batches are in flight (bench.py --lanes).
+        self.fuse_router = bool(fuse_router)
         self._streams = None
         self._side = None
 
@@ -62,6 +66,10 @@ class HotPathPipeline:
             e8, e16 = entropy_maps(x)
             mask, _, _, mode = self.router(e16, e8, want_gate=False)
             cur.wait_event(join)
+        elif not self.fuse_router:
+            e8, e16 = entropy_maps(x)
+            mask, _, _, mode = self.router(e16, e8, want_gate=False)
+            zq, loss, ind = _vq_forward(z, self.vq.embedding.weight, self.vq.beta, self.vq.legacy, None)
         else:
             e8, e16 = entropy_maps(x)
             # VQ and the per-image router share one launch (the router rides in the VQ kernel's shadow)
