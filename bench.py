@@ -265,6 +265,19 @@ def mask_mismatch(hp, x, z, cb, ratio):
             "note": "GPU entropy -> GPU router vs oracle entropy -> oracle router on the same pixels; given equal masks every byte is identical (bpp_match)"}
 
 
+def lanes_rate(vq, codec, ratio, xz, lanes, steps, copies=1):
+    """batches per second of a LaneStream over the given device (x, z) pairs (each used `copies` times as its own slot:
+    distinct output buffers, same inputs)"""
+    import control_gic_amd as cg
+    slots = [p for p in xz for _ in range(copies)]
+    ls = cg.pipeline.LaneStream(vq, ratio[0], ratio[1], slots, lanes=lanes, frequency=codec.huffman)
+    ls.capture()
+    ls.submit(len(slots)); ls.join(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    ls.submit(steps); ls.join(); torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / steps, ls
+
+
 def ratio_sweep(dev, x, z, cb, vq, codec, steps=30):
     out = []
     B, H, W = x.shape[0], x.shape[2], x.shape[3]
@@ -281,8 +294,10 @@ def ratio_sweep(dev, x, z, cb, vq, codec, steps=30):
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
         ok, bpp = check_against_oracle(hp.out, x, z, cb, r, images=range(0, B, 16))
+        dt4, _ = lanes_rate(vq, codec, r, [(xd, zd)], 4, 4 * steps, copies=4)
         out.append({"ratio": [r[0], r[1], round(1 - r[0] - r[1], 6)], "mode": int(hp.out[3]), "MPixels/s": round(steps * B * H * W / dt / 1e6, 1),
-                    "ms_per_step": round(dt / steps * 1e3, 5), "bpp_mean": round(float(np.mean(hp.out[6].bpp(H * W))), 6), "bpp_match": ok})
+                    "ms_per_step": round(dt / steps * 1e3, 5), "MPixels/s_4_in_flight": round(B * H * W / dt4 / 1e6, 1),
+                    "bpp_mean": round(float(np.mean(hp.out[6].bpp(H * W))), 6), "bpp_match": ok})
     return out
 
 
@@ -372,8 +387,12 @@ def tiles_768(dev, cb, vq, codec, B, steps):
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     ok, _ = check_against_oracle(hp.out, x, z, cb, (0.1, 0.8), images=[0, B - 1])
-    return {"workload": f"{B} tiles of 768x768 (the tile size of the 2K path), ratio (0.1,0.8,0.1), encode+decode, one batch after the other, hipGraph replay",
-            "value": round(steps * B * 768 * 768 / dt / 1e6, 2), "unit": "MPixels/s", "ms_per_step": round(dt / steps * 1e3, 5), "bpp_match": bool(ok)}
+    dt4, ls = lanes_rate(vq, codec, (0.1, 0.8), [(hp.x, hp.z)], 4, 4 * steps, copies=4)
+    ok4, _ = check_against_oracle(slot_out(ls, 3), x, z, cb, (0.1, 0.8), images=[0, B - 1])
+    return {"workload": f"{B} tiles of 768x768 (the tile size of the 2K path), ratio (0.1,0.8,0.1), encode+decode, hipGraph replay",
+            "value": round(steps * B * 768 * 768 / dt / 1e6, 2), "unit": "MPixels/s", "ms_per_step": round(dt / steps * 1e3, 5),
+            "note": "value = one batch of tiles after the other on one stream; 4_in_flight = four such batches on independent streams",
+            "MPixels/s_4_in_flight": round(B * 768 * 768 / dt4 / 1e6, 2), "bpp_match": bool(ok and ok4)}
 
 
 def b1_latency(dev, cb, vq, codec):
@@ -513,7 +532,11 @@ def run_rank(a, rank, world, local):
             stream = cg.pipeline.BatchStream(vq, ratio[0], ratio[1], slots_dev, frequency=codec.huffman, hist=hist)
             stream.capture()
         else:
-            stream = SequentialStream(dev, slots_dev, cb, ratio, vq, codec, hist, graph=not a.no_graph, ring=not a.no_ring, lanes=a.lanes, fuse_router=not a.split_router)
+            # control_gic_amd.pipeline.LaneStream: batch t on HIP stream t % lanes, one ring graph per stream, no
+            # dependency between the streams (lanes=1: one batch in flight, the round-1/2a configuration)
+            stream = cg.pipeline.LaneStream(vq, ratio[0], ratio[1], slots_dev, lanes=a.lanes, frequency=codec.huffman, hist=hist,
+                                            graph=not a.no_graph, ring=not a.no_ring, fuse_router=not a.split_router)
+            stream.capture()
         stream.submit(a.warmup)
         stream.join()
         sync()
@@ -565,92 +588,7 @@ def run_rank(a, rank, world, local):
         dist.destroy_process_group()
 
 
-class SequentialStream:
-    """K distinct batches through the five launches of the hot path, batch after batch.  Modes:
-      * eager (graph=False) or one hipGraph per batch (ring=False) on one stream;
-      * ring: ONE hipGraph holds a lane's whole rotation of batches back to back -- successive graph launches are ~7 us
-        apart on the device (rocprofv3 kernel trace: merge -> next entropy), kernels inside a graph are not -- plus the
-        per-batch graphs for what is left of K;
-      * lanes > 1: the rotation is dealt over `lanes` HIP streams (batch t runs on lane t % lanes), each with its own ring
-        graph and NO dependency on the others: two batches are in flight at any time and the GPU runs the
-        one-workgroup-per-image kernels of one (router, coder, decoder: 64-256 workgroups, latency-bound) on the CUs the
-        other's leave idle (tools/probe_overlap2.py: decode+merge next to entropy 31 us instead of 26 + 13).
-    Every batch still goes through the same five launches in order; results are identical (checked afterwards)."""
-
-    def __init__(self, dev, slots_dev, cb, ratio, vq, codec, hist, graph=True, ring=True, lanes=1, fuse_router=True):
-        self.hps = []
-        for x, z in slots_dev:
-            hp = HotPath(dev, x, z, cb, ratio, vq=vq, codec=codec, fuse_router=fuse_router)
-            hp.hist = hist
-            if graph:
-                hp.capture()
-            self.hps.append(hp)
-        self.graph = graph
-        lanes = max(1, min(int(lanes), len(self.hps)))
-        self.lanes = []
-        for j in range(lanes):
-            lane = {"hps": self.hps[j::lanes], "pos": 0, "ring": None,
-                    "stream": torch.cuda.Stream(dev) if lanes > 1 else None}
-            if graph and ring and len(lane["hps"]) > 1:
-                side = torch.cuda.Stream()
-                side.wait_stream(torch.cuda.current_stream())
-                with torch.cuda.stream(side):
-                    g = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(g, stream=side):
-                        for hp in lane["hps"]:
-                            hp.step()                         # hp.out now names the ring's output buffers
-                torch.cuda.current_stream().wait_stream(side)
-                lane["ring"] = g
-            self.lanes.append(lane)
-        self._t = 0
-
-    def submit(self, n=1):
-        L = len(self.lanes)
-        todo = [0] * L
-        for t in range(self._t, self._t + n):                  # batch t belongs to lane t % L
-            todo[t % L] += 1
-        self._t += n
-        cur = torch.cuda.current_stream()
-        for lane in self.lanes:
-            if lane["stream"] is not None:
-                lane["stream"].wait_stream(cur)
-        while any(todo):
-            for j, lane in enumerate(self.lanes):              # one graph launch per lane and turn keeps every queue fed
-                if not todo[j]:
-                    continue
-                m = len(lane["hps"])
-                ctx = torch.cuda.stream(lane["stream"]) if lane["stream"] is not None else _nullctx()
-                with ctx:
-                    if lane["ring"] is not None and lane["pos"] == 0 and todo[j] >= m:
-                        lane["ring"].replay()
-                        todo[j] -= m
-                    else:
-                        hp = lane["hps"][lane["pos"]]
-                        lane["pos"] = (lane["pos"] + 1) % m
-                        hp.graph.replay() if self.graph else hp.step()
-                        todo[j] -= 1
-
-    def join(self):
-        cur = torch.cuda.current_stream()
-        for lane in self.lanes:
-            if lane["stream"] is not None:
-                cur.wait_stream(lane["stream"])
-
-    def last_out(self, k):
-        return self.hps[k].out
-
-
-class _nullctx:
-    def __enter__(self):
-        return self
-
-    def __exit__(self, *exc):
-        return False
-
-
 def slot_out(stream, k):
-    if isinstance(stream, SequentialStream):
-        return stream.last_out(k)
     s = stream.slots[k]
     e = s.enc
     return (e["e8"], e["e16"], e["mask"], e["mode"], e["z_q"], e["ind"], e["comp"], *s.dec)
@@ -684,6 +622,11 @@ def report(a, dev, world, stream, slots_np, vq, codec, ratio):
                            "note": "the SAME batch replayed back to back on one stream (round-1 headline configuration: inputs "
                                    "cache-resident, no overlap between batches) = latency of one batch through all five launches"}
     res["single_batch"]["MPixels/s"] = round(B * H * W / res["single_batch"]["ms_per_step"] / 1e3, 1)
+    if a.schedule == "sequential" and a.lanes > 1 and not a.no_graph:
+        dt1, _ = lanes_rate(vq, codec, ratio, [(sl.x, sl.z) for sl in stream.slots], 1, 20 * len(stream.slots))
+        res["one_batch_in_flight"] = {"ms_per_step": round(dt1 * 1e3, 5), "MPixels/s": round(B * H * W / dt1 / 1e6, 1),
+                                      "note": "the same rotation of distinct batches on ONE stream (lanes=1): every launch waits for the "
+                                              "previous one, the round-1 / early round-2 configuration of `value`"}
     stages = stage_breakdown(hp)
     res["stages_us"] = stages
     # roofline of the dominant kernel: the launch the timed step really makes (VQ + router workgroups in one grid)

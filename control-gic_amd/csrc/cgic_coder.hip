@@ -28,6 +28,34 @@
 // checked against it through the oracle + tests/golden/{coders,compress_cfg1}.npz.
 #include "cgic_common.h"
 
+// VGPR caps of the per-image kernels (registers per lane).  What matters is not their own occupancy but what they
+// leave to the kernels of OTHER batches in flight on the same CU (bench.py --lanes): a 512-thread VQ workgroup takes
+// 2 x 152 of a SIMD's 512 registers per lane.
+#ifndef CGIC_CAP_COMPRESS
+#define CGIC_CAP_COMPRESS 48     // 49 uncapped, no spills at 48: 4 waves x 48 fit beside a VQ workgroup (86.1 -> 87.9 GPixel/s at 4 lanes)
+#endif
+#ifndef CGIC_CAP_DECODE
+#define CGIC_CAP_DECODE 0        // 69 uncapped; 56 / 48 spill 13 / 36 registers and were measured slower (85.8 / 83.3)
+#endif
+#ifndef CGIC_CAP_MERGE
+#define CGIC_CAP_MERGE 0
+#endif
+#if CGIC_CAP_COMPRESS
+#define CGIC_VGPR_CAP_COMPRESS __attribute__((amdgpu_num_vgpr(CGIC_CAP_COMPRESS / 2)))
+#else
+#define CGIC_VGPR_CAP_COMPRESS
+#endif
+#if CGIC_CAP_DECODE
+#define CGIC_VGPR_CAP_DECODE __attribute__((amdgpu_num_vgpr(CGIC_CAP_DECODE / 2)))
+#else
+#define CGIC_VGPR_CAP_DECODE
+#endif
+#if CGIC_CAP_MERGE
+#define CGIC_VGPR_CAP_MERGE __attribute__((amdgpu_num_vgpr(CGIC_CAP_MERGE / 2)))
+#else
+#define CGIC_VGPR_CAP_MERGE
+#endif
+
 namespace cgic {
 
 #ifdef CGIC_PHASE_CLOCKS
@@ -449,7 +477,7 @@ struct CompressArgs {
 
 constexpr int kLdsTable = 1024;          // tables up to this many single-word codes are staged in LDS
 
-__global__ __launch_bounds__(kEncThreads) void compress_streams_kernel(CompressArgs a)
+__global__ __launch_bounds__(kEncThreads) CGIC_VGPR_CAP_COMPRESS void compress_streams_kernel(CompressArgs a)
 {
     __shared__ __attribute__((aligned(16))) uint32_t lds_end[kLdsPos];
     __shared__ uint16_t lds_sym[kLdsPos];
@@ -1387,7 +1415,7 @@ __device__ __forceinline__ void decode_roles(int n0, int n1, int n2, int wgs, in
     *q0 = p0; *q1 = p1; *q2 = p2;
 }
 
-__global__ __launch_bounds__(kDecThreads) void decode_split_kernel(DecodeArgs a)
+__global__ __launch_bounds__(kDecThreads) CGIC_VGPR_CAP_DECODE void decode_split_kernel(DecodeArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t sm[];
     __shared__ int s_count;
@@ -1494,7 +1522,7 @@ struct MergeArgs {
     int64_t band_syms;         // u16 entries reserved for a band's own symbol ranges when stage_sym == 0
 };
 
-__global__ __launch_bounds__(kMergeThreads) void merge_kernel(MergeArgs a)
+__global__ __launch_bounds__(kMergeThreads) CGIC_VGPR_CAP_MERGE void merge_kernel(MergeArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t sm[];
     __shared__ uint32_t scan_smem[kMergeThreads / kWave + 1];

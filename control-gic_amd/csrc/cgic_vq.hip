@@ -961,9 +961,9 @@ __device__ __forceinline__ void vq_filter_body(const VqArgs &a, unsigned char *s
 }
 
 #ifndef CGIC_VQF_THREADS
-#define CGIC_VQF_THREADS 768
+#define CGIC_VQF_THREADS 512
 #endif
-constexpr int kVqfThreads = CGIC_VQF_THREADS;      // one workgroup per CU, 3 waves per SIMD (measured at B=64 x 64x64 latents: 512 threads 23.7 us, 768 22.8, 1024 22.9)
+constexpr int kVqfThreads = CGIC_VQF_THREADS;      // one workgroup per CU, 2 waves per SIMD.  Alone at B=64 x 64x64 latents 512 / 768 / 1024 threads are within 1 us of each other; with several batches in flight (bench.py --lanes 4) 512 leaves a third of the register file to the other batches' kernels: 86.9 vs 83.4 (768) vs 82.9 (1024) GPixel/s
 #define CGIC_VQF_BOUNDS __launch_bounds__(kVqfThreads, kVqfThreads / 256 > 1 ? kVqfThreads / 256 : 1)
 
 template <bool ALIGNED, bool CONV>

@@ -212,3 +212,151 @@ class BatchStream:
         stream = torch.cuda.current_stream(self.device) if stream is None else stream
         self.enc_stream.wait_stream(stream)
         self.dec_stream.wait_stream(stream)
+
+
+def distinct_queue_streams(device, n, candidates=16, spin_cycles=400_000):
+    """`n` HIP streams that sit on DIFFERENT hardware queues.
+
+    ROCm multiplexes all HIP streams of a process onto a few hardware queues (GPU_MAX_HW_QUEUES, 4 by default; the null
+    stream holds one of them), and which queue a stream lands on depends on how many streams the process created before it.
+    Two streams on one queue run their kernels strictly one after the other: four lanes on three queues were measured at
+    71 GPixel/s against 87 on four (rocprofv3 kernel trace, queue_id column).  The mapping is not exposed by the HIP API, so
+    it is measured: a single-thread spin kernel (`torch.cuda._sleep`) on two streams takes one spin if the queues differ and
+    two if they are the same.  Greedy choice over `candidates` pool streams; if fewer than `n` distinct queues exist the
+    remaining lanes share queues (still correct, only less overlap)."""
+    streams = [torch.cuda.Stream(device) for _ in range(max(n, candidates))]
+    if n <= 1:
+        return streams[:n]
+    import time
+
+    def spin(group):
+        torch.cuda.synchronize(device)
+        t0 = time.perf_counter()
+        for st in group:
+            with torch.cuda.stream(st):
+                torch.cuda._sleep(spin_cycles)
+        torch.cuda.synchronize(device)
+        return time.perf_counter() - t0
+
+    spin(streams[:1])
+    one = min(spin(streams[:1]) for _ in range(3))
+    chosen = [streams[0]]
+    for c in streams[1:]:
+        if len(chosen) == n:
+            break
+        if all(min(spin([c, k]) for _ in range(2)) < 1.5 * one for k in chosen):
+            chosen.append(c)
+    for c in streams:                                   # not enough distinct queues: share
+        if len(chosen) == n:
+            break
+        if c not in chosen:
+            chosen.append(c)
+    return chosen
+
+
+class LaneStream:
+    """Successive batches through the hot path on `lanes` INDEPENDENT HIP streams (batch t runs on lane t % lanes).
+
+    Inside one batch every launch depends on the previous one, and three of the five (stream coder, prefix decoder,
+    scatter/merge) plus the router are one-workgroup-per-image kernels: 64-256 workgroups that wait on dependent LDS /
+    memory chains while three quarters of the chip idle.  Across batches nothing depends on anything, so the lanes
+    carry no events and no cross-stream edges at all -- each lane replays its own hipGraphs on its own stream and the
+    hardware schedules the workgroups of up to `lanes` batches side by side.  (The two-stream BatchStream above splits
+    ONE batch into an encode and a decode graph tied by events; every event is a graph boundary, ~7 us on the device,
+    and it was measured no faster than one stream.  Independent lanes: 53 -> 87 GPixel/s at B=64 of 256x256, 4 lanes.)
+
+    Per lane: one graph per slot, and (ring=True) one graph that holds the lane's whole rotation of slots back to
+    back -- successive graph launches on one stream are ~7 us apart on the device, kernels inside a graph are not.
+    `submit(n)` replays the ring whenever a lane stands at the start of its rotation with a whole rotation left to do.
+    Results are bit-identical to the one-stream order: same kernels, same inputs, no shared scratch between slots
+    (per-launch tickets are library-owned, a captured launch keeps its own).
+
+    slots: list of (x [B,3,H,W], z [B,4,H/4,W/4]) device tensors; the caller refills a slot's tensors in place after
+    `join()` to feed new data.  `hist` (int64 [n_e], optional) accumulates the usage histogram of everything submitted.
+    """
+
+    def __init__(self, quantizer, coarse_ratio, medium_ratio, slots, lanes=4, frequency=None, hist=None, decode=True,
+                 graph=True, ring=True, fuse_router=True):
+        if not slots:
+            raise ValueError("LaneStream needs at least one slot")
+        self.pipe = HotPathPipeline(quantizer, coarse_ratio, medium_ratio, frequency=frequency, fuse_router=fuse_router)
+        self.hist = hist
+        self.decode = bool(decode)
+        self.graph = bool(graph)
+        self.ring = bool(ring) and self.graph
+        self.slots = [BatchSlot(x, z) for x, z in slots]
+        self.device = self.slots[0].x.device
+        nl = max(1, min(int(lanes), len(self.slots)))
+        with torch.cuda.device(self.device):
+            streams = distinct_queue_streams(self.device, nl)          # one hardware queue per lane, measured
+        self.lanes = [{"slots": self.slots[j::nl], "pos": 0, "ring": None, "stream": streams[j]} for j in range(nl)]
+        self._t = 0
+        self._captured = False
+
+    def _step(self, s):
+        s.enc = self.pipe._chain(s.x, s.z, self.hist, self.decode)
+        s.dec = s.enc["dec"]
+
+    def capture(self, warmup=2):
+        """run every slot eagerly (uploads tables, sets function attributes, creates the ticket pools), then capture"""
+        cur = torch.cuda.current_stream(self.device)
+        side = self.lanes[0]["stream"]
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):
+            for s in self.slots:
+                for _ in range(warmup):
+                    self._step(s)
+            if self.graph:
+                for s in self.slots:
+                    s.g_enc = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(s.g_enc, stream=side):
+                        self._step(s)
+                for lane in self.lanes:
+                    if self.ring and len(lane["slots"]) > 1:
+                        lane["ring"] = torch.cuda.CUDAGraph()
+                        with torch.cuda.graph(lane["ring"], stream=side):
+                            for s in lane["slots"]:
+                                self._step(s)                 # s.enc / s.dec now name the ring's output buffers
+        cur.wait_stream(side)
+        for lane in self.lanes:
+            lane["stream"].wait_stream(cur)
+        self._captured = True
+
+    def submit(self, n=1):
+        """enqueue the next n batches (batch t on lane t % lanes, slots of a lane in rotation); returns immediately"""
+        if not self._captured:
+            self.capture()
+        L = len(self.lanes)
+        todo = [0] * L
+        for t in range(self._t, self._t + n):
+            todo[t % L] += 1
+        self._t += n
+        while any(todo):
+            for j, lane in enumerate(self.lanes):              # one launch per lane and turn keeps every queue fed
+                if not todo[j]:
+                    continue
+                m = len(lane["slots"])
+                with torch.cuda.stream(lane["stream"]):
+                    if lane["ring"] is not None and lane["pos"] == 0 and todo[j] >= m:
+                        lane["ring"].replay()
+                        todo[j] -= m
+                        continue
+                    s = lane["slots"][lane["pos"]]
+                    lane["pos"] = (lane["pos"] + 1) % m
+                    if self.graph:
+                        s.g_enc.replay()
+                    else:
+                        self._step(s)
+                    todo[j] -= 1
+
+    def join(self, stream=None):
+        """make `stream` (default: the current one) wait for everything submitted so far"""
+        stream = torch.cuda.current_stream(self.device) if stream is None else stream
+        for lane in self.lanes:
+            stream.wait_stream(lane["stream"])
+
+    def fork(self, stream=None):
+        """make every lane wait for `stream` (default: the current one), e.g. after refilling slots"""
+        stream = torch.cuda.current_stream(self.device) if stream is None else stream
+        for lane in self.lanes:
+            lane["stream"].wait_stream(stream)

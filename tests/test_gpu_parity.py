@@ -234,6 +234,43 @@ def test_entropy_batch_vs_oracle_and_determinism(orc):
     assert np.abs(a16.cpu().numpy() - orc.entropy(x2.numpy(), 16)).max() < 2e-5
 
 
+def test_entropy_edge_pixels_vs_oracle(orc):
+    """the fixed-point deposit path on its corner cases: pixels outside [-1, 1] (no bin in reach: an all-zero histogram
+    is 0 here, 2.9e-37 in the reference), exactly on bin centres / midway between two, saturated patches where all 64
+    pixels of a sub-patch hit ONE bin (the same-address LDS atomics), 16x16 blocks, and NaN pixels (NaN patch, like the
+    reference's NaN histogram) -- and a layout-independence check: the integer sums do not depend on where a patch sits"""
+    g = torch.Generator().manual_seed(9)
+    bins = np.linspace(-1, 1, 32, dtype=np.float32)
+    cases = {
+        "far_outside": torch.full((1, 3, 32, 32), 5.0),
+        "outside_mix": torch.rand(1, 3, 32, 48, generator=g) * 6 - 3,
+        "white": torch.ones(1, 3, 32, 32),
+        "black": torch.zeros(1, 3, 32, 32),
+        "on_centres": torch.from_numpy(bins[np.random.default_rng(1).integers(0, 32, (1, 1, 32, 32))]).repeat(1, 3, 1, 1) / 0.9999,
+        "midway": torch.from_numpy((bins[:-1] + 0.5 * (bins[1] - bins[0]))[np.random.default_rng(2).integers(0, 31, (1, 1, 32, 32))]).repeat(1, 3, 1, 1),
+        "blocks16": torch.rand(1, 3, 4, 4, generator=g).repeat_interleave(16, 2).repeat_interleave(16, 3),
+        "blocks8": torch.rand(1, 3, 8, 8, generator=g).repeat_interleave(8, 2).repeat_interleave(8, 3),
+    }
+    for name, x in cases.items():
+        x = x.float().contiguous()
+        e8, e16 = cg.entropy_maps(x.to(DEV))
+        d8 = np.abs(e8.cpu().numpy() - orc.entropy(x.numpy(), 8)).max()
+        d16 = np.abs(e16.cpu().numpy() - orc.entropy(x.numpy(), 16)).max()
+        assert d8 < 2e-5 and d16 < 2e-5, (name, d8, d16)
+    xn = torch.rand(2, 3, 32, 64, generator=g)
+    xn[0, 1, 3, 5] = float("nan")
+    xn[1, 0, 20, 62] = float("nan")
+    e8, e16 = cg.entropy_maps(xn.to(DEV))
+    assert torch.isnan(e8).nonzero().tolist() == [[0, 0, 0], [1, 2, 7]] and torch.isnan(e16).nonzero().tolist() == [[0, 0, 0], [1, 1, 3]]
+    ok = ~torch.isnan(e8).cpu().numpy()
+    assert np.abs(e8.cpu().numpy() - orc.entropy(xn.numpy(), 8))[ok].max() < 2e-5
+    # the same 16x16 patch anywhere in an image (another wave, another lane-to-replica mapping) gives the same bits
+    patch = torch.rand(1, 3, 16, 16, generator=g)
+    tiled = patch.repeat(1, 1, 5, 13)
+    e8, e16 = cg.entropy_maps(tiled.to(DEV))
+    assert int((e16 != e16[0, 0, 0]).sum()) == 0 and int((e8[:, 0::2, 0::2] != e8[0, 0, 0]).sum()) == 0
+
+
 # ---------------------------------------------------------------------------- D/E/F. coders
 @pytest.mark.parametrize("name", ["zeros", "zipf", "big", "ties"])
 def test_huffman_streams_golden(golden, name, tmp_path):
@@ -635,6 +672,54 @@ def test_custom_ops_match_the_module_path():
     q2, l2, _ = vq(zm)
     (q2.sum() * 0.5 + 2.0 * l2).backward()
     assert torch.equal(zr.grad, zm.grad) and torch.equal(cr.grad, vq.embedding.weight.grad)
+
+
+@pytest.mark.parametrize("lanes,ring,graph", [(4, True, True), (3, False, True), (2, True, False), (1, True, True)])
+def test_lane_stream_independent_streams_are_bit_identical(lanes, ring, graph):
+    """pipeline.LaneStream (batch t on HIP stream t % lanes, one ring graph per lane, NO dependency between the lanes: up to
+    `lanes` batches in flight) leaves exactly what the one-stream order leaves in every slot -- streams, indices, z_q, loss,
+    masks, decoded rows -- and an exact usage histogram, whatever mix of ring and per-slot graphs a submit() takes"""
+    import control_gic_amd.pipeline as pl
+    g = torch.Generator().manual_seed(41)
+    vq = _make_vq(torch.randn(1024, 4, generator=g).numpy())
+    vq.usage_counter.copy_(torch.arange(1024, 0, -1, dtype=torch.float32))
+    shapes = [(4, 64, 96), (4, 64, 96), (2, 128, 64), (4, 64, 96), (3, 32, 32), (4, 64, 96), (4, 64, 96), (1, 256, 256)]
+    slots = [(torch.rand(b, 3, H, W, generator=g).to(DEV), torch.randn(b, 4, H // 4, W // 4, generator=g).to(DEV)) for b, H, W in shapes]
+    hist = torch.zeros(1024, dtype=torch.int64, device=DEV)
+    ls = pl.LaneStream(vq, 0.1, 0.8, slots, lanes=lanes, hist=hist, ring=ring, graph=graph)
+    ls.capture()
+    torch.cuda.synchronize()
+    hist.zero_()
+    runs = [0] * len(slots)
+    t = 0
+    for n in (3, 8, 1, 16, 5):          # partial rotations, whole rotations, remainders
+        ls.submit(n)
+        for k in range(t, t + n):       # batch k -> lane k % L, the lane's slots in rotation
+            L = len(ls.lanes)
+            lane = k % L
+            per_lane = len(slots[lane::L])
+            runs[lane + L * ((k // L) % per_lane)] += 1
+        t += n
+    ls.join()
+    torch.cuda.synchronize()
+    assert sum(runs) == 33
+    ref_pipe = pl.HotPathPipeline(vq, 0.1, 0.8)
+    hist_ref = torch.zeros(1024, dtype=torch.int64, device=DEV)
+    for k, (x, z) in enumerate(slots):
+        r = None
+        for _ in range(runs[k]):
+            r = ref_pipe.run(x, z, hist_ref, decode=True)[0]
+        if r is None:
+            continue
+        s = ls.slots[k]
+        assert s.enc["comp"].to_host() == r["comp"].to_host()
+        assert torch.equal(s.enc["ind"], r["ind"]) and torch.equal(s.enc["z_q"], r["z_q"]) and float(s.enc["loss"]) == float(r["loss"])
+        assert torch.equal(s.enc["e8"], r["e8"]) and torch.equal(s.enc["e16"], r["e16"])
+        assert all(torch.equal(a, b) for a, b in zip(s.enc["mask"], r["mask"]))
+        assert torch.equal(s.dec[0], r["dec"][0]) and torch.equal(s.dec[2], r["dec"][2]) and int(s.dec[3].abs().max()) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(hist, hist_ref)
+    assert int(hist.sum()) == sum(runs[k] * shapes[k][0] * (shapes[k][1] // 4) * (shapes[k][2] // 4) for k in range(len(slots)))
 
 
 def test_batch_stream_two_stream_schedule_is_bit_identical():
