@@ -580,7 +580,7 @@ def run_rank(a, rank, world, local):
                        "inputs": f"{n_slots} distinct resident batches in rotation ({n_slots * B * H * W * 13 / 2**20:.0f} MiB > 256 MiB Infinity Cache)",
                        "sharding": "images round-robin over ranks; one RCCL all-reduce of the int64[1024] histogram per run"},
         }
-        if not stub:
+        if not stub and not a.no_report:
             res.update(report(a, dev, world, stream, slots_np, vq, codec, ratio))
         print(json.dumps(res), flush=True)
     if dist is not None:
@@ -699,6 +699,7 @@ def parse_args(argv=None):
     ap.add_argument("--no-ring", action="store_true", help="one hipGraph per batch instead of one per rotation of batches (sequential schedule)")
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying hipGraphs (sequential schedule)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-report", action="store_true", help="only the timed loop and the headline fields (for kernel traces: the last K chains of the trace are the timed steps)")
     ap.add_argument("--no-extra", action="store_true", help="skip the extra data points (mask mismatch, ratio sweep, DIV2K, B=1)")
     ap.add_argument("--stub", action="store_true", help=argparse.SUPPRESS)      # CPU test of the launcher only (gloo, no kernels)
     return ap.parse_args(argv)
