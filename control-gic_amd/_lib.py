@@ -36,6 +36,7 @@ _cv = C.POINTER(Conv1x1)
 PROTOTYPES = {
     "cgic_last_error": (C.c_char_p, []),
     "cgic_abi_version": (_int, []),
+    "cgic_set_decode_mode": (_int, [_int]),
     "cgic_device_count": (_int, []),
     "cgic_vq_workspace_bytes": (_sz, [_i64]),
     "cgic_conv1x1_rows_f32": (_int, [_vp, _i64, _cv, _vp, _vp]),

@@ -22,6 +22,31 @@ def mode_streams(mode):
     return tuple(bool(m >> i & 1) for i in range(_lib.NUM_STREAMS))
 
 
+_DECODE_MODES = {"auto": 0, "latency": 1, "throughput": 2}
+
+
+class decoder_mode:
+    """`with decoder_mode("throughput"):` -- which prefix decoder `GrainCodec.decompress` launches (or captures) inside the
+    block: "latency" = the split-stream kernels (shortest time for one batch on an idle GPU), "throughput" = the
+    self-synchronising one-workgroup-per-image kernel (small footprint: for several batches in flight, pipeline.LaneStream),
+    "auto" = the library default (latency).  Results are identical.  Process-wide (cgic_set_decode_mode); the previous mode
+    is restored on exit."""
+
+    def __init__(self, mode):
+        if mode not in _DECODE_MODES:
+            raise ValueError(f"decoder mode {mode!r}: expected one of {sorted(_DECODE_MODES)}")
+        self.mode = _DECODE_MODES[mode]
+        self.prev = None
+
+    def __enter__(self):
+        self.prev = _lib.call("cgic_set_decode_mode", self.mode)
+        return self
+
+    def __exit__(self, *exc):
+        _lib.call("cgic_set_decode_mode", self.prev)
+        return False
+
+
 class CompressedBatch:
     """streams of B images on the device: data [B, 5, slot] uint8, nbytes [B, 5] int32
     (-1 = not written in this mode, 0 = empty file)"""

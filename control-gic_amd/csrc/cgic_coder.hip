@@ -28,6 +28,8 @@
 // checked against it through the oracle + tests/golden/{coders,compress_cfg1}.npz.
 #include "cgic_common.h"
 
+#include <atomic>
+
 // VGPR caps of the per-image kernels (registers per lane).  What matters is not their own occupancy but what they
 // leave to the kernels of OTHER batches in flight on the same CU (bench.py --lanes): a 512-thread VQ workgroup takes
 // 2 x 152 of a SIMD's 512 registers per lane.
@@ -1713,7 +1715,16 @@ __global__ __launch_bounds__(kDecThreads) void decode_image_kernel(DecodeArgs a,
     {
         int prev = 0;
         for (int g = g0; g < g1; ++g) {
-            const int e = is_first(g) || g == g0 ? 0 : prev;        // guess 0; inside the lane's own run the predecessor is known
+            // the guess: the smallest offset in the residue class the code lengths allow (0 when their gcd is 1); inside the
+            // lane's own run the predecessor is known
+            int e = prev;
+            if (is_first(g)) e = 0;
+            else if (g == g0) {
+                const int sg = (g >= L.c[1]) + (g >= L.c[2]);
+                const int chg = g - sel3(sg, L.c[0], L.c[1], L.c[2]);
+                const int m = (64 * chg) % a.tab.len_gcd;
+                e = m ? a.tab.len_gcd - m : 0;
+            }
             int n;
             prev = ss_walk<false>(a.tab, lut, stage, L, g, e, &n, nop);
             ent[g] = (uint8_t)e; ext[g] = (uint8_t)prev; cnt[g] = (uint8_t)n;
@@ -2330,6 +2341,14 @@ extern "C" int cgic_decode_stream(const cgic_table *t, const uint8_t *in, int64_
 
 static const size_t kLdsBudget = 150 * 1024;
 
+static std::atomic<int> g_decode_mode{CGIC_DECODE_AUTO};
+extern "C" int cgic_set_decode_mode(int mode)
+{
+    CGIC_REQUIRE(mode == CGIC_DECODE_AUTO || mode == CGIC_DECODE_LATENCY || mode == CGIC_DECODE_THROUGHPUT, CGIC_ERR_INVALID,
+                 "set_decode_mode: mode %d", mode);
+    return g_decode_mode.exchange(mode);
+}
+
 extern "C" size_t cgic_decompress_workspace_bytes(int64_t B, int64_t h, int64_t w)
 {
     if (B <= 0 || h <= 0 || w <= 0) return 0;
@@ -2385,7 +2404,7 @@ extern "C" int cgic_decompress_streams(const cgic_table *t, const uint8_t *in, i
     // the three grids can hold x the longest code.  (Longer inputs are an overflow on any path.)
     bool ss = false;
 #ifndef CGIC_DEC_NO_SS
-    if (d.tab.max_len <= 64) {
+    if (d.tab.max_len <= 64 && g_decode_mode.load() == CGIC_DECODE_THROUGHPUT) {
         const size_t bits_cap = per * (size_t)d.tab.max_len + 3 * 64;
         const size_t stage_cap = align16(bits_cap / 8 + 3 * 48), chunk_cap = align16(bits_cap / 64 + 8);
         const size_t lds_ss = sizeof(uint32_t) * ((size_t)1 << d.tab.lut_bits) + stage_cap + 3 * chunk_cap;

@@ -53,6 +53,9 @@ struct TableDev {
     int lut_bits;
     int n_nodes;      // decode trie nodes (child has 2 * n_nodes entries)
     int dbl_rounds;   // pointer-doubling rounds that cover a 64-bit chunk: ceil(log2(ceil(64 / min_len)))
+    int len_gcd;      // gcd of all code lengths: every codeword boundary of a stream is a multiple of it (a table of equal
+                      // lengths never re-synchronises from a wrong offset: the self-synchronising decoder guesses inside the
+                      // right residue class)
 };
 
 // `n` consecutive self-resetting ticket words (zero on entry; the kernel that uses one must leave it zero),

@@ -256,6 +256,13 @@ int table_device_view(const cgic_table *ct, TableDev *out)
     int r = 0;
     while ((1 << r) < hops) ++r;
     out->dbl_rounds = r;
+    int g = 0;                                             // gcd of the code lengths (see TableDev::len_gcd)
+    for (int v : t->len) {
+        int a = v, b = g;
+        while (b) { const int c = a % b; a = b; b = c; }
+        if (v > 0) g = a;
+    }
+    out->len_gcd = g < 1 || g > 64 ? 1 : g;
     return CGIC_OK;
 }
 

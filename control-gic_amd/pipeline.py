@@ -10,7 +10,7 @@ only, so a step can be captured in a hipGraph and replayed.
 """
 import torch
 
-from .codec import GrainCodec
+from .codec import GrainCodec, decoder_mode
 from .entropy import entropy_maps
 from .quantize import _vq_forward, vq_forward_route
 from .router import TripleGrainFixedEntropyRouter
@@ -276,7 +276,7 @@ class LaneStream:
     """
 
     def __init__(self, quantizer, coarse_ratio, medium_ratio, slots, lanes=4, frequency=None, hist=None, decode=True,
-                 graph=True, ring=True, fuse_router=True):
+                 graph=True, ring=True, fuse_router=True, decoder=None):
         if not slots:
             raise ValueError("LaneStream needs at least one slot")
         self.pipe = HotPathPipeline(quantizer, coarse_ratio, medium_ratio, frequency=frequency, fuse_router=fuse_router)
@@ -287,6 +287,8 @@ class LaneStream:
         self.slots = [BatchSlot(x, z) for x, z in slots]
         self.device = self.slots[0].x.device
         nl = max(1, min(int(lanes), len(self.slots)))
+        # several batches in flight: the small-footprint decoder; one at a time: the low-latency one (codec.decoder_mode)
+        self.decoder = decoder if decoder is not None else ("throughput" if nl > 1 else "latency")
         with torch.cuda.device(self.device):
             streams = distinct_queue_streams(self.device, nl)          # one hardware queue per lane, measured
         self.lanes = [{"slots": self.slots[j::nl], "pos": 0, "ring": None, "stream": streams[j]} for j in range(nl)]
@@ -294,7 +296,8 @@ class LaneStream:
         self._captured = False
 
     def _step(self, s):
-        s.enc = self.pipe._chain(s.x, s.z, self.hist, self.decode)
+        with decoder_mode(self.decoder):
+            s.enc = self.pipe._chain(s.x, s.z, self.hist, self.decode)
         s.dec = s.enc["dec"]
 
     def capture(self, warmup=2):

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define CGIC_ABI_VERSION 2
+#define CGIC_ABI_VERSION 3
 
 #define CGIC_OK 0
 #define CGIC_ERR_INVALID (-1)     /* bad argument (shape, ratio, NULL pointer ...) */
@@ -260,6 +260,20 @@ int cgic_compress_streams(const cgic_table *t, const int64_t *ind, const int32_t
                           int64_t w, int mode, uint8_t *out, int64_t slot, int32_t *nbytes,
                           int64_t *hist, void *workspace, cgic_stream_t stream);
 size_t cgic_decompress_workspace_bytes(int64_t B, int64_t h, int64_t w);
+/* Which prefix decoder cgic_decompress_streams launches (same results either way; process-wide, read at launch / capture):
+ *   CGIC_DECODE_LATENCY     the split-stream decoders: every 64-bit chunk's exit offset for all 64 entry offsets, composed
+ *                           across workgroups -- 1-24 workgroups of 1024 threads and 132 KB of LDS per image; shortest time for
+ *                           ONE batch on an otherwise idle GPU (B=64 of 256x256: 15 us)
+ *   CGIC_DECODE_THROUGHPUT  the self-synchronising decoder: one workgroup per image guesses entry offsets and re-walks until
+ *                           they agree -- 256 threads and 41 KB of LDS per 256x256 image, 25 us alone, but it leaves the GPU
+ *                           to the kernels of other batches in flight (pipeline.LaneStream: 86 -> 101 GPixel/s)
+ *   CGIC_DECODE_AUTO        (default) = CGIC_DECODE_LATENCY
+ * Tables with codes longer than 64 bits and grids whose worst case exceeds the LDS budget always take the split-stream
+ * / serial paths.  Returns the previous mode, or CGIC_ERR_INVALID. */
+#define CGIC_DECODE_AUTO 0
+#define CGIC_DECODE_LATENCY 1
+#define CGIC_DECODE_THROUGHPUT 2
+int cgic_set_decode_mode(int mode);
 int cgic_decompress_streams(const cgic_table *t, const uint8_t *in, int64_t slot, const int32_t *nbytes,
                             int64_t B, int64_t h, int64_t w, int mode, int64_t *ind_out,
                             int32_t *mask_c_out, int32_t *mask_m_out, int32_t *mask_f_out,

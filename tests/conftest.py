@@ -24,6 +24,32 @@ def pytest_collection_modifyitems(config, items):
             it.add_marker(skip)
 
 
+# tests of cgic_decompress_streams run once per prefix decoder (cgic_set_decode_mode): the split-stream kernels ("latency")
+# and the self-synchronising per-image kernel ("throughput") must both match the oracle / the reference's files
+BOTH_DECODERS = {
+    "test_compress_config1_bit_identical_bins", "test_compress_batch_vs_oracle_and_roundtrip",
+    "test_decompress_flags_corrupt_streams", "test_fused_post_quant_conv_is_a_second_gather",
+    "test_codec_random_sweep_time_boxed", "test_split_decode_tiny_and_huge_streams_round_trip",
+    "test_tiled_compress_matches_reference_files", "test_decoders_agree_on_adversarial_streams",
+}
+
+
+def pytest_generate_tests(metafunc):
+    if metafunc.function.__name__ in BOTH_DECODERS:
+        metafunc.parametrize("decoder_under_test", ["latency", "throughput"], indirect=True)
+
+
+@pytest.fixture(autouse=True)
+def decoder_under_test(request):
+    mode = getattr(request, "param", None)
+    if mode is None:
+        yield None
+        return
+    import control_gic_amd as cg
+    with cg.decoder_mode(mode):
+        yield mode
+
+
 def load_golden(name):
     return dict(np.load(os.path.join(GOLDEN, name + ".npz")))
 

@@ -402,6 +402,44 @@ def test_compress_batch_vs_oracle_and_roundtrip(orc, golden, B, h, w):
         assert np.array_equal(oind, exp[b0])
 
 
+def test_decoders_agree_on_adversarial_streams(orc, golden):
+    """Streams that re-synchronise slowly or never: a table of EQUAL code lengths (uniform counters: every code is 10 bits, a
+    wrong entry offset stays wrong for ever -- the self-synchronising decoder has to guess inside the residue class of the
+    gcd of the lengths), periodic streams of one long / one short codeword, two alternating symbols, and the ordinary
+    Zipf table with all-fine grids (the longest streams).  Decoded indices == the indices that were encoded, both decoders,
+    and the bytes == the oracle's."""
+    gc = golden("coders")
+    rng = np.random.default_rng(77)
+    cbk = _t(rng.standard_normal((1024, 4)).astype(np.float32))
+    zipf = gc["zipf_freq"]
+    order = orc.param_dict_order(1024)          # the iteration order of the reference's ParameterDict (ties follow it)
+    tables = {"uniform": np.full(1024, 7.0), "zipf": zipf.astype(np.float64)}
+    B, h, w = 3, 64, 64
+    for tname, freq in tables.items():
+        codec = cg.GrainCodec(_freq_mapping(freq, order), cbk)
+        htab = orc.HuffmanTable(freq)
+        long_sym = int(np.argmin(freq)) if tname == "zipf" else 5
+        short_sym = int(np.argmax(freq)) if tname == "zipf" else 900
+        grids = [np.full((h, w), long_sym), np.full((h, w), short_sym),
+                 np.where((np.arange(h * w).reshape(h, w) % 2) == 0, long_sym, short_sym)]
+        ind = np.stack(grids).astype(np.int64)
+        for c, m in ((0.0, 0.0), (0.1, 0.8), (0.0, 1.0)):
+            e16 = (rng.random((B, h // 4, w // 4)) * 2.6).astype(np.float32)
+            e8 = (rng.random((B, h // 2, w // 2)) * 2.6).astype(np.float32)
+            mask, _, _, mode = cg.TripleGrainFixedEntropyRouter(c, m, per_image=True)(_t(e16), _t(e8))
+            comp = codec.compress(_t(ind), mask, mode)
+            host = comp.to_host()
+            mks = [t.cpu().numpy() for t in mask]
+            for b in range(B):
+                assert host[b] == orc.compress_image(ind[b], mks[0][b, 0], mks[1][b, 0], mks[2][b, 0], mode, htab), (tname, mode, b)
+            dind, dmask, zq, status = codec.decompress(comp)
+            assert int(status.abs().max()) == 0
+            exp = np.where(mks[2][:, 0] == 1, ind, 0)
+            exp = exp + np.repeat(np.repeat(np.where(mks[1][:, 0] == 1, ind[:, ::2, ::2], 0), 2, 1), 2, 2)
+            exp = exp + np.repeat(np.repeat(np.where(mks[0][:, 0] == 1, ind[:, ::4, ::4], 0), 4, 1), 4, 2)
+            assert np.array_equal(dind.cpu().numpy(), exp), (tname, mode)
+
+
 def test_decompress_flags_corrupt_streams(golden):
     gc = golden("coders")
     rng = np.random.default_rng(1)
