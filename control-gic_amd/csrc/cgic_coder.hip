@@ -1628,11 +1628,6 @@ __device__ __forceinline__ int ss_walk(const TableDev &t, const uint32_t *lut, c
     return pos - 64;
 }
 
-#ifdef CGIC_PHASE_CLOCKS
-#define SS_WALL(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_phase_clk[i] = wall_clock64(); } while (0)
-#else
-#define SS_WALL(i) do {} while (0)
-#endif
 __global__ __launch_bounds__(kDecThreads) void decode_image_kernel(DecodeArgs a, int stage_cap, int chunk_cap)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t sm[];
@@ -1643,7 +1638,7 @@ __global__ __launch_bounds__(kDecThreads) void decode_image_kernel(DecodeArgs a,
     uint8_t *ent = stage + stage_cap, *ext = ent + chunk_cap, *cnt = ext + chunk_cap;
     const int tid = threadIdx.x, T = blockDim.x, lane = lane_id(), wave = tid >> 6, nw = T >> 6;
     const int64_t b = blockIdx.x;
-    CGIC_STAMP3(0); SS_WALL(22);
+    CGIC_STAMP3(0);
     const uint8_t *in0 = a.in + (b * CGIC_NUM_STREAMS) * a.slot;
     int nb[3];
 #pragma unroll
@@ -1694,7 +1689,7 @@ __global__ __launch_bounds__(kDecThreads) void decode_image_kernel(DecodeArgs a,
             else if (!fits) a.dcount[b * 3 + s] = -3;
     }
     if (!fits) return;
-    CGIC_STAMP3(1); SS_WALL(17);
+    CGIC_STAMP3(1);
     // stage the stream bytes (16-byte copies; the tail beyond the stream is never interpreted: every walk checks `rem`)
 #pragma unroll
     for (int s = 0; s < 3; ++s) {
@@ -1706,7 +1701,7 @@ __global__ __launch_bounds__(kDecThreads) void decode_image_kernel(DecodeArgs a,
         for (int i = tid; i < words; i += T) d[i] = i < lim ? g[i] : uint4{0u, 0u, 0u, 0u};
     }
     __syncthreads();
-    CGIC_STAMP3(2); SS_WALL(18);
+    CGIC_STAMP3(2);
     // blocked ownership: lane tid owns chunks [g0, g1)
     const int R = (C + T - 1) / T;
     const int g0 = tid * R < C ? tid * R : C, g1 = g0 + R < C ? g0 + R : C;
@@ -1731,7 +1726,7 @@ __global__ __launch_bounds__(kDecThreads) void decode_image_kernel(DecodeArgs a,
         }
     }
     __syncthreads();
-    CGIC_STAMP3(3); SS_WALL(19);
+    CGIC_STAMP3(3);
     [[maybe_unused]] int dbg_sweeps = 0;
 #ifdef CGIC_PHASE_CLOCKS
     if (blockIdx.x == 0 && tid == 0) { g_phase_clk[23] = C; g_phase_clk[24] = R; int mx = 0; for (int g = 0; g < C; ++g) mx = cnt[g] > mx ? cnt[g] : mx; g_phase_clk[25] = mx; }
@@ -1750,7 +1745,7 @@ __global__ __launch_bounds__(kDecThreads) void decode_image_kernel(DecodeArgs a,
         }
         if (!__syncthreads_or(changed)) break;
     }
-    CGIC_STAMP3(4); SS_WALL(20);
+    CGIC_STAMP3(4);
 #ifdef CGIC_PHASE_CLOCKS
     if (blockIdx.x == 0 && tid == 0) g_phase_clk[9] = dbg_sweeps;
 #endif
@@ -1783,7 +1778,7 @@ __global__ __launch_bounds__(kDecThreads) void decode_image_kernel(DecodeArgs a,
         }
     }
     __syncthreads();
-    CGIC_STAMP3(5); SS_WALL(21);
+    CGIC_STAMP3(5);
     uint16_t *dst = a.dsym + b * (n_c + n_m + n_f);
     for (int g = g0; g < g1; ++g) {
         const int s = (g >= L.c[1]) + (g >= L.c[2]);
@@ -1795,7 +1790,7 @@ __global__ __launch_bounds__(kDecThreads) void decode_image_kernel(DecodeArgs a,
                       [&](int, int k, int sym) { if (at + k < cap_s) dst_s[k] = (uint16_t)sym; });
         run += n;
     }
-    CGIC_STAMP3(6); SS_WALL(22);
+    CGIC_STAMP3(6);
     if (tid < 3 && sel3(tid, nb[0], nb[1], nb[2]) > 0) {
         const int n = s_base[tid + 1] - s_base[tid];
         a.dcount[b * 3 + tid] = n > sel3(tid, cap[0], cap[1], cap[2]) ? -3 : n;

@@ -22,6 +22,6 @@ if hasattr(l, "cgic_debug_phase_clocks"):
     names = ["header + LUT issue", "stage + barrier", "first walk", "sweeps", "scan", "final walk + stores"]
     for k, n in enumerate(names):
         print(f"   {n:22s} +{(c[k+1]-c[k])/2.29e3:6.2f} us")
-    print("   wall clock (100 MHz): " + " ".join(f"{(c[17+k]-c[16+k])/100:.2f}" for k in range(6)) + f" us; chunks {c[23]} R {c[24]} max symbols in a chunk {c[25]}")
+    print(f"   chunks {c[23]} R {c[24]} max symbols in a chunk {c[25]}")
     print(f"   total {(c[6]-c[0])/2.29e3:6.2f} us; sweeps {c[9]}; nbytes image 0: {comp.nbytes[0].tolist()}")
 print("decompress (decode + merge) graph-timed: best %.2f mean %.2f us" % graph_time(lambda: hp.codec.decompress(comp)))
