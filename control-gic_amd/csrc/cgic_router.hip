@@ -24,7 +24,7 @@ __global__ __launch_bounds__(kRouterThreads) void router_kernel(RouterArgs a)
 
 int router_prepare(const float *e16, const float *e8, int64_t B, int64_t h16, int64_t w16, double c_ratio,
                    double m_ratio, int per_image, int32_t *mask_c, int32_t *mask_m, int32_t *mask_f, float *gate,
-                   RouterArgs *out, int64_t *nseg_out, size_t *lds_out)
+                   RouterArgs *out, int64_t *nseg_out, size_t *lds_out, size_t lds_budget)
 {
     CGIC_REQUIRE(e16 && e8 && mask_c && mask_m && mask_f, CGIC_ERR_INVALID, "router: NULL tensor");
     CGIC_REQUIRE(B > 0 && h16 > 0 && w16 > 0, CGIC_ERR_INVALID, "router: bad shape");
@@ -46,7 +46,7 @@ int router_prepare(const float *e16, const float *e8, int64_t B, int64_t h16, in
     a.per = per; a.h16 = h16; a.w16 = w16; a.mode = mode;
     a.rank_c = (unsigned int)(k_c != 0 ? k_c - 1 : 0);      // sorted[k-1 if k != 0 else k]
     a.rank_m = (unsigned int)(k_m != 0 ? k_m - 1 : 0);
-    const size_t lds = router_lds_bytes(N16, N8, &a.stage);
+    const size_t lds = router_lds_bytes(N16, N8, &a.stage, lds_budget);
     // large per-image segments: several workgroups per image share the mask writing (every one repeats the selects, which
     // costs nothing while most CUs are idle): up to 8, while the launch stays within ~a quarter of the chip
     a.bands = 1;

@@ -96,7 +96,7 @@ struct RouterArgs {
     int mode;
     unsigned int rank_c;   // 0-based rank of the coarse threshold in the segment
     unsigned int rank_m;
-    int stage;             // 1: the segment's e16/e8 are copied to LDS once (all select passes read LDS)
+    int stage;             // 1: the segment's e16/e8 are copied to LDS once (all select passes read LDS); 2: only e8 (router_lds_bytes)
     int bands;             // workgroups per segment (per-image segments only): every one finds the thresholds, each writes
                            // only its band of rows of the masks (one CU per 768x768 tile spent 10 us writing 200 KB of masks)
 };
@@ -123,10 +123,12 @@ __device__ __forceinline__ void router_body(const RouterArgs &a, int64_t blk, un
     if (a.stage) {
         // one round trip to HBM/L2 instead of one per radix pass (8 passes + 3 elementwise sweeps)
         float *l16 = reinterpret_cast<float *>(gc_bits + ((N16 + 63) >> 6));
-        float *l8 = l16 + N16;
-        for (int64_t i = tid; i < N16; i += NT) l16[i] = e16[i];
+        float *l8 = a.stage == 1 ? l16 + N16 : l16;               // stage 2: e16 stays in global memory
+        if (a.stage == 1) {
+            for (int64_t i = tid; i < N16; i += NT) l16[i] = e16[i];
+            e16 = l16;
+        }
         for (int64_t i = tid; i < N8; i += NT) l8[i] = e8[i];
-        e16 = l16;
         e8 = l8;
         __syncthreads();
     }
@@ -257,11 +259,15 @@ __device__ __forceinline__ void router_body(const RouterArgs &a, int64_t blk, un
 }
 
 
-__host__ __device__ inline size_t router_lds_bytes(int64_t N16, int64_t N8, int *stage)
+// stage 1: e16, e8 and the masked copy of e8 live in LDS; stage 2: only e8 and its masked copy (e16 is read from global memory
+// by the coarse select's four passes); 0: nothing staged.  `budget`: the fused VQ + router launch keeps a router workgroup
+// under half a CU's LDS so that it can share the CU with a VQ workgroup (a 768x768 tile: 86 KB full, 77 KB at stage 2).
+__host__ __device__ inline size_t router_lds_bytes(int64_t N16, int64_t N8, int *stage, size_t budget = 96 * 1024)
 {
     size_t lds = 3072 + 8 * (size_t)((N16 + 63) / 64);
-    const int st = lds + 4 * (size_t)(N16 + 2 * N8) <= 96 * 1024 ? 1 : 0;      // e16, e8 and the masked copy of e8
-    if (st) lds += 4 * (size_t)(N16 + 2 * N8);
+    int st = 0;
+    if (lds + 4 * (size_t)(N16 + 2 * N8) <= budget) { st = 1; lds += 4 * (size_t)(N16 + 2 * N8); }
+    else if (lds + 4 * (size_t)(2 * N8) <= budget) { st = 2; lds += 4 * (size_t)(2 * N8); }
     if (stage) *stage = st;
     return lds;
 }
@@ -269,6 +275,6 @@ __host__ __device__ inline size_t router_lds_bytes(int64_t N16, int64_t N8, int 
 // host-side argument preparation shared by the stand-alone and the VQ-fused launch
 int router_prepare(const float *e16, const float *e8, int64_t B, int64_t h16, int64_t w16, double c_ratio,
                    double m_ratio, int per_image, int32_t *mask_c, int32_t *mask_m, int32_t *mask_f, float *gate,
-                   RouterArgs *out, int64_t *nseg, size_t *lds);
+                   RouterArgs *out, int64_t *nseg, size_t *lds, size_t lds_budget = 96 * 1024);
 
 }  // namespace cgic

@@ -964,7 +964,19 @@ __device__ __forceinline__ void vq_filter_body(const VqArgs &a, unsigned char *s
 #define CGIC_VQF_THREADS 512
 #endif
 constexpr int kVqfThreads = CGIC_VQF_THREADS;      // one workgroup per CU, 2 waves per SIMD.  Alone at B=64 x 64x64 latents 512 / 768 / 1024 threads are within 1 us of each other; with several batches in flight (bench.py --lanes 4) 512 leaves a third of the register file to the other batches' kernels: 86.9 vs 83.4 (768) vs 82.9 (1024) GPixel/s
+// 128 registers per lane (4-10 spilled, 20-44 bytes of scratch) instead of 144-150: two 512-thread workgroups then fit a CU's
+// register file, so a ROUTER workgroup of the fused launch (same launch => same allocation) shares its CU with a VQ workgroup
+// instead of holding the CU to itself for ~12 us: fused launch 26.3 -> 24.1 us at B=64 (the VQ kernel alone: 23.3 -> 23.8 on the
+// same GPU), no uneven split of the VQ shares needed any more.
+#ifndef CGIC_VQF_VGPR_CAP
+#define CGIC_VQF_VGPR_CAP 128
+#endif
+#if CGIC_VQF_VGPR_CAP
+// (amdgpu_num_vgpr counts VGPR + AGPR on gfx950: the attribute carries half the cap)
+#define CGIC_VQF_BOUNDS __launch_bounds__(kVqfThreads, kVqfThreads / 256 > 1 ? kVqfThreads / 256 : 1) __attribute__((amdgpu_num_vgpr(CGIC_VQF_VGPR_CAP / 2)))
+#else
 #define CGIC_VQF_BOUNDS __launch_bounds__(kVqfThreads, kVqfThreads / 256 > 1 ? kVqfThreads / 256 : 1)
+#endif
 
 template <bool ALIGNED, bool CONV>
 __global__ CGIC_VQF_BOUNDS void vq_filter_kernel(VqArgs a)
@@ -978,26 +990,17 @@ __global__ CGIC_VQF_BOUNDS void vq_filter_kernel(VqArgs a)
 // workgroups it only starts when the VQ is over.  The router workgroups therefore come FIRST (`nrouter` of them, one CU
 // each for ~11 us); the VQ workgroups that have to wait for those CUs own fewer groups, the others more.
 template <bool ALIGNED, bool CONV>
-__global__ CGIC_VQF_BOUNDS void vq_filter_router_kernel(VqArgs a, RouterArgs r, unsigned int nrouter)
+__global__ CGIC_VQF_BOUNDS void vq_filter_router_kernel(VqArgs a, RouterArgs r, unsigned int nrouter, unsigned int router_behind)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_f[];
-    if (blockIdx.x < nrouter) {
-        router_body<kVqfThreads>(r, (int64_t)blockIdx.x, smem_f);
+    // router workgroups in front of the VQ workgroups (they hold their CUs first; the VQ shares are uneven) or behind them
+    // (every VQ workgroup gets a CU at once and the router workgroups move in beside them)
+    const unsigned int rb = router_behind ? a.nblk : 0u, vb = router_behind ? 0u : nrouter;
+    if (blockIdx.x - rb < nrouter) {
+        router_body<kVqfThreads>(r, (int64_t)(blockIdx.x - rb), smem_f);
         return;
     }
-    vq_filter_body<kVqfThreads, ALIGNED, CONV>(a, smem_f, blockIdx.x - nrouter);
-}
-
-// the same with the router workgroups BEHIND the VQ workgroups (when every VQ workgroup gets a CU at once anyway)
-template <bool ALIGNED, bool CONV>
-__global__ CGIC_VQF_BOUNDS void vq_filter_router_behind_kernel(VqArgs a, RouterArgs r)
-{
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_f[];
-    if (blockIdx.x >= a.nblk) {
-        router_body<kVqfThreads>(r, (int64_t)(blockIdx.x - a.nblk), smem_f);
-        return;
-    }
-    vq_filter_body<kVqfThreads, ALIGNED, CONV>(a, smem_f, blockIdx.x);
+    vq_filter_body<kVqfThreads, ALIGNED, CONV>(a, smem_f, blockIdx.x - vb);
 }
 
 // Plain-VALU restatement: one latent vector per thread, codebook broadcast from
@@ -1203,7 +1206,18 @@ static int launch_filter(const float *z, int64_t hw, int64_t N, const float *cb,
     int64_t per = (ngroups + nblk - 1) / nblk, g_early = per, g_late = per, n_early = nblk;
     const int64_t late = router ? nblk + router_blocks - cus : 0;
     bool router_first = false;
-    if (late > 0 && late < nblk && !dev_knob("CGIC_VQ_NOSPLIT")) {
+#if CGIC_VQF_VGPR_CAP && CGIC_VQF_VGPR_CAP <= 128
+    // A router workgroup can share its CU with a VQ workgroup.  Behind the VQ workgroups in the grid (every VQ workgroup gets a
+    // CU at once and keeps its even share, the routers move in beside them) the router is free as long as it ends before the VQ
+    // does -- beside an issue-bound VQ workgroup it runs ~1.6x slower than alone: 64 images of 256x256 24.1 us fused against
+    // 23.5 for the VQ alone (in front with even shares: 27.1 -- the VQ workgroups pair up on the free CUs).  Few large tiles
+    // (8 of 768x768: router 21 us alone, VQ 26) keep the older scheme: routers in front, uneven VQ shares.
+    const double t_router = 10.9 + 0.000275 * (double)hw, t_vq = 3.0 + 1.25 * (double)per;
+    const bool coresident = router && 1.6 * t_router <= t_vq;
+#else
+    const bool coresident = false;
+#endif
+    if (!coresident && late > 0 && late < nblk && !dev_knob("CGIC_VQ_NOSPLIT")) {
         // how long a router workgroup holds its CU, in groups of VQ work (~1.05 us each per workgroup): measured 12 us at
         // 64x64 latents, 21 us at 192x192 (with its row bands)
         const int64_t delta = (int64_t)((10.9 + 0.000275 * (double)hw) / 1.05 + 0.5);
@@ -1224,16 +1238,10 @@ static int launch_filter(const float *z, int64_t hw, int64_t N, const float *cb,
         return launch_check("vq_filter_kernel");
     }
     if (router_lds > lds) lds = router_lds;
-    if (router_first) {
-        rc = ensure_dynamic_lds((const void *)vq_filter_router_kernel<ALIGNED, CONV>, lds);
-        if (rc) return rc;
-        hipLaunchKernelGGL((vq_filter_router_kernel<ALIGNED, CONV>), dim3(a.nblk + (unsigned int)router_blocks), dim3(kVqfThreads), lds, s, a, *router,
-                           (unsigned int)router_blocks);
-    } else {
-        rc = ensure_dynamic_lds((const void *)vq_filter_router_behind_kernel<ALIGNED, CONV>, lds);
-        if (rc) return rc;
-        hipLaunchKernelGGL((vq_filter_router_behind_kernel<ALIGNED, CONV>), dim3(a.nblk + (unsigned int)router_blocks), dim3(kVqfThreads), lds, s, a, *router);
-    }
+    rc = ensure_dynamic_lds((const void *)vq_filter_router_kernel<ALIGNED, CONV>, lds);
+    if (rc) return rc;
+    hipLaunchKernelGGL((vq_filter_router_kernel<ALIGNED, CONV>), dim3(a.nblk + (unsigned int)router_blocks), dim3(kVqfThreads), lds, s, a, *router,
+                       (unsigned int)router_blocks, router_first ? 0u : 1u);
     return launch_check("vq_filter_router_kernel");
 }
 
@@ -1310,7 +1318,9 @@ extern "C" int cgic_vq_forward_route_f32(const float *z, int64_t B, int64_t hw, 
     RouterArgs r;
     int64_t nseg;
     size_t rlds;
-    rc = router_prepare(e16, e8, B, h16, w16, coarse_ratio, medium_ratio, per_image, mask_c, mask_m, mask_f, gate, &r, &nseg, &rlds);
+    // (78 KB: a router workgroup of the fused launch shares its CU with a VQ workgroup -- two allocations per 160 KB)
+    rc = router_prepare(e16, e8, B, h16, w16, coarse_ratio, medium_ratio, per_image, mask_c, mask_m, mask_f, gate, &r, &nseg, &rlds,
+                        (size_t)78 * 1024);
     if (rc) return rc;
     hipStream_t s = (hipStream_t)stream;
     VqWs ws;
