@@ -1195,6 +1195,7 @@ static int launch_filter(const float *z, int64_t hw, int64_t N, const float *cb,
     const int64_t ngroups = (N + kVqfGroup - 1) / kVqfGroup;
     // one resident workgroup per CU; its waves take groups from a counter.  Fewer groups than CUs x waves: spread them
     // over the CUs first (a small batch then costs one staging + one group per CU, whatever the waves per workgroup)
+    if (dev_knob("CGIC_VQ_WGS_PER_CU") > 1) cus *= dev_knob("CGIC_VQ_WGS_PER_CU");      // dev: several resident workgroups per CU
     int64_t nblk = ngroups < cus ? ngroups : cus;
     VqArgs a;
     a.z = z; a.hw = hw; a.N = N; a.cb = cb; a.K = K; a.idx_out = idx; a.zq_out = zq;
