@@ -1649,6 +1649,7 @@ __global__ __launch_bounds__(kDecThreads) void decode_image_kernel(DecodeArgs a,
         const uint4 *gl = reinterpret_cast<const uint4 *>(a.tab.lut);
         uint4 *dl = reinterpret_cast<uint4 *>(lut);
         const int n4 = (1 << a.tab.lut_bits) >> 2;
+        if (n4 == 0 && tid < (1 << a.tab.lut_bits)) lut[tid] = a.tab.lut[tid];      // (a table of two symbols: a 2-entry LUT)
         for (int base = 0; base < n4; base += 8 * T) {
             uint4 v[8];
 #pragma unroll

@@ -30,7 +30,7 @@ BOTH_DECODERS = {
     "test_compress_config1_bit_identical_bins", "test_compress_batch_vs_oracle_and_roundtrip",
     "test_decompress_flags_corrupt_streams", "test_fused_post_quant_conv_is_a_second_gather",
     "test_codec_random_sweep_time_boxed", "test_split_decode_tiny_and_huge_streams_round_trip",
-    "test_tiled_compress_matches_reference_files", "test_decoders_agree_on_adversarial_streams",
+    "test_tiled_compress_matches_reference_files", "test_decoders_agree_on_adversarial_streams", "test_small_tables_round_trip",
 }
 
 

@@ -440,6 +440,33 @@ def test_decoders_agree_on_adversarial_streams(orc, golden):
             assert np.array_equal(dind.cpu().numpy(), exp), (tname, mode)
 
 
+@pytest.mark.parametrize("n_sym", [2, 3, 64])
+def test_small_tables_round_trip(orc, n_sym):
+    """code tables of 2 / 3 / 64 symbols (1-bit codes: a 2-entry decode LUT) through both decoders: bytes == oracle, indices back"""
+    rng = np.random.default_rng(n_sym)
+    freq = rng.integers(1, 50, n_sym).astype(np.float64)
+    order = orc.param_dict_order(n_sym)
+    codec = cg.GrainCodec(_freq_mapping(freq, order), _t(rng.standard_normal((n_sym, 4)).astype(np.float32)))
+    htab = orc.HuffmanTable(freq)
+    B, h, w = 3, 32, 48
+    ind = rng.integers(0, n_sym, (B, h, w))
+    for c, m in ((0.1, 0.8), (0.0, 0.0), (0.5, 0.5)):
+        e16 = (rng.random((B, h // 4, w // 4)) * 2.6).astype(np.float32)
+        e8 = (rng.random((B, h // 2, w // 2)) * 2.6).astype(np.float32)
+        mask, _, _, mode = cg.TripleGrainFixedEntropyRouter(c, m, per_image=True)(_t(e16), _t(e8))
+        comp = codec.compress(_t(ind), mask, mode)
+        host = comp.to_host()
+        mks = [t.cpu().numpy() for t in mask]
+        for b in range(B):
+            assert host[b] == orc.compress_image(ind[b], mks[0][b, 0], mks[1][b, 0], mks[2][b, 0], mode, htab), (n_sym, mode, b)
+        dind, _, zq, status = codec.decompress(comp)
+        assert int(status.abs().max()) == 0
+        exp = np.where(mks[2][:, 0] == 1, ind, 0)
+        exp = exp + np.repeat(np.repeat(np.where(mks[1][:, 0] == 1, ind[:, ::2, ::2], 0), 2, 1), 2, 2)
+        exp = exp + np.repeat(np.repeat(np.where(mks[0][:, 0] == 1, ind[:, ::4, ::4], 0), 4, 1), 4, 2)
+        assert np.array_equal(dind.cpu().numpy(), exp), (n_sym, mode)
+
+
 def test_decompress_flags_corrupt_streams(golden):
     gc = golden("coders")
     rng = np.random.default_rng(1)
