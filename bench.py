@@ -374,38 +374,20 @@ def div2k_image(dev, cb, vq, codec, iters=8):
     # four such images in flight: one hipGraph per image (its shape groups one after the other) on four independent HIP streams,
     # the small-footprint decoder -- the tiling driver under pipeline.LaneStream's schedule
     try:
-        import control_gic_amd as cg
-        from control_gic_amd.pipeline import distinct_queue_streams
-        lanes = distinct_queue_streams(dev, 4)
-        graphs, outs = [], []
-        with cg.decoder_mode("throughput"):
-            def once_lane():
-                t = highres.compress_tiled(x, encode, codec)
-                p, st = highres.decompress_tiled(t, codec, check=False)
-                return t, p, st
-            once_lane(); torch.cuda.synchronize()
-            for st_ in lanes:
-                st_.wait_stream(torch.cuda.current_stream())
-                g = torch.cuda.CUDAGraph()
-                with torch.cuda.stream(st_):
-                    with torch.cuda.graph(g, stream=st_):
-                        outs.append(once_lane())
-                graphs.append(g)
-        torch.cuda.synchronize()
+        from control_gic_amd.pipeline import GraphLanes
 
-        def burst(n):
-            for _ in range(n):
-                for g, st_ in zip(graphs, lanes):
-                    with torch.cuda.stream(st_):
-                        g.replay()
-            torch.cuda.synchronize()
-        burst(2)
+        def once_lane():
+            t = highres.compress_tiled(x, encode, codec)
+            p, st = highres.decompress_tiled(t, codec, check=False)
+            return t, p, st
+        gl = GraphLanes(dev, [once_lane] * 4)
+        gl.replay(2); gl.join(); torch.cuda.synchronize()
         t0 = time.perf_counter()
-        burst(2 * iters)
-        dt4 = (time.perf_counter() - t0) / (2 * iters * len(lanes))
-        same4 = all(int(o[2].abs().max()) == 0 and o[0].streams() == tiled.streams() for o in outs)
+        gl.replay(2 * iters); gl.join(); torch.cuda.synchronize()
+        dt4 = (time.perf_counter() - t0) / (2 * iters * 4)
+        same4 = all(int(o[2].abs().max()) == 0 and o[0].streams() == tiled.streams() for o in gl.results)
         res["four_in_flight"] = {"ms_per_image": round(dt4 * 1e3, 4), "MPixels/s": round(H * W / dt4 / 1e6, 1), "streams_equal_eager": bool(same4),
-                                 "note": "four images on four independent HIP streams, one hipGraph per image, throughput decoder"}
+                                 "note": "four images on four independent HIP streams (pipeline.GraphLanes), one hipGraph per image, throughput decoder"}
     except Exception as e:
         res["four_in_flight"] = {"error": str(e)[:200]}
     return res

@@ -363,3 +363,43 @@ class LaneStream:
         stream = torch.cuda.current_stream(self.device) if stream is None else stream
         for lane in self.lanes:
             lane["stream"].wait_stream(stream)
+
+
+class GraphLanes:
+    """Arbitrary captured work on independent hardware queues: `fns` are callables that only enqueue work on the current
+    stream (e.g. `highres.compress_tiled` + `decompress_tiled(check=False)` of one image); each is run once eagerly, captured into
+    a hipGraph on its own stream (one per hardware queue, `distinct_queue_streams`) and `replay(n)` launches every graph n
+    times, lane after lane, with no dependency between the lanes.  `results[k]` is what fns[k] returned during capture (its
+    output tensors live in the graph's memory and are refreshed by every replay).  LaneStream is this plus slot rotation and
+    ring graphs for the fixed five-launch step."""
+
+    def __init__(self, device, fns, decoder="throughput"):
+        self.device = device
+        self.decoder = decoder
+        with torch.cuda.device(device):
+            self.streams = distinct_queue_streams(device, len(fns))
+        self.graphs, self.results = [], []
+        cur = torch.cuda.current_stream(device)
+        with decoder_mode(decoder):
+            for fn in fns:
+                fn()                                        # eager once: tables, function attributes, ticket pools
+            torch.cuda.synchronize(device)
+            for fn, st in zip(fns, self.streams):
+                st.wait_stream(cur)
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.stream(st):
+                    with torch.cuda.graph(g, stream=st):
+                        self.results.append(fn())
+                self.graphs.append(g)
+        torch.cuda.synchronize(device)
+
+    def replay(self, n=1):
+        for _ in range(n):
+            for g, st in zip(self.graphs, self.streams):
+                with torch.cuda.stream(st):
+                    g.replay()
+
+    def join(self, stream=None):
+        stream = torch.cuda.current_stream(self.device) if stream is None else stream
+        for st in self.streams:
+            stream.wait_stream(st)

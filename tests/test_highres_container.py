@@ -332,3 +332,56 @@ def test_tiled_shape_groups_on_parallel_streams_give_the_same_streams():
         assert par.streams() == seq.streams() and par.bpp() == seq.bpp()
         for (i0, m0, z0), (i1, m1, z1) in zip(per_seq, per_par):
             assert torch.equal(i0, i1) and torch.equal(z0, z1) and all(torch.equal(a, b) for a, b in zip(m0, m1))
+
+
+@pytest.mark.gpu
+def test_graph_lanes_run_tiled_images_on_independent_queues():
+    """pipeline.GraphLanes: three different images, each captured as one hipGraph (tiling driver, throughput decoder) on its own
+    hardware queue and replayed side by side, give the streams, indices and masks of the eager sequential driver"""
+    import control_gic_amd as cg
+    from control_gic_amd import highres
+    from control_gic_amd.quantize import vq_forward_route
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(33)
+    cb = torch.from_numpy(rng.standard_normal((1024, 4)).astype(np.float32)).to(dev)
+    vq = cg.VectorQuantizer(1024, 4, beta=0.25).to(dev)
+    with torch.no_grad():
+        vq.embedding.weight.copy_(cb)
+    vq.usage_counter.copy_(torch.from_numpy(rng.integers(1, 1000, 1024).astype(np.float32)))
+    codec = cg.GrainCodec(vq.embedding_counter, vq.embedding.weight.detach())
+    xs = [torch.from_numpy(rng.random((1, 3, H, W), dtype=np.float32)).to(dev) for H, W in ((1000, 1800), (512, 768), (784, 1040))]
+    zs_seq = {}
+
+    def make(x):
+        def fn():
+            t = highres.compress_tiled(x, encode_for(x), codec)
+            p, st = highres.decompress_tiled(t, codec, check=False)
+            return t, p, st
+        return fn
+
+    def encode_for(x):                      # the stand-in latent depends on the tile shape only, so eager and captured runs agree
+        def enc(tiles):
+            T, _, th, tw = tiles.shape
+            key = (T, th, tw)
+            if key not in zs_seq:
+                zs_seq[key] = torch.from_numpy(np.random.default_rng(th + 3 * tw + T).standard_normal((T, 4, th // 4, tw // 4), dtype=np.float32)).to(dev)
+            e8, e16 = cg.entropy_maps(tiles)
+            _, _, ind, mask, _, mode = vq_forward_route(zs_seq[key], vq.embedding.weight, 0.25, True, e16, e8, 0.1, 0.8, per_image=True)
+            return ind, mask, mode
+        return enc
+
+    ref = []
+    for x in xs:
+        t = highres.compress_tiled(x, encode_for(x), codec)
+        p, _ = highres.decompress_tiled(t, codec)
+        ref.append((t.streams(), t.bpp(), p))
+    gl = cg.GraphLanes(dev, [make(x) for x in xs])
+    assert len({id(s) for s in gl.streams}) == 3
+    for _ in range(3):
+        gl.replay(2)
+        gl.join()
+        torch.cuda.synchronize()
+        for (t, p, st), (streams, bpp, pref) in zip(gl.results, ref):
+            assert int(st.abs().max()) == 0 and t.streams() == streams and t.bpp() == bpp
+            for (i0, m0, z0), (i1, m1, z1) in zip(pref, p):
+                assert torch.equal(i0, i1) and torch.equal(z0, z1) and all(torch.equal(a, b) for a, b in zip(m0, m1))
