@@ -669,8 +669,10 @@ def report(a, dev, world, stream, slots_np, vq, codec, ratio):
                 "in a hipGraph, HIP events on the launch stream), priced against the dense fp32 MFMA peak (results are "
                 "bit-identical to the fp32 sequence); the kernel issues fp16 MFMAs with 16 K-slots per 4-dim contraction "
                 f"({2.0 * N * 1024 * 16 / 1e9:.1f} GFLOP per launch = {2.0 * N * 1024 * 16 / t_dom / 2.5e15:.2f} of the 2.5 PFLOP/s fp16 peak) "
-                "and is bound by VALU issue (one half-rate v_min3 per two scores), not by the matrix cores; frac = the fused launch "
-                "(router workgroups hold 64 CUs for ~12 us), vq_alone_frac = the VQ kernel by itself; see DESIGN.md 4.1"}
+                "and is bound by VALU issue (one half-rate v_min3 per two scores), not by the matrix cores; frac = the fused launch ALONE "
+                "(the router workgroups share CUs with VQ workgroups), vq_alone_frac = the VQ kernel by itself; in the timed step the "
+                "launch shares the GPU with the kernels of three other batches, where four streams of it alone sustain 16.0 us per "
+                "launch (DESIGN.md 4.1, 4.3, 4.8)"}
     if world == 1 and (B, H) == (64, 256) and not a.no_extra:
         hp.step()
         res["mask_mismatch"] = mask_mismatch(hp, x, z, cb, ratio)

@@ -65,7 +65,10 @@ __device__ long long g_phase_clk[32];
 __device__ long long g_blk_t[2 * 4096];
 #endif
 
-constexpr int kEncThreads = 1024;         // x kEncItems = 4096 positions per scan round: one round per 256x256 stream
+#ifndef CGIC_ENC_THREADS
+#define CGIC_ENC_THREADS 1024
+#endif
+constexpr int kEncThreads = CGIC_ENC_THREADS;         // x kEncItems = 4096 positions per scan round: one round per 256x256 stream
 constexpr int kEncItems = 4;            // consecutive positions per thread per scan round
 constexpr int kLdsPos = 8192;           // streams up to this many positions keep phase-A results in LDS
 constexpr int kDecLutMax = 1 << kLutBitsMax;        // 13-bit LUT
