@@ -169,6 +169,33 @@ def stage_breakdown(hp):
     return {k: round(v, 2) for k, v in st.items()}
 
 
+def saturated_launch_time(hp, lanes=4, per_graph=20, reps=6):
+    """microseconds per launch of the fused VQ + router kernel when `lanes` independent streams replay graphs of it alone: what the
+    launch costs the GPU with other batches in flight (its launch, ramp and tail hide behind the other streams' launches)"""
+    from control_gic_amd.quantize import vq_forward_route
+    from control_gic_amd.pipeline import GraphLanes
+    e8, e16 = hp.cg.entropy_maps(hp.x)
+    zs = [hp.z] + [hp.z.clone() for _ in range(lanes - 1)]
+
+    def make(z):
+        def fn():
+            out = None
+            for _ in range(per_graph):
+                out = vq_forward_route(z, hp.vq.embedding.weight, 0.25, True, e16, e8, hp.router.coarse_grain_ratio, hp.router.medium_grain_ratio)
+            return out
+        return fn
+    gl = GraphLanes(hp.x.device, [make(z) for z in zs])
+    best = 1e9
+    for _ in range(reps):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        gl.replay(1)
+        gl.join()
+        torch.cuda.synchronize()
+        best = min(best, time.perf_counter() - t0)
+    return best * 1e6 / (per_graph * lanes)
+
+
 def cpu_baseline(x, z, cb, ratio, budget_s=12.0):
     """the oracle (a scalar C port of the reference algorithm) on ONE host core, same workload,
     bounded sample of the batch"""
@@ -673,6 +700,14 @@ def report(a, dev, world, stream, slots_np, vq, codec, ratio):
                 "(the router workgroups share CUs with VQ workgroups), vq_alone_frac = the VQ kernel by itself; in the timed step the "
                 "launch shares the GPU with the kernels of three other batches, where four streams of it alone sustain 16.0 us per "
                 "launch (DESIGN.md 4.1, 4.3, 4.8)"}
+    if not a.no_extra:
+        try:
+            t_sat = saturated_launch_time(hp)
+            res["roofline"]["four_streams"] = {"us_per_launch": round(t_sat, 2), "achieved": round(flops / (t_sat * 1e-6) / 1e12, 2),
+                                                "frac": round(flops / (t_sat * 1e-6) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
+                                                "note": "the same launch replayed by four independent streams at once (wall time / launches)"}
+        except Exception as e:                                   # an extra data point: never fail the bench line
+            res["roofline"]["four_streams"] = {"error": str(e)[:200]}
     if world == 1 and (B, H) == (64, 256) and not a.no_extra:
         hp.step()
         res["mask_mismatch"] = mask_mismatch(hp, x, z, cb, ratio)
