@@ -9,6 +9,7 @@ from oracle import cgic_oracle as orc
 g = np.load(os.path.join(ROOT, "tests", "golden", "coders.npz"))
 rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 0)
 budget = float(sys.argv[2]) if len(sys.argv) > 2 else 60
+cg._lib.call("cgic_set_decode_mode", {"auto": 0, "latency": 1, "throughput": 2}[sys.argv[3] if len(sys.argv) > 3 else "auto"])   # 3rd argument: decoder
 
 
 class _Item:
