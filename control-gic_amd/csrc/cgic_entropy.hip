@@ -8,14 +8,14 @@
 // next patch are requested before the current one is computed.  Waves never synchronise with each other.
 //
 // Per pixel only the bins within +-2 of its own bin can be non-zero in fp32 (exp underflows to exactly 0 beyond
-// 14.42 sigma = 2.24 bin widths, in the reference too) and only +-1 can matter (beyond: < 3e-17 per pixel), so
-// 3 exps per pixel instead of 32.  The histogram of an 8x8 sub-patch is the sum of those kernel values per bin.
+// 14.42 sigma = 2.24 bin widths, in the reference too) and only the two that bracket it matter (every other bin is
+// >= 6.45 sigma away: <= 9e-10 per pixel, < 1e-7 of entropy), so 2 exps per pixel instead of 32.  The histogram of an 8x8 sub-patch is the sum of those kernel values per bin.
 // Round 2 (second half): the values are DEPOSITED, not gathered -- each one is converted to fixed point (quantum
-// 2^-28) and added with a return-less 32-bit LDS atomic into a wave-private table [bin][sub-patch][replica]; integer
+// 2^-26) and added with a return-less 32-bit LDS atomic into a wave-private table [bin][sub-patch][replica]; integer
 // addition is associative, so the result does not depend on the order in which the LDS serves the lanes
 // (deterministic, run to run and across layouts).  Eight replicas per (bin, sub-patch), chosen by the pixel's row,
 // keep same-address collisions at <= 2 lanes per instruction (a smooth patch puts all its pixels into one bin) and a
-// replica's total at <= 8 pixels * 2^28 < 2^32.  Lane = (bin, half-wave) then reads its 8 replicas (two b128
+// replica's total at <= 8 pixels * 2^26 = 2^29.  Lane = (bin, half-wave) then reads its 8 replicas (two b128
 // loads), converts and adds them in a fixed tree.  Before: every value was written into a [bin][pixel] LDS tile and
 // each bin summed all 64 columns (8 b128 reads + 31 adds per lane and sub-patch for 192 non-zero values):
 // ~420 VALU instructions per patch against ~200 now.
@@ -35,9 +35,9 @@ namespace cgic {
 constexpr int kEntThreads = 256;
 constexpr int kEntWaves = kEntThreads / kWave;
 constexpr int kBins = 32;
-constexpr int kWin = 3;            // bins evaluated per pixel: the nearest one and its two neighbours
+constexpr int kWin = 2;            // bins evaluated per pixel: the two that bracket it
 constexpr int kHistStride = 36;    // dwords per bin: 4 sub-patches x 8 replicas + 4 pad (conflict-free b128 rows)
-constexpr float kFixScale = 268435456.f;          // 2^28: a replica collects <= 8 pixels with values <= 1
+constexpr float kFixScale = 67108864.f;           // 2^26: a replica collects <= 8 pixels with values <= 1, four replicas < 2^31
 
 struct BinsArg { float v[kBins]; };   // passed by value in the kernarg segment
 
@@ -93,7 +93,7 @@ __device__ __forceinline__ int cvt_floor_i32(float v)
 __device__ __forceinline__ unsigned int cvt_round_u32(float v)
 {
     int r;
-    asm("v_cvt_rpi_i32_f32 %0, %1" : "=v"(r) : "v"(v));      // floor(v + 0.5); v in [0, 2^28]; NaN -> 0
+    asm("v_cvt_rpi_i32_f32 %0, %1" : "=v"(r) : "v"(v));      // floor(v + 0.5); v in [0, 2^26]; NaN -> 0
     return (unsigned int)r;
 }
 
@@ -148,7 +148,7 @@ __global__ __launch_bounds__(kEntThreads) void entropy_maps_kernel(
     const uint4 zero4 = {0u, 0u, 0u, 0u};
     own0[0] = zero4; own0[1] = zero4; own1[0] = zero4; own1[1] = zero4;
     __syncthreads();                                      // bins[]; the only workgroup-wide barrier
-    const float k0 = -bins[0] * 15.5f - 0.5f;             // (g - bins[0]) * 15.5 - 0.5: floor() = nearest bin - 1
+    const float k0 = -bins[0] * 15.5f;                    // floor((g - bins[0]) * 15.5) = the bin below the pixel
 
 #pragma unroll 1
     for (int64_t patch = p_lo + wave; patch < p_end; patch += kEntWaves) {
@@ -162,10 +162,11 @@ __global__ __launch_bounds__(kEntThreads) void entropy_maps_kernel(
         CGIC_STAMP(17);
 
         unsigned long long nan_lanes = 0;      // lanes that hold a NaN pixel (the reference's histogram turns NaN)
-        // candidate window: nearest bin +-1.  A bin further than 1.5 bin widths holds exp(-0.5 (0.0968/sigma)^2)
-        // <= 3e-17 (sigma <= 0.0111; 4.5e-21 at the reference's 0.01): nonzero in fp32 and summed by the reference,
-        // but worth < 1e-15 of entropy.  All twelve bin centres are fetched before the first deposit (the compiler
-        // does not move LDS reads across the atomics).
+        // candidate window: the two bins that bracket the pixel.  Every other bin is at least one bin width = 6.45 sigma away
+        // and holds <= exp(-0.5 * 6.45^2) = 9e-10 (6.5e-9 at the largest sigma accepted): nonzero in fp32 and summed by the
+        // reference, but worth < 1e-7 of entropy against this op's ~1e-6 transcendental noise (a third bin was evaluated until
+        // the kernel turned out to carry 31 % of the step's VALU instructions: 12 -> 8 values per lane and patch).  All eight
+        // bin centres are fetched before the first deposit (the compiler does not move LDS reads across the atomics).
         int jlo[4];
         float bc[4][kWin];
 #pragma unroll
@@ -196,8 +197,8 @@ __global__ __launch_bounds__(kEntThreads) void entropy_maps_kernel(
             uint4 *own = k ? own1 : own0;
             const uint4 a = own[0], c = own[1];
             own[0] = zero4; own[1] = zero4;    // ready for the next patch
-            s8[k] = (((float)a.x + (float)a.y) + ((float)a.z + (float)a.w)) +
-                    (((float)c.x + (float)c.y) + ((float)c.z + (float)c.w));
+            // four replicas add up as integers (<= 32 pixels * 2^26 < 2^32), the two halves as floats: 6 + 3 instructions
+            s8[k] = (float)((a.x + a.y) + (a.z + a.w)) + (float)((c.x + c.y) + (c.z + c.w));
         }
         __builtin_amdgcn_wave_barrier();
         float s16 = s8[0] + s8[1];
@@ -249,10 +250,10 @@ extern "C" int cgic_entropy_maps_f32(const float *x, int64_t B, int64_t H, int64
     CGIC_REQUIRE(B >= 0 && H > 0 && W > 0 && H % 16 == 0 && W % 16 == 0, CGIC_ERR_INVALID,
                  "entropy: H=%lld W=%lld must be positive multiples of 16", (long long)H, (long long)W);
     CGIC_REQUIRE(B <= 65535 && H / 16 <= 65535, CGIC_ERR_UNSUPPORTED, "entropy: batch/height exceed the grid limits");
-    // The +-1-bin candidate window drops kernel values <= exp(-0.5 (1.5 * (2/31) / sigma)^2): 3e-17 at the bound
-    // below, 4.5e-21 at the reference's sigma
-    CGIC_REQUIRE(sigma > 0.f && sigma <= 0.0111f, CGIC_ERR_UNSUPPORTED,
-                 "entropy: sigma=%g; the 3-bin window assumes the reference's sigma=0.01 (model.py:481)", sigma);
+    // The two-bin window drops kernel values <= exp(-0.5 ((2/31) / sigma)^2): 6.5e-9 at the bound below, 9e-10 at the
+    // reference's sigma
+    CGIC_REQUIRE(sigma > 0.f && sigma <= 0.0105f, CGIC_ERR_UNSUPPORTED,
+                 "entropy: sigma=%g; the 2-bin window assumes the reference's sigma=0.01 (model.py:481)", sigma);
     for (int i = 1; i < kBins; ++i)
         CGIC_REQUIRE(fabsf((bins[i] - bins[i - 1]) - 2.0f / 31.0f) < 1e-5f, CGIC_ERR_UNSUPPORTED,
                      "entropy: bins are not linspace(-1, 1, 32)");
