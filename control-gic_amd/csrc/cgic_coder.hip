@@ -1824,10 +1824,15 @@ struct MergeArgs {
     int64_t band_syms;         // u16 entries reserved for a band's own symbol ranges when stage_sym == 0
 };
 
-__global__ __launch_bounds__(kMergeThreads) CGIC_VGPR_CAP_MERGE void merge_kernel(MergeArgs a)
+// NT threads per workgroup: 512 with >= 4 row bands per image (the shortest launch for one batch on an idle GPU), or 1024 with ONE
+// band per image (throughput mode, grids up to 64x64): every band repeats the staging, the bitsets and the prefixes, so four bands
+// of 512 threads execute 1.10 M VALU instructions per batch of 64 images where one band of 1024 executes less than half --
+// instructions that, with several batches in flight, come out of the same VALU budget as the VQ's.
+template <int NT>
+__global__ __launch_bounds__(NT) CGIC_VGPR_CAP_MERGE void merge_kernel(MergeArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t sm[];
-    __shared__ uint32_t scan_smem[kMergeThreads / kWave + 1];
+    __shared__ uint32_t scan_smem[NT / kWave + 1];
     __shared__ int s_status;
     __shared__ int s_hdr[8];            // nbytes[3], nbytes[4], dcount[0..2]
     const int tid = threadIdx.x;
@@ -1863,17 +1868,17 @@ __global__ __launch_bounds__(kMergeThreads) CGIC_VGPR_CAP_MERGE void merge_kerne
     if (tid == 0) s_status = 0;
     if (tid < 2) s_hdr[tid] = a.nbytes[b * CGIC_NUM_STREAMS + 3 + tid];
     else if (tid < 5) s_hdr[tid] = a.dcount[b * 3 + (tid - 2)];
-    if (send_mc) for (int64_t i = tid; i < wc + 2; i += kMergeThreads) rawc[i] = reinterpret_cast<const uint32_t *>(in_mc)[i];
-    if (send_mm) for (int64_t i = tid; i < wm + 2; i += kMergeThreads) rawm[i] = reinterpret_cast<const uint32_t *>(in_mm)[i];
+    if (send_mc) for (int64_t i = tid; i < wc + 2; i += NT) rawc[i] = reinterpret_cast<const uint32_t *>(in_mc)[i];
+    if (send_mm) for (int64_t i = tid; i < wm + 2; i += NT) rawm[i] = reinterpret_cast<const uint32_t *>(in_mm)[i];
     const uint16_t *gsym = a.dsym + b * nsym;
     if (a.stage_sym) {
         // nsym = 21 * n_c is even; the per-image base is 4-byte aligned when nsym is even
         const uint32_t *g32 = reinterpret_cast<const uint32_t *>(gsym);
         uint32_t *l32 = reinterpret_cast<uint32_t *>(lsym);
-        for (int64_t i = tid; i < (nsym + 1) / 2; i += kMergeThreads) l32[i] = g32[i];
+        for (int64_t i = tid; i < (nsym + 1) / 2; i += NT) l32[i] = g32[i];
     }
     if (a.stage_cb && a.zq)
-        for (int i = tid; i < a.K; i += kMergeThreads) cbk[i] = reinterpret_cast<const float4 *>(a.codebook)[i];
+        for (int i = tid; i < a.K; i += NT) cbk[i] = reinterpret_cast<const float4 *>(a.codebook)[i];
     __syncthreads();
     CGIC_STAMP(11);
 
@@ -1929,7 +1934,7 @@ __global__ __launch_bounds__(kMergeThreads) CGIC_VGPR_CAP_MERGE void merge_kerne
         cnt_c = s_cnt[0];
         cnt_m = s_cnt[1];
     } else {
-        for (int64_t i = tid; i < wc; i += kMergeThreads) {
+        for (int64_t i = tid; i < wc; i += NT) {
             uint32_t v = 0;
             if (send_mc) v = stream_word(rawc, i, n_c);
             else if (mode == 4) {                                                   // ones (:355)
@@ -1940,7 +1945,7 @@ __global__ __launch_bounds__(kMergeThreads) CGIC_VGPR_CAP_MERGE void merge_kerne
             mcb[i] = v;
         }
         __syncthreads();
-        for (int64_t i = tid; i < wm; i += kMergeThreads) {
+        for (int64_t i = tid; i < wm; i += NT) {
             uint32_t v = 0;
             if (send_mm) v = stream_word(rawm, i, n_m);
             else if (mode == 3 || mode == 5) {
@@ -1958,9 +1963,9 @@ __global__ __launch_bounds__(kMergeThreads) CGIC_VGPR_CAP_MERGE void merge_kerne
             mmb[i] = v;
         }
         __syncthreads();
-        if (wc <= kMergeThreads && wm <= kMergeThreads) {
+        if (wc <= NT && wm <= NT) {
             // both prefixes from ONE block scan of (coarse count << 32 | medium count): three barriers instead of six
-            __shared__ unsigned long long scan64[kMergeThreads / kWave + 1];
+            __shared__ unsigned long long scan64[NT / kWave + 1];
             const unsigned long long c = ((unsigned long long)(tid < wc ? __popc(mcb[tid]) : 0) << 32) | (unsigned long long)(tid < wm ? __popc(mmb[tid]) : 0);
             unsigned long long tot;
             const unsigned long long ex = block_exclusive_scan(c, scan64, &tot);
@@ -1971,7 +1976,7 @@ __global__ __launch_bounds__(kMergeThreads) CGIC_VGPR_CAP_MERGE void merge_kerne
             __syncthreads();
         } else {
         uint32_t carry = 0, total;
-        for (int64_t base = 0; base < wc; base += kMergeThreads) {
+        for (int64_t base = 0; base < wc; base += NT) {
             const int64_t i = base + tid;
             const uint32_t c = i < wc ? (uint32_t)__popc(mcb[i]) : 0u;
             const uint32_t ex = block_exclusive_scan(c, scan_smem, &total);
@@ -1980,7 +1985,7 @@ __global__ __launch_bounds__(kMergeThreads) CGIC_VGPR_CAP_MERGE void merge_kerne
         }
         cnt_c = carry;
         carry = 0;
-        for (int64_t base = 0; base < wm; base += kMergeThreads) {
+        for (int64_t base = 0; base < wm; base += NT) {
             const int64_t i = base + tid;
             const uint32_t c = i < wm ? (uint32_t)__popc(mmb[i]) : 0u;
             const uint32_t ex = block_exclusive_scan(c, scan_smem, &total);
@@ -2014,7 +2019,7 @@ __global__ __launch_bounds__(kMergeThreads) CGIC_VGPR_CAP_MERGE void merge_kerne
         // ~40 instructions -- the merge launch took twice as long as its first band.)
         uint32_t mine = 0;
         const int wvm = tid >> 6, lnm = tid & 63;
-        for (int y2 = wvm; y2 < (int)(r0 >> 1); y2 += kMergeThreads / 64)
+        for (int y2 = wvm; y2 < (int)(r0 >> 1); y2 += NT / 64)
             for (int x2 = lnm; x2 < (int)w2; x2 += 64) {
                 bool bc, bm;
                 mine += fine_flag(2 * y2, 2 * x2, &bc, &bm) ? 4u : 0u;
@@ -2040,9 +2045,9 @@ __global__ __launch_bounds__(kMergeThreads) CGIC_VGPR_CAP_MERGE void merge_kerne
         const int64_t f0 = fbase, f1 = f0 + (r1 - r0) * w;                    // at most every position of the band
         const int64_t nc = c1 - c0, nm = m1 - m0, nf = (f1 < n_f ? f1 : n_f) - f0;
         if (nc >= 0 && nm >= 0 && nf >= 0 && nc + nm + nf + 3 <= a.band_syms) {
-            for (int64_t i = tid; i < nc; i += kMergeThreads) bsym[i] = ds_c[c0 + i];
-            for (int64_t i = tid; i < nm; i += kMergeThreads) bsym[nc + i] = ds_m[m0 + i];
-            for (int64_t i = tid; i < nf; i += kMergeThreads) bsym[nc + nm + i] = ds_f[f0 + i];
+            for (int64_t i = tid; i < nc; i += NT) bsym[i] = ds_c[c0 + i];
+            for (int64_t i = tid; i < nm; i += NT) bsym[nc + i] = ds_m[m0 + i];
+            for (int64_t i = tid; i < nf; i += NT) bsym[nc + nm + i] = ds_f[f0 + i];
             __syncthreads();
             off_c = c0; off_m = m0 - nc; off_f = f0 - nc - nm;     // ds_x[rank] == bsym[rank - off_x]
             ds_c = bsym; ds_m = bsym; ds_f = bsym;
@@ -2068,7 +2073,7 @@ __global__ __launch_bounds__(kMergeThreads) CGIC_VGPR_CAP_MERGE void merge_kerne
     // medium cells, so a quad costs one coarse and two medium rank lookups instead of four of each, and every output is one
     // 16-byte store per plane (the per-position form issued 4-byte stores 8 bytes apart).
     const int w4i = (int)w4;
-    for (int64_t qbase = r0 * w4; qbase < r1 * w4; qbase += kMergeThreads) {
+    for (int64_t qbase = r0 * w4; qbase < r1 * w4; qbase += NT) {
         const int64_t q = qbase + tid;
         const bool live = q < r1 * w4;
         int64_t v[4] = {0, 0, 0, 0};
@@ -2484,9 +2489,16 @@ extern "C" int cgic_decompress_streams(const cgic_table *t, const uint8_t *in, i
         const int64_t need = rows_per * w * 21 / 16 + 8;
         if (lds_m + (size_t)need * 2 <= 64 * 1024) { m.band_syms = need; lds_m += (size_t)need * 2; }
     }
+    if (g_decode_mode.load() == CGIC_DECODE_THROUGHPUT && !large && m.stage_sym) {
+        // several batches in flight: one band of 1024 threads per image (see merge_kernel)
+        if (lds_m > 48 * 1024)
+            { int rc_ = ensure_dynamic_lds((const void *)merge_kernel<1024>, (size_t)lds_m); if (rc_) return rc_; }
+        hipLaunchKernelGGL(merge_kernel<1024>, dim3(1u, (unsigned)B), dim3(1024), lds_m, s, m);
+        return launch_check("merge_kernel");
+    }
     if (lds_m > 48 * 1024)
-        { int rc_ = ensure_dynamic_lds((const void *)merge_kernel, (size_t)lds_m); if (rc_) return rc_; }
-    hipLaunchKernelGGL(merge_kernel, dim3((unsigned)nbands, (unsigned)B), dim3(kMergeThreads), lds_m, s, m);
+        { int rc_ = ensure_dynamic_lds((const void *)merge_kernel<kMergeThreads>, (size_t)lds_m); if (rc_) return rc_; }
+    hipLaunchKernelGGL(merge_kernel<kMergeThreads>, dim3((unsigned)nbands, (unsigned)B), dim3(kMergeThreads), lds_m, s, m);
     return launch_check("merge_kernel");
 }
 
