@@ -78,9 +78,11 @@ __device__ __forceinline__ float sum32_all(float v)
 // the reference gives 2.9e-37).  NaN totals stay NaN.
 __device__ __forceinline__ float hist_entropy(float s)
 {
+    // (+ 1e-30 instead of max(., 1e-30): a full-rate add where v_max_f32 holds the issue port for two slots; it changes
+    // nothing above 1e-23 and turns an empty histogram / an empty bin into 0 * finite)
     const float S = sum32_all(s);                                   // sum over bins          (:457)
-    const float p = s * __builtin_amdgcn_rcpf(fmaxf(S, 1e-30f));    //                        (:458)
-    const float t = p * __builtin_amdgcn_logf(fmaxf(p, 1e-30f));    // p log2 p, 0 for an empty bin
+    const float p = s * __builtin_amdgcn_rcpf(S + 1e-30f);          //                        (:458)
+    const float t = p * __builtin_amdgcn_logf(p + 1e-30f);          // p log2 p, 0 for an empty bin
     return -0.6931471805599453f * sum32_upper(t);                   //                        (:459)
 }
 
