@@ -266,7 +266,8 @@ size_t cgic_decompress_workspace_bytes(int64_t B, int64_t h, int64_t w);
  *                           ONE batch on an otherwise idle GPU (B=64 of 256x256: 15 us)
  *   CGIC_DECODE_THROUGHPUT  the self-synchronising decoder: one workgroup per image guesses entry offsets and re-walks until
  *                           they agree -- 256 threads and 41 KB of LDS per 256x256 image, 25 us alone, but it leaves the GPU
- *                           to the kernels of other batches in flight (pipeline.LaneStream: 86 -> 101 GPixel/s)
+ *                           to the kernels of other batches in flight (pipeline.LaneStream: 86 -> 101 GPixel/s); the merge
+ *                           that follows runs one band of 1024 threads per image instead of four of 512 (half the instructions)
  *   CGIC_DECODE_AUTO        (default) = CGIC_DECODE_LATENCY
  * Tables with codes longer than 64 bits and grids whose worst case exceeds the LDS budget always take the split-stream
  * / serial paths.  Returns the previous mode, or CGIC_ERR_INVALID. */
