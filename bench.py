@@ -92,7 +92,7 @@ class HotPath:
         self.router = cg.TripleGrainFixedEntropyRouter(ratio[0], ratio[1], per_image=True)
         self.hist = torch.zeros(1024, dtype=torch.int64, device=dev)
         self.out = None
-        self.pipe = cg.pipeline.HotPathPipeline(self.vq, ratio[0], ratio[1], frequency=self.codec.huffman, fuse_router=fuse_router)
+        self.pipe = cg.pipeline.HotPathPipeline(self.vq, ratio[0], ratio[1], frequency=self.codec.huffman, fuse_router=fuse_router, prepare=True)
 
     def step(self):
         r = self.pipe.run(self.x, self.z, self.hist, decode=True)[0]
@@ -155,15 +155,18 @@ def stage_breakdown(hp):
     cg = hp.cg
     e8, e16 = cg.entropy_maps(hp.x)
     mask, _, _, mode = hp.router(e16, e8, want_gate=False)
+    prep = hp.pipe.prepared                   # the codebook image the timed launches use (made once per codebook)
     _, _, ind = _vq_forward(hp.z, hp.vq.embedding.weight, 0.25, True, None)
     comp = hp.codec.compress(ind, mask, mode)
     st = {}
     st["entropy_maps"] = graph_kernel_time(lambda: cg.entropy_maps(hp.x))
     st["router_alone"] = graph_kernel_time(lambda: hp.router(e16, e8, want_gate=False))
     st["vq+router_fused_launch"] = graph_kernel_time(lambda: vq_forward_route(
+        hp.z, hp.vq.embedding.weight, 0.25, True, e16, e8, hp.router.coarse_grain_ratio, hp.router.medium_grain_ratio, prepared=prep))
+    st["vq+router_fused_launch_unprepared"] = graph_kernel_time(lambda: vq_forward_route(
         hp.z, hp.vq.embedding.weight, 0.25, True, e16, e8, hp.router.coarse_grain_ratio, hp.router.medium_grain_ratio))
-    st["vq_kernel_alone"] = graph_kernel_time(lambda: _vq_forward(hp.z, hp.vq.embedding.weight, 0.25, True, None))
-    st["vq_kernel_indices_only"] = graph_kernel_time(lambda: hp.vq.indices(hp.z))
+    st["vq_kernel_alone"] = graph_kernel_time(lambda: _vq_forward(hp.z, hp.vq.embedding.weight, 0.25, True, None, prepared=prep))
+    st["vq_kernel_indices_only"] = graph_kernel_time(lambda: _vq_forward(hp.z, hp.vq.embedding.weight, 0.25, True, None, False, False, prepared=prep))
     st["compress_streams+hist"] = graph_kernel_time(lambda: hp.codec.compress(ind, mask, mode, hist=hp.hist))
     st["decompress_streams"] = graph_kernel_time(lambda: hp.codec.decompress(comp))
     return {k: round(v, 2) for k, v in st.items()}
@@ -181,7 +184,8 @@ def saturated_launch_time(hp, lanes=4, per_graph=20, reps=6):
         def fn():
             out = None
             for _ in range(per_graph):
-                out = vq_forward_route(z, hp.vq.embedding.weight, 0.25, True, e16, e8, hp.router.coarse_grain_ratio, hp.router.medium_grain_ratio)
+                out = vq_forward_route(z, hp.vq.embedding.weight, 0.25, True, e16, e8, hp.router.coarse_grain_ratio, hp.router.medium_grain_ratio,
+                                       prepared=hp.pipe.prepared)
             return out
         return fn
     gl = GraphLanes(hp.x.device, [make(z) for z in zs])
@@ -300,6 +304,7 @@ def lanes_rate(vq, codec, ratio, xz, lanes, steps, copies=1):
     ls = cg.pipeline.LaneStream(vq, ratio[0], ratio[1], slots, lanes=lanes, frequency=codec.huffman)
     ls.capture()
     ls.submit(len(slots)); ls.join(); torch.cuda.synchronize()
+    ls.prepare(steps); torch.cuda.synchronize()
     t0 = time.perf_counter()
     ls.submit(steps); ls.join(); torch.cuda.synchronize()
     return (time.perf_counter() - t0) / steps, ls
@@ -581,11 +586,16 @@ def run_rank(a, rank, world, local):
             # control_gic_amd.pipeline.LaneStream: batch t on HIP stream t % lanes, one ring graph per stream, no
             # dependency between the streams (lanes=1: one batch in flight, the round-1/2a configuration)
             stream = cg.pipeline.LaneStream(vq, ratio[0], ratio[1], slots_dev, lanes=a.lanes, frequency=codec.huffman, hist=hist,
-                                            graph=not a.no_graph, ring=not a.no_ring, fuse_router=not a.split_router)
+                                            graph=not a.no_graph, ring=not a.no_ring, fuse_router=not a.split_router, max_ring=a.max_ring,
+                                            quick_start=False)
             stream.capture()
+            stream.prepare(a.warmup)
         stream.submit(a.warmup)
         stream.join()
         sync()
+        if hasattr(stream, "prepare"):
+            stream.prepare(a.steps)                         # captures the graphs the timed submit replays (outside the timed region)
+            sync()
         hist.zero_()
 
     barrier()
@@ -621,8 +631,8 @@ def run_rank(a, rank, world, local):
                            f"{a.schedule}: " + ("encode-side and decode-side hipGraphs of successive batches on two HIP streams"
                                                 if a.schedule == "pipelined" and not a.no_graph else
                                                 ("eager, one stream" if a.no_graph else "one hipGraph per batch, one stream" if a.no_ring else
-                                                 f"{a.lanes} independent HIP stream(s), batch t on stream t % {a.lanes}, one hipGraph per stream's rotation of "
-                                                 f"{n_slots // max(1, a.lanes)} batches (per-batch graphs for the remainder of K)"))),
+                                                 f"{a.lanes} independent HIP stream(s), batch t on stream t % {a.lanes}, one hipGraph launch per run of up to "
+                                                 f"{a.max_ring} consecutive batches of a stream (captured before the timed region)"))),
                        "inputs": f"{n_slots} distinct resident batches in rotation ({n_slots * B * H * W * 13 / 2**20:.0f} MiB > 256 MiB Infinity Cache)",
                        "sharding": "images round-robin over ranks; one RCCL all-reduce of the int64[1024] histogram per run"},
         }
@@ -751,6 +761,7 @@ def parse_args(argv=None):
                     help="sequential: one hipGraph per batch on one stream; pipelined: BatchStream, encode side of batch i+1 next to the decode side of batch i")
     ap.add_argument("--slots", type=int, default=0, help="distinct resident input batches in rotation (0: enough to exceed the Infinity Cache)")
     ap.add_argument("--lanes", type=int, default=4, help="independent HIP streams the rotation of batches is dealt over (sequential schedule); 1 = one batch in flight")
+    ap.add_argument("--max-ring", type=int, default=8, help="batches per hipGraph launch of a lane (sequential schedule)")
     ap.add_argument("--split-router", action="store_true", help="router as its own launch instead of riding in the VQ launch")
     ap.add_argument("--no-ring", action="store_true", help="one hipGraph per batch instead of one per rotation of batches (sequential schedule)")
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying hipGraphs (sequential schedule)")

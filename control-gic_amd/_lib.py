@@ -40,10 +40,12 @@ PROTOTYPES = {
     "cgic_device_count": (_int, []),
     "cgic_vq_workspace_bytes": (_sz, [_i64]),
     "cgic_conv1x1_rows_f32": (_int, [_vp, _i64, _cv, _vp, _vp]),
-    "cgic_vq_forward_f32": (_int, [_vp, _i64, _i64, _vp, _int, _int, _f32, _int, _vp, _vp, _vp, _vp, _vp, _cv, _vp]),
+    "cgic_vq_prepared_bytes": (_sz, [_int]),
+    "cgic_vq_prepare_f32": (_int, [_vp, _int, _int, _vp, _vp]),
+    "cgic_vq_forward_f32": (_int, [_vp, _i64, _i64, _vp, _int, _int, _f32, _int, _vp, _vp, _vp, _vp, _vp, _cv, _vp, _vp]),
     "cgic_vq_forward_valu_f32": (_int, [_vp, _i64, _i64, _vp, _int, _int, _f32, _int, _vp, _vp, _vp, _vp, _vp, _cv, _vp]),
     "cgic_vq_forward_route_f32": (_int, [_vp, _i64, _i64, _vp, _int, _int, _f32, _int, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64,
-                                         _f64, _f64, _int, _vp, _vp, _vp, _vp, C.POINTER(_int), _cv, _vp]),
+                                         _f64, _f64, _int, _vp, _vp, _vp, _vp, C.POINTER(_int), _cv, _vp, _vp]),
     "cgic_vq_backward_workspace_bytes": (_sz, [_i64, _int]),
     "cgic_vq_backward_f32": (_int, [_vp, _i64, _i64, _vp, _int, _int, _vp, _vp, _vp, _f32, _int, _vp, _vp, _vp, _vp]),
     "cgic_index_histogram": (_int, [_vp, _i64, _int, _vp, _vp]),
@@ -67,7 +69,7 @@ PROTOTYPES = {
     "cgic_compress_streams": (_int, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _int, _vp, _i64, _vp, _vp, _vp, _vp]),
     "cgic_decompress_workspace_bytes": (_sz, [_i64, _i64, _i64]),
     "cgic_decompress_streams": (_int, [_vp, _vp, _i64, _vp, _i64, _i64, _i64, _int, _vp, _vp, _vp, _vp, _vp, _int,
-                                       _int, _vp, _vp, _vp, _vp, _vp, _vp]),
+                                       _int, _vp, _vp, _vp, _vp, _vp, _int, _vp]),
     "cgic_grain_merge_f32": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _int, _i64, _i64, _vp, _vp]),
     "cgic_avgpool_f32": (_int, [_vp, _i64, _i64, _i64, _int, _vp, _vp]),
     "cgic_decoder_blend_medium_f32": (_int, [_vp, _vp, _vp, _vp, _i64, _int, _i64, _i64, _vp, _vp]),

@@ -7,6 +7,7 @@ direction and keeps the streams in one device tensor; `write_legacy()` emits
 exactly the reference's files for one image, byte for byte.
 """
 import os
+import threading
 
 import torch
 
@@ -23,28 +24,46 @@ def mode_streams(mode):
 
 
 _DECODE_MODES = {"auto": 0, "latency": 1, "throughput": 2}
+_tls = threading.local()
+
+
+def set_default_decoder(mode):
+    """process-wide default of calls that name no decoder (cgic_set_decode_mode); returns the previous one"""
+    prev = _lib.call("cgic_set_decode_mode", _DECODE_MODES[mode])
+    return {v: k for k, v in _DECODE_MODES.items()}[prev]
 
 
 class decoder_mode:
     """`with decoder_mode("throughput"):` -- which prefix decoder `GrainCodec.decompress` launches (or captures) inside the
-    block: "latency" = the split-stream kernels (shortest time for one batch on an idle GPU), "throughput" = the
-    self-synchronising one-workgroup-per-image kernel (small footprint: for several batches in flight, pipeline.LaneStream),
-    "auto" = the library default (latency).  Results are identical.  Process-wide (cgic_set_decode_mode); the previous mode
-    is restored on exit."""
+    block when the call itself names none: "latency" = the split-stream kernels (shortest time for one batch on an idle GPU),
+    "throughput" = the self-synchronising one-workgroup-per-image kernel (small footprint: for several batches in flight,
+    pipeline.LaneStream), "auto" = the process default (set_default_decoder; latency unless changed).  Results are identical.
+    The choice is a property of each call (the `decoder` argument of cgic_decompress_streams): this context only supplies
+    the calling THREAD's default, so two threads can decode in different modes at the same time."""
 
     def __init__(self, mode):
         if mode not in _DECODE_MODES:
             raise ValueError(f"decoder mode {mode!r}: expected one of {sorted(_DECODE_MODES)}")
-        self.mode = _DECODE_MODES[mode]
+        self.mode = mode
         self.prev = None
 
     def __enter__(self):
-        self.prev = _lib.call("cgic_set_decode_mode", self.mode)
+        self.prev = getattr(_tls, "mode", None)
+        _tls.mode = self.mode
         return self
 
     def __exit__(self, *exc):
-        _lib.call("cgic_set_decode_mode", self.prev)
+        _tls.mode = self.prev
         return False
+
+
+def _decoder_flag(decoder):
+    mode = decoder if decoder is not None else getattr(_tls, "mode", None)
+    if mode is None:
+        return 0
+    if mode not in _DECODE_MODES:
+        raise ValueError(f"decoder mode {mode!r}: expected one of {sorted(_DECODE_MODES)}")
+    return _DECODE_MODES[mode]
 
 
 class CompressedBatch:
@@ -53,27 +72,25 @@ class CompressedBatch:
 
     def __init__(self, data, nbytes, mode, h, w):
         self.data, self.nbytes, self.mode, self.h, self.w = data, nbytes, int(mode), int(h), int(w)
-        self._host = None
 
     @property
     def batch(self):
         return self.data.shape[0]
 
     def to_host(self):
-        """list (per image) of {stream name: bytes} for the streams the mode writes"""
-        if self._host is None:
-            nb = self.nbytes.cpu()
-            if int(nb.min()) < -1:
-                bad = int(nb.min()) + 10
-                if bad == _lib.ERR_INVALID:
-                    raise KeyError("a symbol is not in the code table")
-                raise _lib.CgicError(bad, "compress_streams failed on the device")
-            top = max(int(nb.max()), 0)
-            blob = self.data[:, :, :top].cpu().numpy()
-            self._host = [{STREAM_NAMES[s]: blob[b, s, :int(nb[b, s])].tobytes()
-                           for s in range(_lib.NUM_STREAMS) if int(nb[b, s]) >= 0}
-                          for b in range(self.batch)]
-        return self._host
+        """list (per image) of {stream name: bytes} for the streams the mode writes.  Reads the device buffers on every
+        call (nothing is cached: the buffers of a captured launch are rewritten by every replay)"""
+        nb = self.nbytes.cpu()
+        if int(nb.min()) < -1:
+            bad = int(nb.min()) + 10
+            if bad == _lib.ERR_INVALID:
+                raise KeyError("a symbol is not in the code table")
+            raise _lib.CgicError(bad, "compress_streams failed on the device")
+        top = max(int(nb.max()), 0)
+        blob = self.data[:, :, :top].cpu().numpy()
+        return [{STREAM_NAMES[s]: blob[b, s, :int(nb[b, s])].tobytes()
+                 for s in range(_lib.NUM_STREAMS) if int(nb[b, s]) >= 0}
+                for b in range(self.batch)]
 
     def total_bytes(self):
         """[B] int64 on the device: sum of stream sizes per image"""
@@ -84,10 +101,11 @@ class CompressedBatch:
         num_pixels = 16 * self.h * self.w if num_pixels is None else num_pixels
         return [int(t) * 8 / num_pixels for t in self.total_bytes().cpu().tolist()]
 
-    def write_legacy(self, path, b=0):
-        """write image b's streams under the reference's fixed file names; returns the paths"""
+    def write_legacy(self, path, b=0, host=None):
+        """write image b's streams under the reference's fixed file names; returns the paths (`host`: a to_host() result
+        to reuse when several images of the batch are written)"""
         out = []
-        for name, data in self.to_host()[b].items():
+        for name, data in (self.to_host() if host is None else host)[b].items():
             p = os.path.join(path, name + ".bin")
             with open(p, "wb") as f:
                 f.write(data)
@@ -169,11 +187,12 @@ class GrainCodec:
         del keep
         return out
 
-    def decompress(self, cb, want_masks=True, want_zq=True, post_quant_conv=None, conv_bias_first=False):
+    def decompress(self, cb, want_masks=True, want_zq=True, post_quant_conv=None, conv_bias_first=False, decoder=None):
         """CompressedBatch -> (ind [B,h,w] int64, [mask_c, mask_m, mask_f] int32 [B,1,.,.] or None,
         z_q [B,4,h,w] fp32 or None, status [B] int32 on the device (0 = ok)).
         With post_quant_conv (a Conv2d(4, 4, 1) or (weight, bias)) the third element is the pair
-        (z_q, post_quant_conv(z_q)) -- what CGIC.decode feeds the decoder (model.py:114-116) -- from the same pass."""
+        (z_q, post_quant_conv(z_q)) -- what CGIC.decode feeds the decoder (model.py:114-116) -- from the same pass.
+        decoder: "latency" / "throughput" / "auto" for THIS call (None: the enclosing decoder_mode block, else the process default)."""
         B, h, w, dev = cb.batch, cb.h, cb.w, cb.data.device
         l = _lib.lib()
         ind = torch.empty((B, h, w), dtype=torch.int64, device=dev)
@@ -203,5 +222,6 @@ class GrainCodec:
                       _lib.ptr(masks[0]) if masks else None, _lib.ptr(masks[1]) if masks else None,
                       _lib.ptr(masks[2]) if masks else None, _lib.ptr(cbk),
                       cbk.shape[0] if cbk is not None else 0, cbk.shape[1] if cbk is not None else 0,
-                      _lib.ptr(zq), _lib.ptr(cbk2), _lib.ptr(zq2), _lib.ptr(status), _lib.ptr(ws), _lib.current_stream(dev))
+                      _lib.ptr(zq), _lib.ptr(cbk2), _lib.ptr(zq2), _lib.ptr(status), _lib.ptr(ws), _decoder_flag(decoder),
+                      _lib.current_stream(dev))
         return ind, masks, (zq, zq2) if post_quant_conv is not None else zq, status

@@ -2366,11 +2366,15 @@ extern "C" int cgic_decompress_streams(const cgic_table *t, const uint8_t *in, i
                                        int32_t *mask_c_out, int32_t *mask_m_out, int32_t *mask_f_out,
                                        const float *codebook, int K, int e_dim, float *z_q, const float *codebook2,
                                        float *z_q2, int32_t *status,
-                                       void *workspace, cgic_stream_t stream)
+                                       void *workspace, int decoder, cgic_stream_t stream)
 {
     int rc = check_grid(B, h, w, mode);
     if (rc) return rc;
     CGIC_REQUIRE(t && in && nbytes && workspace, CGIC_ERR_INVALID, "decompress_streams: NULL argument");
+    CGIC_REQUIRE(decoder == CGIC_DECODE_AUTO || decoder == CGIC_DECODE_LATENCY || decoder == CGIC_DECODE_THROUGHPUT, CGIC_ERR_INVALID,
+                 "decompress_streams: decoder %d", decoder);
+    // which prefix decoder: a property of THIS call (AUTO = the process default of cgic_set_decode_mode)
+    const int dec_mode = decoder != CGIC_DECODE_AUTO ? decoder : g_decode_mode.load();
     CGIC_REQUIRE(slot % 16 == 0 && slot >= 16 && slot < ((int64_t)1 << 28), CGIC_ERR_INVALID,
                  "decompress_streams: slot must be a multiple of 16 below 2^28");
     CGIC_REQUIRE(!z_q || (codebook && e_dim == 4 && K > 0), CGIC_ERR_UNSUPPORTED,
@@ -2408,7 +2412,7 @@ extern "C" int cgic_decompress_streams(const cgic_table *t, const uint8_t *in, i
     // the three grids can hold x the longest code.  (Longer inputs are an overflow on any path.)
     bool ss = false;
 #ifndef CGIC_DEC_NO_SS
-    if (d.tab.max_len <= 64 && g_decode_mode.load() == CGIC_DECODE_THROUGHPUT) {
+    if (d.tab.max_len <= 64 && dec_mode == CGIC_DECODE_THROUGHPUT) {
         const size_t bits_cap = per * (size_t)d.tab.max_len + 3 * 64;
         const size_t stage_cap = align16(bits_cap / 8 + 3 * 48), chunk_cap = align16(bits_cap / 64 + 8);
         const size_t lds_ss = sizeof(uint32_t) * ((size_t)1 << d.tab.lut_bits) + stage_cap + 3 * chunk_cap;
@@ -2489,7 +2493,7 @@ extern "C" int cgic_decompress_streams(const cgic_table *t, const uint8_t *in, i
         const int64_t need = rows_per * w * 21 / 16 + 8;
         if (lds_m + (size_t)need * 2 <= 64 * 1024) { m.band_syms = need; lds_m += (size_t)need * 2; }
     }
-    if (g_decode_mode.load() == CGIC_DECODE_THROUGHPUT && !large && m.stage_sym) {
+    if (dec_mode == CGIC_DECODE_THROUGHPUT && !large && m.stage_sym) {
         // several batches in flight: one band of 1024 threads per image (see merge_kernel)
         if (lds_m > 48 * 1024)
             { int rc_ = ensure_dynamic_lds((const void *)merge_kernel<1024>, (size_t)lds_m); if (rc_) return rc_; }

@@ -77,6 +77,8 @@ extern __device__ long long g_phase_clk[32];
 extern __device__ long long g_blk_t[2 * 4096];   // per-workgroup (start, end) on the 100 MHz clock
 #define CGIC_BLK_BEGIN() do { if (threadIdx.x == 0 && blockIdx.x < 4096) g_blk_t[2 * blockIdx.x] = wall_clock64(); } while (0)
 #define CGIC_BLK_END() do { if (threadIdx.x == 0 && blockIdx.x < 4096) g_blk_t[2 * blockIdx.x + 1] = wall_clock64(); } while (0)
+// dbg counters: slot 2 * (2048 + workgroup) (+1) of g_blk_t counts events of that workgroup (launches of <= 2048 workgroups)
+#define CGIC_DBG_COUNT(which, n) do { if (lane_id() == 0 && blockIdx.x < 2048) atomicAdd((unsigned long long *)&g_blk_t[2 * (2048 + blockIdx.x) + (which)], (unsigned long long)(n)); } while (0)
 #define CGIC_STAMP(i) do { if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) g_phase_clk[i] = clock64(); \
         if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 192 && (i) >= 2 && (i) <= 7) g_phase_clk[8 + (i)] = clock64(); } while (0)
 // span of a whole launch over ALL workgroups (constant 100 MHz clock): [28] = earliest start, [29] = latest end,
@@ -89,6 +91,7 @@ extern __device__ long long g_blk_t[2 * 4096];   // per-workgroup (start, end) o
 #define CGIC_STAMP2(i) do { if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) g_phase_clk[i] = clock64(); } while (0)
 #else
 #define CGIC_STAMP(i) do {} while (0)
+#define CGIC_DBG_COUNT(which, n) do {} while (0)
 #define CGIC_STAMP2(i) do {} while (0)
 #define CGIC_STAMP3(i) do {} while (0)
 #define CGIC_BLK_BEGIN() do {} while (0)

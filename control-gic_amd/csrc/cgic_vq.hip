@@ -208,6 +208,9 @@ struct VqArgs {
     // quant_conv fused in front of the quantiser (model.py:51,110): z = W h (+ b), 4 -> 4, or NULL
     const float *conv_w, *conv_b;
     int conv_bias_first;
+    // filter path: the LDS image of the codebook (split fp16 A operands, padded fp32 rows, row norms, maxima) as
+    // vq_prepare_kernel left it, or NULL: every workgroup then derives it from `cb` itself
+    const void *prep;
 };
 
 // The reference's quant_conv is a torch.nn.Conv2d(4, 4, 1) on the CPU.  Its fp32 rounding sequence is an fma chain over
@@ -516,6 +519,74 @@ __host__ __device__ constexpr size_t vqf_rows_off(int K) { return (size_t)K * 32
 __host__ __device__ constexpr size_t vqf_ees_off(int K) { return vqf_rows_off(K) + (size_t)(K + K / 32) * 16; }
 __host__ __device__ constexpr size_t vqf_lds_bytes(int K) { return vqf_ees_off(K) + (size_t)(K + K / 8) * 4; }
 
+// The codebook's LDS image of the filter path: fp32 rows (at rowpos()), row norms (at eepos()), the split fp16 A operands
+// and, in s_max[0..1], the bit patterns of max |e_kj| and max ee_k (they fix the fp16 scaling).  Ends with a barrier.
+template <int NT>
+__device__ __forceinline__ void vqf_stage(const float *__restrict__ cb, const int K, unsigned char *smem, unsigned int *s_max)
+{
+    uint4 *ldsA = reinterpret_cast<uint4 *>(smem);                                  // [K/32][64]
+    float4 *cbs = reinterpret_cast<float4 *>(smem + vqf_rows_off(K));               // fp32 rows, at rowpos()
+    float *ees = reinterpret_cast<float *>(smem + vqf_ees_off(K));                  // their squared norms, at eepos()
+    const int tid = threadIdx.x, lane = tid & 63;
+    // Phase 1: fp32 rows, row norms and the codebook maxima.
+    if (tid < 2) s_max[tid] = 0;
+    constexpr int kRows = (kVqfMaxK + NT - 1) / NT;          // rows per thread (2 at 512 threads)
+    float4 rows[kRows];
+    float rowee[kRows];
+    {
+        float emax = 0.f, eemax = 0.f;
+#pragma unroll
+        for (int q = 0; q < kRows; ++q) {
+            const int k = tid + q * NT;
+            rows[q] = k < K ? reinterpret_cast<const float4 *>(cb)[k] : float4{0.f, 0.f, 0.f, 0.f};
+        }
+        __syncthreads();                    // s_max is zero
+#pragma unroll
+        for (int q = 0; q < kRows; ++q) {
+            const int k = tid + q * NT;
+            const float4 e = rows[q];
+            rowee[q] = sumsq4(e.x, e.y, e.z, e.w);
+            if (k < K) { cbs[rowpos(k)] = e; ees[eepos(k)] = rowee[q]; }
+            emax = fmaxf(emax, fmaxf(fmaxf(fabsf(e.x), fabsf(e.y)), fmaxf(fabsf(e.z), fabsf(e.w))));
+            eemax = fmaxf(eemax, rowee[q]);
+            // fmaxf drops NaNs: route them into the maxima by hand (a NaN anywhere in the codebook disables the filter)
+            if (!(rowee[q] == rowee[q])) eemax = rowee[q];
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const float oe = __shfl_xor(emax, off, kWave), oee = __shfl_xor(eemax, off, kWave);
+            emax = fmaxf(emax, oe);
+            eemax = (oee != oee || eemax != eemax) ? __builtin_nanf("") : fmaxf(eemax, oee);
+        }
+        // non-negative floats order like their bit patterns; a NaN lands above every finite value
+        if (lane == 0) { atomicMax(&s_max[0], __float_as_uint(emax)); atomicMax(&s_max[1], __float_as_uint(eemax)); }
+    }
+    __syncthreads();
+    const float Emax = __uint_as_float(s_max[0]), EEmax = __uint_as_float(s_max[1]);
+    // 2 Emax 2^b and EEmax 2^be in [2^13, 2^14)
+    const int sb = 13 - (exponent_of(Emax) + 1), sbe = 13 - exponent_of(EEmax);
+    // Phase 2: the split A operands.  Row k = 32 T + i feeds lanes i (K-slots 0..7) and 32 + i (K-slots 8..15) of tile T:
+    //   slots 0..7  : wh0 wm0 wh0 | wh1 wm1 wh1 | wh2 wm2        against  zh0 zh0 zm0 | zh1 zh1 zm1 | zh2 zh2
+    //   slots 8..15 : wh2 | wh3 wm3 wh3 | eh em el | 0          against  zm2 | zh3 zh3 zm3 | 2^s 2^s 2^s | 0
+#pragma unroll
+    for (int q = 0; q < kRows; ++q) {
+        const int k = tid + q * NT;
+        if (k < K) {
+            const float4 e = rows[q];
+            unsigned int wh0, wm0, wh1, wm1, wh2, wm2, wh3, wm3, eh, em, el;
+            split2h(ldexpf(-2.0f * e.x, sb), wh0, wm0);
+            split2h(ldexpf(-2.0f * e.y, sb), wh1, wm1);
+            split2h(ldexpf(-2.0f * e.z, sb), wh2, wm2);
+            split2h(ldexpf(-2.0f * e.w, sb), wh3, wm3);
+            split3h(ldexpf(rowee[q], sbe), eh, em, el);
+            uint4 *dst = ldsA + (k >> 5) * 64 + (k & 31);
+            dst[0] = make_uint4(wh0 | (wm0 << 16), wh0 | (wh1 << 16), wm1 | (wh1 << 16), wh2 | (wm2 << 16));
+            dst[32] = make_uint4(wh2 | (wh3 << 16), wm3 | (wh3 << 16), eh | (em << 16), el);
+        }
+    }
+    __syncthreads();
+}
+
 // ALIGNED: hw % 64 == 0 -- a group of 64 consecutive vectors never straddles two images, so (image, position) of a
 // group is wave-uniform and every address is a scalar base plus a per-lane offset that is computed once.
 template <int NT, bool ALIGNED, bool CONV>
@@ -603,65 +674,24 @@ __device__ __forceinline__ void vq_filter_body(const VqArgs &a, unsigned char *s
     int64_t cur = blk_lo + wave;
     if (cur < blk_hi) load_group(cur, zn);
 
-    // ---- stage.  Phase 1: fp32 rows, row norms and the codebook maxima (they fix the fp16 scaling).
-    if (tid < 2) s_max[tid] = 0;
-    constexpr int kRows = (kVqfMaxK + NT - 1) / NT;          // rows per thread (2 at 512 threads)
-    float4 rows[kRows];
-    float rowee[kRows];
-    {
-        float emax = 0.f, eemax = 0.f;
-#pragma unroll
-        for (int q = 0; q < kRows; ++q) {
-            const int k = tid + q * NT;
-            rows[q] = k < K ? reinterpret_cast<const float4 *>(a.cb)[k] : float4{0.f, 0.f, 0.f, 0.f};
-        }
-        __syncthreads();                    // s_max is zero
-#pragma unroll
-        for (int q = 0; q < kRows; ++q) {
-            const int k = tid + q * NT;
-            const float4 e = rows[q];
-            rowee[q] = sumsq4(e.x, e.y, e.z, e.w);
-            if (k < K) { cbs[rowpos(k)] = e; ees[eepos(k)] = rowee[q]; }
-            emax = fmaxf(emax, fmaxf(fmaxf(fabsf(e.x), fabsf(e.y)), fmaxf(fabsf(e.z), fabsf(e.w))));
-            eemax = fmaxf(eemax, rowee[q]);
-            // fmaxf drops NaNs: route them into the maxima by hand (a NaN anywhere in the codebook disables the filter)
-            if (!(rowee[q] == rowee[q])) eemax = rowee[q];
-        }
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) {
-            const float oe = __shfl_xor(emax, off, kWave), oee = __shfl_xor(eemax, off, kWave);
-            emax = fmaxf(emax, oe);
-            eemax = (oee != oee || eemax != eemax) ? __builtin_nanf("") : fmaxf(eemax, oee);
-        }
-        // non-negative floats order like their bit patterns; a NaN lands above every finite value
-        if (lane == 0) { atomicMax(&s_max[0], __float_as_uint(emax)); atomicMax(&s_max[1], __float_as_uint(eemax)); }
+    // ---- stage: the codebook's LDS image -- copied from the prepared image (cgic_vq_prepare_f32: inference, the codebook
+    // does not change between launches) or derived from the fp32 rows here
+    if (a.prep) {
+        const uint4 *src = reinterpret_cast<const uint4 *>(a.prep);
+        uint4 *dst = reinterpret_cast<uint4 *>(smem);
+        const int n16 = (int)(vqf_lds_bytes(K) / 16);
+#pragma unroll 8
+        for (int i = tid; i < n16; i += NT) dst[i] = src[i];
+        if (tid < 2) s_max[tid] = reinterpret_cast<const unsigned int *>(src + n16)[tid];
+        __syncthreads();
+    } else {
+        vqf_stage<NT>(a.cb, K, smem, s_max);
     }
-    __syncthreads();
     const float Emax = __uint_as_float(s_max[0]), EEmax = __uint_as_float(s_max[1]);
     // the filter needs a finite, non-zero codebook (an all-zero one ties everywhere: exact path)
     const bool filter_ok = Emax > 0.f && EEmax > 0.f && EEmax < __builtin_inff() && Emax < __builtin_inff();
     // 2 Emax 2^b and EEmax 2^be in [2^13, 2^14)
     const int sb = 13 - (exponent_of(Emax) + 1), sbe = 13 - exponent_of(EEmax);
-    // Phase 2: the split A operands.  Row k = 32 T + i feeds lanes i (K-slots 0..7) and 32 + i (K-slots 8..15) of tile T:
-    //   slots 0..7  : wh0 wm0 wh0 | wh1 wm1 wh1 | wh2 wm2        against  zh0 zh0 zm0 | zh1 zh1 zm1 | zh2 zh2
-    //   slots 8..15 : wh2 | wh3 wm3 wh3 | eh em el | 0          against  zm2 | zh3 zh3 zm3 | 2^s 2^s 2^s | 0
-#pragma unroll
-    for (int q = 0; q < kRows; ++q) {
-        const int k = tid + q * NT;
-        if (k < K) {
-            const float4 e = rows[q];
-            unsigned int wh0, wm0, wh1, wm1, wh2, wm2, wh3, wm3, eh, em, el;
-            split2h(ldexpf(-2.0f * e.x, sb), wh0, wm0);
-            split2h(ldexpf(-2.0f * e.y, sb), wh1, wm1);
-            split2h(ldexpf(-2.0f * e.z, sb), wh2, wm2);
-            split2h(ldexpf(-2.0f * e.w, sb), wh3, wm3);
-            split3h(ldexpf(rowee[q], sbe), eh, em, el);
-            uint4 *dst = ldsA + (k >> 5) * 64 + (k & 31);
-            dst[0] = make_uint4(wh0 | (wm0 << 16), wh0 | (wh1 << 16), wm1 | (wh1 << 16), wh2 | (wm2 << 16));
-            dst[32] = make_uint4(wh2 | (wh3 << 16), wm3 | (wh3 << 16), eh | (em << 16), el);
-        }
-    }
-    __syncthreads();
     CGIC_STAMP(1);
     // exponent window of the per-vector scale 2^a: 2^s, s = a + sb - sbe, must be a normal fp16
     const int a_cap = 15 + sbe - sb, a_min = -14 + sbe - sb;
@@ -806,6 +836,7 @@ __device__ __forceinline__ void vq_filter_body(const VqArgs &a, unsigned char *s
             }
             // ... and on the other half's best tile where it is a candidate too (lexicographic merge)
             if (__ballot(valid && other && !flag)) {
+                CGIC_DBG_COUNT(1, 1);
                 const int cb1 = 32 * tile_of(firstB ? A1 : B1) + (firstB ? 0 : 4);
                 const float4 *rb = cbs + rowpos(cb1);
                 const float *eb = ees + eepos(cb1);
@@ -825,6 +856,7 @@ __device__ __forceinline__ void vq_filter_body(const VqArgs &a, unsigned char *s
             }
             const unsigned long long fmask = __ballot(flag);               // one bit per vector, wave-uniform
             const int nflag = __builtin_popcountll(fmask);
+            CGIC_DBG_COUNT(0, nflag);
             if (nflag != 0 && nflag <= kVqfBulk) {
                 // a few near-ties: the whole wave scans all K codes exactly for each such vector
                 unsigned long long todo = fmask;
@@ -1003,6 +1035,22 @@ __global__ CGIC_VQF_BOUNDS void vq_filter_router_kernel(VqArgs a, RouterArgs r, 
     vq_filter_body<kVqfThreads, ALIGNED, CONV>(a, smem_f, blockIdx.x - vb);
 }
 
+// The codebook's LDS image, computed ONCE (cgic_vq_prepare_f32) instead of by every workgroup of every launch: inference
+// runs thousands of launches against one codebook, and deriving the image (two block-wide maxima, 11 fp16 splits per row, three
+// barriers) was ~3 us at the head of every ~23 us launch.  One workgroup; the image is followed by the two maxima.
+__global__ __launch_bounds__(kVqfThreads) void vq_prepare_kernel(const float *__restrict__ cb, int K, uint4 *__restrict__ out)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_f[];
+    __shared__ unsigned int s_max[2];
+    const int n16 = (int)(vqf_lds_bytes(K) / 16);
+    uint4 *img = reinterpret_cast<uint4 *>(smem_f);
+    for (int i = threadIdx.x; i < n16; i += kVqfThreads) img[i] = make_uint4(0u, 0u, 0u, 0u);      // the padding rows: defined bytes
+    __syncthreads();
+    vqf_stage<kVqfThreads>(cb, K, smem_f, s_max);
+    for (int i = threadIdx.x; i < n16; i += kVqfThreads) out[i] = img[i];
+    if (threadIdx.x == 0) out[n16] = make_uint4(s_max[0], s_max[1], (unsigned int)K, 0x43474951u);
+}
+
 // Plain-VALU restatement: one latent vector per thread, codebook broadcast from
 // LDS.  Independent of the MFMA path; used to cross-check it on hardware.
 __global__ __launch_bounds__(kVqThreads) void vq_valu_kernel(
@@ -1118,6 +1166,13 @@ static int vq_check(const float *z, int64_t B, int64_t hw, const float *cb, int 
     return CGIC_OK;
 }
 
+static int prepared_check(const void *prepared, int K)
+{
+    CGIC_REQUIRE(!prepared || (((uintptr_t)prepared & 15) == 0 && K % 64 == 0 && K <= 1024), CGIC_ERR_INVALID,
+                 "vq: a prepared codebook image must be 16-byte aligned and made for this K (cgic_vq_prepare_f32)");
+    return CGIC_OK;
+}
+
 static int conv_check(const cgic_conv1x1 *qc)
 {
     CGIC_REQUIRE(!qc || qc->weight, CGIC_ERR_INVALID, "vq: quant_conv without a weight");
@@ -1147,6 +1202,7 @@ static int launch_mfma(const float *z, int64_t hw, int64_t N, const float *cb, i
     a.z = z; a.hw = hw; a.N = N; a.cb = cb; a.K = K; a.idx_out = idx; a.zq_out = zq;
     a.sq_partial = loss ? ws.partial : nullptr; a.ticket = ws.ticket; a.beta = beta; a.legacy = legacy; a.loss = loss;
     a.nblk = (unsigned int)((N + per_block - 1) / per_block);
+    a.n_early = a.g_early = a.g_late = 0; a.conv_w = a.conv_b = nullptr; a.conv_bias_first = 0; a.prep = nullptr;
     size_t lds = sizeof(float) * (size_t)K * 5;
     if (!router) {
         int rc = ensure_dynamic_lds((const void *)vq_mfma_kernel<ZT>, lds);
@@ -1187,7 +1243,7 @@ static int dev_knob(const char *) { return 0; }      // the environment knobs ex
 template <bool ALIGNED, bool CONV>
 static int launch_filter(const float *z, int64_t hw, int64_t N, const float *cb, int K, int64_t *idx, float *zq,
                          VqWs ws, float beta, int legacy, float *loss, hipStream_t s, const RouterArgs *router,
-                         int64_t router_blocks, size_t router_lds, const cgic_conv1x1 *qc)
+                         int64_t router_blocks, size_t router_lds, const cgic_conv1x1 *qc, const void *prepared)
 {
     int cus = 0;
     int rc = device_cu_count(&cus);
@@ -1202,6 +1258,7 @@ static int launch_filter(const float *z, int64_t hw, int64_t N, const float *cb,
     a.sq_partial = loss ? ws.partial : nullptr; a.ticket = ws.ticket; a.beta = beta; a.legacy = legacy; a.loss = loss;
     a.nblk = (unsigned int)nblk;
     a.conv_w = CONV ? qc->weight : nullptr; a.conv_b = CONV ? qc->bias : nullptr; a.conv_bias_first = CONV ? qc->bias_first : 0;
+    a.prep = prepared;
     // groups per workgroup.  Router workgroups in front: the `late` VQ workgroups that must wait for a router's CU
     // (~11 us at 256x256, ~`delta` groups of VQ work) own `g_late` groups, the others `g_early`, a multiple of 4
     int64_t per = (ngroups + nblk - 1) / nblk, g_early = per, g_late = per, n_early = nblk;
@@ -1248,11 +1305,11 @@ static int launch_filter(const float *z, int64_t hw, int64_t N, const float *cb,
 
 static int vq_dispatch(const float *z, int64_t hw, int64_t N, const float *codebook, int K, int64_t *indices, float *z_q,
                        VqWs ws, float beta, int legacy, float *loss, hipStream_t s, const RouterArgs *router,
-                       int64_t router_blocks, size_t router_lds, const cgic_conv1x1 *qc)
+                       int64_t router_blocks, size_t router_lds, const cgic_conv1x1 *qc, const void *prepared)
 {
     const int force_zt = dev_knob("CGIC_VQ_ZT");          // dev: tile count of the exact loop
     if (!dev_knob("CGIC_VQ_EXACT") && K % 64 == 0 && K <= kVqfMaxK) {
-#define CGIC_VQF_LAUNCH(AL, CV) launch_filter<AL, CV>(z, hw, N, codebook, K, indices, z_q, ws, beta, legacy, loss, s, router, router_blocks, router_lds, qc)
+#define CGIC_VQF_LAUNCH(AL, CV) launch_filter<AL, CV>(z, hw, N, codebook, K, indices, z_q, ws, beta, legacy, loss, s, router, router_blocks, router_lds, qc, prepared)
         if (hw % kVqfGroup == 0) return qc ? CGIC_VQF_LAUNCH(true, true) : CGIC_VQF_LAUNCH(true, false);
         return qc ? CGIC_VQF_LAUNCH(false, true) : CGIC_VQF_LAUNCH(false, false);
 #undef CGIC_VQF_LAUNCH
@@ -1282,14 +1339,35 @@ extern "C" size_t cgic_vq_workspace_bytes(int64_t n_vectors)
     return sizeof(double) * (size_t)((n_vectors + 15) / 16 + 1);
 }
 
+extern "C" size_t cgic_vq_prepared_bytes(int K)
+{
+    // the filter path's LDS image + 16 bytes (the two maxima); 0: this K has no filter path (nothing to prepare)
+    return (K > 0 && K % 64 == 0 && K <= kVqfMaxK) ? vqf_lds_bytes(K) + 16 : 0;
+}
+
+extern "C" int cgic_vq_prepare_f32(const float *codebook, int K, int e_dim, void *prepared, cgic_stream_t stream)
+{
+    CGIC_REQUIRE(codebook && prepared, CGIC_ERR_INVALID, "vq_prepare: NULL argument");
+    CGIC_REQUIRE(e_dim == 4, CGIC_ERR_UNSUPPORTED, "vq_prepare: e_dim=%d; this build implements embed_dim == 4", e_dim);
+    CGIC_REQUIRE(cgic_vq_prepared_bytes(K) != 0, CGIC_ERR_UNSUPPORTED, "vq_prepare: K=%d has no filter path (need K %% 64 == 0, K <= %d)", K, kVqfMaxK);
+    CGIC_REQUIRE(((uintptr_t)prepared & 15) == 0, CGIC_ERR_INVALID, "vq_prepare: the image must be 16-byte aligned");
+    const size_t lds = vqf_lds_bytes(K);
+    int rc = ensure_dynamic_lds((const void *)vq_prepare_kernel, lds);
+    if (rc) return rc;
+    hipLaunchKernelGGL(vq_prepare_kernel, dim3(1), dim3(kVqfThreads), lds, (hipStream_t)stream, codebook, K, (uint4 *)prepared);
+    return launch_check("vq_prepare_kernel");
+}
+
 extern "C" int cgic_vq_forward_f32(const float *z, int64_t B, int64_t hw, const float *codebook, int K,
                                    int e_dim, float beta, int legacy, int64_t *indices, float *z_q,
                                    float *loss, int64_t *hist, void *workspace, const cgic_conv1x1 *quant_conv,
-                                   cgic_stream_t stream)
+                                   const void *prepared, cgic_stream_t stream)
 {
     int rc = vq_check(z, B, hw, codebook, K, e_dim, loss, workspace, hist && !indices);
     if (rc) return rc;
     rc = conv_check(quant_conv);
+    if (rc) return rc;
+    rc = prepared_check(prepared, K);
     if (rc) return rc;
     const int64_t N = B * hw;
     if (N == 0) return CGIC_OK;
@@ -1297,7 +1375,7 @@ extern "C" int cgic_vq_forward_f32(const float *z, int64_t B, int64_t hw, const 
     VqWs ws;
     rc = vq_ws(loss ? workspace : nullptr, s, &ws);
     if (rc) return rc;
-    rc = vq_dispatch(z, hw, N, codebook, K, indices, z_q, ws, beta, legacy, loss, s, nullptr, 0, 0, quant_conv);
+    rc = vq_dispatch(z, hw, N, codebook, K, indices, z_q, ws, beta, legacy, loss, s, nullptr, 0, 0, quant_conv, prepared);
     if (rc == CGIC_OK && hist) rc = launch_hist(indices, N, K, hist, s);
     return rc;
 }
@@ -1307,11 +1385,13 @@ extern "C" int cgic_vq_forward_route_f32(const float *z, int64_t B, int64_t hw, 
                                          void *workspace, const float *e16, const float *e8, int64_t h16, int64_t w16,
                                          double coarse_ratio, double medium_ratio, int per_image, int32_t *mask_c,
                                          int32_t *mask_m, int32_t *mask_f, float *gate, int *mode_out,
-                                         const cgic_conv1x1 *quant_conv, cgic_stream_t stream)
+                                         const cgic_conv1x1 *quant_conv, const void *prepared, cgic_stream_t stream)
 {
     int rc = vq_check(z, B, hw, codebook, K, e_dim, loss, workspace, false);
     if (rc) return rc;
     rc = conv_check(quant_conv);
+    if (rc) return rc;
+    rc = prepared_check(prepared, K);
     if (rc) return rc;
     if (mode_out) *mode_out = cgic_router_mode(coarse_ratio, medium_ratio);
     const int64_t N = B * hw;
@@ -1327,7 +1407,7 @@ extern "C" int cgic_vq_forward_route_f32(const float *z, int64_t B, int64_t hw, 
     VqWs ws;
     rc = vq_ws(loss ? workspace : nullptr, s, &ws);
     if (rc) return rc;
-    return vq_dispatch(z, hw, N, codebook, K, indices, z_q, ws, beta, legacy, loss, s, &r, nseg, rlds, quant_conv);
+    return vq_dispatch(z, hw, N, codebook, K, indices, z_q, ws, beta, legacy, loss, s, &r, nseg, rlds, quant_conv, prepared);
 }
 
 extern "C" int cgic_vq_forward_valu_f32(const float *z, int64_t B, int64_t hw, const float *codebook, int K,

@@ -12,13 +12,18 @@ import torch
 
 from .codec import GrainCodec, decoder_mode
 from .entropy import entropy_maps
-from .quantize import _vq_forward, vq_forward_route
+from .quantize import _vq_forward, vq_forward_route, prepare_codebook
 from .router import TripleGrainFixedEntropyRouter
 
 
 class HotPathPipeline:
-    def __init__(self, quantizer, coarse_ratio, medium_ratio, chunks=1, frequency=None, fork_vq=False, fuse_router=True):
+    def __init__(self, quantizer, coarse_ratio, medium_ratio, chunks=1, frequency=None, fork_vq=False, fuse_router=True,
+                 prepare=False):
         self.vq = quantizer
+        # prepare=True: inference against a codebook that does not change -- the VQ kernel's codebook image is made once
+        # (quantize.prepare_codebook, a snapshot of the weights NOW; refresh_codebook() after changing them) instead of by
+        # every workgroup of every launch
+        self.prepared = prepare_codebook(quantizer.embedding.weight) if prepare else None
         self.router = TripleGrainFixedEntropyRouter(coarse_ratio, medium_ratio, per_image=True)
         self.codec = GrainCodec(frequency if frequency is not None else quantizer.embedding_counter,
                                 quantizer.embedding.weight)
@@ -31,12 +36,16 @@ class HotPathPipeline:
         self._streams = None
         self._side = None
 
+    def refresh_codebook(self):
+        if self.prepared is not None:
+            self.prepared = prepare_codebook(self.vq.embedding.weight)
+
     def _get_streams(self, device):
         if self._streams is None or self._streams[0].device != device:
             self._streams = [torch.cuda.Stream(device) for _ in range(self.chunks)]
         return self._streams
 
-    def _chain(self, x, z, hist, decode):
+    def _chain(self, x, z, hist, decode, decoder=None):
         if self.fork_vq == 2:
             # entropy, then the router on a side stream next to the VQ kernel
             cur = torch.cuda.current_stream(x.device)
@@ -50,7 +59,7 @@ class HotPathPipeline:
                 mask, _, _, mode = self.router(e16, e8, want_gate=False)
                 join = torch.cuda.Event()
                 join.record(self._side)
-            zq, loss, ind = _vq_forward(z, self.vq.embedding.weight, self.vq.beta, self.vq.legacy, None)
+            zq, loss, ind = _vq_forward(z, self.vq.embedding.weight, self.vq.beta, self.vq.legacy, None, prepared=self.prepared)
             cur.wait_event(join)
         elif self.fork_vq:
             cur = torch.cuda.current_stream(x.device)
@@ -60,7 +69,7 @@ class HotPathPipeline:
             fork.record(cur)
             self._side.wait_event(fork)
             with torch.cuda.stream(self._side):
-                zq, loss, ind = _vq_forward(z, self.vq.embedding.weight, self.vq.beta, self.vq.legacy, None)
+                zq, loss, ind = _vq_forward(z, self.vq.embedding.weight, self.vq.beta, self.vq.legacy, None, prepared=self.prepared)
                 join = torch.cuda.Event()
                 join.record(self._side)
             e8, e16 = entropy_maps(x)
@@ -69,15 +78,15 @@ class HotPathPipeline:
         elif not self.fuse_router:
             e8, e16 = entropy_maps(x)
             mask, _, _, mode = self.router(e16, e8, want_gate=False)
-            zq, loss, ind = _vq_forward(z, self.vq.embedding.weight, self.vq.beta, self.vq.legacy, None)
+            zq, loss, ind = _vq_forward(z, self.vq.embedding.weight, self.vq.beta, self.vq.legacy, None, prepared=self.prepared)
         else:
             e8, e16 = entropy_maps(x)
             # VQ and the per-image router share one launch (the router rides in the VQ kernel's shadow)
             zq, loss, ind, mask, _, mode = vq_forward_route(
                 z, self.vq.embedding.weight, self.vq.beta, self.vq.legacy, e16, e8,
-                self.router.coarse_grain_ratio, self.router.medium_grain_ratio, per_image=True)
+                self.router.coarse_grain_ratio, self.router.medium_grain_ratio, per_image=True, prepared=self.prepared)
         comp = self.codec.compress(ind, mask, mode, hist=hist)      # usage histogram rides on the coder launch
-        dec = self.codec.decompress(comp) if decode else None
+        dec = self.codec.decompress(comp, decoder=decoder) if decode else None
         return {"e8": e8, "e16": e16, "mask": mask, "mode": mode, "z_q": zq, "loss": loss, "ind": ind,
                 "comp": comp, "dec": dec}
 
@@ -265,25 +274,37 @@ class LaneStream:
     ONE batch into an encode and a decode graph tied by events; every event is a graph boundary, ~7 us on the device,
     and it was measured no faster than one stream.  Independent lanes: 53 -> 87 GPixel/s at B=64 of 256x256, 4 lanes.)
 
-    Per lane: one graph per slot, and (ring=True) one graph that holds the lane's whole rotation of slots back to
-    back -- successive graph launches on one stream are ~7 us apart on the device, kernels inside a graph are not.
-    `submit(n)` replays the ring whenever a lane stands at the start of its rotation with a whole rotation left to do.
+    Graphs.  A lane's work is a sequence of steps over its slots in rotation.  `submit(n)` cuts each lane's share into
+    runs of at most `max_ring` consecutive steps and replays ONE hipGraph per run (successive graph launches on one
+    stream are ~7 us apart on the device and cost the host tens of microseconds each; kernels inside a graph are
+    back to back).  A graph is keyed by (first slot position, number of steps) and captured the first time it is
+    needed -- `prepare(n)` captures what the next `submit(n)` will replay, so that no capture lands inside a timed or
+    latency-critical region.  `ring=False` keeps one graph per step.
+    Every graph owns the output buffers of the steps it holds.  After a replay, `slot.enc` / `slot.dec` name the
+    buffers of the graph that ran the slot LAST (a slot refilled between two submits is therefore always read back
+    from the launch that really processed the new input, whichever mix of graphs the submits took).
     Results are bit-identical to the one-stream order: same kernels, same inputs, no shared scratch between slots
     (per-launch tickets are library-owned, a captured launch keeps its own).
 
     slots: list of (x [B,3,H,W], z [B,4,H/4,W/4]) device tensors; the caller refills a slot's tensors in place after
     `join()` to feed new data.  `hist` (int64 [n_e], optional) accumulates the usage histogram of everything submitted.
+    `launch_threads=True` hands each lane's replays to a thread of its own (graph launches release the GIL): the lanes
+    start together instead of one host launch after the other.
     """
 
     def __init__(self, quantizer, coarse_ratio, medium_ratio, slots, lanes=4, frequency=None, hist=None, decode=True,
-                 graph=True, ring=True, fuse_router=True, decoder=None):
+                 graph=True, ring=True, fuse_router=True, decoder=None, max_ring=8, launch_threads=False, quick_start=True,
+                 prepare=True):
         if not slots:
             raise ValueError("LaneStream needs at least one slot")
-        self.pipe = HotPathPipeline(quantizer, coarse_ratio, medium_ratio, frequency=frequency, fuse_router=fuse_router)
+        # prepare: a stream of batches is inference against ONE codebook -- its image is made once, when capture() runs
+        # (a captured launch holds a snapshot of the codebook either way: HotPathPipeline.prepare)
+        self.pipe = HotPathPipeline(quantizer, coarse_ratio, medium_ratio, frequency=frequency, fuse_router=fuse_router, prepare=prepare)
         self.hist = hist
         self.decode = bool(decode)
         self.graph = bool(graph)
         self.ring = bool(ring) and self.graph
+        self.max_ring = max(1, int(max_ring)) if self.ring else 1
         self.slots = [BatchSlot(x, z) for x, z in slots]
         self.device = self.slots[0].x.device
         nl = max(1, min(int(lanes), len(self.slots)))
@@ -291,66 +312,134 @@ class LaneStream:
         self.decoder = decoder if decoder is not None else ("throughput" if nl > 1 else "latency")
         with torch.cuda.device(self.device):
             streams = distinct_queue_streams(self.device, nl)          # one hardware queue per lane, measured
-        self.lanes = [{"slots": self.slots[j::nl], "pos": 0, "ring": None, "stream": streams[j]} for j in range(nl)]
+        self.lanes = [{"slots": self.slots[j::nl], "pos": 0, "stream": streams[j], "graphs": {}} for j in range(nl)]
+        # quick_start: a lane's first run of a submit is split into (1 step) + (the rest): a graph launch costs the host
+        # ~12 us + ~0.55 us per kernel node, and lane j only starts after the launches of lanes 0..j-1
+        self.quick_start = bool(quick_start) and nl > 1
+        self._pool = None
+        if launch_threads and nl > 1:
+            from concurrent.futures import ThreadPoolExecutor
+            self._pool = ThreadPoolExecutor(max_workers=nl, thread_name_prefix="cgic-lane")
         self._t = 0
         self._captured = False
 
     def _step(self, s):
-        with decoder_mode(self.decoder):
-            s.enc = self.pipe._chain(s.x, s.z, self.hist, self.decode)
-        s.dec = s.enc["dec"]
+        """one batch through the hot path on the current stream -> (enc dict, dec tuple)"""
+        enc = self.pipe._chain(s.x, s.z, self.hist, self.decode, decoder=self.decoder)
+        return enc, enc["dec"]
 
     def capture(self, warmup=2):
-        """run every slot eagerly (uploads tables, sets function attributes, creates the ticket pools), then capture"""
+        """run every slot eagerly (uploads tables, sets function attributes, creates the ticket pools) and capture the
+        one-step graph of every slot"""
         cur = torch.cuda.current_stream(self.device)
         side = self.lanes[0]["stream"]
         side.wait_stream(cur)
         with torch.cuda.stream(side):
+            self.pipe.refresh_codebook()                # the weights as they are now
             for s in self.slots:
                 for _ in range(warmup):
-                    self._step(s)
-            if self.graph:
-                for s in self.slots:
-                    s.g_enc = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(s.g_enc, stream=side):
-                        self._step(s)
-                for lane in self.lanes:
-                    if self.ring and len(lane["slots"]) > 1:
-                        lane["ring"] = torch.cuda.CUDAGraph()
-                        with torch.cuda.graph(lane["ring"], stream=side):
-                            for s in lane["slots"]:
-                                self._step(s)                 # s.enc / s.dec now name the ring's output buffers
+                    s.enc, s.dec = self._step(s)
         cur.wait_stream(side)
+        self._captured = True
+        if self.graph:
+            for lane in self.lanes:
+                for p in range(len(lane["slots"])):
+                    self._graph(lane, p, 1)
         for lane in self.lanes:
             lane["stream"].wait_stream(cur)
-        self._captured = True
+
+    def _graph(self, lane, start, count):
+        """the hipGraph of `count` consecutive steps of `lane` from slot position `start` (captured on first use):
+        (graph, {slot position: (enc, dec) of the LAST step of that slot inside the graph})"""
+        key = (start, count)
+        hit = lane["graphs"].get(key)
+        if hit is not None:
+            return hit
+        m = len(lane["slots"])
+        cur = torch.cuda.current_stream(self.device)
+        st = lane["stream"]
+        st.wait_stream(cur)
+        g = torch.cuda.CUDAGraph()
+        outs = {}
+        with torch.cuda.stream(st):
+            with torch.cuda.graph(g, stream=st):
+                for i in range(count):
+                    p = (start + i) % m
+                    outs[p] = None                    # an earlier step's buffers of this slot go back to the graph's pool
+                    outs[p] = self._step(lane["slots"][p])
+        cur.wait_stream(st)
+        lane["graphs"][key] = (g, outs)
+        return g, outs
+
+    def _plan(self, n):
+        """[(lane, start, count), ...] per lane for the next n batches, without advancing"""
+        L = len(self.lanes)
+        todo = [0] * L
+        for t in range(self._t, self._t + n):
+            todo[t % L] += 1
+        plans = []
+        for j, lane in enumerate(self.lanes):
+            m, pos, runs = len(lane["slots"]), lane["pos"], []
+            c = todo[j]
+            while c:
+                k = min(c, self.max_ring)
+                if self.quick_start and not runs and k > 2:
+                    k = 1                                  # every lane starts after one short launch
+                runs.append((pos, k))
+                pos = (pos + k) % m
+                c -= k
+            plans.append(runs)
+        return plans
+
+    def prepare(self, n):
+        """capture (outside any timed region) every graph the next submit(n) will replay"""
+        if not self._captured:
+            self.capture()
+        if self.graph:
+            for lane, runs in zip(self.lanes, self._plan(n)):
+                for start, count in runs:
+                    self._graph(lane, start, count)
+
+    def _run_lane(self, lane, runs):
+        with torch.cuda.device(self.device), torch.cuda.stream(lane["stream"]):
+            for start, count in runs:
+                self._graph(lane, start, count)[0].replay()
 
     def submit(self, n=1):
         """enqueue the next n batches (batch t on lane t % lanes, slots of a lane in rotation); returns immediately"""
         if not self._captured:
             self.capture()
-        L = len(self.lanes)
-        todo = [0] * L
-        for t in range(self._t, self._t + n):
-            todo[t % L] += 1
+        plans = self._plan(n)
         self._t += n
-        while any(todo):
-            for j, lane in enumerate(self.lanes):              # one launch per lane and turn keeps every queue fed
-                if not todo[j]:
-                    continue
+        if self.graph:
+            for lane, runs in zip(self.lanes, plans):                  # captures (if any are missing) before the first launch
+                for start, count in runs:
+                    self._graph(lane, start, count)
+            if self._pool is not None:
+                for f in [self._pool.submit(self._run_lane, lane, runs) for lane, runs in zip(self.lanes, plans) if runs]:
+                    f.result()
+            else:
+                depth = max(len(r) for r in plans)
+                for i in range(depth):                                  # one launch per lane and turn keeps every queue fed
+                    for lane, runs in zip(self.lanes, plans):
+                        if i < len(runs):
+                            with torch.cuda.stream(lane["stream"]):
+                                self._graph(lane, *runs[i])[0].replay()
+            for lane, runs in zip(self.lanes, plans):
                 m = len(lane["slots"])
-                with torch.cuda.stream(lane["stream"]):
-                    if lane["ring"] is not None and lane["pos"] == 0 and todo[j] >= m:
-                        lane["ring"].replay()
-                        todo[j] -= m
-                        continue
-                    s = lane["slots"][lane["pos"]]
-                    lane["pos"] = (lane["pos"] + 1) % m
-                    if self.graph:
-                        s.g_enc.replay()
-                    else:
-                        self._step(s)
-                    todo[j] -= 1
+                for start, count in runs:
+                    for p, (enc, dec) in self._graph(lane, start, count)[1].items():
+                        lane["slots"][p].enc, lane["slots"][p].dec = enc, dec
+                    lane["pos"] = (start + count) % m
+        else:
+            depth = max(sum(c for _, c in r) for r in plans)
+            for i in range(depth):
+                for lane, runs in zip(self.lanes, plans):
+                    if i < sum(c for _, c in runs):
+                        s = lane["slots"][lane["pos"]]
+                        lane["pos"] = (lane["pos"] + 1) % len(lane["slots"])
+                        with torch.cuda.stream(lane["stream"]):
+                            s.enc, s.dec = self._step(s)
 
     def join(self, stream=None):
         """make `stream` (default: the current one) wait for everything submitted so far"""

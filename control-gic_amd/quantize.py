@@ -91,9 +91,29 @@ def vq_backward(z, weight, idx, g_zq, g_loss, beta, legacy, want_gz=True, want_g
     return gz, gw
 
 
-def _vq_forward(z, weight, beta, legacy, hist, want_zq=True, want_loss=True, kernel="mfma", quant_conv=None, conv_bias_first=False):
+def prepare_codebook(weight):
+    """The codebook image cgic_vq_prepare_f32 makes for the filter path (uint8 tensor; None if this K has no filter path):
+    row norms, the maxima that fix the fp16 scaling and the split MFMA operands -- what every workgroup of every launch
+    otherwise derives from `weight` (torch.sum(embedding.weight**2) of quantize.py:73-75 is per call in the reference too).
+    A SNAPSHOT: pass it only to launches against the same, unchanged weights."""
+    _lib.require_device(weight)
+    wt = weight.detach().contiguous()
+    if wt.dtype != torch.float32 or wt.dim() != 2:
+        raise TypeError("prepare_codebook: fp32 [K, e_dim] weight expected")
+    nbytes = int(_lib.lib().cgic_vq_prepared_bytes(wt.shape[0]))
+    if nbytes == 0:
+        return None
+    img = torch.empty(nbytes, dtype=torch.uint8, device=wt.device)
+    with torch.cuda.device(wt.device):
+        _lib.call("cgic_vq_prepare_f32", _lib.ptr(wt), wt.shape[0], wt.shape[1], _lib.ptr(img), _lib.current_stream(wt.device))
+    return img
+
+
+def _vq_forward(z, weight, beta, legacy, hist, want_zq=True, want_loss=True, kernel="mfma", quant_conv=None, conv_bias_first=False,
+                prepared=None):
     """quant_conv: optional Conv2d(4, 4, 1) (or (weight, bias)) applied to z inside the kernel -- CGIC.quant_conv
-    (model.py:51,110); conv_bias_first selects which of the CPU reference's two rounding sequences to reproduce"""
+    (model.py:51,110); conv_bias_first selects which of the CPU reference's two rounding sequences to reproduce;
+    prepared: prepare_codebook(weight) of the same, unchanged weight (MFMA kernels only)"""
     _lib.require_device(z, weight)
     if z.dtype != torch.float32 or weight.dtype != torch.float32:
         raise TypeError("VectorQuantizer computes in fp32 like the reference; got "
@@ -110,16 +130,17 @@ def _vq_forward(z, weight, beta, legacy, hist, want_zq=True, want_loss=True, ker
         ws = torch.empty(_lib.lib().cgic_vq_workspace_bytes(N), dtype=torch.uint8, device=z.device)
     fn = "cgic_vq_forward_f32" if kernel == "mfma" else "cgic_vq_forward_valu_f32"
     qc, keep = _lib.conv_arg(quant_conv, conv_bias_first)
+    extra = (_lib.ptr(prepared),) if kernel == "mfma" else ()
     with torch.cuda.device(z.device):
         _lib.call(fn, _lib.ptr(z), B, h * w, _lib.ptr(weight), weight.shape[0], C, float(beta), int(bool(legacy)),
-                  _lib.ptr(idx), _lib.ptr(z_q), _lib.ptr(loss), _lib.ptr(hist), _lib.ptr(ws), qc,
+                  _lib.ptr(idx), _lib.ptr(z_q), _lib.ptr(loss), _lib.ptr(hist), _lib.ptr(ws), qc, *extra,
                   _lib.current_stream(z.device))
     del keep
     return z_q, loss, idx
 
 
 def vq_forward_route(z, weight, beta, legacy, e16, e8, coarse_ratio, medium_ratio, per_image=True, want_gate=False,
-                     want_zq=True, want_loss=True, quant_conv=None, conv_bias_first=False):
+                     want_zq=True, want_loss=True, quant_conv=None, conv_bias_first=False, prepared=None):
     """VectorQuantize2.forward and TripleGrainFixedEntropyRouter.forward in ONE launch (the router's per-image
     workgroups ride behind the VQ workgroups; see cgic_vq_forward_route_f32).  Returns
     (z_q, loss, indices, [mask_c, mask_m, mask_f], gate, mode) -- identical to the two separate calls."""
@@ -149,7 +170,7 @@ def vq_forward_route(z, weight, beta, legacy, e16, e8, coarse_ratio, medium_rati
         _lib.call("cgic_vq_forward_route_f32", _lib.ptr(z), B, h * w, _lib.ptr(weight), weight.shape[0], C, float(beta),
                   int(bool(legacy)), _lib.ptr(idx), _lib.ptr(z_q), _lib.ptr(loss), _lib.ptr(ws), _lib.ptr(e16), _lib.ptr(e8),
                   h16, w16, float(coarse_ratio), float(medium_ratio), int(bool(per_image)), _lib.ptr(mc), _lib.ptr(mm),
-                  _lib.ptr(mf), _lib.ptr(gate), ctypes.byref(mode), qc, _lib.current_stream(dev))
+                  _lib.ptr(mf), _lib.ptr(gate), ctypes.byref(mode), qc, _lib.ptr(prepared), _lib.current_stream(dev))
     del keep
     return z_q, loss, idx, [mc, mm, mf], gate, mode.value
 
@@ -207,6 +228,7 @@ class VectorQuantize2(nn.Module):
             state[f"{prefix}embedding_counter.{k}"] = c[int(k):int(k) + 1].clone()
 
     def _load_counter(self, state, prefix, local_metadata, strict, missing, unexpected, errors):
+        self._prepared = None                       # new weights are coming in: the snapshot is stale
         for k in list(state.keys()):
             if k.startswith(prefix + "embedding_counter."):
                 i = int(k[len(prefix) + len("embedding_counter."):])
@@ -237,6 +259,23 @@ class VectorQuantize2(nn.Module):
             self.usage_counter += self.usage_hist.to(self.usage_counter.dtype)
             self.usage_hist.zero_()
 
+    def prepare(self):
+        """Inference: snapshot the codebook image of the HIP kernel once (prepare_codebook) instead of deriving it at the head
+        of every launch.  Used by forward() / indices() while the module is in eval mode and autograd is off; dropped by
+        train() and load_state_dict().  Call it again after changing embedding.weight by hand."""
+        self._prepared = prepare_codebook(self.embedding.weight)
+        return self
+
+    def train(self, mode=True):
+        if mode:
+            self._prepared = None
+        return super().train(mode)
+
+    def _prepared_image(self):
+        if self.training or torch.is_grad_enabled():
+            return None
+        return getattr(self, "_prepared", None)
+
     def forward(self, z):
         if z.dtype != torch.float32:
             z = z.float()                   # (autocast regions hand over fp16 / bf16: the reference quantises in fp32)
@@ -247,14 +286,16 @@ class VectorQuantize2(nn.Module):
             z_q, loss, idx = _VQFunction.apply(z, self.embedding.weight, self.beta, self.legacy, hist)
         else:
             z_q, loss, idx = _vq_forward(z, self.embedding.weight, self.beta, self.legacy, hist, quant_conv=conv,
-                                         conv_bias_first=conv.bias_first if conv is not None else False)
+                                         conv_bias_first=conv.bias_first if conv is not None else False,
+                                         prepared=self._prepared_image())
         if self.training:
             self.fold_usage_hist()
         return z_q, loss, idx
 
     def indices(self, z, kernel="mfma"):
         """argmin only (no z_q / loss): what compress() consumes (model.py:216)."""
-        return _vq_forward(z, self.embedding.weight, self.beta, self.legacy, None, False, False, kernel)[2]
+        return _vq_forward(z, self.embedding.weight, self.beta, self.legacy, None, False, False, kernel,
+                           prepared=self._prepared_image() if kernel == "mfma" else None)[2]
 
 
 VectorQuantizer = VectorQuantize2

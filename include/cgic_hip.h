@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define CGIC_ABI_VERSION 3
+#define CGIC_ABI_VERSION 4
 
 #define CGIC_OK 0
 #define CGIC_ERR_INVALID (-1)     /* bad argument (shape, ratio, NULL pointer ...) */
@@ -74,6 +74,12 @@ int cgic_device_count(void);
  *   workspace device, cgic_vq_workspace_bytes(B*hw) bytes, or NULL iff loss==NULL
  *   quant_conv NULL, or the 1x1 convolution in front of the quantiser (CGIC.quant_conv, model.py:51,110) to apply to
  *            every latent vector first: then `z` is the encoder output h and everything above refers to W h + b
+ *   prepared NULL, or the image cgic_vq_prepare_f32 made of THIS codebook (16-byte aligned, cgic_vq_prepared_bytes(K)
+ *            bytes): what every workgroup otherwise derives from `codebook` at the head of every launch (row norms, the
+ *            maxima that fix the fp16 scaling, the split operands of the candidate filter: torch.sum(embedding.weight**2)
+ *            of quantize.py:73-75 is recomputed by the reference on every call as well).  Inference keeps one codebook for
+ *            thousands of launches: prepare once, pass it along.  The caller re-prepares when the weights change
+ *            (VectorQuantize2 keys it on the weight's version counter); results are identical with and without it.
  * Two implementations behind the same contract, bit-identical results: for K % 64 == 0, K <= 1024 (the reference's
  * 1024 x 4 codebook) an fp16-MFMA candidate filter with an exact fp32 resolve, otherwise the fp32-MFMA loop over
  * every code (no fused quant_conv there: CGIC_ERR_UNSUPPORTED).
@@ -94,9 +100,13 @@ typedef struct cgic_conv1x1 {
 int cgic_conv1x1_rows_f32(const float *rows, int64_t n, const cgic_conv1x1 *conv, float *out, cgic_stream_t stream);
 
 size_t cgic_vq_workspace_bytes(int64_t n_vectors);
+/* bytes of the prepared codebook image (0: this K only has the exact loop, which needs none) / make it (one small launch) */
+size_t cgic_vq_prepared_bytes(int K);
+int cgic_vq_prepare_f32(const float *codebook, int K, int e_dim, void *prepared, cgic_stream_t stream);
 int cgic_vq_forward_f32(const float *z, int64_t B, int64_t hw, const float *codebook, int K, int e_dim,
                         float beta, int legacy, int64_t *indices, float *z_q, float *loss,
-                        int64_t *hist, void *workspace, const cgic_conv1x1 *quant_conv, cgic_stream_t stream);
+                        int64_t *hist, void *workspace, const cgic_conv1x1 *quant_conv, const void *prepared,
+                        cgic_stream_t stream);
 /* cgic_vq_forward_f32 and cgic_router_f32 in ONE launch: the router's per-image workgroups share the grid with
  * the VQ workgroups (neither needs the other's output; both need what precedes them, i.e. the latent and
  * the entropy maps).  Same contracts as the two separate calls. */
@@ -105,7 +115,7 @@ int cgic_vq_forward_route_f32(const float *z, int64_t B, int64_t hw, const float
                               void *workspace, const float *e16, const float *e8, int64_t h16, int64_t w16,
                               double coarse_ratio, double medium_ratio, int per_image, int32_t *mask_c,
                               int32_t *mask_m, int32_t *mask_f, float *gate, int *mode_out,
-                              const cgic_conv1x1 *quant_conv, cgic_stream_t stream);
+                              const cgic_conv1x1 *quant_conv, const void *prepared, cgic_stream_t stream);
 /* same contract, plain-VALU kernel (no MFMA); kept as an independent
  * implementation for cross-checking the MFMA kernel's rounding */
 int cgic_vq_forward_valu_f32(const float *z, int64_t B, int64_t hw, const float *codebook, int K,
@@ -279,7 +289,7 @@ int cgic_decompress_streams(const cgic_table *t, const uint8_t *in, int64_t slot
                             int64_t B, int64_t h, int64_t w, int mode, int64_t *ind_out,
                             int32_t *mask_c_out, int32_t *mask_m_out, int32_t *mask_f_out,
                             const float *codebook, int K, int e_dim, float *z_q, const float *codebook2,
-                            float *z_q2, int32_t *status, void *workspace, cgic_stream_t stream);
+                            float *z_q2, int32_t *status, void *workspace, int decoder, cgic_stream_t stream);
 
 /* ---------------------------------------------------------------------------
  * Three-grain latent merge in front of the quantiser --

@@ -739,8 +739,99 @@ def test_custom_ops_match_the_module_path():
     assert torch.equal(zr.grad, zm.grad) and torch.equal(cr.grad, vq.embedding.weight.grad)
 
 
-@pytest.mark.parametrize("lanes,ring,graph", [(4, True, True), (3, False, True), (2, True, False), (1, True, True)])
-def test_lane_stream_independent_streams_are_bit_identical(lanes, ring, graph):
+def test_prepared_codebook_image_changes_nothing():
+    """cgic_vq_prepare_f32: the codebook image made once == the image every workgroup derives itself -- indices, z_q, loss,
+    masks bit-identical with and without it, for several K, scales, a fused quant_conv, ragged and aligned shapes; the module's
+    prepare() snapshot is dropped by train() and load_state_dict()"""
+    from control_gic_amd.quantize import _vq_forward, vq_forward_route, prepare_codebook
+    g = torch.Generator().manual_seed(5)
+    for K, scale, (B, h, w) in ((1024, 1.0, (3, 16, 16)), (1024, 1.0 / 1024, (2, 16, 24)), (256, 37.0, (1, 20, 12)), (64, 1.0, (2, 8, 8)), (1024, 1.0, (5, 7, 9))):
+        cb = (torch.randn(K, 4, generator=g) * scale).to(DEV)
+        z = (torch.randn(B, 4, h, w, generator=g) * scale).to(DEV)
+        prep = prepare_codebook(cb)
+        assert prep is not None and prep.numel() == cg._lib.lib().cgic_vq_prepared_bytes(K)
+        a = _vq_forward(z, cb, 0.25, True, None)
+        b = _vq_forward(z, cb, 0.25, True, None, prepared=prep)
+        assert torch.equal(a[2], b[2]) and torch.equal(a[0], b[0]) and float(a[1]) == float(b[1])
+        conv = torch.nn.Conv2d(4, 4, 1).to(DEV)
+        a = _vq_forward(z, cb, 0.25, True, None, quant_conv=conv)
+        b = _vq_forward(z, cb, 0.25, True, None, quant_conv=conv, prepared=prep)
+        assert torch.equal(a[2], b[2]) and torch.equal(a[0], b[0]) and float(a[1]) == float(b[1])
+        if h % 4 == 0 and w % 4 == 0:
+            e16 = torch.rand(B, h // 4, w // 4, generator=g).to(DEV) * 2.6
+            e8 = torch.rand(B, h // 2, w // 2, generator=g).to(DEV) * 2.6
+            a = vq_forward_route(z, cb, 0.25, True, e16, e8, 0.1, 0.8)
+            b = vq_forward_route(z, cb, 0.25, True, e16, e8, 0.1, 0.8, prepared=prep)
+            assert torch.equal(a[2], b[2]) and torch.equal(a[0], b[0]) and all(torch.equal(x, y) for x, y in zip(a[3], b[3]))
+    assert cg._lib.lib().cgic_vq_prepared_bytes(2048) == 0 and prepare_codebook(torch.randn(2048, 4).to(DEV)) is None
+    # degenerate codebooks (all zero / non-finite): the image carries the maxima that switch the filter off
+    for cbk in (torch.zeros(1024, 4), torch.full((1024, 4), float("nan"))):
+        cbk = cbk.to(DEV)
+        z = torch.randn(2, 4, 8, 8, generator=g).to(DEV)
+        a = _vq_forward(z, cbk, 0.25, True, None)
+        b = _vq_forward(z, cbk, 0.25, True, None, prepared=prepare_codebook(cbk))
+        assert torch.equal(a[2], b[2])
+    vq = _make_vq(torch.randn(1024, 4, generator=g).numpy())
+    z = torch.randn(2, 4, 16, 16, generator=g).to(DEV)
+    with torch.no_grad():
+        ref = vq(z)
+        vq.prepare()
+        assert vq._prepared_image() is not None
+        got = vq(z)
+        assert torch.equal(ref[2], got[2]) and torch.equal(ref[0], got[0]) and torch.equal(vq.indices(z), ref[2])
+    assert vq._prepared_image() is None                 # autograd on: the live weights
+    vq.train()
+    assert getattr(vq, "_prepared", None) is None
+    vq.eval().prepare()
+    vq.load_state_dict(vq.state_dict())
+    assert vq._prepared is None
+
+
+def test_decoder_choice_is_per_call_two_threads():
+    """the prefix decoder is an argument of each cgic_decompress_streams call (ABI 4), not a process-wide switch: two threads
+    decode the same batch at the same time, one per decoder, on their own streams, and both match the one-thread result"""
+    import threading
+    g = torch.Generator().manual_seed(9)
+    vq = _make_vq(torch.randn(1024, 4, generator=g).numpy())
+    vq.usage_counter.copy_(torch.arange(1024, 0, -1, dtype=torch.float32))
+    codec = cg.GrainCodec(vq.embedding_counter, vq.embedding.weight)
+    B, h, w = 6, 64, 64
+    ind = torch.randint(0, 1024, (B, h, w), generator=g).to(DEV)
+    e16 = (torch.rand(B, h // 4, w // 4, generator=g) * 2.6).to(DEV)
+    e8 = (torch.rand(B, h // 2, w // 2, generator=g) * 2.6).to(DEV)
+    mask, _, _, mode = cg.TripleGrainFixedEntropyRouter(0.1, 0.8, per_image=True)(e16, e8)
+    comp = codec.compress(ind, mask, mode)
+    ref = codec.decompress(comp, decoder="latency")
+    torch.cuda.synchronize()
+    out, err = {}, []
+
+    def work(name):
+        try:
+            st = torch.cuda.Stream()
+            with torch.cuda.stream(st):
+                for it in range(40):
+                    if it % 2:
+                        r = codec.decompress(comp, decoder=name)            # named in the call
+                    else:
+                        with cg.decoder_mode(name):                         # or the thread's default
+                            r = codec.decompress(comp)
+                    assert torch.equal(r[0], ref[0]) and torch.equal(r[2], ref[2]) and int(r[3].abs().max()) == 0
+                out[name] = r
+            st.synchronize()
+        except Exception as e:          # noqa: BLE001 -- reported by the main thread
+            err.append((name, repr(e)))
+
+    ts = [threading.Thread(target=work, args=(n,)) for n in ("latency", "throughput")]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    assert not err, err
+    assert set(out) == {"latency", "throughput"}
+    with pytest.raises(ValueError):
+        codec.decompress(comp, decoder="fastest")
+
+
+@pytest.mark.parametrize("lanes,ring,graph,threads", [(4, True, True, False), (4, True, True, True), (3, False, True, False), (2, True, False, False), (1, True, True, False)])
+def test_lane_stream_independent_streams_are_bit_identical(lanes, ring, graph, threads):
     """pipeline.LaneStream (batch t on HIP stream t % lanes, one ring graph per lane, NO dependency between the lanes: up to
     `lanes` batches in flight) leaves exactly what the one-stream order leaves in every slot -- streams, indices, z_q, loss,
     masks, decoded rows -- and an exact usage histogram, whatever mix of ring and per-slot graphs a submit() takes"""
@@ -751,7 +842,7 @@ def test_lane_stream_independent_streams_are_bit_identical(lanes, ring, graph):
     shapes = [(4, 64, 96), (4, 64, 96), (2, 128, 64), (4, 64, 96), (3, 32, 32), (4, 64, 96), (4, 64, 96), (1, 256, 256)]
     slots = [(torch.rand(b, 3, H, W, generator=g).to(DEV), torch.randn(b, 4, H // 4, W // 4, generator=g).to(DEV)) for b, H, W in shapes]
     hist = torch.zeros(1024, dtype=torch.int64, device=DEV)
-    ls = pl.LaneStream(vq, 0.1, 0.8, slots, lanes=lanes, hist=hist, ring=ring, graph=graph)
+    ls = pl.LaneStream(vq, 0.1, 0.8, slots, lanes=lanes, hist=hist, ring=ring, graph=graph, max_ring=3, launch_threads=threads)
     ls.capture()
     torch.cuda.synchronize()
     hist.zero_()
@@ -785,6 +876,50 @@ def test_lane_stream_independent_streams_are_bit_identical(lanes, ring, graph):
     torch.cuda.synchronize()
     assert torch.equal(hist, hist_ref)
     assert int(hist.sum()) == sum(runs[k] * shapes[k][0] * (shapes[k][1] // 4) * (shapes[k][2] // 4) for k in range(len(slots)))
+
+
+@pytest.mark.parametrize("lanes,max_ring,threads,one", [(2, 8, False, True), (2, 2, True, False), (4, 3, False, False), (1, 8, False, True), (4, 8, False, True)])
+def test_lane_stream_refilled_slots_between_partial_submits(lanes, max_ring, threads, one):
+    """slots are refilled IN PLACE between submits whose lengths are not multiples of the rotation: every slot must be read
+    back from the launch that really processed its new input, whichever graph (one step, a run of a rotation, a run that
+    wraps around) the submit took (round-2 advisor finding: per-slot graphs and ring graphs used to own different output
+    buffers and `slot.enc` named the ring's)"""
+    import control_gic_amd.pipeline as pl
+    g = torch.Generator().manual_seed(77)
+    vq = _make_vq(torch.randn(1024, 4, generator=g).numpy())
+    vq.usage_counter.copy_(torch.arange(1024, 0, -1, dtype=torch.float32))
+    n_slots = 4
+    slots = [(torch.rand(3, 3, 64, 64, generator=g).to(DEV), torch.randn(3, 4, 16, 16, generator=g).to(DEV)) for _ in range(n_slots)]
+    ls = pl.LaneStream(vq, 0.1, 0.8, slots, lanes=lanes, max_ring=max_ring, launch_threads=threads, quick_start=one)
+    ls.capture()
+    ref_pipe = pl.HotPathPipeline(vq, 0.1, 0.8)
+    L = len(ls.lanes)
+    per_lane = [len(slots[j::L]) for j in range(L)]
+    t = 0
+    for rnd, n in enumerate((4, 3, 5, 1, 2, 7, 9)):
+        torch.cuda.synchronize()
+        for x, z in slots:                               # new content in the same tensors
+            x.copy_(torch.rand(x.shape, generator=g))
+            z.copy_(torch.randn(z.shape, generator=g))
+        torch.cuda.synchronize()
+        ls.fork()
+        if rnd % 2:
+            ls.prepare(n)
+        ls.submit(n)
+        ls.join()
+        torch.cuda.synchronize()
+        ran = set()
+        for k in range(t, t + n):
+            lane = k % L
+            ran.add(lane + L * ((k // L) % per_lane[lane]))
+        t += n
+        for k in ran:
+            r = ref_pipe.run(slots[k][0], slots[k][1], None, decode=True)[0]
+            s = ls.slots[k]
+            assert s.enc["comp"].to_host() == r["comp"].to_host(), (rnd, k)
+            assert torch.equal(s.enc["ind"], r["ind"]) and torch.equal(s.enc["z_q"], r["z_q"]), (rnd, k)
+            assert all(torch.equal(a, b) for a, b in zip(s.enc["mask"], r["mask"])), (rnd, k)
+            assert torch.equal(s.dec[0], r["dec"][0]) and torch.equal(s.dec[2], r["dec"][2]) and int(s.dec[3].abs().max()) == 0, (rnd, k)
 
 
 def test_batch_stream_two_stream_schedule_is_bit_identical():

@@ -21,7 +21,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(l, name), f"{name} declared in cgic_hip.h but not exported"
     assert declared == set(_lib.PROTOTYPES), "ctypes prototype table out of sync with the header"
-    assert _lib.lib().cgic_abi_version() == 3
+    assert _lib.lib().cgic_abi_version() == 4
 
 
 def test_device_count_does_not_abort_without_gpu():
@@ -111,13 +111,13 @@ def test_product_path_refuses_cpu_tensors():
 
 def test_argument_validation_happens_before_any_launch():
     l = _lib.lib()
-    assert l.cgic_vq_forward_f32(None, 1, 16, None, 1024, 4, 0.25, 1, None, None, None, None, None, None, None) == _lib.ERR_INVALID
+    assert l.cgic_vq_forward_f32(None, 1, 16, None, 1024, 4, 0.25, 1, None, None, None, None, None, None, None, None) == _lib.ERR_INVALID
     one = ctypes.c_void_p(16)
-    assert l.cgic_vq_forward_f32(one, 1, 16, one, 1024, 3, 0.25, 1, None, None, None, None, None, None, None) == _lib.ERR_UNSUPPORTED
+    assert l.cgic_vq_forward_f32(one, 1, 16, one, 1024, 3, 0.25, 1, None, None, None, None, None, None, None, None) == _lib.ERR_UNSUPPORTED
     assert b"embed_dim == 4" in l.cgic_last_error()
-    assert l.cgic_vq_forward_f32(one, 1, 16, one, 1000, 4, 0.25, 1, None, None, None, None, None, None, None) == _lib.ERR_UNSUPPORTED
+    assert l.cgic_vq_forward_f32(one, 1, 16, one, 1000, 4, 0.25, 1, None, None, None, None, None, None, None, None) == _lib.ERR_UNSUPPORTED
     conv = _lib.Conv1x1(None, None, 0)
-    assert l.cgic_vq_forward_f32(one, 1, 16, one, 1024, 4, 0.25, 1, None, None, None, None, None, ctypes.byref(conv), None) == _lib.ERR_INVALID      # quant_conv without a weight
+    assert l.cgic_vq_forward_f32(one, 1, 16, one, 1024, 4, 0.25, 1, None, None, None, None, None, ctypes.byref(conv), None, None) == _lib.ERR_INVALID      # quant_conv without a weight
     assert l.cgic_vq_backward_f32(one, 1, 16, one, 1024, 4, None, None, None, 0.25, 1, None, None, None, None) == _lib.ERR_INVALID
     assert l.cgic_vq_backward_f32(one, 1, 16, one, 1024, 4, one, None, None, 0.25, 1, None, one, None, None) == _lib.ERR_INVALID          # codebook gradient without workspace
     # router: k > n is an IndexError in the reference
