@@ -106,9 +106,7 @@ class HotPath:
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
             self.step()
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, stream=side):
-                self.step()
+        g, _ = self.cg.capture_graph(self.step, side)
         torch.cuda.current_stream().wait_stream(side)
         self.graph = g
         return g
@@ -132,11 +130,13 @@ def graph_kernel_time(fn, per_graph=20, reps=5):
     torch.cuda.synchronize()
     side = torch.cuda.Stream()
     side.wait_stream(torch.cuda.current_stream())
+    import control_gic_amd as cg
+
+    def body():
+        for _ in range(per_graph):
+            fn()
+    g, _ = cg.capture_graph(body, side)
     with torch.cuda.stream(side):
-        g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g, stream=side):
-            for _ in range(per_graph):
-                fn()
         g.replay()
         side.synchronize()
         s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -200,12 +200,20 @@ def saturated_launch_time(hp, lanes=4, per_graph=20, reps=6):
     return best * 1e6 / (per_graph * lanes)
 
 
-def cpu_baseline(x, z, cb, ratio, budget_s=12.0):
-    """the oracle (a scalar C port of the reference algorithm) on ONE host core, same workload,
-    bounded sample of the batch"""
+def cpu_baseline(x, z, cb, ratio, budget_s=12.0, threads=None):
+    """the oracle (a scalar C port of the reference algorithm) on the HOST'S CORES: the same workload, images in parallel over
+    `threads` worker threads (the C calls release the GIL; default: every core the process may run on, at most 64), bounded
+    sample; the one-core figure of the same port is kept next to it.  SURVEY.md 8(d): the reference itself runs on torch's
+    thread pool (inference.py:157-170)."""
+    from concurrent.futures import ThreadPoolExecutor
     from oracle import cgic_oracle as orc
     htab = orc.HuffmanTable(zipf_freq())
     H, W = x.shape[2], x.shape[3]
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    threads = max(1, min(int(threads) if threads else avail, 64))
 
     def one(b):
         e8 = orc.entropy(x[b:b + 1], 8)
@@ -218,16 +226,36 @@ def cpu_baseline(x, z, cb, ratio, budget_s=12.0):
         orc.gather(dind, cb)
         return streams
 
+    def timed(nthreads, budget):
+        stop = [False]
+        counts = [0] * nthreads
+
+        def worker(k):
+            i = k
+            while not stop[0]:
+                one(i % x.shape[0])
+                counts[k] += 1
+                i += nthreads
+
+        t0 = time.perf_counter()
+        with ThreadPoolExecutor(max_workers=nthreads) as ex:
+            futs = [ex.submit(worker, k) for k in range(nthreads)]
+            time.sleep(budget)
+            stop[0] = True
+            for f in futs:
+                f.result()
+        dt = time.perf_counter() - t0
+        return sum(counts), dt
+
     one(0)                                   # warm caches / page in the library
-    t0 = time.perf_counter()
-    n = 0
-    while time.perf_counter() - t0 < budget_s:
-        one(n % x.shape[0])
-        n += 1
-    dt = time.perf_counter() - t0
-    return {"value": round(n * H * W / dt / 1e6, 4), "unit": "MPixels/s", "cores": 1, "kind": "port",
-            "sample": f"{n} images of the same workload ({H}x{W} each, cycling through the batch), encode+decode hot "
-                      f"path, oracle/cgic_oracle.c on one thread, {dt:.1f} s; host has {os.cpu_count()} logical cores"}
+    n1, dt1 = timed(1, budget_s / 3)
+    nN, dtN = timed(threads, budget_s) if threads > 1 else (n1, dt1)
+    one_core = round(n1 * H * W / dt1 / 1e6, 4)
+    return {"value": round(nN * H * W / dtN / 1e6, 4), "unit": "MPixels/s", "cores": threads, "kind": "port",
+            "cpu_baseline_1core": one_core,
+            "sample": f"{nN} images of the same workload ({H}x{W} each, cycling through the batch), encode+decode hot "
+                      f"path, oracle/cgic_oracle.c, {threads} worker threads (one image each at a time) for {dtN:.1f} s; one thread: {n1} images "
+                      f"in {dt1:.1f} s; host has {os.cpu_count()} logical cores, {avail} available to this process"}
 
 
 def check_against_oracle(out, x, z, cb, ratio, images=None):
@@ -294,6 +322,60 @@ def mask_mismatch(hp, x, z, cb, ratio):
     return {"images": B, "mask_elements": n_elems, "differing_mask_elements": diff_elems, "images_with_a_difference": int(diff_images),
             "bin_files": files, "differing_bin_files": int(diff_files), "max_abs_entropy_diff": max_de,
             "note": "GPU entropy -> GPU router vs oracle entropy -> oracle router on the same pixels; given equal masks every byte is identical (bpp_match)"}
+
+
+def mask_flip_families(dev, z, cb, vq, codec, ratio):
+    """pixels -> masks -> bytes on TIE-HEAVY content (round-2 verdict, item 3): four synthetic 8-bit families of 64 images of
+    256x256 (quantised noise, smooth gradients + faint texture, flat regions with edges, 8x8-blocky) and 8 tiles of 768x768,
+    GPU entropy -> GPU router -> GPU coder against the REFERENCE'S OWN ARITHMETIC for the entropy maps (oracle/entropy_torch.py:
+    the same torch CPU operators on the same shapes as CGIC/models/model.py:433-483, pinned bit for bit against the real class
+    in the build container) -> oracle router -> oracle coder, same latent indices on both sides."""
+    from oracle import cgic_oracle as orc, entropy_torch as et
+    from oracle.content_families import families
+    from control_gic_amd.quantize import vq_forward_route
+    htab = orc.HuffmanTable(zipf_freq())
+
+    def run(x, zz):
+        B, H, W = x.shape[0], x.shape[2], x.shape[3]
+        h, w = H // 4, W // 4
+        xd, zd = torch.from_numpy(x).to(dev), torch.from_numpy(zz).to(dev)
+        e8, e16 = cg_entropy(xd)
+        _, _, ind, mask, _, mode = vq_forward_route(zd, vq.embedding.weight, 0.25, True, e16, e8, ratio[0], ratio[1], per_image=True)
+        host = codec.compress(ind, mask, mode).to_host()
+        torch.cuda.synchronize()
+        mk = [m.cpu().numpy() for m in mask]
+        ind_h = ind.view(-1, h, w).cpu().numpy()
+        g8, g16 = e8.cpu().numpy(), e16.cpu().numpy()
+        elems = imgs = files = dfiles = 0
+        dmax = 0.0
+        for b0 in range(0, B, 8):
+            xt = torch.from_numpy(x[b0:b0 + 8])
+            r8, r16 = et.entropy_map(xt, 8).numpy(), et.entropy_map(xt, 16).numpy()
+            dmax = max(dmax, float(np.abs(r8 - g8[b0:b0 + 8]).max()), float(np.abs(r16 - g16[b0:b0 + 8]).max()))
+            for i in range(r8.shape[0]):
+                b = b0 + i
+                omc, omm, omf, _, omode = orc.router(r16[i:i + 1], r8[i:i + 1], ratio[0], ratio[1])
+                d = sum(int((mk[k][b, 0] != o[0, 0]).sum()) for k, o in enumerate((omc, omm, omf)))
+                elems += d
+                imgs += d > 0
+                ref = orc.compress_image(ind_h[b], omc[0, 0], omm[0, 0], omf[0, 0], omode, htab)
+                files += len(ref)
+                dfiles += sum(host[b].get(k) != v for k, v in ref.items())
+        return {"images": B, "size": f"{W}x{H}", "differing_mask_elements": elems, "mask_elements": B * (h * w + h * w // 4 + h * w // 16),
+                "images_with_a_difference": int(imgs), "bin_files": files, "differing_bin_files": int(dfiles), "max_abs_entropy_diff": dmax}
+
+    from control_gic_amd import entropy_maps as cg_entropy
+    out = {}
+    for name, x in families(n=64).items():
+        out[name] = run(x, z)
+    t = families(n=2, H=768, W=768, seed=11)
+    tiles = np.concatenate([t[k] for k in ("noise8", "smooth8", "flat_edges", "blocky8")])
+    zt = np.random.default_rng(5).standard_normal((tiles.shape[0], 4, 192, 192), dtype=np.float32)
+    out["tiles_768"] = run(tiles, zt)
+    out["note"] = ("reference side = the reference's torch-CPU entropy arithmetic evaluated on this host (oracle/entropy_torch.py) -> oracle router; "
+                   "a differing mask element is a patch whose entropy lies within ~1e-6 of a threshold (k-th smallest value, strict '<'); the masks are "
+                   "part of the bitstream, so every stream decodes either way")
+    return out
 
 
 def lanes_rate(vq, codec, ratio, xz, lanes, steps, copies=1):
@@ -385,10 +467,8 @@ def div2k_image(dev, cb, vq, codec, iters=8):
         once_graph(); torch.cuda.synchronize()
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
-        g = torch.cuda.CUDAGraph()
-        with torch.cuda.stream(side):
-            with torch.cuda.graph(g, stream=side):
-                tg, pg, stg = once_graph()
+        import control_gic_amd as cg
+        g, (tg, pg, stg) = cg.capture_graph(once_graph, side)
         torch.cuda.current_stream().wait_stream(side)
         for _ in range(3):
             g.replay()
@@ -721,6 +801,10 @@ def report(a, dev, world, stream, slots_np, vq, codec, ratio):
     if world == 1 and (B, H) == (64, 256) and not a.no_extra:
         hp.step()
         res["mask_mismatch"] = mask_mismatch(hp, x, z, cb, ratio)
+        try:
+            res["mask_mismatch"]["tie_heavy_content"] = mask_flip_families(dev, z, cb, vq, codec, ratio)
+        except Exception as e:                                   # an extra data point: never fail the bench line
+            res["mask_mismatch"]["tie_heavy_content"] = {"error": str(e)[:200]}
         res["ratio_sweep"] = ratio_sweep(dev, x, z, cb, vq, codec)
         res["b1_latency"] = b1_latency(dev, cb, vq, codec)
         res["div2k_image"] = div2k_image(dev, cb, vq, codec)

@@ -38,6 +38,10 @@ PROTOTYPES = {
     "cgic_abi_version": (_int, []),
     "cgic_set_decode_mode": (_int, [_int]),
     "cgic_device_count": (_int, []),
+    "cgic_ticket_scope_begin": (_int, []),
+    "cgic_ticket_scope_end": (_int, []),
+    "cgic_ticket_scope_release": (_int, [_int]),
+    "cgic_ticket_slots_in_use": (_int, []),
     "cgic_vq_workspace_bytes": (_sz, [_i64]),
     "cgic_conv1x1_rows_f32": (_int, [_vp, _i64, _cv, _vp, _vp]),
     "cgic_vq_prepared_bytes": (_sz, [_int]),
@@ -127,6 +131,33 @@ def conv_arg(conv, bias_first=False):
     require_device(w, b)
     st = Conv1x1(w.data_ptr(), None if b is None else b.data_ptr(), int(bool(bias_first)))
     return C.byref(st), (st, w, b)
+
+
+class ticket_scope:
+    """`with ticket_scope() as sc:` around the capture of a hipGraph (on this thread): the ticket slots its launches take are
+    tagged; `sc.release()` -- or `sc.release_with(obj)`: when `obj`, the graph object, is garbage-collected -- returns them
+    to the library's pool (cgic_ticket_scope_begin / _end / _release in include/cgic_hip.h)"""
+
+    def __init__(self):
+        self.id = 0
+
+    def __enter__(self):
+        self.id = call("cgic_ticket_scope_begin")
+        return self
+
+    def __exit__(self, *exc):
+        call("cgic_ticket_scope_end")
+        return False
+
+    def release(self):
+        if self.id:
+            lib().cgic_ticket_scope_release(self.id)
+            self.id = 0
+
+    def release_with(self, obj):
+        import weakref
+        weakref.finalize(obj, lib().cgic_ticket_scope_release, self.id)
+        return obj
 
 
 def current_stream(device=None):

@@ -42,47 +42,93 @@ int hip_fail(hipError_t e, const char *what, const char *file, int line)
 // Kernels that hand work to "the last workgroup to arrive" need counters that are zero when the
 // launch starts.  A memset node per launch costs ~5 us as a fill kernel, so the library owns
 // zero-initialised device memory and every user resets its counter when it is done:
-//  * eager launches take the next slots of a ring (a slot is reused only after thousands of
-//    later launches, far beyond any stream queue depth);
-//  * launches being captured into a hipGraph take slots that are never handed out again (the
-//    graph may be replayed at any time later).
-// Both pools are created on the first EAGER call on a device (allocation is illegal in capture).
+//  * eager launches take the next slots of a ring that belongs to THEIR STREAM (launches of one stream run in order, so a
+//    slot is reused only by a launch that starts after its previous user has ended and reset it; with one ring for all
+//    streams, two streams with large batches in flight could be handed the same slots -- round-2 advisor finding);
+//  * launches being captured into a hipGraph take slots of a per-device pool that stay theirs (the graph may be replayed
+//    at any time later) until the caller says the graph is gone: captures made between cgic_ticket_scope_begin() and
+//    cgic_ticket_scope_end() on a thread are tagged with the scope's id and cgic_ticket_scope_release(id) returns their
+//    slots (pipeline.LaneStream / GraphLanes do this when a graph object is destroyed).  Captures outside a scope keep
+//    their slots for the life of the process, as before.
+// Pools and rings are created by EAGER calls (allocation is illegal in capture): call an entry point once eagerly on a
+// device -- and on a stream whose eager launches will need tickets -- before capturing.
 constexpr size_t kRingSlots = 16384, kChunkSlots = 262144;
+struct TicketRange { size_t start, count; };
 struct TicketPool {
-    unsigned int *ring = nullptr;
-    size_t ring_next = 0;
+    std::map<hipStream_t, std::pair<unsigned int *, size_t>> rings;     // stream -> (memory, next slot)
     unsigned int *chunk = nullptr;
-    size_t chunk_next = kChunkSlots;
+    size_t chunk_next = 0;                                               // bump pointer behind the recycled ranges
+    std::vector<TicketRange> free_ranges;                                // returned by released scopes, sorted by start
+    std::map<int, std::vector<TicketRange>> scopes;                      // scope id -> ranges its captures hold
 };
+static std::mutex g_ticket_mu;
+static std::map<int, TicketPool> g_ticket_pools;
+static int g_next_scope = 1;
+static thread_local int t_scope = 0;
+
+static void free_range(TicketPool &p, TicketRange r)
+{
+    auto it = p.free_ranges.begin();
+    while (it != p.free_ranges.end() && it->start < r.start) ++it;
+    it = p.free_ranges.insert(it, r);
+    if (it + 1 != p.free_ranges.end() && it->start + it->count == (it + 1)->start) {     // merge with the successor
+        it->count += (it + 1)->count;
+        p.free_ranges.erase(it + 1);
+    }
+    if (it != p.free_ranges.begin() && (it - 1)->start + (it - 1)->count == it->start) {   // ... and the predecessor
+        (it - 1)->count += it->count;
+        it = p.free_ranges.erase(it) - 1;
+    }
+    if (it->start + it->count == p.chunk_next) {                                            // the tail goes back to the bump pointer
+        p.chunk_next = it->start;
+        p.free_ranges.erase(it);
+    }
+}
 
 int acquire_tickets(hipStream_t s, int n, unsigned int **ptr)
 {
-    static std::mutex mu;
-    static std::map<int, TicketPool> pools;
     CGIC_REQUIRE(n > 0 && (size_t)n <= kRingSlots / 4, CGIC_ERR_INVALID, "acquire_tickets: bad count %d", n);
     int dev = 0;
     CGIC_HIP_TRY(hipGetDevice(&dev));
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
     CGIC_HIP_TRY(hipStreamIsCapturing(s, &cap));
-    std::lock_guard<std::mutex> lock(mu);
-    TicketPool &p = pools[dev];
+    std::lock_guard<std::mutex> lock(g_ticket_mu);
+    TicketPool &p = g_ticket_pools[dev];
     if (cap == hipStreamCaptureStatusNone) {
-        if (!p.ring) {
-            CGIC_HIP_TRY(hipMalloc((void **)&p.ring, sizeof(unsigned int) * kTicketStride * kRingSlots));
-            CGIC_HIP_TRY(hipMemset(p.ring, 0, sizeof(unsigned int) * kTicketStride * kRingSlots));
+        if (!p.chunk) {
             CGIC_HIP_TRY(hipMalloc((void **)&p.chunk, sizeof(unsigned int) * kTicketStride * kChunkSlots));
             CGIC_HIP_TRY(hipMemset(p.chunk, 0, sizeof(unsigned int) * kTicketStride * kChunkSlots));
-            p.chunk_next = 0;
         }
-        if (p.ring_next % kRingSlots + (size_t)n > kRingSlots) p.ring_next += kRingSlots - p.ring_next % kRingSlots;   // no wrap inside a range
-        *ptr = p.ring + (p.ring_next % kRingSlots) * kTicketStride;
-        p.ring_next += (size_t)n;
-    } else {
-        CGIC_REQUIRE(p.chunk && p.chunk_next + (size_t)n <= kChunkSlots, CGIC_ERR_INVALID,
-                     "call once outside stream capture on this device before capturing (or too many captured launches)");
-        *ptr = p.chunk + p.chunk_next * kTicketStride;
+        auto &ring = p.rings[s];
+        if (!ring.first) {
+            CGIC_HIP_TRY(hipMalloc((void **)&ring.first, sizeof(unsigned int) * kTicketStride * kRingSlots));
+            CGIC_HIP_TRY(hipMemset(ring.first, 0, sizeof(unsigned int) * kTicketStride * kRingSlots));
+            ring.second = 0;
+        }
+        if (ring.second % kRingSlots + (size_t)n > kRingSlots) ring.second += kRingSlots - ring.second % kRingSlots;   // no wrap inside a range
+        *ptr = ring.first + (ring.second % kRingSlots) * kTicketStride;
+        ring.second += (size_t)n;
+        return CGIC_OK;
+    }
+    CGIC_REQUIRE(p.chunk, CGIC_ERR_INVALID, "call once outside stream capture on this device before capturing");
+    size_t start = kChunkSlots;
+    for (auto it = p.free_ranges.begin(); it != p.free_ranges.end(); ++it)               // first fit among the recycled ranges
+        if (it->count >= (size_t)n) {
+            start = it->start;
+            it->start += (size_t)n;
+            it->count -= (size_t)n;
+            if (!it->count) p.free_ranges.erase(it);
+            break;
+        }
+    if (start == kChunkSlots) {
+        CGIC_REQUIRE(p.chunk_next + (size_t)n <= kChunkSlots, CGIC_ERR_INVALID,
+                     "the pool of ticket slots for captured launches is used up (%zu slots): release the scopes of destroyed graphs "
+                     "(cgic_ticket_scope_release)", kChunkSlots);
+        start = p.chunk_next;
         p.chunk_next += (size_t)n;
     }
+    if (t_scope) p.scopes[t_scope].push_back(TicketRange{start, (size_t)n});
+    *ptr = p.chunk + start * kTicketStride;
     return CGIC_OK;
 }
 
@@ -272,6 +318,47 @@ using namespace cgic;
 
 extern "C" const char *cgic_last_error(void) { return g_err; }
 extern "C" int cgic_abi_version(void) { return CGIC_ABI_VERSION; }
+
+extern "C" int cgic_ticket_scope_begin(void)
+{
+    std::lock_guard<std::mutex> lock(g_ticket_mu);
+    CGIC_REQUIRE(t_scope == 0, CGIC_ERR_INVALID, "ticket_scope_begin: this thread already has an open scope (%d)", t_scope);
+    t_scope = g_next_scope++;
+    return t_scope;
+}
+
+extern "C" int cgic_ticket_scope_end(void)
+{
+    const int id = t_scope;
+    CGIC_REQUIRE(id != 0, CGIC_ERR_INVALID, "ticket_scope_end: no open scope on this thread");
+    t_scope = 0;
+    return id;
+}
+
+extern "C" int cgic_ticket_scope_release(int scope)
+{
+    CGIC_REQUIRE(scope > 0, CGIC_ERR_INVALID, "ticket_scope_release: bad scope %d", scope);
+    std::lock_guard<std::mutex> lock(g_ticket_mu);
+    int freed = 0;
+    for (auto &kv : g_ticket_pools) {
+        auto it = kv.second.scopes.find(scope);
+        if (it == kv.second.scopes.end()) continue;
+        for (const TicketRange &r : it->second) { free_range(kv.second, r); freed += (int)r.count; }
+        kv.second.scopes.erase(it);
+    }
+    return freed;
+}
+
+extern "C" int cgic_ticket_slots_in_use(void)
+{
+    int dev = 0;
+    CGIC_HIP_TRY(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lock(g_ticket_mu);
+    const TicketPool &p = g_ticket_pools[dev];
+    size_t used = p.chunk_next;
+    for (const TicketRange &r : p.free_ranges) used -= r.count;
+    return (int)used;
+}
 
 extern "C" int cgic_device_count(void)
 {

@@ -107,6 +107,12 @@ class _Fork:
         self.enabled = enabled
         self.used = []
         self.device = device
+        # ONE fork point, recorded before lane 0's body is queued: a side lane waits for what precedes the fork, not for the
+        # (largest) group that lane 0 runs -- recorded lazily, the side lanes only started once that group was over
+        self.fork_ev = None
+        if enabled:
+            self.fork_ev = torch.cuda.Event()
+            self.fork_ev.record(self.cur)
 
     def lane(self, k):
         if not self.enabled or k == 0:
@@ -116,9 +122,7 @@ class _Fork:
             pool.append(torch.cuda.Stream(self.device))
         st = pool[k - 1]
         if st not in self.used:
-            ev = torch.cuda.Event()
-            ev.record(self.cur)                      # (recorded when the first side lane starts: everything before the fork)
-            st.wait_event(ev)
+            st.wait_event(self.fork_ev)              # everything before the fork
             self.used.append(st)
         return st
 
@@ -147,9 +151,9 @@ def compress_tiled(x, encode, codec, tile=TILE, concurrent=False):
     for i, (_, _, th, tw) in enumerate(tiles):
         by_shape.setdefault((th, tw), []).append(i)
     groups = []
-    fork = _Fork(x.device, concurrent)
     # the largest group first: it is the long pole, and lane 0 (no fork latency) is its stream
     order = sorted(by_shape.items(), key=lambda kv: -len(kv[1]) * kv[0][0] * kv[0][1])
+    fork = _Fork(x.device, concurrent)              # (after the pad: the tiles are views of xp)
     for lane, ((th, tw), idxs) in enumerate(order):
         with torch.cuda.stream(fork.lane(lane)):
             batch = torch.stack([xp[0, :, tiles[i][0]:tiles[i][0] + th, tiles[i][1]:tiles[i][1] + tw] for i in idxs])

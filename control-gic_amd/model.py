@@ -142,7 +142,10 @@ def install(model, per_image=False, fuse_convs=True):
     """swap VectorQuantize2 / Entropy / router target / compress of a reference CGIC instance in place.
     per_image=False keeps the reference's routing for encode() / forward() / training (thresholds over the flattened
     batch, RouterTriple.py:21-31); compress_batch / compress / the tiling driver always route per image.
-    fuse_convs: move quant_conv into the VQ kernel and post_quant_conv into the decode-side gather (under no_grad)."""
+    fuse_convs: move quant_conv into the VQ kernel and post_quant_conv into the decode-side gather (under no_grad).  The
+    hand-off is explicit: under no_grad `model.quant_conv(h)` returns a quantize.PendingQuantConv (its input, tagged) that
+    `model.quantize` convolves inside its kernel; used anywhere else it behaves as the convolved latent, and a latent that
+    reaches `model.quantize` as an ordinary tensor is quantised as it is."""
     old = model.quantize
     dev = old.embedding.weight.device
     q = VectorQuantize2(old.n_e, old.e_dim, beta=old.beta, legacy=getattr(old, "legacy", True))
@@ -160,8 +163,7 @@ def install(model, per_image=False, fuse_convs=True):
     # post_quant_conv becomes a second gather table of the decode-side merge kernel (inference only; autograd sees Conv2d)
     if fuse_convs and isinstance(getattr(model, "quant_conv", None), torch.nn.Conv2d) \
             and tuple(model.quant_conv.weight.shape) == (4, 4, 1, 1) and q.n_e % 64 == 0 and q.n_e <= 1024:
-        model.quant_conv = FusedQuantConv.adopt(model.quant_conv)
-        object.__setattr__(q, "_fused_quant_conv", model.quant_conv)        # a reference, not a submodule: state_dict keys stay put
+        model.quant_conv = FusedQuantConv.adopt(model.quant_conv)          # hands its input to the quantiser as a PendingQuantConv
     model._cgic_fuse_post_quant_conv = bool(fuse_convs)
     model.compress = types.MethodType(compress, model)
     model.compress_batch = types.MethodType(compress_batch, model)

@@ -10,6 +10,7 @@ only, so a step can be captured in a hipGraph and replayed.
 """
 import torch
 
+from . import _lib
 from .codec import GrainCodec, decoder_mode
 from .entropy import entropy_maps
 from .quantize import _vq_forward, vq_forward_route, prepare_codebook
@@ -180,13 +181,9 @@ class BatchStream:
                     if self.decode:
                         self._decode(s)
             for s in self.slots:
-                s.g_enc = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(s.g_enc, stream=self.enc_stream):
-                    self._encode(s)
+                s.g_enc, _ = capture_graph(lambda s=s: self._encode(s), self.enc_stream)
                 if self.decode:
-                    s.g_dec = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(s.g_dec, stream=self.enc_stream):
-                        self._decode(s)
+                    s.g_dec, _ = capture_graph(lambda s=s: self._decode(s), self.enc_stream)
         cur.wait_stream(self.enc_stream)
         self.dec_stream.wait_stream(cur)
         self._captured = True
@@ -221,6 +218,19 @@ class BatchStream:
         stream = torch.cuda.current_stream(self.device) if stream is None else stream
         self.enc_stream.wait_stream(stream)
         self.dec_stream.wait_stream(stream)
+
+
+def capture_graph(fn, stream):
+    """capture `fn()` (which only enqueues work on the current stream) into a hipGraph on `stream` -> (graph, fn's result).
+    The ticket slots the captured launches take from the library's pool are returned when the graph object is
+    garbage-collected (_lib.ticket_scope), so a long-lived process can capture per image shape for as long as it likes."""
+    g = torch.cuda.CUDAGraph()
+    with _lib.ticket_scope() as sc:
+        with torch.cuda.stream(stream):
+            with torch.cuda.graph(g, stream=stream):
+                out = fn()
+    sc.release_with(g)
+    return g, out
 
 
 def distinct_queue_streams(device, n, candidates=16, spin_cycles=400_000):
@@ -359,14 +369,14 @@ class LaneStream:
         cur = torch.cuda.current_stream(self.device)
         st = lane["stream"]
         st.wait_stream(cur)
-        g = torch.cuda.CUDAGraph()
         outs = {}
-        with torch.cuda.stream(st):
-            with torch.cuda.graph(g, stream=st):
-                for i in range(count):
-                    p = (start + i) % m
-                    outs[p] = None                    # an earlier step's buffers of this slot go back to the graph's pool
-                    outs[p] = self._step(lane["slots"][p])
+
+        def body():
+            for i in range(count):
+                p = (start + i) % m
+                outs[p] = None                        # an earlier step's buffers of this slot go back to the graph's pool
+                outs[p] = self._step(lane["slots"][p])
+        g, _ = capture_graph(body, st)
         cur.wait_stream(st)
         lane["graphs"][key] = (g, outs)
         return g, outs
@@ -475,10 +485,8 @@ class GraphLanes:
             torch.cuda.synchronize(device)
             for fn, st in zip(fns, self.streams):
                 st.wait_stream(cur)
-                g = torch.cuda.CUDAGraph()
-                with torch.cuda.stream(st):
-                    with torch.cuda.graph(g, stream=st):
-                        self.results.append(fn())
+                g, out = capture_graph(fn, st)
+                self.results.append(out)
                 self.graphs.append(g)
         torch.cuda.synchronize(device)
 

@@ -175,10 +175,54 @@ def vq_forward_route(z, weight, beta, legacy, e16, e8, coarse_ratio, medium_rati
     return z_q, loss, idx, [mc, mm, mf], gate, mode.value
 
 
+class PendingQuantConv(torch.Tensor):
+    """What FusedQuantConv returns under no_grad: the convolution's INPUT, tagged with the convolution that is still due.
+
+    The hand-off to the quantiser is explicit: VectorQuantize2.forward recognises the type and applies W h + b inside its
+    kernel (on the four channel values each lane holds anyway: one HBM round trip of the latent less).  Anybody else who
+    touches the tensor -- arithmetic, another module, .cpu(), printing -- gets the convolved latent: every torch function
+    first materialises the pending convolution (a plain F.conv2d) and runs on its result, so `model.quant_conv(h)` used on
+    its own is still the convolution, and a latent that was convolved some other way is an ordinary tensor that the quantiser
+    takes as it is.  Only shape / dtype / device queries are answered without materialising (a 1x1 convolution keeps them)."""
+
+    _METADATA = None
+
+    @staticmethod
+    def __new__(cls, h, conv):
+        t = torch.Tensor._make_subclass(cls, h.detach(), False)
+        t._cgic_conv = conv
+        return t
+
+    def plain(self):
+        """the untouched convolution input as an ordinary tensor (same storage)"""
+        with torch._C.DisableTorchFunctionSubclass():
+            return self.as_subclass(torch.Tensor)
+
+    def materialize(self):
+        conv = self._cgic_conv
+        return torch.nn.functional.conv2d(self.plain(), conv.weight, conv.bias)
+
+    @classmethod
+    def __torch_function__(cls, func, types, args=(), kwargs=None):
+        kwargs = kwargs or {}
+        if cls._METADATA is None:
+            T = torch.Tensor
+            cls._METADATA = {T.shape.__get__, T.dtype.__get__, T.device.__get__, T.is_cuda.__get__, T.ndim.__get__, T.layout.__get__,
+                             T.requires_grad.__get__, T.dim, T.size, T.numel, T.is_contiguous, T.is_floating_point, T.get_device,
+                             T.stride, T.storage_offset, T.element_size}
+        if func in cls._METADATA:
+            with torch._C.DisableTorchFunctionSubclass():
+                return func(*args, **kwargs)
+        from torch.utils._pytree import tree_map
+        done = lambda a: a.materialize() if isinstance(a, PendingQuantConv) else a
+        return func(*tree_map(done, args), **tree_map(done, kwargs))
+
+
 class FusedQuantConv(nn.Conv2d):
-    """CGIC.quant_conv (model.py:51) with its work moved into the quantiser's kernel: under no_grad it returns its input
-    unchanged and VectorQuantize2 applies the convolution to the four channel values each lane already holds (one HBM
-    round trip of the latent less).  With autograd on it is a plain Conv2d again.  Same parameters, same state_dict keys."""
+    """CGIC.quant_conv (model.py:51) with its work moved into the quantiser's kernel: under no_grad, on the GPU, it returns a
+    PendingQuantConv -- its input, tagged -- and VectorQuantize2 applies the convolution in its kernel; any other consumer
+    of that tensor gets the convolved latent (see PendingQuantConv).  With autograd on it is a plain Conv2d.  Same
+    parameters, same state_dict keys."""
 
     bias_first = False      # which of the CPU reference's two rounding sequences the fused kernel reproduces (cgic_hip.h)
 
@@ -191,11 +235,12 @@ class FusedQuantConv(nn.Conv2d):
         m.train(conv.training)
         return m
 
-    def passes_through(self):
-        return not torch.is_grad_enabled() and self.weight.is_cuda
+    def defers(self, x):
+        return (not torch.is_grad_enabled()) and self.weight.is_cuda and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 \
+            and not isinstance(x, PendingQuantConv)
 
     def forward(self, x):
-        return x if self.passes_through() else super().forward(x)
+        return PendingQuantConv(x, self) if self.defers(x) else super().forward(x)
 
 
 class VectorQuantize2(nn.Module):
@@ -241,11 +286,13 @@ class VectorQuantize2(nn.Module):
     def embedding_counter(self):
         return _CounterView(self)
 
-    #: under torch.distributed (DDP training, config_train.yaml:9-15) sum the step's histogram over all ranks before it is
-    #: folded in, so that every rank's counter -- the Huffman frequency table that ends up in the checkpoint -- counts the
-    #: whole batch.  (The reference's counters are requires_grad=False Parameters that DDP never reduces: each rank counts
-    #: its own shard and rank 0's partial counts are what gets saved; set False to reproduce that.)
-    sync_usage_counter = True
+    #: False (default) = the reference: every rank counts its own shard (its counters are requires_grad=False Parameters that DDP
+    #: never reduces, quantize.py:28,79-81) and no collective sits inside forward() -- an asymmetric training-mode forward
+    #: (a rank-0-only calibration pass, uneven step counts) cannot hang the job.  True: all-reduce the step's histogram over
+    #: the process group before it is folded in, so that every rank's counter -- the Huffman frequency table that ends up in
+    #: the checkpoint -- counts the whole batch (one blocking 8 KB collective per training-mode forward on EVERY rank).  The
+    #: cheaper way to the same table: leave this off and call `sync_usage_counter_now()` once at checkpoint / epoch end.
+    sync_usage_counter = False
 
     def fold_usage_hist(self):
         """Add the kernel's exact int64 histogram into the fp32 counters and clear it; with a process group, all-reduce it
@@ -276,12 +323,26 @@ class VectorQuantize2(nn.Module):
             return None
         return getattr(self, "_prepared", None)
 
+    def sync_usage_counter_now(self):
+        """sum the fp32 usage counters over the process group, once (checkpoint / epoch end): every rank then holds the
+        counts of the whole data set, like sync_usage_counter=True would have accumulated step by step (exact while the totals
+        stay below 2^24, the fp32 counter's own limit).  Collective: call it on every rank."""
+        from . import dist as cdist
+        with torch.no_grad():
+            total = self.usage_counter.to(torch.float64).round().to(torch.int64)
+            cdist.all_reduce_histogram(total)
+            self.usage_counter.copy_(total.to(self.usage_counter.dtype))
+
     def forward(self, z):
-        if z.dtype != torch.float32:
+        if not isinstance(z, PendingQuantConv) and z.dtype != torch.float32:
             z = z.float()                   # (autocast regions hand over fp16 / bf16: the reference quantises in fp32)
         hist = self.usage_hist if self.training else None
-        fused = getattr(self, "_fused_quant_conv", None)      # model.install(): quant_conv handed its input through
-        conv = fused if fused is not None and fused.passes_through() else None
+        conv = None
+        if isinstance(z, PendingQuantConv):                   # FusedQuantConv handed its INPUT over: the convolution is due here
+            if torch.is_grad_enabled() or self.n_e % 64 or self.n_e > 1024:
+                z = z.materialize()                           # (autograd switched on in between / no fused kernel for this K)
+            else:
+                conv, z = z._cgic_conv, z.plain()
         if torch.is_grad_enabled() and (z.requires_grad or self.embedding.weight.requires_grad):
             z_q, loss, idx = _VQFunction.apply(z, self.embedding.weight, self.beta, self.legacy, hist)
         else:

@@ -49,11 +49,20 @@ typedef void *cgic_stream_t;
 
 /* Launch resources: kernels whose workgroups hand work to each other (the VQ loss hand-off, the split index streams of
  * grids beyond 64x64 in compress / decompress) use self-resetting ticket slots in library-owned device memory.  Eager
- * launches take them from a ring; launches being captured into a hipGraph take them from a pool of 262 144 slots per
- * device that is never recycled (the graph may be replayed at any time later): a VQ launch takes 1 slot, a split-stream
- * compress 6 per image, a split-stream decompress 3 per image (CGIC_ERR_INVALID once the pool is used up; batches of
- * more than 682 / 1365 such images fall back to unsplit streams / two launches).  Call each entry point once eagerly
- * on a device before capturing it (allocations and function attributes are set up on first use). */
+ * launches take them from a ring that belongs to their stream.  Launches being captured into a hipGraph take them from a
+ * pool of 262 144 slots per device and keep them while the graph may still be replayed: a VQ launch takes 1 slot, a
+ * split-stream compress 6 per image, a split-stream decompress 3 per image (batches of more than 682 / 1365 such images
+ * fall back to unsplit streams / two launches).  The caller says when a captured graph is gone:
+ *   id = cgic_ticket_scope_begin();  ... capture (on this thread) ...;  cgic_ticket_scope_end();
+ *   ... replay for as long as needed ...;  destroy the graph;  cgic_ticket_scope_release(id);     -> slots returned
+ * Captures made outside a scope keep their slots for the life of the process (CGIC_ERR_INVALID once the pool is used up).
+ * Call each entry point once eagerly on a device before capturing it (allocations and function attributes are set up on
+ * first use).  cgic_ticket_scope_begin / _end return the scope id, _release the number of slots returned, _slots_in_use the
+ * captured slots currently held on the current device; all return CGIC_ERR_* (< 0) on misuse. */
+int cgic_ticket_scope_begin(void);
+int cgic_ticket_scope_end(void);
+int cgic_ticket_scope_release(int scope);
+int cgic_ticket_slots_in_use(void);
 const char *cgic_last_error(void);
 int cgic_abi_version(void);
 /* number of visible HIP devices, or CGIC_ERR_HIP; never throws, never aborts */

@@ -146,6 +146,8 @@ def _counter_worker(rank, world, port, out_dir):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     import control_gic_amd as cg
     vq = cg.VectorQuantizer(1024, 4, beta=0.25).train()          # CPU module: no kernel is launched below
+    assert vq.sync_usage_counter is False                          # the default is the reference's: no collective inside forward()
+    vq.sync_usage_counter = True                                   # opt in: every step's histogram summed over the ranks
     rng = np.random.default_rng(50 + rank)
     total = np.zeros(1024, np.int64)
     for step in range(3):                                          # what forward() does after the kernel filled usage_hist
@@ -153,11 +155,14 @@ def _counter_worker(rank, world, port, out_dir):
         vq.usage_hist += torch.from_numpy(h)
         vq.fold_usage_hist()
         total += h
-    local = cg.VectorQuantizer(1024, 4, beta=0.25).train()
-    local.sync_usage_counter = False                               # the reference's behaviour: every rank counts its own shard
+    local = cg.VectorQuantizer(1024, 4, beta=0.25).train()        # the default = the reference: every rank counts its own shard
     local.usage_hist += torch.from_numpy(total)
     local.fold_usage_hist()
-    torch.save({"synced": vq.usage_counter.clone(), "local": local.usage_counter.clone(), "mine": torch.from_numpy(total),
+    late = cg.VectorQuantizer(1024, 4, beta=0.25).train()         # per-rank counting, ONE reduction at "checkpoint time"
+    late.usage_hist += torch.from_numpy(total)
+    late.fold_usage_hist()
+    late.sync_usage_counter_now()
+    torch.save({"synced": vq.usage_counter.clone(), "local": local.usage_counter.clone(), "mine": torch.from_numpy(total), "late": late.usage_counter.clone(),
                 "hist_left": int(vq.usage_hist.abs().sum()), "key3": float(vq.embedding_counter["3"].item())},
                os.path.join(out_dir, f"c{rank}.pt"))
     dist.barrier()
@@ -166,7 +171,8 @@ def _counter_worker(rank, world, port, out_dir):
 
 def test_training_usage_counter_is_reduced_over_ranks(tmp_path):
     """VectorQuantize2 in training mode under a process group: every rank's embedding_counter counts the WHOLE batch
-    (sum over ranks, exact), identically on all ranks; sync_usage_counter=False keeps the reference's per-rank counts"""
+    (sum over ranks, exact), identically on all ranks, with sync_usage_counter=True (a collective per step) or with one
+    sync_usage_counter_now() at the end; the default keeps the reference's per-rank counts and puts no collective in forward()"""
     world = 2
     mp.spawn(_counter_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
     res = [torch.load(tmp_path / f"c{r}.pt") for r in range(world)]
@@ -174,4 +180,5 @@ def test_training_usage_counter_is_reduced_over_ranks(tmp_path):
     for r in res:
         assert torch.equal(r["synced"], want) and r["hist_left"] == 0 and r["key3"] == float(want[3])
         assert torch.equal(r["local"], r["mine"].float())
+        assert torch.equal(r["late"], want)                      # sync_usage_counter_now(): the same table from one collective
     assert not torch.equal(res[0]["local"], res[1]["local"])

@@ -260,13 +260,29 @@ def test_install_and_compress_on_a_cgic_shaped_model(tmp_path, orc):
     for b, (dec, bpp, pmap) in enumerate(outs):
         assert pmap is None and bpp == bpp_b[b] and torch.equal(dec[0], dec_b[b])
     # quant_conv ran inside the VQ kernel, post_quant_conv inside the decode-side gather: same result as the plain modules
-    assert isinstance(model.quant_conv, cg.quantize.FusedQuantConv) and model.quantize._fused_quant_conv is model.quant_conv
+    assert isinstance(model.quant_conv, cg.quantize.FusedQuantConv)
     with torch.no_grad():
         h_lat = model.encoder(x, *(cg.entropy_maps(x)[::-1]))["h"]
-        assert model.quant_conv(h_lat) is h_lat                                        # handed through under no_grad
+        pend = model.quant_conv(h_lat)
+        # handed over under no_grad: the convolution's input, tagged -- same storage, same metadata, no launch yet
+        assert isinstance(pend, cg.quantize.PendingQuantConv) and pend.plain().data_ptr() == h_lat.data_ptr()
+        assert pend.shape == h_lat.shape and pend.dtype == h_lat.dtype and pend.is_cuda
         z_plain = torch.nn.functional.conv2d(h_lat, model.quant_conv.weight, model.quant_conv.bias)
         zq_plain, _, ind_plain = cg.quantize._vq_forward(z_plain, model.quantize.embedding.weight, 0.25, True, None)
-        zq_fused, _, ind_fused = model.quantize(h_lat)
+        zq_fused, _, ind_fused = model.quantize(pend)
+        # (round-2 advisor finding) the hand-off is explicit, not global state: anybody else who uses quant_conv's output gets
+        # the convolved latent ...
+        assert torch.equal(pend + 0.0, z_plain) and torch.equal(pend.cpu(), z_plain.cpu()) and torch.equal(torch.relu(pend), torch.relu(z_plain))
+        assert torch.equal(model.quant_conv(h_lat).clone(), z_plain)
+        # ... a latent convolved some other way is quantised as it is (no second convolution) ...
+        zq_pre, _, ind_pre = model.quantize(z_plain)
+        assert torch.equal(ind_pre, ind_plain) and torch.equal(zq_pre, zq_plain)
+        # ... and so is the raw encoder output when the caller leaves quant_conv out
+        zq_raw, _, ind_raw = model.quantize(h_lat)
+        assert torch.equal(ind_raw, cg.quantize._vq_forward(h_lat, model.quantize.embedding.weight, 0.25, True, None)[2])
+    with torch.enable_grad():                       # autograd switched on between the two calls: the pending conv is materialised
+        zq_g, _, ind_g = model.quantize(pend)
+        assert torch.equal(ind_g, ind_plain)
     # (the GPU's own Conv2d may round differently from the fused fma chain by an ulp: indices agree except at near-ties)
     assert (ind_plain != ind_fused).float().mean() < 1e-3 and (zq_plain - zq_fused).abs().max() < 1e-5
     with torch.enable_grad():
