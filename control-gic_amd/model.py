@@ -21,41 +21,28 @@ ROUTER_TARGET = "control_gic_amd.router.TripleGrainFixedEntropyRouter"
 
 def grain_merge(h_coarse, h_medium, h_fine, mask):
     """h = up4(h_coarse)*up4(mask[0]) + up2(h_medium)*up2(mask[1]) + h_fine*mask[2]
-    (vqvae_blocks.py:361-366) in one pass; mask = the router's three int32 tensors"""
-    _lib.require_device(h_coarse, h_medium, h_fine, *mask)
-    hc, hm, hf = (t.contiguous().float() for t in (h_coarse, h_medium, h_fine))
-    mc, mm, mf = (m.contiguous() for m in mask)
-    B, C, h, w = hf.shape
-    if tuple(hc.shape) != (B, C, h // 4, w // 4) or tuple(hm.shape) != (B, C, h // 2, w // 2):
-        raise ValueError("h_coarse / h_medium must be the fine map's shape divided by 4 / 2")
-    out = torch.empty_like(hf)
-    with torch.cuda.device(hf.device):
-        _lib.call("cgic_grain_merge_f32", _lib.ptr(hc), _lib.ptr(hm), _lib.ptr(hf), _lib.ptr(mc), _lib.ptr(mm),
-                  _lib.ptr(mf), B, C, h, w, _lib.ptr(out), _lib.current_stream(hf.device))
-    return out
+    (vqvae_blocks.py:361-366) in one pass; mask = the router's three int32 tensors.  Differentiable w.r.t. the three
+    latents (torch.ops.cgic.grain_merge: the op sits inside the reference's training graph)."""
+    return torch.ops.cgic.grain_merge(h_coarse, h_medium, h_fine, mask[0], mask[1], mask[2])
 
 
 def avg_pool(x, k):
     """torch.nn.AvgPool2d(k, k, 0) for k in (2, 4) -- decoder.py:304-305,366-367; bit-identical to the CPU kernel
-    (row-major running sum of the window, divided by k*k)"""
-    _lib.require_device(x)
-    x = x.contiguous().float()
-    B, C, H, W = x.shape
-    out = torch.empty((B, C, H // k, W // k), dtype=torch.float32, device=x.device)
-    with torch.cuda.device(x.device):
-        _lib.call("cgic_avgpool_f32", _lib.ptr(x), B * C, H, W, int(k), _lib.ptr(out), _lib.current_stream(x.device))
-    return out
+    (row-major running sum of the window, divided by k*k); differentiable (torch.ops.cgic.avg_pool)"""
+    return torch.ops.cgic.avg_pool(x, int(k))
 
 
 def decoder_blend_medium(h, h_medium, mask, out=None):
-    """h * up2(mask[0]) + h_medium * mask[1] on the medium grid (decoder.py:372-374); `out` may be `h` (in place)"""
+    """h * up2(mask[0]) + h_medium * mask[1] on the medium grid (decoder.py:372-374).  Differentiable
+    (torch.ops.cgic.decoder_blend_medium); with `out` (which may be `h`: in place) the raw kernel call, no autograd."""
+    if out is None:
+        return torch.ops.cgic.decoder_blend_medium(h, h_medium, mask[0], mask[1])
     _lib.require_device(h, h_medium, mask[0], mask[1])
     h, hm = h.contiguous().float(), h_medium.contiguous().float()
     mc, mm = mask[0].contiguous(), mask[1].contiguous()
     B, C, hh, ww = h.shape
     if tuple(hm.shape) != (B, C, hh, ww) or mc.numel() != B * (hh // 2) * (ww // 2) or mm.numel() != B * hh * ww:
         raise ValueError("decoder_blend_medium: h, h_medium on the medium grid; mask[0] at half of it, mask[1] on it")
-    out = torch.empty_like(h) if out is None else out
     with torch.cuda.device(h.device):
         _lib.call("cgic_decoder_blend_medium_f32", _lib.ptr(h), _lib.ptr(hm), _lib.ptr(mc), _lib.ptr(mm), B, C, hh, ww,
                   _lib.ptr(out), _lib.current_stream(h.device))
@@ -63,7 +50,10 @@ def decoder_blend_medium(h, h_medium, mask, out=None):
 
 
 def decoder_blend_fine(h, h_fine, mask, out=None):
-    """h * up4(mask[0]) + h * up2(mask[1]) + h_fine * mask[2] on the fine grid (decoder.py:375-378)"""
+    """h * up4(mask[0]) + h * up2(mask[1]) + h_fine * mask[2] on the fine grid (decoder.py:375-378).  Differentiable
+    (torch.ops.cgic.decoder_blend_fine); with `out` the raw kernel call (in place if `out is h`), no autograd."""
+    if out is None:
+        return torch.ops.cgic.decoder_blend_fine(h, h_fine, mask[0], mask[1], mask[2])
     _lib.require_device(h, h_fine, *mask)
     h, hf = h.contiguous().float(), h_fine.contiguous().float()
     mc, mm, mf = (m.contiguous() for m in mask)
@@ -71,7 +61,6 @@ def decoder_blend_fine(h, h_fine, mask, out=None):
     if tuple(hf.shape) != (B, C, hh, ww) or mc.numel() != B * (hh // 4) * (ww // 4) or mm.numel() != B * (hh // 2) * (ww // 2) \
             or mf.numel() != B * hh * ww:
         raise ValueError("decoder_blend_fine: h, h_fine on the fine grid; masks at 1/4, 1/2, 1/1 of it")
-    out = torch.empty_like(h) if out is None else out
     with torch.cuda.device(h.device):
         _lib.call("cgic_decoder_blend_fine_f32", _lib.ptr(h), _lib.ptr(hf), _lib.ptr(mc), _lib.ptr(mm), _lib.ptr(mf), B, C, hh, ww,
                   _lib.ptr(out), _lib.current_stream(h.device))

@@ -158,6 +158,108 @@ def test_grain_merge_bit_exact():
 
 
 @pytest.mark.gpu
+def test_merge_ops_are_differentiable_like_the_reference_expressions():
+    """torch.ops.cgic.grain_merge / avg_pool / decoder_blend_medium / decoder_blend_fine sit inside the reference's training
+    graph (vqvae_blocks.py:361-366, decoder.py:304-305,366-378): their gradients against torch autograd of the reference's own
+    expressions (stock torch ops on the device).  The blends are elementwise (bit-exact gradients); the two window sums of
+    grain_merge's backward and the pool's 1/k^2 scaling: 1e-6 relative (summation order of a 4x4 window)."""
+    g = torch.Generator().manual_seed(17)
+    B, C, h, w = 2, 5, 16, 24
+    up2 = torch.nn.Upsample(scale_factor=2, mode="nearest")
+    up4 = torch.nn.Upsample(scale_factor=4, mode="nearest")
+    e16 = torch.rand(B, h // 4, w // 4, generator=g).cuda()
+    e8 = torch.rand(B, h // 2, w // 2, generator=g).cuda()
+    mask, _, _, _ = cg.TripleGrainFixedEntropyRouter(0.3, 0.4, per_image=True)(e16, e8)
+    mk = [m.float() for m in mask]
+
+    def leaves(*shapes):
+        return [torch.randn(*s, generator=g).cuda().requires_grad_() for s in shapes]
+
+    def clones(ts):
+        return [t.detach().clone().requires_grad_() for t in ts]
+
+    wgt = torch.randn(B, C, h, w, generator=g).cuda()
+    # grain merge
+    a = leaves((B, C, h // 4, w // 4), (B, C, h // 2, w // 2), (B, C, h, w))
+    b = clones(a)
+    out = cg.grain_merge(a[0], a[1], a[2], mask)
+    ref = up4(b[0]) * up4(mk[0]) + up2(b[1]) * up2(mk[1]) + b[2] * mk[2]
+    assert torch.equal(out, ref)
+    (out * wgt).sum().backward()
+    (ref * wgt).sum().backward()
+    assert torch.equal(a[2].grad, b[2].grad)
+    assert torch.allclose(a[0].grad, b[0].grad, rtol=1e-6, atol=1e-6) and torch.allclose(a[1].grad, b[1].grad, rtol=1e-6, atol=1e-6)
+    # average pools
+    for k in (2, 4):
+        x, = leaves((B, C, h, w))
+        y = x.detach().clone().requires_grad_()
+        wk = torch.randn(B, C, h // k, w // k, generator=g).cuda()
+        (cg.avg_pool(x, k) * wk).sum().backward()
+        (torch.nn.functional.avg_pool2d(y, k, k, 0) * wk).sum().backward()
+        assert torch.allclose(x.grad, y.grad, rtol=1e-6, atol=1e-7)
+    # decoder blends
+    a = leaves((B, C, h // 2, w // 2), (B, C, h // 2, w // 2))
+    b = clones(a)
+    wm = torch.randn(B, C, h // 2, w // 2, generator=g).cuda()
+    (cg.decoder_blend_medium(a[0], a[1], mask) * wm).sum().backward()
+    ((b[0] * up2(mk[0]) + b[1] * mk[1]) * wm).sum().backward()
+    assert torch.equal(a[0].grad, b[0].grad) and torch.equal(a[1].grad, b[1].grad)
+    a = leaves((B, C, h, w), (B, C, h, w))
+    b = clones(a)
+    (cg.decoder_blend_fine(a[0], a[1], mask) * wgt).sum().backward()
+    ((b[0] * up4(mk[0]) + b[0] * up2(mk[1]) + b[1] * mk[2]) * wgt).sum().backward()
+    assert torch.equal(a[0].grad, b[0].grad) and torch.equal(a[1].grad, b[1].grad)
+    # the ops are what the module-level functions call; under no_grad they are the plain kernels
+    with torch.no_grad():
+        assert torch.equal(torch.ops.cgic.grain_merge(a[0][:, :, ::4, ::4].contiguous(), a[0][:, :, ::2, ::2].contiguous(), a[1], *mask),
+                           cg.grain_merge(a[0][:, :, ::4, ::4].contiguous(), a[0][:, :, ::2, ::2].contiguous(), a[1], mask))
+
+
+@pytest.mark.gpu
+def test_codec_custom_ops_equal_the_module_path(orc):
+    """torch.ops.cgic.compress_streams / decompress_streams / encode_stream / decode_stream / index_histogram == GrainCodec /
+    HuffmanCoding / the quantiser's histogram (same C entry points), bytes == oracle"""
+    g = torch.Generator().manual_seed(23)
+    freq = np.floor(1e6 / (1 + np.arange(1024)) ** 1.1).astype(np.int64)
+    vq = cg.VectorQuantizer(1024, 4, beta=0.25).cuda().eval()
+    vq.embedding.weight.data.normal_(generator=None)
+    vq.usage_counter.copy_(torch.from_numpy(freq.astype(np.float32)))
+    codec = cg.GrainCodec(vq.embedding_counter, vq.embedding.weight)
+    table = codec.huffman.table.handle.value
+    B, h, w = 3, 32, 48
+    ind = torch.randint(0, 1024, (B, h, w), generator=g).cuda()
+    e16 = (torch.rand(B, h // 4, w // 4, generator=g) * 2.6).cuda()
+    e8 = (torch.rand(B, h // 2, w // 2, generator=g) * 2.6).cuda()
+    mask, _, _, mode = cg.TripleGrainFixedEntropyRouter(0.1, 0.8, per_image=True)(e16, e8)
+    hist = torch.zeros(1024, dtype=torch.int64, device="cuda")
+    data, nbytes = torch.ops.cgic.compress_streams(ind.reshape(-1), mask[0], mask[1], mask[2], mode, table, hist)
+    comp = codec.compress(ind, mask, mode)
+    assert torch.equal(nbytes, comp.nbytes) and cg.CompressedBatch(data, nbytes, mode, h, w).to_host() == comp.to_host()
+    assert torch.equal(hist, torch.bincount(ind.reshape(-1), minlength=1024))
+    hist2 = torch.zeros_like(hist)
+    torch.ops.cgic.index_histogram(ind.reshape(-1), hist2)
+    assert torch.equal(hist2, hist)
+    htab = orc.HuffmanTable(freq)
+    mks = [m.cpu().numpy() for m in mask]
+    host = comp.to_host()
+    for b in range(B):
+        assert host[b] == orc.compress_image(ind[b].cpu().numpy(), mks[0][b, 0], mks[1][b, 0], mks[2][b, 0], mode, htab)
+    ref = codec.decompress(comp)
+    for dec in ("auto", "latency", "throughput"):
+        out = torch.ops.cgic.decompress_streams(data, nbytes, h, w, mode, table, vq.embedding.weight, dec)
+        assert torch.equal(out[0], ref[0]) and all(torch.equal(a, b) for a, b in zip(out[1:4], ref[1])) and torch.equal(out[4], ref[2])
+        assert int(out[5].abs().max()) == 0
+    syms = torch.randint(0, 1024, (777,), generator=g).cuda()
+    by, nb = torch.ops.cgic.encode_stream(syms, table)
+    want = codec.huffman.encode_to_bytes(syms)
+    assert bytes(by[:int(nb)].cpu().numpy().tobytes()) == want
+    buf = torch.zeros(int(nb) + 16, dtype=torch.uint8, device="cuda")
+    buf[:int(nb)] = by[:int(nb)]
+    back, cnt = torch.ops.cgic.decode_stream(buf, int(nb), table)
+    assert int(cnt) == 777 and torch.equal(back[:777], syms)
+
+
+@pytest.mark.gpu
 def test_decoder_blends_and_avgpool_bit_exact():
     """decoder.py:304-305,366-378 -- the reference's own expressions (stock torch ops) are the oracle: the blends
     evaluated on the device, the average pools on the CPU (ATen's CPU summation order is what the kernel follows)"""
