@@ -55,6 +55,11 @@ class stdout_to_stderr:
 
     def __exit__(self, *exc):
         sys.stdout.flush()
+        try:                                               # the banner sits in libc's stdout buffer (fully buffered when fd 1 is a
+            import ctypes                                  # pipe or a file): push it out while fd 1 still points at stderr
+            ctypes.CDLL(None).fflush(None)
+        except Exception:                                  # noqa: BLE001
+            pass
         os.dup2(self._saved, 1)
         os.close(self._saved)
 
@@ -614,20 +619,31 @@ def run_rank(a, rank, world, local):
             raise SystemExit(f"bench.py: rank {rank} needs GPU {local} but only {torch.cuda.device_count()} are visible")
         torch.cuda.set_device(local)
         dev = torch.device("cuda", local)
-    ranks_seen = 1
-    if world > 1 or "RANK" in os.environ:                   # under torch.distributed.run also with one rank
+    ranks_seen = None
+    dist_note = None
+    # N = 1 goes through the same code as N > 1: a one-rank communicator (RCCL on the GPU, gloo for the CPU stub), so that
+    # `rccl_ranks` is read back from a communicator and the histogram all-reduce is the same call at every N
+    if world > 1 or "RANK" in os.environ or not a.no_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29500")
-        with stdout_to_stderr():
-            if stub:
-                dist.init_process_group("gloo", rank=rank, world_size=world)
-            else:
-                dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)  # "nccl" is RCCL on ROCm
-            one = torch.ones(1, dtype=torch.int64, device=dev)
-            dist.all_reduce(one)                            # creates the communicator (and its banner) now
-            ranks_seen = int(one.item())                    # read back from the communicator: how many ranks really joined
-        if ranks_seen != a.gpus:
+        if "MASTER_PORT" not in os.environ:
+            os.environ["MASTER_PORT"] = str(free_port()) if world == 1 else "29500"
+        try:
+            with stdout_to_stderr():
+                if stub:
+                    dist.init_process_group("gloo", rank=rank, world_size=world)
+                else:
+                    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)  # "nccl" is RCCL on ROCm
+                one = torch.ones(1, dtype=torch.int64, device=dev)
+                dist.all_reduce(one)                            # creates the communicator (and its banner) now
+                ranks_seen = int(one.item())                    # read back from the communicator: how many ranks really joined
+        except Exception as e:                                  # noqa: BLE001
+            if world > 1:
+                raise
+            dist_note = f"one-rank communicator could not be created ({str(e)[:120]}): ran without torch.distributed"
+            log("bench.py: " + dist_note)
+            dist = None
+        if dist is not None and ranks_seen != a.gpus:
             raise SystemExit(f"bench.py: --gpus {a.gpus} but the communicator has {ranks_seen} ranks")
 
     def sync():
@@ -636,7 +652,7 @@ def run_rank(a, rank, world, local):
 
     def barrier():
         sync()
-        if dist is not None:
+        if dist is not None and world > 1:                  # (one rank: nothing to wait for -- a no-op collective would only add its launch)
             dist.barrier()
         sync()
 
@@ -682,15 +698,32 @@ def run_rank(a, rank, world, local):
     t0 = time.perf_counter()
     stream.submit(a.steps)                                  # exactly K steps
     stream.join()
-    if dist is not None:
+    if dist is not None and world > 1:
         # the path's only exchange: global usage histogram (int64, exact) -- once per stream of batches
         dist.all_reduce(hist, op=dist.ReduceOp.SUM)
     barrier()
     dt = time.perf_counter() - t0
+    if dist is not None and world == 1:
+        dist.all_reduce(hist, op=dist.ReduceOp.SUM)        # one rank: the identity, issued all the same (outside the timed region)
+        sync()
+    per_rank = [dt]
+    allreduce_us = None
     if dist is not None:
-        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax.item())
+        mine = torch.tensor([dt], dtype=torch.float64, device=dev)
+        every = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(every, mine)
+        per_rank = [float(v.item()) for v in every]
+        dt = max(per_rank)                                  # the job is as slow as its slowest rank
+        # the path's only collective by itself (outside the timed region, communicator warm): int64[1024] SUM
+        probe = torch.zeros(1024, dtype=torch.int64, device=dev)
+        best = 1e9
+        for _ in range(5):
+            barrier()
+            ta = time.perf_counter()
+            dist.all_reduce(probe, op=dist.ReduceOp.SUM)
+            sync()
+            best = min(best, time.perf_counter() - ta)
+        allreduce_us = round(best * 1e6, 1)
     hist_total = int(hist.sum().item())
     if hist_total != world * a.steps * B * h * w:
         raise SystemExit(f"bench.py: usage histogram lost counts ({hist_total} != {world * a.steps * B * h * w})")
@@ -701,6 +734,8 @@ def run_rank(a, rank, world, local):
             "value": round(world * a.steps * B * H * W / dt / 1e6, 2),
             "unit": "MPixels/s",
             "n_gpus": world, "rccl_ranks": ranks_seen, "steps": a.steps, "warmup": a.warmup,
+            "per_rank_MPixels/s": [round(a.steps * B * H * W / t / 1e6, 2) for t in per_rank],
+            "histogram_allreduce_us": allreduce_us,
             "ms_per_step": round(dt / a.steps * 1e3, 5),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
@@ -716,6 +751,8 @@ def run_rank(a, rank, world, local):
                        "inputs": f"{n_slots} distinct resident batches in rotation ({n_slots * B * H * W * 13 / 2**20:.0f} MiB > 256 MiB Infinity Cache)",
                        "sharding": "images round-robin over ranks; one RCCL all-reduce of the int64[1024] histogram per run"},
         }
+        if dist_note:
+            res["config"]["distributed"] = dist_note
         if not stub and not a.no_report:
             res.update(report(a, dev, world, stream, slots_np, vq, codec, ratio))
         print(json.dumps(res), flush=True)
@@ -850,6 +887,7 @@ def parse_args(argv=None):
     ap.add_argument("--no-ring", action="store_true", help="one hipGraph per batch instead of one per rotation of batches (sequential schedule)")
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying hipGraphs (sequential schedule)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-dist", action="store_true", help="N=1 only: do not create the one-rank communicator")
     ap.add_argument("--no-report", action="store_true", help="only the timed loop and the headline fields (for kernel traces: the last K chains of the trace are the timed steps)")
     ap.add_argument("--no-extra", action="store_true", help="skip the extra data points (mask mismatch, ratio sweep, DIV2K, B=1)")
     ap.add_argument("--stub", action="store_true", help=argparse.SUPPRESS)      # CPU test of the launcher only (gloo, no kernels)

@@ -56,7 +56,9 @@ def run(rank, world, expect_world=None):
 
     bpps = []
     blobs = []
-    for i in cdist.shard(len(sizes), rank, world):
+    mine = cdist.shard(len(sizes), rank, world)
+    work = None
+    for i in mine:
         H, W = sizes[i]
         x = torch.from_numpy(np.random.default_rng(100 + i).random((1, 3, H, W), dtype=np.float32)).to(dev)
         x = x[:, :, :H // 16 * 16, :W // 16 * 16] if H <= 768 and W <= 768 else x       # small images: centre-crop rule of inference.py:66-70
@@ -64,6 +66,10 @@ def run(rank, world, expect_world=None):
         entries = container.entries_from_tiled(tiled, image_id=i)
         blobs.append(container.pack(entries))
         bpps.append(tiled.bpp())                              # per image, the reference's accounting (unpadded pixels)
+        if i == mine[-1]:
+            # the histogram is complete once the LAST image is encoded: the path's only collective goes out now
+            # (async_op: RCCL's own stream, ordered after the encode kernels) and runs under this image's decode side
+            work = cdist.all_reduce_histogram(hist, async_op=True)
         # decode side on the same rank: every tile must come back (masks exactly; indices wherever the fine grain kept them)
         per_tile, _ = highres.decompress_tiled(tiled, codec)
         for idxs, _, (ind0, masks0, _) in tiled.groups:
@@ -73,7 +79,10 @@ def run(rank, world, expect_world=None):
             assert torch.equal(got[fine], ind0.reshape(T, -1)[fine])
             for g in range(3):
                 assert torch.equal(torch.cat([per_tile[t][1][g] for t in idxs]).reshape(T, -1), masks0[g].reshape(T, -1))
-    cdist.all_reduce_histogram(hist)                       # the path's only collective
+    if work is not None:
+        work.wait()                                        # (None: one rank, or no image on this rank)
+    elif not mine:
+        cdist.all_reduce_histogram(hist)                   # a rank without images still takes part in the collective
     bpp = cdist.average_bpp(bpps, device=dev)              # unweighted mean over images, like inference.py:168-171
     if rank == 0:
         total = int(hist.sum())

@@ -123,8 +123,13 @@ def test_bench_spawns_its_own_ranks():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["rccl_ranks"] == 2 and d["steps"] == 3 and d["scaling"] == "weak"
     assert abs(d["value"] - 2 * 3 * 64 * 256 * 256 / (d["ms_per_step"] * 3 * 1e-3) / 1e6) / d["value"] < 1e-3
+    # per-rank rates and the collective's own time are on the line (the driver computes scaling efficiency from `value`)
+    assert len(d["per_rank_MPixels/s"]) == 2 and min(d["per_rank_MPixels/s"]) * 2 >= d["value"] * 0.999 and d["histogram_allreduce_us"] > 0
+    # N = 1 takes the same path: a one-rank communicator, `rccl_ranks` read back from it
     one = json.loads(_bench(["--gpus", "1", "--stub", "--steps", "3", "--warmup", "1"]).stdout.strip())
-    assert one["n_gpus"] == 1 and one["rccl_ranks"] == 1
+    assert one["n_gpus"] == 1 and one["rccl_ranks"] == 1 and len(one["per_rank_MPixels/s"]) == 1 and one["histogram_allreduce_us"] is not None
+    solo = json.loads(_bench(["--gpus", "1", "--stub", "--steps", "3", "--warmup", "1", "--no-dist"]).stdout.strip())
+    assert solo["rccl_ranks"] is None and solo["histogram_allreduce_us"] is None
 
 
 def test_bench_refuses_a_mismatched_world():
