@@ -1,0 +1,300 @@
+// cgic_decode_ss.hip -- the self-synchronising prefix decoder of the throughput mode (split off cgic_coder.hip in round 3).
+#include "cgic_coder_dev.h"
+
+namespace cgic {
+
+// -------------------------------------------------------------------------------------------
+// Self-synchronising decoder: ONE workgroup per image decodes all three index streams (round 2, second half).
+//
+// The kernels above find the codeword boundaries of a chunk for EVERY possible entry offset (64 speculative starts per
+// 64-bit chunk, pointer doubling, function composition): worst-case parallel time, but ~11 000 wave instructions, 16 waves
+// and 132 KB of LDS per 1 KB stream -- one workgroup per CU and stream for ~11 us.  With several batches in flight
+// (pipeline.LaneStream) what counts is the CU time a launch consumes, not its latency, and that was the second largest
+// item of the step (decode + merge 14.7 of 46.8 us).
+//
+// Here a lane owns a 64-bit chunk and simply GUESSES its entry offset (0), decodes the chunk serially from the LUT and
+// notes where it ran out (exit offset = entry of the next chunk) and how many symbols it saw.  Then every lane compares
+// its guess with its predecessor's exit and decodes again if they differ, until a sweep changes nothing.  The first chunk
+// of a stream is right from the start, so chunk k is right after at most k sweeps (exact for any input: the fixpoint is
+// unique); a Huffman stream re-synchronises within a few codewords, so in practice the second sweep already changes
+// nothing for almost every chunk.  A block scan of the counts gives the output positions and a last walk stores the
+// symbols.  Work: ~4 serial walks of ~9 LUT lookups per chunk instead of 64 starts x 6 doubling rounds; footprint: a
+// 256-thread workgroup and LUT + stream bytes of LDS (41 KB for a 256x256 image), three or more workgroups per CU.
+// Worst case (a stream built never to re-synchronise) degrades to one sweep per chunk -- still exact.
+// Entry offsets stay below 64 because a codeword is at most 64 bits (max_len <= 64; longer tables take the serial path).
+// -------------------------------------------------------------------------------------------
+constexpr int kSsEnd = 0xFF;            // "the stream ended before this chunk" as an entry / exit offset
+
+struct SsLayout {                       // wave-uniform description of the image's three streams
+    int nbits[3];                       // payload bits
+    int c[4];                           // first chunk of stream s; c[3] = total
+    int off[3];                         // byte offset of the stream's copy in the LDS stage (16-byte aligned)
+};
+// (selects, not indexed loads: a private array indexed by a per-lane value would live in scratch memory)
+__device__ __forceinline__ int sel3(int s, int v0, int v1, int v2) { return s == 0 ? v0 : (s == 1 ? v1 : v2); }
+
+// 32 payload bits starting at bit `pos` (0..63) of the 96-bit big-endian window d0:d1:d2
+__device__ __forceinline__ uint32_t ss_bits(uint32_t d0, uint32_t d1, uint32_t d2, int pos)
+{
+    const uint32_t hi = pos < 32 ? d0 : d1, lo = pos < 32 ? d1 : d2;
+    const uint32_t r = __builtin_amdgcn_alignbit(hi, lo, 32u - ((uint32_t)pos & 31u));      // shift amount is mod 32
+    return (pos & 31) ? r : hi;
+}
+
+// One serial walk over chunk g from `entry`: returns the exit offset (entry of the next chunk; kSsEnd when the stream
+// ends in this chunk), *count = codewords that start in the chunk.  A lone wave issues an instruction every 5-9 cycles,
+// so the walk is priced by its instruction count per codeword: 32-bit funnel shifts instead of 64-bit vector shifts, and
+// the end-of-stream checks only in the stream's last two chunks (`rem` < 128).
+template <bool WRITE, typename Put>
+__device__ __forceinline__ int ss_walk(const TableDev &t, const uint32_t *lut, const uint8_t *stage, const SsLayout &L, int g,
+                                       int entry, int *count, Put put)
+{
+    const int s = (g >= L.c[1]) + (g >= L.c[2]);
+    const int ch = g - sel3(s, L.c[0], L.c[1], L.c[2]);
+    const int rem = sel3(s, L.nbits[0], L.nbits[1], L.nbits[2]) - 64 * ch;            // payload bits from the start of this chunk
+    *count = 0;
+    if (entry == kSsEnd) return kSsEnd;
+    // payload byte 8*ch sits at stage byte 1 + 8*ch (byte 0 is the pad count): five aligned words, shifted by one byte
+    const uint32_t *q = reinterpret_cast<const uint32_t *>(stage + sel3(s, L.off[0], L.off[1], L.off[2]) + 8 * ch);
+    const uint32_t r0 = __builtin_bswap32(q[0]), r1 = __builtin_bswap32(q[1]), r2 = __builtin_bswap32(q[2]),
+                   r3 = __builtin_bswap32(q[3]), r4 = __builtin_bswap32(q[4]);
+    const uint32_t d0 = __builtin_amdgcn_alignbit(r0, r1, 24), d1 = __builtin_amdgcn_alignbit(r1, r2, 24),
+                   d2 = __builtin_amdgcn_alignbit(r2, r3, 24), d3 = __builtin_amdgcn_alignbit(r3, r4, 24);      // payload bits 0..127
+    const int LB = t.lut_bits;
+    int pos = entry, n = 0;
+    if (t.max_len <= LB) {
+        // The common case: every code fits the LUT window.  `w` holds the payload from `pos` on, left-aligned, and is
+        // shifted by each code length.  Shifting loses bits at the bottom, so the window is rebuilt once, when the walk
+        // crosses bit 32 (valid bits left >= 64 - 44).  The loop is PREDICATED, not divergent: every lane runs the same
+        // ~14 instructions until no lane of the wave has a codeword left (one wave-uniform branch per trip); as a
+        // structured loop with early exits it cost ~750 cycles per codeword -- a lone wave pays ~20 cycles for every
+        // exec-mask update and taken branch, not for the arithmetic.
+        const unsigned long long W01 = ((unsigned long long)d0 << 32) | d1, W23 = ((unsigned long long)d2 << 32) | d3;
+        unsigned long long w = pos ? (W01 << pos) | (W23 >> (64 - pos)) : W01;
+        const int sh = 64 - LB;
+        bool ended = false;
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            const int lim = rem < (half ? 64 : 32) ? rem : (half ? 64 : 32);
+            while (__builtin_amdgcn_ballot_w64(pos < lim) != 0) {
+                const bool go = pos < lim;
+                const uint32_t e = lut[(uint32_t)(w >> sh)];
+                int len = (int)(e & 0xFF);
+                const bool ok = go && len != 0 && pos + len <= rem;      // a code of this table that ends inside the stream
+                ended = ended || (go && !ok);                              // else: trailing partial codeword / not a code
+                if (WRITE) { if (ok) put(s, n, (int)(e >> 8)); }
+                len = ok ? len : 0;
+                w <<= len;
+                pos = (go && !ok) ? (1 << 20) : pos + len;
+                n += ok ? 1 : 0;
+            }
+            if (half == 0) {
+                const unsigned long long W12 = ((unsigned long long)d1 << 32) | d2, W3 = (unsigned long long)d3 << 32;
+                const int p = (pos - 32) & 63;
+                w = p ? (W12 << p) | (W3 >> (64 - p)) : W12;
+            }
+        }
+        *count = n;
+        return ended || pos < 64 ? kSsEnd : pos - 64;             // pos < 64: the stream ended at a codeword boundary in here
+    }
+    while (pos < 64) {
+        if (pos >= rem) { *count = n; return kSsEnd; }
+        const uint32_t bits = ss_bits(d0, d1, d2, pos);
+        const uint32_t e = lut[bits >> (32 - LB)];
+        int len = (int)(e & 0xFF), sym = (int)(e >> 8);
+        if (len == 0) {
+            if (sym == 0xFFFFFF) { *count = n; return kSsEnd; }
+            const unsigned long long w0 = ((unsigned long long)d0 << 32) | d1, w1 = ((unsigned long long)d2 << 32) | d3;
+            const unsigned long long win = pos ? (w0 << pos) | (w1 >> (64 - pos)) : w0;
+            int node = sym, k = LB;
+            sym = -1;
+            while (pos + k < rem && k < 64) {
+                const int c = t.child[2 * node + (int)((win >> (63 - k)) & 1ull)];
+                ++k;
+                if (c == INT32_MIN) break;
+                if (c < 0) { sym = ~c; break; }
+                node = c;
+            }
+            if (sym < 0) { *count = n; return kSsEnd; }
+            len = k;
+        }
+        if (pos + len > rem) { *count = n; return kSsEnd; }          // trailing partial codeword: dropped by the reference
+        if (WRITE) put(s, n, sym);
+        pos += len;
+        ++n;
+    }
+    *count = n;
+    return pos - 64;
+}
+
+__global__ __launch_bounds__(kDecThreads) void decode_image_kernel(DecodeArgs a, int stage_cap, int chunk_cap)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t sm[];
+    __shared__ int s_scan[kDecWaves + 1];
+    __shared__ int s_base[4];
+    uint32_t *lut = sm;                                             // [1 << lut_bits]
+    uint8_t *stage = reinterpret_cast<uint8_t *>(lut + (1 << a.tab.lut_bits));
+    uint8_t *ent = stage + stage_cap, *ext = ent + chunk_cap, *cnt = ext + chunk_cap;
+    const int tid = threadIdx.x, T = blockDim.x, lane = lane_id(), wave = tid >> 6, nw = T >> 6;
+    const int64_t b = blockIdx.x;
+    CGIC_STAMP3(0);
+    const uint8_t *in0 = a.in + (b * CGIC_NUM_STREAMS) * a.slot;
+    int nb[3];
+#pragma unroll
+    for (int s = 0; s < 3; ++s) nb[s] = (a.stream_mask >> s & 1) ? a.nbytes[b * CGIC_NUM_STREAMS + s] : -2;
+    const int pad[3] = {in0[0], in0[a.slot], in0[2 * a.slot]};      // (slot memory is always readable)
+    {   // LUT -> LDS: eight 16-byte loads in flight per thread (a plain strided loop pays one memory round trip per trip:
+        // 32 trips of a 256-thread workgroup = 25 us)
+        const uint4 *gl = reinterpret_cast<const uint4 *>(a.tab.lut);
+        uint4 *dl = reinterpret_cast<uint4 *>(lut);
+        const int n4 = (1 << a.tab.lut_bits) >> 2;
+        if (n4 == 0 && tid < (1 << a.tab.lut_bits)) lut[tid] = a.tab.lut[tid];      // (a table of two symbols: a 2-entry LUT)
+        for (int base = 0; base < n4; base += 8 * T) {
+            uint4 v[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int i = base + k * T + tid;
+                v[k] = i < n4 ? gl[i] : uint4{0u, 0u, 0u, 0u};
+            }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int i = base + k * T + tid;
+                if (i < n4) dl[i] = v[k];
+            }
+        }
+    }
+    const int64_t n_c = (a.h >> 2) * (a.w >> 2), n_m = (a.h >> 1) * (a.w >> 1), n_f = a.h * a.w;
+    const int cap[3] = {(int)n_c, (int)n_m, (int)n_f};
+    SsLayout L;
+    int stage_used = 0;
+    bool fits = true;
+    L.c[0] = 0;
+#pragma unroll
+    for (int s = 0; s < 3; ++s) {
+        if (nb[s] > a.slot) nb[s] = (int)a.slot;                    // (a corrupt length cannot reach beyond the slot)
+        int bits = nb[s] <= 0 || pad[s] == 0 ? 0 : (nb[s] - 1) * 8 - pad[s];        // remove_padding :131-138; text[:-0] is empty
+        bits = bits < 0 ? 0 : bits;
+        L.nbits[s] = bits;
+        L.c[s + 1] = L.c[s] + ((bits + 63) >> 6);
+        L.off[s] = stage_used;
+        stage_used += bits ? (((bits + 7) >> 3) + 1 + 24 + 15) & ~15 : 0;          // header + payload + the two words a walk reads past its chunk
+    }
+    const int C = L.c[3];
+    if (stage_used > stage_cap || C > chunk_cap) fits = false;     // more bits than the grids can hold symbols: overflow
+    if (tid == 0) {
+        if (a.status) a.status[b] = 0;
+#pragma unroll
+        for (int s = 0; s < 3; ++s)
+            if (nb[s] <= 0) a.dcount[b * 3 + s] = nb[s] == 0 ? -1 : -2;             // empty file (None) / not sent
+            else if (!fits) a.dcount[b * 3 + s] = -3;
+    }
+    if (!fits) return;
+    CGIC_STAMP3(1);
+    // stage the stream bytes (16-byte copies; the tail beyond the stream is never interpreted: every walk checks `rem`)
+#pragma unroll
+    for (int s = 0; s < 3; ++s) {
+        if (!L.nbits[s]) continue;
+        const int words = ((((L.nbits[s] + 7) >> 3) + 1 + 24 + 15) & ~15) >> 4;
+        const uint4 *g = reinterpret_cast<const uint4 *>(in0 + s * a.slot);
+        uint4 *d = reinterpret_cast<uint4 *>(stage + L.off[s]);
+        const int lim = (int)(a.slot >> 4);                         // stay inside the slot
+        for (int i = tid; i < words; i += T) d[i] = i < lim ? g[i] : uint4{0u, 0u, 0u, 0u};
+    }
+    __syncthreads();
+    CGIC_STAMP3(2);
+    // blocked ownership: lane tid owns chunks [g0, g1)
+    const int R = (C + T - 1) / T;
+    const int g0 = tid * R < C ? tid * R : C, g1 = g0 + R < C ? g0 + R : C;
+    auto is_first = [&](int g) { return g == L.c[0] || g == L.c[1] || g == L.c[2]; };
+    auto nop = [](int, int, int) {};
+    {
+        int prev = 0;
+        for (int g = g0; g < g1; ++g) {
+            // the guess: the smallest offset in the residue class the code lengths allow (0 when their gcd is 1); inside the
+            // lane's own run the predecessor is known
+            int e = prev;
+            if (is_first(g)) e = 0;
+            else if (g == g0) {
+                const int sg = (g >= L.c[1]) + (g >= L.c[2]);
+                const int chg = g - sel3(sg, L.c[0], L.c[1], L.c[2]);
+                const int m = (64 * chg) % a.tab.len_gcd;
+                e = m ? a.tab.len_gcd - m : 0;
+            }
+            int n;
+            prev = ss_walk<false>(a.tab, lut, stage, L, g, e, &n, nop);
+            ent[g] = (uint8_t)e; ext[g] = (uint8_t)prev; cnt[g] = (uint8_t)n;
+        }
+    }
+    __syncthreads();
+    CGIC_STAMP3(3);
+    [[maybe_unused]] int dbg_sweeps = 0;
+#ifdef CGIC_PHASE_CLOCKS
+    if (blockIdx.x == 0 && tid == 0) { g_phase_clk[23] = C; g_phase_clk[24] = R; int mx = 0; for (int g = 0; g < C; ++g) mx = cnt[g] > mx ? cnt[g] : mx; g_phase_clk[25] = mx; }
+#endif
+    for (;;) {
+        ++dbg_sweeps;
+        int changed = 0;
+        for (int g = g0; g < g1; ++g) {
+            const int e = is_first(g) ? 0 : ext[g - 1];
+            if (e != ent[g]) {
+                int n;
+                const int x = ss_walk<false>(a.tab, lut, stage, L, g, e, &n, nop);
+                ent[g] = (uint8_t)e; ext[g] = (uint8_t)x; cnt[g] = (uint8_t)n;
+                changed = 1;
+            }
+        }
+        if (!__syncthreads_or(changed)) break;
+    }
+    CGIC_STAMP3(4);
+#ifdef CGIC_PHASE_CLOCKS
+    if (blockIdx.x == 0 && tid == 0) g_phase_clk[9] = dbg_sweeps;
+#endif
+    // output positions: exclusive prefix of the counts over the chunks, restarted at every stream
+    int mine = 0;
+    for (int g = g0; g < g1; ++g) mine += cnt[g];
+    int inc = wave_inclusive_scan(mine);
+    if (lane == kWave - 1) s_scan[wave] = inc;
+    __syncthreads();
+    if (wave == 0) {
+        const int v = lane < nw ? s_scan[lane] : 0;
+        const int vi = wave_inclusive_scan(v);
+        if (lane < nw) s_scan[lane] = vi - v;
+        if (lane == nw - 1) s_scan[kDecWaves] = vi;
+    }
+    __syncthreads();
+    int run = s_scan[wave] + inc - mine;
+    const int total = s_scan[kDecWaves];
+    {
+        int r = run;
+        for (int g = g0; g < g1; ++g) {
+            if (g == L.c[1]) s_base[1] = r;
+            if (g == L.c[2]) s_base[2] = r;
+            r += cnt[g];
+        }
+        if (tid == 0) {
+            s_base[0] = 0; s_base[3] = total;
+            if (L.c[2] == C) s_base[2] = total;
+            if (L.c[1] == C) s_base[1] = total;
+        }
+    }
+    __syncthreads();
+    CGIC_STAMP3(5);
+    uint16_t *dst = a.dsym + b * (n_c + n_m + n_f);
+    for (int g = g0; g < g1; ++g) {
+        const int s = (g >= L.c[1]) + (g >= L.c[2]);
+        const int at = run - s_base[s];
+        const int cap_s = sel3(s, cap[0], cap[1], cap[2]);
+        uint16_t *dst_s = dst + sel3(s, 0, (int)n_c, (int)(n_c + n_m)) + at;
+        int n;
+        ss_walk<true>(a.tab, lut, stage, L, g, (int)ent[g], &n,
+                      [&](int, int k, int sym) { if (at + k < cap_s) dst_s[k] = (uint16_t)sym; });
+        run += n;
+    }
+    CGIC_STAMP3(6);
+    if (tid < 3 && sel3(tid, nb[0], nb[1], nb[2]) > 0) {
+        const int n = s_base[tid + 1] - s_base[tid];
+        a.dcount[b * 3 + tid] = n > sel3(tid, cap[0], cap[1], cap[2]) ? -3 : n;
+    }
+}
+
+}  // namespace cgic

@@ -51,8 +51,8 @@ typedef void *cgic_stream_t;
  * grids beyond 64x64 in compress / decompress) use self-resetting ticket slots in library-owned device memory.  Eager
  * launches take them from a ring that belongs to their stream.  Launches being captured into a hipGraph take them from a
  * pool of 262 144 slots per device and keep them while the graph may still be replayed: a VQ launch takes 1 slot, a
- * split-stream compress 6 per image, a split-stream decompress 3 per image (batches of more than 682 / 1365 such images
- * fall back to unsplit streams / two launches).  The caller says when a captured graph is gone:
+ * split-stream compress 6 per image, a split-stream decompress 3 per image (a compress of more than 682 such images falls
+ * back to unsplit streams, a decompress of more than 1365 images is cut into several launches).  The caller says when a captured graph is gone:
  *   id = cgic_ticket_scope_begin();  ... capture (on this thread) ...;  cgic_ticket_scope_end();
  *   ... replay for as long as needed ...;  destroy the graph;  cgic_ticket_scope_release(id);     -> slots returned
  * Captures made outside a scope keep their slots for the life of the process (CGIC_ERR_INVALID once the pool is used up).

@@ -338,6 +338,33 @@ def test_captured_ticket_slots_are_recycled_and_eager_rings_are_per_stream(orc, 
     assert not err, err
 
 
+def test_decompress_of_more_images_than_one_ticket_request(orc, golden):
+    """1500 tiny images: the latency decoder takes 3 ticket slots per image and one request holds 4096, so the batch is cut into
+    two launches of decode_split_kernel (rounds 1-2 kept a two-launch pair of kernels for this case: removed in round 3);
+    both decoders agree and every image round-trips"""
+    rng = np.random.default_rng(8)
+    codec, table = _zipf_codec(orc, golden, rng)
+    B, h, w = 1500, 8, 8
+    e16 = torch.from_numpy((rng.random((B, 2, 2)) * 2.6).astype(np.float32)).to(DEV)
+    e8 = torch.from_numpy((rng.random((B, 4, 4)) * 2.6).astype(np.float32)).to(DEV)
+    ind = torch.from_numpy(rng.integers(0, 1024, (B, h, w))).to(DEV)
+    mask, _, _, mode = cg.TripleGrainFixedEntropyRouter(0.25, 0.5, per_image=True)(e16, e8)
+    comp = codec.compress(ind, mask, mode)
+    a = codec.decompress(comp, decoder="latency")
+    b = codec.decompress(comp, decoder="throughput")
+    assert int(a[3].abs().max()) == 0 and int(b[3].abs().max()) == 0
+    assert torch.equal(a[0], b[0]) and torch.equal(a[2], b[2]) and all(torch.equal(x, y) for x, y in zip(a[1], b[1]))
+    assert all(torch.equal(x, y) for x, y in zip(a[1], mask))
+    fine = mask[2].reshape(B, -1).bool()
+    assert torch.equal(a[0].reshape(B, -1)[fine], ind.reshape(B, -1)[fine])
+    host = comp.to_host()
+    mks = [t.cpu().numpy() for t in mask]
+    for i in (0, 1364, 1365, 1366, B - 1):                      # either side of the launch boundary
+        assert host[i] == orc.compress_image(ind[i].cpu().numpy(), mks[0][i, 0], mks[1][i, 0], mks[2][i, 0], mode, table)
+        oind, _, _, _ = orc.decompress_image(host[i], mode, h, w, table)
+        assert np.array_equal(a[0][i].cpu().numpy(), oind)
+
+
 def _zipf_codec(orc, golden, rng):
     g = golden("coders")
 

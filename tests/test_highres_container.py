@@ -174,7 +174,7 @@ def test_f2_f4_against_tensors_captured_from_the_real_reference(golden):
         cb = t(g[k + "codebook"]).requires_grad_()
         zq, loss, idx = torch.ops.cgic.vq_forward(z, cb, 0.25, legacy)
         assert np.array_equal(idx.cpu().numpy(), g[k + "idx"].astype(np.int64)) and np.array_equal(zq.detach().cpu().numpy(), g[k + "zq"])
-        assert abs(float(loss) - float(g[k + "loss"])) <= 1e-6 * abs(float(g[k + "loss"]))
+        assert abs(float(loss.detach()) - float(g[k + "loss"])) <= 1e-6 * abs(float(g[k + "loss"]))
         (torch.sum(zq * t(g[k + "w"])) + 2.0 * loss).backward()
         assert torch.allclose(z.grad.cpu(), torch.from_numpy(g[k + "gz"]), rtol=1e-6, atol=1e-7)
         assert torch.allclose(cb.grad.cpu(), torch.from_numpy(g[k + "gw"]), rtol=2e-6, atol=1e-8)

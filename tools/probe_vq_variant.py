@@ -19,11 +19,15 @@ if "nolanes" not in sys.argv:
     slots_np = [bench.make_inputs(64, 256, 256, seed=1000 + s) for s in range(8)]
     slots = [(torch.from_numpy(a).to(dev), torch.from_numpy(b).to(dev)) for a, b, _ in slots_np]
     codec = cg.GrainCodec(hp.vq.embedding_counter, w)
-    ls = cg.pipeline.LaneStream(hp.vq, 0.1, 0.8, slots, lanes=4, frequency=codec.huffman)
-    ls.capture(); ls.prepare(200); ls.submit(40); ls.join(); torch.cuda.synchronize()
-    best = 1e9
-    for _ in range(5):
-        t0 = time.perf_counter(); ls.submit(200); ls.join(); torch.cuda.synchronize()
-        best = min(best, (time.perf_counter() - t0) / 200)
-    out += f", 4 lanes K=200: {best * 1e6:.2f} us/step = {64 * 65536 / best / 1e9:.1f} GPixel/s"
+    for with_hist in (False, True):
+        hist = torch.zeros(1024, dtype=torch.int64, device=dev) if with_hist else None
+        ls = cg.pipeline.LaneStream(hp.vq, 0.1, 0.8, slots, lanes=4, frequency=codec.huffman, hist=hist, quick_start=False)
+        ls.capture(); ls.prepare(200); ls.submit(40); ls.join(); torch.cuda.synchronize()
+        ts = []
+        for _ in range(7):
+            t0 = time.perf_counter(); ls.submit(200); ls.join(); torch.cuda.synchronize()
+            ts.append((time.perf_counter() - t0) / 200)
+        ts.sort()
+        out += f", 4 lanes K=200 hist={with_hist}: best {ts[0] * 1e6:.2f} median {ts[3] * 1e6:.2f} worst {ts[-1] * 1e6:.2f} us/step"
+        del ls
 print(out, flush=True)

@@ -1,6 +1,6 @@
 """From a rocprofv3 --kernel-trace rocpd database of bench.py: the timed loop's per-kernel durations (as dispatched on the lane
-streams) and how many kernels ran at the same time.  usage: python tools/trace_concurrency.py results.db steps"""
-import sqlite3, sys, collections
+streams) and how many kernels ran at the same time.  usage: python tools/trace_concurrency.py results.db steps [out.json]"""
+import json, sqlite3, sys, collections
 db = sqlite3.connect(sys.argv[1]); steps = int(sys.argv[2])
 rows = db.execute("select name, start, end, queue_id, stream_id from kernels order by start").fetchall()
 short = lambda n: n.split("(")[0].replace("void ", "").replace("cgic::", "")[:34]
@@ -35,3 +35,6 @@ for r in loop: d[short(r[0])].append((r[2] - r[1]) / 1e3)
 print("| kernel | launches | avg duration in the loop (us) |"); print("|---|---:|---:|")
 for k, v in sorted(d.items(), key=lambda kv: -sum(kv[1])): print(f"| {k} | {len(v)} | {sum(v) / len(v):.2f} |")
 print(f"sum of the average durations {sum(sum(v) / len(v) for v in d.values()):.1f} us per batch")
+if len(sys.argv) > 3:
+    json.dump({"steps": steps, "us_per_step_under_profiler": (t1 - t0) / 1e3 / steps,
+               "kernels": {k: {"launches": len(v), "avg_us": sum(v) / len(v)} for k, v in d.items()}}, open(sys.argv[3], "w"), indent=1)
