@@ -63,39 +63,46 @@ __device__ __forceinline__ int ss_walk(const TableDev &t, const uint32_t *lut, c
     const int LB = t.lut_bits;
     int pos = entry, n = 0;
     if (t.max_len <= LB) {
-        // The common case: every code fits the LUT window.  `w` holds the payload from `pos` on, left-aligned, and is
-        // shifted by each code length.  Shifting loses bits at the bottom, so the window is rebuilt once, when the walk
-        // crosses bit 32 (valid bits left >= 64 - 44).  The loop is PREDICATED, not divergent: every lane runs the same
-        // ~14 instructions until no lane of the wave has a codeword left (one wave-uniform branch per trip); as a
-        // structured loop with early exits it cost ~750 cycles per codeword -- a lone wave pays ~20 cycles for every
-        // exec-mask update and taken branch, not for the arithmetic.
-        const unsigned long long W01 = ((unsigned long long)d0 << 32) | d1, W23 = ((unsigned long long)d2 << 32) | d3;
-        unsigned long long w = pos ? (W01 << pos) | (W23 >> (64 - pos)) : W01;
-        const int sh = 64 - LB;
-        bool ended = false;
-#pragma unroll
-        for (int half = 0; half < 2; ++half) {
-            const int lim = rem < (half ? 64 : 32) ? rem : (half ? 64 : 32);
-            while (__builtin_amdgcn_ballot_w64(pos < lim) != 0) {
-                const bool go = pos < lim;
-                const uint32_t e = lut[(uint32_t)(w >> sh)];
-                int len = (int)(e & 0xFF);
-                const bool ok = go && len != 0 && pos + len <= rem;      // a code of this table that ends inside the stream
-                ended = ended || (go && !ok);                              // else: trailing partial codeword / not a code
-                if (WRITE) { if (ok) put(s, n, (int)(e >> 8)); }
-                len = ok ? len : 0;
-                w <<= len;
-                pos = (go && !ok) ? (1 << 20) : pos + len;
-                n += ok ? 1 : 0;
-            }
-            if (half == 0) {
-                const unsigned long long W12 = ((unsigned long long)d1 << 32) | d2, W3 = (unsigned long long)d3 << 32;
-                const int p = (pos - 32) & 63;
-                w = p ? (W12 << p) | (W3 >> (64 - p)) : W12;
-            }
+        // The common case: every code fits the LUT window.  (w0:w1:w2) holds the 96 payload bits from `pos` on, left-aligned, and is
+        // shifted by each code length with 32-bit funnel shifts (the 64-bit vector shifts of the first version are quarter-rate:
+        // a lone wave is priced by its dependent instruction chain, ~12 VALU instructions + one LDS lookup per codeword now, ~32
+        // before).  The loop is PREDICATED, not divergent: every lane runs the same instructions until no lane of the wave has a
+        // codeword left (one wave-uniform branch per trip); as a structured loop with early exits it cost ~750 cycles per
+        // codeword -- a lone wave pays ~20 cycles for every exec-mask update and taken branch.
+        // End of walk without extra state: the staged LUT marks "no such prefix" with length 255 (decode_image_kernel), and
+        // `remc` = min(rem, 128) bounds every legal end (a codeword that starts before bit 64 ends before bit 64 + 64): a lane
+        // whose codeword is no code of the table, or ends beyond the stream, lands on pos > remc and is neither counted nor
+        // continued.  pos < 64 after the loop: the stream ended at a codeword boundary inside this chunk.
+        const uint32_t a0 = pos < 32 ? d0 : d1, a1 = pos < 32 ? d1 : d2, a2 = pos < 32 ? d2 : d3, a3 = pos < 32 ? d3 : 0u;
+        const uint32_t sft = 32u - ((uint32_t)pos & 31u);                       // alignbit shifts right by (amount & 31)
+        const bool al = ((uint32_t)pos & 31u) == 0u;
+        uint32_t w0 = al ? a0 : __builtin_amdgcn_alignbit(a0, a1, sft), w1 = al ? a1 : __builtin_amdgcn_alignbit(a1, a2, sft),
+                 w2 = al ? a2 : __builtin_amdgcn_alignbit(a2, a3, sft);
+        const int remc = rem < 128 ? rem : 128, lim = rem < 64 ? rem : 64;
+        const uint32_t ish = 30u - (uint32_t)LB;                                 // index in bytes: (w0 >> (32 - LB)) * 4
+        const uint32_t imask = ((1u << LB) - 1u) << 2;
+        const char *lutb = reinterpret_cast<const char *>(lut);
+        auto step = [&]() {
+            const bool go = pos < lim;
+            const uint32_t e = *reinterpret_cast<const uint32_t *>(lutb + ((w0 >> ish) & imask));
+            const int len = (int)(e & 0xFF);
+            const int np = pos + len;
+            const bool ok = go && np <= remc;                                   // a code of this table that ends inside the stream
+            if (WRITE) { if (ok) put(s, n, (int)(e >> 8)); }
+            const uint32_t r = 32u - (uint32_t)len;                             // (len 0 or 255 only on lanes that are done: their window is dead)
+            w0 = __builtin_amdgcn_alignbit(w0, w1, r);
+            w1 = __builtin_amdgcn_alignbit(w1, w2, r);
+            w2 <<= (len & 31);
+            pos = go ? np : pos;
+            n += ok ? 1 : 0;
+        };
+        // two codewords per trip: the wave-uniform test and the taken branch cost a lone wave as much as three instructions
+        while (__builtin_amdgcn_ballot_w64(pos < lim) != 0) {
+            step();
+            step();
         }
         *count = n;
-        return ended || pos < 64 ? kSsEnd : pos - 64;             // pos < 64: the stream ended at a codeword boundary in here
+        return (pos < 64 || pos > remc) ? kSsEnd : pos - 64;
     }
     while (pos < 64) {
         if (pos >= rem) { *count = n; return kSsEnd; }
@@ -148,7 +155,11 @@ __global__ __launch_bounds__(kDecThreads) void decode_image_kernel(DecodeArgs a,
         const uint4 *gl = reinterpret_cast<const uint4 *>(a.tab.lut);
         uint4 *dl = reinterpret_cast<uint4 *>(lut);
         const int n4 = (1 << a.tab.lut_bits) >> 2;
-        if (n4 == 0 && tid < (1 << a.tab.lut_bits)) lut[tid] = a.tab.lut[tid];      // (a table of two symbols: a 2-entry LUT)
+        // every code fits the LUT window (ss_walk's predicated loop): "no such prefix" (length 0) is staged as length 255, which
+        // ends a walk without a test of its own
+        const bool mark = a.tab.max_len <= a.tab.lut_bits;
+        auto fix = [mark](uint32_t e) { return mark && (e & 0xFFu) == 0u ? e | 0xFFu : e; };
+        if (n4 == 0 && tid < (1 << a.tab.lut_bits)) lut[tid] = fix(a.tab.lut[tid]);      // (a table of two symbols: a 2-entry LUT)
         for (int base = 0; base < n4; base += 8 * T) {
             uint4 v[8];
 #pragma unroll
@@ -159,7 +170,7 @@ __global__ __launch_bounds__(kDecThreads) void decode_image_kernel(DecodeArgs a,
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
                 const int i = base + k * T + tid;
-                if (i < n4) dl[i] = v[k];
+                if (i < n4) dl[i] = uint4{fix(v[k].x), fix(v[k].y), fix(v[k].z), fix(v[k].w)};
             }
         }
     }
