@@ -433,6 +433,7 @@ __device__ int encode_binary_stream(int64_t npos, BitAt bit_at, uint8_t *out, in
 }
 
 struct CompressArgs {
+    int combine;             // unsplit streams: workgroups per image = fine | medium | coarse + both masks | histogram
     TableDev tab;
     const int64_t *ind;
     const int32_t *mc, *mm, *mf;
@@ -466,14 +467,6 @@ __global__ __launch_bounds__(kEncThreads) CGIC_VGPR_CAP_COMPRESS void compress_s
     // Split streams wait for each other: their launch is (jobs, B) -- the parts of a stream are neighbours in dispatch order,
     // so a workgroup never holds a CU waiting for one that is hundreds of workgroups behind it in the queue.
     const bool jobs_fastest = a.tick != nullptr;
-    int s, part = 0, nparts = 1;
-    {
-        int y = (int)(jobs_fastest ? blockIdx.x : blockIdx.y);
-        if (y < a.parts[2]) { s = 2; part = y; nparts = a.parts[2]; }
-        else if ((y -= a.parts[2]) < a.parts[1]) { s = 1; part = y; nparts = a.parts[1]; }
-        else if ((y -= a.parts[1]) < a.parts[0]) { s = 0; part = y; nparts = a.parts[0]; }
-        else { y -= a.parts[0]; s = y == 0 ? 4 : y == 1 ? 3 : 5; }
-    }
     const int64_t b = jobs_fastest ? blockIdx.y : blockIdx.x;
     CGIC_STAMP2(0);
     CGIC_SPAN_BEGIN();
@@ -482,76 +475,106 @@ __global__ __launch_bounds__(kEncThreads) CGIC_VGPR_CAP_COMPRESS void compress_s
     if (threadIdx.x == 0 && dbg_lin < 4096) g_blk_t[2 * dbg_lin] = wall_clock64();
     struct DbgEnd { unsigned int lin; __device__ ~DbgEnd() { if (threadIdx.x == 0 && lin < 4096) g_blk_t[2 * lin + 1] = wall_clock64(); } } dbg_end{dbg_lin};
 #endif
-    if (s == CGIC_NUM_STREAMS) {
-        // job 5: usage histogram of this image's indices (quantize.py:79-81) -- LDS histogram, then
-        // at most one global atomic per non-empty bin per image
-        unsigned int *lh = lds_end;
-        const int K = a.tab.n;
-        for (int k = threadIdx.x; k < K; k += kEncThreads) lh[k] = 0;
-        __syncthreads();
-        const int64_t n = a.h * a.w;
-        const int64_t *ind = a.ind + b * n;
-        for (int64_t i = threadIdx.x; i < n; i += kEncThreads) {
-            const int64_t v = ind[i];
-            if (v >= 0 && v < K) atomicAdd(&lh[v], 1u);
-        }
-        __syncthreads();
-        for (int k = threadIdx.x; k < K; k += kEncThreads)
-            if (lh[k]) atomicAdd(&a.hist[k], (unsigned long long)lh[k]);
-        return;
-    }
-    int32_t *nb = a.nbytes + b * CGIC_NUM_STREAMS + s;
-    if (!((a.stream_mask >> s) & 1)) {
-        if (threadIdx.x == 0 && part == nparts - 1) *nb = -1;
-        return;
-    }
-    uint8_t *out = a.out + (b * CGIC_NUM_STREAMS + s) * a.slot;
     const int64_t h = a.h, w = a.w;
-    int rc;
-    if (s < 3) {
-        // code table -> LDS (length + code lookups then cost an LDS access, not an L2 round trip each)
-        if (a.tab.n <= kLdsTable && a.tab.words == 1) {
-            for (int i = threadIdx.x; i < a.tab.n; i += kEncThreads) { lds_len[i] = a.tab.len[i]; lds_code[i] = a.tab.code[i]; }
-            a.tab.len = lds_len;
-            a.tab.code = lds_code;
+    // one job = one stream of one image (or a part of it), or the image's usage histogram
+    auto run_job = [&](const int s, const int part, const int nparts) {
+        if (s == CGIC_NUM_STREAMS) {
+            // job 5: usage histogram of this image's indices (quantize.py:79-81) -- LDS histogram, then
+            // at most one global atomic per non-empty bin per image
+            unsigned int *lh = lds_end;
+            const int K = a.tab.n;
+            for (int k = threadIdx.x; k < K; k += kEncThreads) lh[k] = 0;
             __syncthreads();
+            const int64_t n = a.h * a.w;
+            const int64_t *ind = a.ind + b * n;
+            for (int64_t i = threadIdx.x; i < n; i += kEncThreads) {
+                const int64_t v = ind[i];
+                if (v >= 0 && v < K) atomicAdd(&lh[v], 1u);
+            }
+            __syncthreads();
+            for (int k = threadIdx.x; k < K; k += kEncThreads)
+                if (lh[k]) atomicAdd(&a.hist[k], (unsigned long long)lh[k]);
+            return;
         }
-        const int sh = 2 - s;                                   // stride 4, 2, 1
-        const int64_t gh = h >> sh, gw = w >> sh, npos = gh * gw;
-        const int32_t *mask = (s == 0 ? a.mc : s == 1 ? a.mm : a.mf) + b * npos;
-        const int64_t *ind = a.ind + b * h * w;
-        // this workgroup's positions: all of them, or the part-th of nparts ranges (whole groups of four)
-        const int64_t per = nparts > 1 ? (((npos + nparts - 1) / nparts) + 3) & ~(int64_t)3 : npos;
-        const int64_t pos0 = (int64_t)part * per < npos ? (int64_t)part * per : npos;
-        const int64_t mypos = pos0 + per < npos ? per : npos - pos0;
-        EncStorage st, st_glob;
-        st.cend = lds_end; st.csym = lds_sym;
-        st_glob.cend = a.ws_end + (b * 3 + s) * a.ws_stride + pos0;
-        st_glob.csym = a.ws_sym + (b * 3 + s) * a.ws_stride + pos0;
-        // ind[:, ::4, ::4][mask_c == 1] etc.: row-major over the granularity's own grid (:219-221)
-        auto sym_at = [&](int64_t i, bool *flag) -> int64_t {
-            // both loads are issued unconditionally so that they share one memory round trip
-            const int ii = (int)(i + pos0), gwi = (int)gw;              // 32-bit divide (h*w < 2^26)
-            const int y = ii / gwi, x = ii - y * gwi;
-            const int64_t v = ind[((int64_t)(y << sh) * w) + (x << sh)];
-            *flag = mask[ii] == 1;
-            return v;
-        };
-        if (nparts > 1) {
-            const EncExchange ex{a.tick + ((b * 3 + s) * 2) * kTicketStride, part, nparts};
-            rc = encode_huffman_stream_long(a.tab, mypos, sym_at, lds_stage, st, st_glob, out, a.slot, sh == 0 ? ind + pos0 : nullptr,
-                                            sh == 0 ? mask + pos0 : nullptr, &ex);
-        } else if (npos <= kLdsPos) rc = encode_huffman_stream(a.tab, npos, sym_at, st, out, a.slot);
-        else if (a.stage_positions >= npos)
-            rc = encode_huffman_stream_long(a.tab, npos, sym_at, lds_stage, st, st_glob, out, a.slot, sh == 0 ? ind : nullptr, sh == 0 ? mask : nullptr);
-        else rc = encode_huffman_stream(a.tab, npos, sym_at, st_glob, out, a.slot);
+        int32_t *nb = a.nbytes + b * CGIC_NUM_STREAMS + s;
+        if (!((a.stream_mask >> s) & 1)) {
+            if (threadIdx.x == 0 && part == nparts - 1) *nb = -1;
+            return;
+        }
+        uint8_t *out = a.out + (b * CGIC_NUM_STREAMS + s) * a.slot;
+        int rc;
+        if (s < 3) {
+            TableDev tab = a.tab;
+            // code table -> LDS (length + code lookups then cost an LDS access, not an L2 round trip each)
+            if (tab.n <= kLdsTable && tab.words == 1) {
+                for (int i = threadIdx.x; i < tab.n; i += kEncThreads) { lds_len[i] = tab.len[i]; lds_code[i] = tab.code[i]; }
+                tab.len = lds_len;
+                tab.code = lds_code;
+                __syncthreads();
+            }
+            const int sh = 2 - s;                                   // stride 4, 2, 1
+            const int64_t gh = h >> sh, gw = w >> sh, npos = gh * gw;
+            const int32_t *mask = (s == 0 ? a.mc : s == 1 ? a.mm : a.mf) + b * npos;
+            const int64_t *ind = a.ind + b * h * w;
+            // this workgroup's positions: all of them, or the part-th of nparts ranges (whole groups of four)
+            const int64_t per = nparts > 1 ? (((npos + nparts - 1) / nparts) + 3) & ~(int64_t)3 : npos;
+            const int64_t pos0 = (int64_t)part * per < npos ? (int64_t)part * per : npos;
+            const int64_t mypos = pos0 + per < npos ? per : npos - pos0;
+            EncStorage st, st_glob;
+            st.cend = lds_end; st.csym = lds_sym;
+            st_glob.cend = a.ws_end + (b * 3 + s) * a.ws_stride + pos0;
+            st_glob.csym = a.ws_sym + (b * 3 + s) * a.ws_stride + pos0;
+            // ind[:, ::4, ::4][mask_c == 1] etc.: row-major over the granularity's own grid (:219-221)
+            auto sym_at = [&](int64_t i, bool *flag) -> int64_t {
+                // both loads are issued unconditionally so that they share one memory round trip
+                const int ii = (int)(i + pos0), gwi = (int)gw;              // 32-bit divide (h*w < 2^26)
+                const int y = ii / gwi, x = ii - y * gwi;
+                const int64_t v = ind[((int64_t)(y << sh) * w) + (x << sh)];
+                *flag = mask[ii] == 1;
+                return v;
+            };
+            if (nparts > 1) {
+                const EncExchange ex{a.tick + ((b * 3 + s) * 2) * kTicketStride, part, nparts};
+                rc = encode_huffman_stream_long(tab, mypos, sym_at, lds_stage, st, st_glob, out, a.slot, sh == 0 ? ind + pos0 : nullptr,
+                                                sh == 0 ? mask + pos0 : nullptr, &ex);
+            } else if (npos <= kLdsPos) rc = encode_huffman_stream(tab, npos, sym_at, st, out, a.slot);
+            else if (a.stage_positions >= npos)
+                rc = encode_huffman_stream_long(tab, npos, sym_at, lds_stage, st, st_glob, out, a.slot, sh == 0 ? ind : nullptr, sh == 0 ? mask : nullptr);
+            else rc = encode_huffman_stream(tab, npos, sym_at, st_glob, out, a.slot);
+        } else {
+            const int sh = s == 3 ? 2 : 1;
+            const int64_t npos = (h >> sh) * (w >> sh);
+            const int32_t *mask = (s == 3 ? a.mc : a.mm) + b * npos;   // grain_mask[k].flatten() (:230-231)
+            rc = encode_binary_stream(npos, [&](int64_t i) { return (int)mask[i]; }, out, a.slot);
+        }
+        if (threadIdx.x == 0 && part == nparts - 1) *nb = rc < 0 ? rc - 10 : rc;     // errors are CGIC_ERR_* - 10 (-1 means "not written")
+    };
+    int y = (int)(jobs_fastest ? blockIdx.x : blockIdx.y);
+    if (a.combine) {
+        // unsplit streams (grids up to kLdsPos positions): the fine stream, the medium stream, ONE workgroup for the three short
+        // streams one after the other (coarse indices, the two masks), and the histogram if asked for.  As six workgroups per
+        // image the launch spent its first ~4 us handing out 1024-thread workgroups (~100 per us), three of them for a few
+        // hundred positions each.  (The histogram in the same workgroup as the short streams made that one the long pole:
+        // 9.5 us alone against 7.6.)
+        if (y < 2) {
+            run_job(2 - y, 0, 1);
+        } else if (y == 2) {
+            run_job(0, 0, 1);
+            __syncthreads();
+            run_job(3, 0, 1);
+            __syncthreads();
+            run_job(4, 0, 1);
+        } else {
+            run_job(CGIC_NUM_STREAMS, 0, 1);
+        }
     } else {
-        const int sh = s == 3 ? 2 : 1;
-        const int64_t npos = (h >> sh) * (w >> sh);
-        const int32_t *mask = (s == 3 ? a.mc : a.mm) + b * npos;   // grain_mask[k].flatten() (:230-231)
-        rc = encode_binary_stream(npos, [&](int64_t i) { return (int)mask[i]; }, out, a.slot);
+        int s, part = 0, nparts = 1;
+        if (y < a.parts[2]) { s = 2; part = y; nparts = a.parts[2]; }
+        else if ((y -= a.parts[2]) < a.parts[1]) { s = 1; part = y; nparts = a.parts[1]; }
+        else if ((y -= a.parts[1]) < a.parts[0]) { s = 0; part = y; nparts = a.parts[0]; }
+        else { y -= a.parts[0]; s = y == 0 ? 4 : y == 1 ? 3 : 5; }
+        run_job(s, part, nparts);
     }
-    if (threadIdx.x == 0 && part == nparts - 1) *nb = rc < 0 ? rc - 10 : rc;     // errors are CGIC_ERR_* - 10 (-1 means "not written")
     CGIC_SPAN_END();
 }
 
@@ -706,7 +729,9 @@ extern "C" int cgic_compress_streams(const cgic_table *t, const int64_t *ind, co
         rc = acquire_tickets((hipStream_t)stream, (int)(B * 6), &a.tick);
         if (rc) return rc;
     }
-    const unsigned jobs = (unsigned)(a.parts[0] + a.parts[1] + a.parts[2]) + 2u + (hist ? 1u : 0u);
+    // every index stream fits the static LDS arrays and nothing is split: the short jobs of an image share one workgroup
+    a.combine = (!a.tick && h * w <= kLdsPos) ? 1 : 0;
+    const unsigned jobs = a.combine ? 3u + (hist ? 1u : 0u) : (unsigned)(a.parts[0] + a.parts[1] + a.parts[2]) + 2u + (hist ? 1u : 0u);
     hipLaunchKernelGGL(compress_streams_kernel, a.tick ? dim3(jobs, (unsigned)B) : dim3((unsigned)B, jobs), dim3(kEncThreads), dyn,
                        (hipStream_t)stream, a);
     return launch_check("compress_streams_kernel");
