@@ -22,11 +22,12 @@ def fns(hp):
     e8, e16, mask, mode, zq, ind, comp = hp.out[:7]
     return {
         "entropy": lambda: cg.entropy_maps(hp.x),
-        "vq+router": lambda: vq_forward_route(hp.z, vq.embedding.weight, 0.25, True, e16, e8, 0.1, 0.8, per_image=True),
+        "vq+router": lambda: vq_forward_route(hp.z, vq.embedding.weight, 0.25, True, e16, e8, 0.1, 0.8, per_image=True, prepared=hp.pipe.prepared),
         "vq": lambda: _vq_forward(hp.z, vq.embedding.weight, 0.25, True, None),
         "router": lambda: hp.router(e16, e8, want_gate=False),
         "compress": lambda: codec.compress(ind, mask, mode, hist=hp.hist),
-        "decode+merge": lambda: codec.decompress(comp),
+        "decode+merge (throughput)": lambda: codec.decompress(comp, decoder="throughput"),
+        "decode+merge (latency)": lambda: codec.decompress(comp, decoder="latency"),
     }
 F = [fns(h) for h in hps]
 def make_graph(fn, stream):
@@ -54,5 +55,5 @@ for k in F[0]:
     t1 = run(gs[:1]) / N
     t4 = run(gs) / (N * NL)
     print(f"{k:14s} alone {t1:6.2f} us   {NL} lanes {t4:6.2f} us per launch")
-    if k not in ("vq", "router"): tot1 += t1; tot4 += t4
+    if k not in ("vq", "router", "decode+merge (latency)"): tot1 += t1; tot4 += t4
 print(f"sum over the step's four launches: alone {tot1:.1f}, self-contended {tot4:.1f}")
