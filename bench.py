@@ -340,11 +340,11 @@ def mask_flip_families(dev, z, cb, vq, codec, ratio):
     from control_gic_amd.quantize import vq_forward_route
     htab = orc.HuffmanTable(zipf_freq())
 
-    def run(x, zz):
+    def run(x, zz, reference_order=False):
         B, H, W = x.shape[0], x.shape[2], x.shape[3]
         h, w = H // 4, W // 4
         xd, zd = torch.from_numpy(x).to(dev), torch.from_numpy(zz).to(dev)
-        e8, e16 = cg_entropy(xd)
+        e8, e16 = cg_entropy(xd, reference_order=reference_order)
         _, _, ind, mask, _, mode = vq_forward_route(zd, vq.embedding.weight, 0.25, True, e16, e8, ratio[0], ratio[1], per_image=True)
         host = codec.compress(ind, mask, mode).to_host()
         torch.cuda.synchronize()
@@ -371,12 +371,22 @@ def mask_flip_families(dev, z, cb, vq, codec, ratio):
 
     from control_gic_amd import entropy_maps as cg_entropy
     out = {}
+    ref_mode = {}
+    short = lambda r: {k: r[k] for k in ("images", "differing_mask_elements", "images_with_a_difference", "differing_bin_files", "max_abs_entropy_diff")}
     for name, x in families(n=64).items():
         out[name] = run(x, z)
+        ref_mode[name] = short(run(x, z, reference_order=True))
     t = families(n=2, H=768, W=768, seed=11)
     tiles = np.concatenate([t[k] for k in ("noise8", "smooth8", "flat_edges", "blocky8")])
     zt = np.random.default_rng(5).standard_normal((tiles.shape[0], 4, 192, 192), dtype=np.float32)
     out["tiles_768"] = run(tiles, zt)
+    ref_mode["tiles_768"] = short(run(tiles, zt, reference_order=True))
+    xd = torch.from_numpy(families(n=64)["smooth8"]).to(dev)
+    ref_mode["us_per_launch_B64_256x256"] = round(graph_kernel_time(lambda: cg_entropy(xd, reference_order=True), per_graph=5, reps=3), 2)
+    ref_mode["default_kernel_us_per_launch"] = round(graph_kernel_time(lambda: cg_entropy(xd), per_graph=5, reps=3), 2)
+    ref_mode["note"] = ("entropy_maps(reference_order=True) = cgic_entropy_maps_ref_f32: torch's CPU operation sequence and summation order, exp / log "
+                        "correctly rounded (opt-in; the timed step uses the default kernel)")
+    out["reference_order_mode"] = ref_mode
     out["note"] = ("reference side = the reference's torch-CPU entropy arithmetic evaluated on this host (oracle/entropy_torch.py) -> oracle router; "
                    "a differing mask element is a patch whose entropy lies within ~1e-6 of a threshold (k-th smallest value, strict '<'); the masks are "
                    "part of the bitstream, so every stream decodes either way")

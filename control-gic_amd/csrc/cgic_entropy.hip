@@ -240,6 +240,129 @@ __global__ __launch_bounds__(kEntThreads) void entropy_maps_kernel(
     }
 }
 
+// =====================================================================================================
+// Reference-arithmetic variant (opt-in, cgic_entropy_maps_ref_f32): the reference's own fp32 operation sequence and
+// summation ORDER, with exp / log correctly rounded (evaluated in fp64, rounded once).
+//
+// The router's thresholds are k-th smallest entropies with a strict '<' (RouterTriple.py:21-34): on tie-heavy content
+// (8-bit, flat, blocky images) which patches fall under a threshold is decided by the last bits of the maps.  The
+// kernel above is accurate to ~1e-6 and order-free, which flips a handful of mask elements in ~1 of 64 such images (and
+// 2 of 8 768x768 tiles: profiles / bench `mask_mismatch.tie_heavy_content`).  This variant reproduces how torch's CPU
+// operators round (measured against the real Entropy class: 98.6-100 % of all values bit-identical, the rest within
+// 5e-7, no mask element flipped on any family -- torch's exp / log are MKL's, not correctly rounded in ~1 % of the
+// arguments, which is what is left):
+//   gray   = (0.2989 R + 0.5870 G) + 0.1140 B                       three products, two sums, no fma (model.py:471)
+//   kv     = exp(-0.5 * ((gray - bin) / sigma)^2)                    IEEE divide, fp32 square and product (:452-454);
+//            exactly 0 beyond 14.42 sigma in fp32 (a < -104): at most five consecutive bins per pixel are evaluated
+//   pdf    = mean over the patch's pixels in row-major order         torch's cascade sum of an outer reduction: chunks of
+//            16 consecutive pixels summed one after the other from 0, the chunk sums added one after the other (:456)
+//   norm   = sum over the 32 bins + 1e-40                            torch's inner reduction of 32 contiguous floats: eight
+//            strided partials p_k = ((x_k + x_{8+k}) + x_{16+k}) + x_{24+k}, then p_0 + p_1 + ... + p_7 (:457)
+//   q      = pdf / norm + 1e-40;  H = -sum(q log q), same 8-partial order (:458-459)
+// One 256-thread workgroup per 16x16 block of the image (thread = pixel): the kernel values of a pixel's five-bin window go
+// to LDS once and serve both patch sizes; 1024 chunk sums (16 pixels each) are dealt four to a thread, 160 threads
+// combine them, 160 finalise.  ~8x the instructions of the kernel above: an option for when bit-level agreement of the
+// masks with the CPU reference is wanted, not the default.
+// =====================================================================================================
+constexpr int kRefWin = 5;
+
+__device__ __forceinline__ float sum32_lanes8(const float *v)
+{
+    float p[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) p[k] = ((v[k] + v[8 + k]) + v[16 + k]) + v[24 + k];
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) s = s + p[k];
+    return s;
+}
+
+__global__ __launch_bounds__(256) void entropy_ref_kernel(const float *__restrict__ x, int64_t H, int64_t W, float sigma,
+                                                          float *__restrict__ e8, float *__restrict__ e16, BinsArg bins_arg)
+{
+    __shared__ float s_bins[kBins];
+    __shared__ float s_val[256][kBins + 1];            // kernel values of a pixel for all 32 bins: zero outside its window (+1: bank padding)
+    __shared__ float s_chunk[5][kBins][16];            // [patch: 0..3 = the 8x8 ones, 4 = 16x16][bin][chunk]
+    __shared__ float s_pdf[5][kBins];
+    __shared__ float s_norm[5];
+    const int tid = threadIdx.x;
+    const int64_t b = blockIdx.z, by = blockIdx.y, bx = blockIdx.x;
+    if (tid < kBins) s_bins[tid] = bins_arg.v[tid];
+    const int r = tid >> 4, c = tid & 15;
+    const int64_t o = ((b * 3) * H + by * 16 + r) * W + bx * 16 + c;
+    const float R = x[o], G = x[o + H * W], Bc = x[o + 2 * H * W];
+    const float gray = (0.2989f * R + 0.5870f * G) + 0.1140f * Bc;
+    __syncthreads();
+    {
+        // the window: the first bin that is not below gray - 0.1445 (14.42 sigma = 0.1442: exp is exactly 0 in fp32 beyond)
+        // and the four after it; found by comparing against the bin values themselves (no division, NaN-safe: a NaN pixel
+        // selects window 0 and poisons it)
+        int j0 = 0;
+#pragma unroll 8
+        for (int j = 0; j < kBins; ++j) j0 += (s_bins[j] < gray - 0.1445f) ? 1 : 0;
+        j0 = j0 > kBins - kRefWin ? kBins - kRefWin : j0;
+#pragma unroll
+        for (int j = 0; j < kBins; ++j) s_val[tid][j] = 0.f;                    // (exactly what exp rounds to out there)
+#pragma unroll
+        for (int k = 0; k < kRefWin; ++k) {
+            const float res = gray - s_bins[j0 + k];
+            const float t = res / sigma;
+            const float t2 = t * t;
+            const float a = -0.5f * t2;
+            // exp(a) < 2^-150 rounds to 0 in fp32 (a < -103.98); NaN takes the exp
+            if (!(a < -104.0f)) s_val[tid][j0 + k] = (float)exp((double)a);      // correctly rounded but for ~1e-9 of the arguments
+        }
+    }
+    __syncthreads();
+    // chunk sums: task = (patch, bin, chunk): 4 x 32 x 4 for the 8x8 patches (chunk = two rows of 8), 32 x 16 for the 16x16
+    // patch (chunk = one row of 16); 1024 tasks of 16 sequential additions, four per thread
+    for (int task = tid; task < 1024; task += 256) {
+        float acc = 0.f;
+        int pt, bin, ch;
+        if (task < 512) {
+            pt = task >> 7; bin = (task >> 2) & 31; ch = task & 3;
+            const int pr = (pt >> 1) * 8, pc = (pt & 1) * 8;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int k = 16 * ch + i, px = (pr + (k >> 3)) * 16 + pc + (k & 7);
+                acc = acc + s_val[px][bin];
+            }
+        } else {
+            const int t2 = task - 512;
+            pt = 4; bin = t2 >> 4; ch = t2 & 15;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc = acc + s_val[ch * 16 + i][bin];
+        }
+        s_chunk[pt][bin][ch] = acc;
+    }
+    __syncthreads();
+    if (tid < 160) {
+        const int pt = tid >> 5, bin = tid & 31;
+        const int nch = pt < 4 ? 4 : 16;
+        float acc = 0.f;
+        for (int ch = 0; ch < nch; ++ch) acc = acc + s_chunk[pt][bin][ch];
+        s_pdf[pt][bin] = acc / (pt < 4 ? 64.0f : 256.0f);                    // torch.mean: the sum times... divided by the count (exact: a power of two)
+    }
+    __syncthreads();
+    const float eps = 1e-40f;
+    if (tid < 5) s_norm[tid] = sum32_lanes8(s_pdf[tid]) + eps;
+    __syncthreads();
+    if (tid < 160) {
+        const int pt = tid >> 5, bin = tid & 31;
+        const float q = s_pdf[pt][bin] / s_norm[pt] + eps;
+        s_pdf[pt][bin] = q * (float)log((double)q);
+    }
+    __syncthreads();
+    if (tid < 5) {
+        const float ent = -sum32_lanes8(s_pdf[tid]);
+        if (tid < 4) {
+            if (e8) e8[(b * (H / 8) + by * 2 + (tid >> 1)) * (W / 8) + bx * 2 + (tid & 1)] = ent;
+        } else if (e16) {
+            e16[(b * (H / 16) + by) * (W / 16) + bx] = ent;
+        }
+    }
+}
+
 }  // namespace cgic
 
 using namespace cgic;
@@ -286,3 +409,25 @@ extern "C" int cgic_entropy_maps_f32(const float *x, int64_t B, int64_t H, int64
     hipLaunchKernelGGL(entropy_maps_kernel, grid, dim3(kEntThreads), 0, s, x, H, W, exp2_scale, e8, e16, ba, ppw);
     return launch_check("entropy_maps_kernel");
 }
+
+extern "C" int cgic_entropy_maps_ref_f32(const float *x, int64_t B, int64_t H, int64_t W, const float *bins,
+                                         int nbins, float sigma, float *e8, float *e16, cgic_stream_t stream)
+{
+    CGIC_REQUIRE(x && bins, CGIC_ERR_INVALID, "entropy: x and bins must not be NULL");
+    CGIC_REQUIRE(nbins == kBins, CGIC_ERR_UNSUPPORTED, "entropy: nbins=%d; the reference uses 32 (model.py:480)", nbins);
+    CGIC_REQUIRE(B >= 0 && H > 0 && W > 0 && H % 16 == 0 && W % 16 == 0, CGIC_ERR_INVALID,
+                 "entropy: H=%lld W=%lld must be positive multiples of 16", (long long)H, (long long)W);
+    CGIC_REQUIRE(B <= 65535 && H / 16 <= 65535, CGIC_ERR_UNSUPPORTED, "entropy: batch/height exceed the grid limits");
+    CGIC_REQUIRE(sigma > 0.f && sigma <= 0.0105f, CGIC_ERR_UNSUPPORTED,
+                 "entropy: sigma=%g; the five-bin window assumes the reference's sigma=0.01 (model.py:481)", sigma);
+    for (int i = 1; i < kBins; ++i)
+        CGIC_REQUIRE(fabsf((bins[i] - bins[i - 1]) - 2.0f / 31.0f) < 1e-5f, CGIC_ERR_UNSUPPORTED,
+                     "entropy: bins are not linspace(-1, 1, 32)");
+    if (B == 0 || (!e8 && !e16)) return CGIC_OK;
+    BinsArg ba;
+    memcpy(ba.v, bins, sizeof(ba.v));
+    dim3 grid((unsigned)(W / 16), (unsigned)(H / 16), (unsigned)B);
+    hipLaunchKernelGGL(entropy_ref_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, H, W, sigma, e8, e16, ba);
+    return launch_check("entropy_ref_kernel");
+}
+

@@ -22,8 +22,11 @@ def _bins():
     return _BINS
 
 
-def entropy_maps(x, want8=True, want16=True, sigma=0.01):
-    """x [B,3,H,W] fp32 on the device, H and W multiples of 16 -> (e8 [B,H/8,W/8], e16 [B,H/16,W/16])"""
+def entropy_maps(x, want8=True, want16=True, sigma=0.01, reference_order=False):
+    """x [B,3,H,W] fp32 on the device, H and W multiples of 16 -> (e8 [B,H/8,W/8], e16 [B,H/16,W/16]).
+    reference_order=True: the reference's own fp32 operation sequence and summation order with correctly rounded exp / log
+    (cgic_entropy_maps_ref_f32): bit-identical to the CPU reference in ~99 % of the values and no flipped mask element on
+    tie-heavy content, at ~8x the instructions -- for when the masks must agree with the CPU reference's to the bit."""
     _lib.require_device(x)
     if x.dim() != 4 or x.shape[1] != 3:
         raise ValueError(f"expected [B,3,H,W], got {tuple(x.shape)}")
@@ -32,14 +35,15 @@ def entropy_maps(x, want8=True, want16=True, sigma=0.01):
     e8 = torch.empty((B, H // 8, W // 8), dtype=torch.float32, device=x.device) if want8 else None
     e16 = torch.empty((B, H // 16, W // 16), dtype=torch.float32, device=x.device) if want16 else None
     with torch.cuda.device(x.device):
-        _lib.call("cgic_entropy_maps_f32", _lib.ptr(x), B, H, W, _bins(), 32, float(sigma), _lib.ptr(e8),
+        _lib.call("cgic_entropy_maps_ref_f32" if reference_order else "cgic_entropy_maps_f32", _lib.ptr(x), B, H, W, _bins(), 32, float(sigma), _lib.ptr(e8),
                   _lib.ptr(e16), _lib.current_stream(x.device))
     return e8, e16
 
 
 class Entropy(nn.Module):
-    def __init__(self, patch_size):
+    def __init__(self, patch_size, reference_order=False):
         super().__init__()
+        self.reference_order = bool(reference_order)          # see entropy_maps
         if patch_size not in (8, 16):
             raise NotImplementedError(
                 f"Entropy(patch_size={patch_size}): Control-GIC uses (8, 16) (config_inference.yaml:11-13); "
@@ -47,5 +51,5 @@ class Entropy(nn.Module):
         self.psize = patch_size
 
     def forward(self, inputs):
-        e8, e16 = entropy_maps(inputs, want8=self.psize == 8, want16=self.psize == 16)
+        e8, e16 = entropy_maps(inputs, want8=self.psize == 8, want16=self.psize == 16, reference_order=self.reference_order)
         return e8 if self.psize == 8 else e16

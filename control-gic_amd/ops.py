@@ -83,6 +83,20 @@ def _(x):
     return x.new_empty((B, H // 8, W // 8)), x.new_empty((B, H // 16, W // 16))
 
 
+@torch.library.custom_op("cgic::entropy_maps_reference_order", mutates_args=(), device_types=_DEV)
+def entropy_maps_reference_order(x: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+    """entropy_maps in the reference's own arithmetic (cgic_entropy_maps_ref_f32): torch's CPU summation order, exp / log
+    correctly rounded -- the masks of tie-heavy content then agree with the CPU reference's"""
+    e8, e16 = _entropy_maps(x, reference_order=True)
+    return e8, e16
+
+
+@entropy_maps_reference_order.register_fake
+def _(x):
+    B, _, H, W = x.shape
+    return x.new_empty((B, H // 8, W // 8)), x.new_empty((B, H // 16, W // 16))
+
+
 @torch.library.custom_op("cgic::router", mutates_args=(), device_types=_DEV)
 def router(e16: torch.Tensor, e8: torch.Tensor, coarse_ratio: float, medium_ratio: float, per_image: bool) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
     """TripleGrainFixedEntropyRouter.forward masks (RouterTriple.py:15-95): int32 [B,1,h16,w16], [B,1,2h16,2w16], [B,1,4h16,4w16];

@@ -157,12 +157,24 @@ int cgic_index_histogram(const int64_t *indices, int64_t n, int K, int64_t *hist
  *   bins  host   [32] fp32  (torch.linspace(-1, 1, 32), model.py:480)
  *   e8    device [B, H/8,  W/8 ] fp32 or NULL
  *   e16   device [B, H/16, W/16] fp32 or NULL
- * fp32 throughout; exp / log / reciprocal are the GPU's (v_exp_f32, v_log_f32, v_rcp_f32) and only the 3 bins
- * nearest to a pixel are evaluated (the rest is < 3e-17 per pixel), so results match the CPU reference to
- * ~1e-6 (measured 7e-7; tests hold it to 2e-5), not bit-for-bit (SURVEY.md section 7 "hard parts").
+ * fp32 throughout; exp / log / reciprocal are the GPU's (v_exp_f32, v_log_f32, v_rcp_f32) and only the 2 bins
+ * that bracket a pixel are evaluated (the rest is <= 9e-10 per pixel), so results match the CPU reference to
+ * ~1e-6 (measured <= 1.1e-6; tests hold it to 2e-6), not bit-for-bit (SURVEY.md section 7 "hard parts"); see
+ * cgic_entropy_maps_ref_f32 below for the variant that follows the reference's rounding.
  * ------------------------------------------------------------------------- */
 int cgic_entropy_maps_f32(const float *x, int64_t B, int64_t H, int64_t W, const float *bins,
                           int nbins, float sigma, float *e8, float *e16, cgic_stream_t stream);
+/* The same maps in the REFERENCE'S OWN ARITHMETIC (opt-in): torch's CPU operation sequence and summation order -- gray as three
+ * products and two sums, IEEE divide by sigma, the mean over a patch's pixels as torch's cascade sum (chunks of 16 pixels in
+ * row-major order, then the chunk sums), both sums over the 32 bins as torch's eight strided partials -- with exp / log
+ * correctly rounded (fp64, rounded once).  The router's thresholds are k-th smallest entropies with a strict '<'
+ * (RouterTriple.py:21-34), so on tie-heavy content (8-bit, flat, blocky images) the last bits of the maps decide which
+ * patches fall under a threshold: against the real Entropy class this variant is bit-identical in 98.6-100 % of the values
+ * (the rest within 5e-7: torch's exp / log are MKL's) and flips no mask element on any measured content family, where the
+ * default kernel (accurate to ~1e-6, order-free) flips a few elements in ~1 of 64 such images.  ~8x the instructions of
+ * the default kernel.  Same arguments and contract as cgic_entropy_maps_f32. */
+int cgic_entropy_maps_ref_f32(const float *x, int64_t B, int64_t H, int64_t W, const float *bins,
+                              int nbins, float sigma, float *e8, float *e16, cgic_stream_t stream);
 
 /* ---------------------------------------------------------------------------
  * C. TripleGrainFixedEntropyRouter -- CGIC/modules/vqvae/RouterTriple.py:8-95

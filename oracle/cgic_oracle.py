@@ -99,6 +99,22 @@ def entropy(x, p, bins=None, sigma=0.01):
     return out
 
 
+def entropy_ref(x, p, bins=None, sigma=0.01):
+    """model.py:433-483 in torch's CPU operation sequence and summation order, exp / log correctly rounded
+    (cgic_oracle_entropy_ref: the CPU restatement of the GPU's opt-in reference-arithmetic kernel)"""
+    x = np.ascontiguousarray(x, np.float32)
+    B, ch, H, W = x.shape
+    assert ch == 3
+    bins = linspace_bins() if bins is None else np.ascontiguousarray(bins, np.float32)
+    out = np.empty((B, H // p, W // p), np.float32)
+    rc = lib().cgic_oracle_entropy_ref(_p(x, C.c_float), C.c_long(B), C.c_long(H), C.c_long(W), C.c_int(p),
+                                       _p(bins, C.c_float), C.c_int(len(bins)), C.c_float(np.float32(sigma)),
+                                       _p(out, C.c_float))
+    if rc:
+        raise RuntimeError(f"cgic_oracle_entropy_ref rc={rc}")
+    return out
+
+
 def router_mode(c, m):
     lib().cgic_oracle_router_mode.argtypes = [C.c_double, C.c_double]
     return lib().cgic_oracle_router_mode(float(c), float(m))

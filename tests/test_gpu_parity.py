@@ -207,6 +207,59 @@ def test_entropy_tie_families_vs_reference_fixture(golden, name):
     assert np.abs(e16.cpu().numpy() - g[name + "_e16"]).max() < 2e-6
 
 
+def test_reference_arithmetic_entropy_kernel(orc, golden):
+    """cgic_entropy_maps_ref_f32 (opt-in): bit for bit the oracle's restatement of the same arithmetic (torch's CPU operation
+    sequence and summation order, exp / log correctly rounded) -- on the reference's 8-bit fixtures, U(0,1) images, signed /
+    out-of-range pixels, a ragged width -- hence, through the fixture, most values equal to the REAL Entropy class's to the bit
+    and the rest within 5e-7; NaN pixels poison their patches like the reference's NaN histogram"""
+    g = golden("ties")
+    rng = np.random.default_rng(12)
+    cases = {n: g[n + "_u8"].astype(np.float32) / 255.0 for n in ("noise8", "smooth8", "flat_edges", "blocky8")}
+    cases["rand"] = rng.random((3, 3, 64, 112), dtype=np.float32)
+    cases["signed"] = (rng.random((1, 3, 32, 48), dtype=np.float32) * 3 - 1.5)
+    cases["const"] = np.full((1, 3, 32, 32), 0.5, np.float32)
+    for name, x in cases.items():
+        e8, e16 = cg.entropy_maps(torch.from_numpy(x).to(DEV), reference_order=True)
+        o8, o16 = orc.entropy_ref(x, 8), orc.entropy_ref(x, 16)
+        assert np.array_equal(e8.cpu().numpy().view(np.int32), o8.view(np.int32)), (name, float(np.abs(e8.cpu().numpy() - o8).max()))
+        assert np.array_equal(e16.cpu().numpy().view(np.int32), o16.view(np.int32)), (name, float(np.abs(e16.cpu().numpy() - o16).max()))
+        if name + "_e8" in g:
+            assert np.abs(e8.cpu().numpy() - g[name + "_e8"]).max() < 5e-7 and (e8.cpu().numpy() == g[name + "_e8"]).mean() > 0.85
+        m8 = cg.Entropy(8, reference_order=True).to(DEV)(torch.from_numpy(x).to(DEV))
+        assert torch.equal(m8, e8)
+        r8, r16 = torch.ops.cgic.entropy_maps_reference_order(torch.from_numpy(x).to(DEV))
+        assert torch.equal(r8, e8) and torch.equal(r16, e16)
+        d8, _ = cg.entropy_maps(torch.from_numpy(x).to(DEV))
+        assert np.abs(d8.cpu().numpy() - e8.cpu().numpy()).max() < 2e-6               # the default kernel agrees to its tolerance
+    xn = torch.rand(1, 3, 32, 64)
+    xn[0, 1, 3, 5] = float("nan")
+    e8, e16 = cg.entropy_maps(xn.to(DEV), reference_order=True)
+    assert torch.isnan(e8).nonzero().tolist() == [[0, 0, 0]] and torch.isnan(e16).nonzero().tolist() == [[0, 0, 0]]
+
+
+def test_reference_arithmetic_entropy_flips_no_mask(orc):
+    """the opt-in reference-arithmetic entropy maps -> GPU router against the reference's torch-CPU arithmetic -> oracle router
+    on the tie-heavy families (16 images each) and two 768x768 tiles: no differing mask element (measured; the default kernel
+    differs in 0-1 images of 64 per family, test_mask_flips_on_tie_heavy_content)"""
+    from oracle import entropy_torch as et
+    from oracle.content_families import families
+    router = cg.TripleGrainFixedEntropyRouter(0.1, 0.8, per_image=True)
+    sets = dict(families(n=16))
+    t = families(n=1, H=768, W=768, seed=11)
+    sets["tiles"] = np.concatenate([t["flat_edges"], t["smooth8"]])
+    total = 0
+    for name, x in sets.items():
+        e8, e16 = cg.entropy_maps(torch.from_numpy(x).to(DEV), reference_order=True)
+        mk = [m.cpu().numpy() for m in router(e16, e8)[0]]
+        xt = torch.from_numpy(x)
+        r8, r16 = et.entropy_map(xt, 8).numpy(), et.entropy_map(xt, 16).numpy()
+        assert max(np.abs(r8 - e8.cpu().numpy()).max(), np.abs(r16 - e16.cpu().numpy()).max()) < 1e-6, name
+        for b in range(x.shape[0]):
+            ref = orc.router(r16[b:b + 1], r8[b:b + 1], 0.1, 0.8)
+            total += sum(int((mk[k][b, 0] != ref[k][0, 0]).sum()) for k in range(3))
+    assert total <= 8, total        # (0 measured; a few elements of slack for another host's MKL)
+
+
 def test_mask_flips_on_tie_heavy_content(orc):
     """pixels -> masks on 8-bit / smooth / flat / blocky content (64 images of 256x256 per family + two 768x768 tiles): the GPU's
     entropy maps -> GPU router against the reference's own torch-CPU arithmetic (oracle/entropy_torch.py, pinned bit for bit

@@ -156,3 +156,19 @@ def test_entropy_torch_restatement_pinned_by_reference_fixture(orc, golden, name
     # the plain-C oracle agrees to its tolerance (libm exp/log, sequential sums), not to the bit
     assert np.abs(orc.entropy(x, 8) - g[name + "_e8"]).max() < 2e-6
     assert np.abs(orc.entropy(x, 16) - g[name + "_e16"]).max() < 2e-6
+
+
+@pytest.mark.parametrize("name", FAMILIES)
+def test_reference_arithmetic_entropy_port_vs_reference_fixture(orc, golden, name):
+    """cgic_oracle_entropy_ref (torch's CPU operation sequence and summation order, exp / log correctly rounded: the CPU
+    restatement of the GPU's opt-in cgic_entropy_maps_ref_f32) against the REAL Entropy class's maps: most values to the bit,
+    the rest within 5e-7 (torch's exp / log are MKL's), and the reference's masks exactly"""
+    g = golden("ties")
+    x = g[name + "_u8"].astype(np.float32) / 255.0
+    a8, a16 = orc.entropy_ref(x, 8), orc.entropy_ref(x, 16)
+    assert np.abs(a8 - g[name + "_e8"]).max() < 5e-7 and np.abs(a16 - g[name + "_e16"]).max() < 5e-7
+    assert (a8 == g[name + "_e8"]).mean() > 0.85 and (a16 == g[name + "_e16"]).mean() > 0.85
+    for b in range(x.shape[0]):
+        mc, mm, mf, _, _ = orc.router(a16[b:b + 1], a8[b:b + 1], 0.1, 0.8)
+        for k, m in zip("cmf", (mc, mm, mf)):
+            assert np.array_equal(np.packbits(m.astype(np.uint8).reshape(-1)), g[f"{name}_{b}_m{k}"])
