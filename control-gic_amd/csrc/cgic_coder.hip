@@ -37,7 +37,7 @@ __device__ long long g_blk_t[2 * 4096];
 #endif
 
 #ifndef CGIC_ENC_THREADS
-#define CGIC_ENC_THREADS 1024
+#define CGIC_ENC_THREADS 512       // 1024 -> 512 in round 3: with four batches in flight 36.3 -> 35.5 us per step (smaller workgroups find a CU sooner); alone +0.5 us
 #endif
 constexpr int kEncThreads = CGIC_ENC_THREADS;         // x kEncItems = 4096 positions per scan round: one round per 256x256 stream
 constexpr int kEncItems = 4;            // consecutive positions per thread per scan round

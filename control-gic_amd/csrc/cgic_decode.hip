@@ -765,6 +765,10 @@ __global__ __launch_bounds__(kDecThreads) CGIC_VGPR_CAP_DECODE void decode_split
 }
 
 constexpr int kMergeThreads = 512;
+#ifndef CGIC_MERGE_ONE_BAND_THREADS
+#define CGIC_MERGE_ONE_BAND_THREADS 512      // 1024 until round 3: 512 measured ~0.5-1 us per step better in flight
+#endif
+constexpr int kMergeOneBandThreads = CGIC_MERGE_ONE_BAND_THREADS;       // throughput mode: one band per image
 constexpr int kMergeBands = 4;          // row bands per image at least; more for few large images (gridDim.x)
 
 struct MergeArgs {
@@ -1301,8 +1305,8 @@ extern "C" int cgic_decompress_streams(const cgic_table *t, const uint8_t *in, i
     if (dec_mode == CGIC_DECODE_THROUGHPUT && !large && m.stage_sym) {
         // several batches in flight: one band of 1024 threads per image (see merge_kernel)
         if (lds_m > 48 * 1024)
-            { int rc_ = ensure_dynamic_lds((const void *)merge_kernel<1024>, (size_t)lds_m); if (rc_) return rc_; }
-        hipLaunchKernelGGL(merge_kernel<1024>, dim3(1u, (unsigned)B), dim3(1024), lds_m, s, m);
+            { int rc_ = ensure_dynamic_lds((const void *)merge_kernel<kMergeOneBandThreads>, (size_t)lds_m); if (rc_) return rc_; }
+        hipLaunchKernelGGL(merge_kernel<kMergeOneBandThreads>, dim3(1u, (unsigned)B), dim3(kMergeOneBandThreads), lds_m, s, m);
         return launch_check("merge_kernel");
     }
     if (lds_m > 48 * 1024)
