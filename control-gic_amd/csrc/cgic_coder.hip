@@ -41,7 +41,11 @@ __device__ long long g_blk_t[2 * 4096];
 #endif
 constexpr int kEncThreads = CGIC_ENC_THREADS;         // x kEncItems = 4096 positions per scan round: one round per 256x256 stream
 constexpr int kEncItems = 4;            // consecutive positions per thread per scan round
-constexpr int kLdsPos = 8192;           // streams up to this many positions keep phase-A results in LDS
+#ifndef CGIC_LDS_POS
+#define CGIC_LDS_POS 8192
+#endif
+constexpr int kLdsPos = CGIC_LDS_POS;           // streams up to this many positions keep phase-A results in LDS
+constexpr int kLdsPosSmall = 4096;              // ... and the small instantiation of the compress kernel (grids up to 64x64)
 
 // -------------------------------------------------------------------------------------------
 // encode
@@ -378,7 +382,7 @@ __device__ int encode_huffman_stream_long(const TableDev &t, int64_t npos, SymAt
     unsigned long long total;
     unsigned long long excl = block_exclusive_scan(local, scan_smem, &total);
     const uint32_t count = (uint32_t)(total >> 32);
-    const EncStorage st = count <= (uint32_t)kLdsPos ? st_lds : st_glob;
+    const EncStorage st = count <= (uint32_t)kLdsPos ? st_lds : st_glob;      // (only the kLdsPos instantiation of the kernel gets here)
     uint32_t ci = (uint32_t)(excl >> 32), bit = (uint32_t)excl;
     for (int64_t i = lo; i < hi; i += 4) {
         const uint2 q = *reinterpret_cast<const uint2 *>(stage + i);
@@ -453,10 +457,14 @@ struct CompressArgs {
 
 constexpr int kLdsTable = 1024;          // tables up to this many single-word codes are staged in LDS
 
+// LP: positions the static LDS arrays hold.  kLdsPos (8192: 48 KB) in general; kLdsPosSmall (4096: 24 KB, 32 KB with the code
+// table) when no grid of the launch has more positions than that -- a 256x256 image -- because what such a latency-bound workgroup
+// costs the kernels of OTHER batches in flight is the LDS it holds: 33.6 -> 32.7 us per step at four lanes (round 3).
+template <int LP>
 __global__ __launch_bounds__(kEncThreads) CGIC_VGPR_CAP_COMPRESS void compress_streams_kernel(CompressArgs a)
 {
-    __shared__ __attribute__((aligned(16))) uint32_t lds_end[kLdsPos];
-    __shared__ uint16_t lds_sym[kLdsPos];
+    __shared__ __attribute__((aligned(16))) uint32_t lds_end[LP];
+    __shared__ uint16_t lds_sym[LP];
     __shared__ int32_t lds_len[kLdsTable];
     __shared__ uint32_t lds_code[kLdsTable];
     extern __shared__ __attribute__((aligned(16))) uint16_t lds_stage[];     // [h*w] for long streams (see encode_huffman_stream_long)
@@ -537,7 +545,7 @@ __global__ __launch_bounds__(kEncThreads) CGIC_VGPR_CAP_COMPRESS void compress_s
                 const EncExchange ex{a.tick + ((b * 3 + s) * 2) * kTicketStride, part, nparts};
                 rc = encode_huffman_stream_long(tab, mypos, sym_at, lds_stage, st, st_glob, out, a.slot, sh == 0 ? ind + pos0 : nullptr,
                                                 sh == 0 ? mask + pos0 : nullptr, &ex);
-            } else if (npos <= kLdsPos) rc = encode_huffman_stream(tab, npos, sym_at, st, out, a.slot);
+            } else if (npos <= LP) rc = encode_huffman_stream(tab, npos, sym_at, st, out, a.slot);
             else if (a.stage_positions >= npos)
                 rc = encode_huffman_stream_long(tab, npos, sym_at, lds_stage, st, st_glob, out, a.slot, sh == 0 ? ind : nullptr, sh == 0 ? mask : nullptr);
             else rc = encode_huffman_stream(tab, npos, sym_at, st_glob, out, a.slot);
@@ -721,7 +729,7 @@ extern "C" int cgic_compress_streams(const cgic_table *t, const int64_t *ind, co
     if (longest > 0 && (size_t)longest * 2 <= 96 * 1024) {
         dyn = (((size_t)longest + 3) / 4 * 4 * 2 + 64 + 15) & ~(size_t)15;       // whole 4-entry groups (+ slack)
         a.stage_positions = longest;
-        { int rc_ = ensure_dynamic_lds((const void *)compress_streams_kernel, dyn); if (rc_) return rc_; }
+        { int rc_ = ensure_dynamic_lds((const void *)compress_streams_kernel<kLdsPos>, dyn); if (rc_) return rc_; }
     } else if (longest > 0) {
         a.parts[0] = a.parts[1] = a.parts[2] = 1;                 // no staging room: the round-by-round form, unsplit
     }
@@ -732,7 +740,11 @@ extern "C" int cgic_compress_streams(const cgic_table *t, const int64_t *ind, co
     // every index stream fits the static LDS arrays and nothing is split: the short jobs of an image share one workgroup
     a.combine = (!a.tick && h * w <= kLdsPos) ? 1 : 0;
     const unsigned jobs = a.combine ? 3u + (hist ? 1u : 0u) : (unsigned)(a.parts[0] + a.parts[1] + a.parts[2]) + 2u + (hist ? 1u : 0u);
-    hipLaunchKernelGGL(compress_streams_kernel, a.tick ? dim3(jobs, (unsigned)B) : dim3((unsigned)B, jobs), dim3(kEncThreads), dyn,
+    if (a.combine && h * w <= kLdsPosSmall && (!hist || cgic_table_num_symbols(t) <= kLdsPosSmall)) {
+        hipLaunchKernelGGL(compress_streams_kernel<kLdsPosSmall>, dim3((unsigned)B, jobs), dim3(kEncThreads), 0, (hipStream_t)stream, a);
+        return launch_check("compress_streams_kernel");
+    }
+    hipLaunchKernelGGL(compress_streams_kernel<kLdsPos>, a.tick ? dim3(jobs, (unsigned)B) : dim3((unsigned)B, jobs), dim3(kEncThreads), dyn,
                        (hipStream_t)stream, a);
     return launch_check("compress_streams_kernel");
 }
