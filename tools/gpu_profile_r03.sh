@@ -28,6 +28,10 @@ cp profiles/pmc_vq.json $O/pmc_hbm.json
 python tools/pmc_sq_summary.py $(find $O/pmc_sq -name '*.db' | head -1) > $O/pmc_sq.md 2>&1
 (cd /tmp && timeout 600 rocprofv3 --pmc SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_BUSY_CYCLES --kernel-trace -d $GRAFT_REPO_ROOT/$O/pmc_sq2 -o pmc -- python $GRAFT_REPO_ROOT/tools/run_roofline_cmd.py fused) > $O/pmc_sq2.log 2>&1
 python tools/pmc_sq_summary.py --match vq_filter $(find $O/pmc_sq2 -name '*.db' | head -1) > $O/pmc_sq_vq.md 2>&1
+# ... and of the kernels the four-lane step uses instead (throughput decoder, one-band merge), eager on four streams
+CMD4="python $GRAFT_REPO_ROOT/bench.py --steps 40 --warmup 10 --no-report --lanes 4 --no-graph --no-dist"
+(cd /tmp && timeout 600 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAVES SQ_ACTIVE_INST_VALU --kernel-trace -d $GRAFT_REPO_ROOT/$O/pmc_sq4 -o pmc -- $CMD4) > $O/pmc_sq4.log 2>&1
+python tools/pmc_sq_summary.py $(find $O/pmc_sq4 -name '*.db' | head -1) > $O/pmc_sq_lanes4.md 2>&1
 python tools/roofline_json.py $O > $O/roofline.log 2>&1
 find $O -name '*.db' -size +6M -delete
 find $O -name '*.csv' -size +2M -delete
