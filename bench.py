@@ -693,7 +693,7 @@ def run_rank(a, rank, world, local):
             # dependency between the streams (lanes=1: one batch in flight, the round-1/2a configuration)
             stream = cg.pipeline.LaneStream(vq, ratio[0], ratio[1], slots_dev, lanes=a.lanes, frequency=codec.huffman, hist=hist,
                                             graph=not a.no_graph, ring=not a.no_ring, fuse_router=not a.split_router, max_ring=a.max_ring,
-                                            quick_start=False)
+                                            )
             stream.capture()
             stream.prepare(a.warmup)
         stream.submit(a.warmup)

@@ -303,7 +303,7 @@ class LaneStream:
     """
 
     def __init__(self, quantizer, coarse_ratio, medium_ratio, slots, lanes=4, frequency=None, hist=None, decode=True,
-                 graph=True, ring=True, fuse_router=True, decoder=None, max_ring=8, launch_threads=False, quick_start=True,
+                 graph=True, ring=True, fuse_router=True, decoder=None, max_ring=8, launch_threads=False, quick_start=False,
                  prepare=True):
         if not slots:
             raise ValueError("LaneStream needs at least one slot")
@@ -324,7 +324,8 @@ class LaneStream:
             streams = distinct_queue_streams(self.device, nl)          # one hardware queue per lane, measured
         self.lanes = [{"slots": self.slots[j::nl], "pos": 0, "stream": streams[j], "graphs": {}} for j in range(nl)]
         # quick_start: a lane's first run of a submit is split into (1 step) + (the rest): a graph launch costs the host
-        # ~12 us + ~0.55 us per kernel node, and lane j only starts after the launches of lanes 0..j-1
+        # ~12 us + ~0.55 us per kernel node, and lane j only starts after the launches of lanes 0..j-1 (measured: no gain at
+        # K=20 -- the window is bound by resources, not by the last lane's start -- hence off by default)
         self.quick_start = bool(quick_start) and nl > 1
         self._pool = None
         if launch_threads and nl > 1:
