@@ -38,6 +38,7 @@ PROTOTYPES = {
     "cgic_abi_version": (_int, []),
     "cgic_set_decode_mode": (_int, [_int]),
     "cgic_device_count": (_int, []),
+    "cgic_launch_graphs": (_int, [C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_int), _int, _int]),
     "cgic_ticket_scope_begin": (_int, []),
     "cgic_ticket_scope_end": (_int, []),
     "cgic_ticket_scope_release": (_int, [_int]),

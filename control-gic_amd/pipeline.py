@@ -304,7 +304,7 @@ class LaneStream:
 
     def __init__(self, quantizer, coarse_ratio, medium_ratio, slots, lanes=4, frequency=None, hist=None, decode=True,
                  graph=True, ring=True, fuse_router=True, decoder=None, max_ring=8, launch_threads=False, quick_start=False,
-                 prepare=True):
+                 prepare=True, native_launch=1):
         if not slots:
             raise ValueError("LaneStream needs at least one slot")
         # prepare: a stream of batches is inference against ONE codebook -- its image is made once, when capture() runs
@@ -327,6 +327,10 @@ class LaneStream:
         # ~12 us + ~0.55 us per kernel node, and lane j only starts after the launches of lanes 0..j-1 (measured: no gain at
         # K=20 -- the window is bound by resources, not by the last lane's start -- hence off by default)
         self.quick_start = bool(quick_start) and nl > 1
+        # native_launch: 1 (default) = all graph launches of a submit in ONE C call (cgic_launch_graphs: no interpreter between
+        # them: host time of a K=20 submit 115 -> 93 us, the window 777 -> 756 us), 2 = ... each lane's launches on its own
+        # persistent C thread (host 60 us, the window no shorter: the runtime serialises the launches), 0 = replay() from Python
+        self.native_launch = int(native_launch) if self.graph and hasattr(torch.cuda.CUDAGraph, "raw_cuda_graph_exec") else 0
         self._pool = None
         if launch_threads and nl > 1:
             from concurrent.futures import ThreadPoolExecutor
@@ -407,9 +411,35 @@ class LaneStream:
         if not self._captured:
             self.capture()
         if self.graph:
-            for lane, runs in zip(self.lanes, self._plan(n)):
+            plans = self._plan(n)
+            for lane, runs in zip(self.lanes, plans):
                 for start, count in runs:
                     self._graph(lane, start, count)
+            if self.native_launch:
+                self._native_args_for(plans)
+
+    def _native_args_for(self, plans):
+        import ctypes
+        key = tuple(tuple(r) for r in plans)
+        cached = getattr(self, "_native_args", {}).get(key)
+        if cached is None:
+            execs, streams, lane_of = [], [], []
+            depth = max(len(r) for r in plans)
+            for i in range(depth):                                       # one launch per lane and turn, like the Python loop
+                for j, (lane, runs) in enumerate(zip(self.lanes, plans)):
+                    if i < len(runs):
+                        execs.append(self._graph(lane, *runs[i])[0].raw_cuda_graph_exec())
+                        streams.append(lane["stream"].cuda_stream)
+                        lane_of.append(j)
+            n = len(execs)
+            cached = ((ctypes.c_void_p * n)(*execs), (ctypes.c_void_p * n)(*streams), (ctypes.c_int * n)(*lane_of), n)
+            self.__dict__.setdefault("_native_args", {})[key] = cached
+        return cached
+
+    def _launch_native(self, plans):
+        e, s, l, n = self._native_args_for(plans)
+        with torch.cuda.device(self.device):
+            _lib.call("cgic_launch_graphs", e, s, l, n, len(self.lanes) if self.native_launch >= 2 else 1)
 
     def _run_lane(self, lane, runs):
         with torch.cuda.device(self.device), torch.cuda.stream(lane["stream"]):
@@ -426,7 +456,9 @@ class LaneStream:
             for lane, runs in zip(self.lanes, plans):                  # captures (if any are missing) before the first launch
                 for start, count in runs:
                     self._graph(lane, start, count)
-            if self._pool is not None:
+            if self.native_launch:
+                self._launch_native(plans)
+            elif self._pool is not None:
                 for f in [self._pool.submit(self._run_lane, lane, runs) for lane, runs in zip(self.lanes, plans) if runs]:
                     f.result()
             else:

@@ -63,6 +63,11 @@ int cgic_ticket_scope_begin(void);
 int cgic_ticket_scope_end(void);
 int cgic_ticket_scope_release(int scope);
 int cgic_ticket_slots_in_use(void);
+/* Launch n captured hipGraphs in one call: graph_execs[i] (hipGraphExec_t) on streams[i] (hipStream_t), in order.  threads <= 1 (or
+ * lane_of == NULL): back to back on the calling thread.  threads > 1: the launches with the same lane_of[i] (0..63) keep their order on
+ * one persistent worker thread per lane, different lanes are launched concurrently.  For runtimes of several independent streams of
+ * batches (pipeline.LaneStream): from Python every launch is an interpreter round trip and the last lane starts ~100 us after the first. */
+int cgic_launch_graphs(void *const *graph_execs, void *const *streams, const int *lane_of, int n, int threads);
 const char *cgic_last_error(void);
 int cgic_abi_version(void);
 /* number of visible HIP devices, or CGIC_ERR_HIP; never throws, never aborts */

@@ -945,8 +945,8 @@ def test_decoder_choice_is_per_call_two_threads():
         codec.decompress(comp, decoder="fastest")
 
 
-@pytest.mark.parametrize("lanes,ring,graph,threads", [(4, True, True, False), (4, True, True, True), (3, False, True, False), (2, True, False, False), (1, True, True, False)])
-def test_lane_stream_independent_streams_are_bit_identical(lanes, ring, graph, threads):
+@pytest.mark.parametrize("lanes,ring,graph,threads,native", [(4, True, True, False, 1), (4, True, True, True, 0), (4, True, True, False, 2), (3, False, True, False, 0), (2, True, False, False, 1), (1, True, True, False, 1)])
+def test_lane_stream_independent_streams_are_bit_identical(lanes, ring, graph, threads, native):
     """pipeline.LaneStream (batch t on HIP stream t % lanes, one ring graph per lane, NO dependency between the lanes: up to
     `lanes` batches in flight) leaves exactly what the one-stream order leaves in every slot -- streams, indices, z_q, loss,
     masks, decoded rows -- and an exact usage histogram, whatever mix of ring and per-slot graphs a submit() takes"""
@@ -957,7 +957,7 @@ def test_lane_stream_independent_streams_are_bit_identical(lanes, ring, graph, t
     shapes = [(4, 64, 96), (4, 64, 96), (2, 128, 64), (4, 64, 96), (3, 32, 32), (4, 64, 96), (4, 64, 96), (1, 256, 256)]
     slots = [(torch.rand(b, 3, H, W, generator=g).to(DEV), torch.randn(b, 4, H // 4, W // 4, generator=g).to(DEV)) for b, H, W in shapes]
     hist = torch.zeros(1024, dtype=torch.int64, device=DEV)
-    ls = pl.LaneStream(vq, 0.1, 0.8, slots, lanes=lanes, hist=hist, ring=ring, graph=graph, max_ring=3, launch_threads=threads)
+    ls = pl.LaneStream(vq, 0.1, 0.8, slots, lanes=lanes, hist=hist, ring=ring, graph=graph, max_ring=3, launch_threads=threads, native_launch=native)
     ls.capture()
     torch.cuda.synchronize()
     hist.zero_()

@@ -14,9 +14,9 @@ cb = slots_np[0][2]
 vq = bench.make_quantizer(dev, cb)
 codec = cg.GrainCodec(vq.embedding_counter, vq.embedding.weight)
 slots = [(torch.from_numpy(x).to(dev), torch.from_numpy(z).to(dev)) for x, z, _ in slots_np]
-for lanes, max_ring, threads, one in ((4, 2, False, False), (4, 8, False, False), (4, 8, False, True), (4, 4, False, True)):
+for lanes, max_ring, threads, one, native in ((4, 8, False, False, 0), (4, 8, False, False, 1), (4, 8, False, False, 2), (4, 8, False, False, 0), (4, 8, False, False, 1), (4, 8, False, False, 2)):
     hist = torch.zeros(1024, dtype=torch.int64, device=dev)
-    ls = cg.pipeline.LaneStream(vq, 0.1, 0.8, slots, lanes=lanes, frequency=codec.huffman, hist=hist, max_ring=max_ring, launch_threads=threads, quick_start=one)
+    ls = cg.pipeline.LaneStream(vq, 0.1, 0.8, slots, lanes=lanes, frequency=codec.huffman, hist=hist, max_ring=max_ring, launch_threads=threads, quick_start=one, native_launch=native)
     ls.capture()
     res, host = [], []
     for rep in range(9):
@@ -46,6 +46,6 @@ for lanes, max_ring, threads, one in ((4, 2, False, False), (4, 8, False, False)
     torch.cuda.synchronize()
     offs = [(round(base.elapsed_time(s) * 1e3), round(base.elapsed_time(e) * 1e3)) for s, e in zip(starts, ends)]
     res.sort(); host.sort()
-    print(f"lanes={lanes} max_ring={max_ring} threads={threads} quick_start={one}: K={K} wall min {res[0]:.0f} med {res[len(res)//2]:.0f} max {res[-1]:.0f} us "
+    print(f"lanes={lanes} max_ring={max_ring} threads={threads} quick_start={one} native_launch={native}: K={K} wall min {res[0]:.0f} med {res[len(res)//2]:.0f} max {res[-1]:.0f} us "
           f"({res[len(res)//2]/K:.1f} us/step), host submit med {host[len(host)//2]:.0f} us, lane (start,end) us {offs}", flush=True)
     del ls
