@@ -225,10 +225,15 @@ def capture_graph(fn, stream):
     The ticket slots the captured launches take from the library's pool are returned when the graph object is
     garbage-collected (_lib.ticket_scope), so a long-lived process can capture per image shape for as long as it likes."""
     g = torch.cuda.CUDAGraph()
-    with _lib.ticket_scope() as sc:
-        with torch.cuda.stream(stream):
-            with torch.cuda.graph(g, stream=stream):
-                out = fn()
+    sc = _lib.ticket_scope()
+    try:
+        with sc:
+            with torch.cuda.stream(stream):
+                with torch.cuda.graph(g, stream=stream):
+                    out = fn()
+    except BaseException:
+        sc.release()                                  # a failed capture keeps nothing
+        raise
     sc.release_with(g)
     return g, out
 
