@@ -517,6 +517,43 @@ def div2k_image(dev, cb, vq, codec, iters=8):
                                  "note": "four images on four independent HIP streams (pipeline.GraphLanes), one hipGraph per image, throughput decoder"}
     except Exception as e:
         res["four_in_flight"] = {"error": str(e)[:200]}
+    # eight images of that size at once (highres.compress_tiled_batch: the equal-shape tiles of all the images are one batch per
+    # shape group -- 16 + 8 + 16 + 8 tiles instead of 2 + 1 + 2 + 1), one at a time and four such batches in flight
+    try:
+        from control_gic_amd.pipeline import GraphLanes
+        N = 8
+        xs = torch.from_numpy(np.random.default_rng(5).random((N, 3, H, W), dtype=np.float32)).to(dev)
+
+        def once_batch(concurrent):
+            def fn():
+                ts = highres.compress_tiled_batch(xs, encode, codec, concurrent=concurrent)
+                p, st = highres.decompress_tiled_batch(ts, codec, concurrent=concurrent, check=False)
+                return ts, p, st
+            return fn
+        ts, p, st = once_batch(False)(); torch.cuda.synchronize()
+        okb = int(st.abs().max()) == 0
+        for t, pt in zip(ts, p):
+            for idxs, _, (ind0, masks0, _) in t.groups:
+                fine = masks0[2].reshape(len(idxs), -1).bool()
+                got = torch.cat([pt[i][0].reshape(1, -1) for i in idxs])
+                okb = okb and bool(torch.equal(got[fine], ind0.reshape(len(idxs), -1)[fine]))
+        gl1 = GraphLanes(dev, [once_batch(True)], decoder="latency")
+        gl1.replay(2); gl1.join(); torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        gl1.replay(2 * iters); gl1.join(); torch.cuda.synchronize()
+        dt1 = (time.perf_counter() - t0) / (2 * iters * N)
+        gl = GraphLanes(dev, [once_batch(False)] * 4)
+        gl.replay(2); gl.join(); torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        gl.replay(2 * iters); gl.join(); torch.cuda.synchronize()
+        dt4 = (time.perf_counter() - t0) / (2 * iters * 4 * N)
+        res["batch_of_8"] = {"ms_per_image": round(dt1 * 1e3, 4), "MPixels/s": round(H * W / dt1 / 1e6, 1),
+                             "four_in_flight_ms_per_image": round(dt4 * 1e3, 4), "four_in_flight_MPixels/s": round(H * W / dt4 / 1e6, 1),
+                             "round_trip_ok": bool(okb), "bpp_mean": round(float(np.mean([t.bpp() for t in ts])), 6),
+                             "note": "highres.compress_tiled_batch + decompress_tiled_batch on 8 images of one size: one batch of tiles per shape group; "
+                                     "one hipGraph per batch (groups on parallel streams), then four batches on four HIP streams"}
+    except Exception as e:
+        res["batch_of_8"] = {"error": str(e)[:200]}
     return res
 
 

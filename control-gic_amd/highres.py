@@ -137,30 +137,116 @@ class _Fork:
         self.used = []
 
 
-def compress_tiled(x, encode, codec, tile=TILE, concurrent=False):
-    """x [1,3,H,W] on the device; encode(tiles [T,3,th,tw]) -> (ind [T*h*w] int64, masks [3 x int32], mode)
-    with per-tile routing (the reference's per-tile B=1 call); codec: GrainCodec.  -> TiledImage.
-    concurrent: the shape groups run on parallel streams (same results; see _Fork)"""
-    if x.dim() != 4 or x.shape[0] != 1:
-        raise ValueError("compress_tiled takes one image [1,3,H,W] (the reference script uses batch 1)")
-    H, W = x.shape[-2:]
+def _compress_groups(x, encode, codec, tile, concurrent):
+    """x [N,3,H,W]: the shape groups of N images of one size, each group ONE batch of N * T tiles (image-major)
+    -> (H, W), pad, tiles, [(tile indices, CompressedBatch, (ind, masks, mode))]"""
+    N, _, H, W = x.shape
     pad, _ = compute_padding(H, W)
-    xp = torch.nn.functional.pad(x, pad, mode="constant", value=0)
-    tiles = tile_grid(xp.shape[-2], xp.shape[-1], tile)
+    left, right, top, bottom = pad
+    tiles = tile_grid(H + top + bottom, W + left + right, tile)
     by_shape = {}
     for i, (_, _, th, tw) in enumerate(tiles):
         by_shape.setdefault((th, tw), []).append(i)
     groups = []
     # the largest group first: it is the long pole, and lane 0 (no fork latency) is its stream
     order = sorted(by_shape.items(), key=lambda kv: -len(kv[1]) * kv[0][0] * kv[0][1])
-    fork = _Fork(x.device, concurrent)              # (after the pad: the tiles are views of xp)
+    fork = _Fork(x.device, concurrent)
     for lane, ((th, tw), idxs) in enumerate(order):
         with torch.cuda.stream(fork.lane(lane)):
-            batch = torch.stack([xp[0, :, tiles[i][0]:tiles[i][0] + th, tiles[i][1]:tiles[i][1] + tw] for i in idxs])
-            ind, masks, mode = encode(batch)
+            # pad + cut in ONE copy per tile (F.pad of the whole image and a stack of views would move every pixel twice): a tile
+            # is the part of the image it covers, zeros where it reaches into the centred pad
+            inner = all(tiles[i][0] >= top and tiles[i][0] + th <= top + H and tiles[i][1] >= left and tiles[i][1] + tw <= left + W
+                        for i in idxs)
+            batch = (torch.empty if inner else torch.zeros)((N, len(idxs), 3, th, tw), dtype=x.dtype, device=x.device)
+            for k, i in enumerate(idxs):
+                y0, x0 = tiles[i][0] - top, tiles[i][1] - left                  # in unpadded coordinates
+                sy0, sy1, sx0, sx1 = max(y0, 0), min(y0 + th, H), max(x0, 0), min(x0 + tw, W)
+                batch[:, k, :, sy0 - y0:sy1 - y0, sx0 - x0:sx1 - x0] = x[:, :, sy0:sy1, sx0:sx1]
+            ind, masks, mode = encode(batch.view(-1, 3, th, tw))
             groups.append((idxs, codec.compress(ind, masks, mode), (ind, masks, mode)))
     fork.join([(c, e) for _, c, e in groups])
-    return TiledImage((H, W), pad, tiles, groups)
+    return (H, W), pad, tiles, groups
+
+
+def compress_tiled(x, encode, codec, tile=TILE, concurrent=False):
+    """x [1,3,H,W] on the device; encode(tiles [T,3,th,tw]) -> (ind [T*h*w] int64, masks [3 x int32], mode)
+    with per-tile routing (the reference's per-tile B=1 call); codec: GrainCodec.  -> TiledImage.
+    concurrent: the shape groups run on parallel streams (same results; see _Fork)"""
+    if x.dim() != 4 or x.shape[0] != 1:
+        raise ValueError("compress_tiled takes one image [1,3,H,W] (the reference script uses batch 1); "
+                         "compress_tiled_batch takes several of one size")
+    return TiledImage(*_compress_groups(x, encode, codec, tile, concurrent))
+
+
+def compress_tiled_batch(x, encode, codec, tile=TILE, concurrent=False):
+    """x [N,3,H,W]: N images of ONE size (a folder of camera frames, a DIV2K bucket) -> list of N TiledImage, each what
+    compress_tiled gives for that image alone (routing is per tile, so batching across images changes no byte).  The tiles
+    of equal shape of ALL the images go through the kernels as one batch: a 2040x1356 image alone is four launch chains of one or
+    two tiles each (a handful of workgroups per launch); eight images are chains of 8-16 tiles.  The TiledImages hold views
+    of the shared per-group buffers"""
+    if x.dim() != 4:
+        raise ValueError("compress_tiled_batch takes [N,3,H,W]")
+    N = x.shape[0]
+    hw, pad, tiles, groups = _compress_groups(x, encode, codec, tile, concurrent)
+    out = []
+    for n in range(N):
+        mine = []
+        for idxs, comp, (ind, masks, mode) in groups:
+            T = len(idxs)
+            sl = slice(n * T, (n + 1) * T)
+            per = ind.numel() // (N * T)
+            mine.append((idxs, type(comp)(comp.data[sl], comp.nbytes[sl], comp.mode, comp.h, comp.w),
+                         (ind.view(N * T, per)[sl].reshape(-1), [m[sl] for m in masks], mode)))
+        t = TiledImage(hw, pad, tiles, mine)
+        t._whole = (groups, n, N)                 # decompress_tiled_batch of the whole list reads the shared buffers in place
+        out.append(t)
+    return out
+
+
+def decompress_tiled_batch(tiled_list, codec, concurrent=False, check=True):
+    """inverse of compress_tiled_batch for TiledImages of one geometry (from it, or from N compress_tiled calls on images
+    of one size, or rebuilt from containers): ONE decompress per shape group over all the images
+    -> list (per image) of per-tile (ind, masks, z_q); check=False: (that, [N * tiles] status tensor)"""
+    if not tiled_list:
+        return []
+    first = tiled_list[0]
+    for t in tiled_list[1:]:
+        if t.tiles != first.tiles or [g[0] for g in t.groups] != [g[0] for g in first.groups] or \
+                any(a[1].mode != b[1].mode for a, b in zip(t.groups, first.groups)):
+            raise ValueError("decompress_tiled_batch: the images differ in geometry or routing mode")
+    N = len(tiled_list)
+    per_image = [[None] * len(first.tiles) for _ in range(N)]
+    dev = first.groups[0][1].data.device
+    fork = _Fork(dev, concurrent)
+    outs, statuses = [], []
+    whole = getattr(first, "_whole", None)
+    if whole is not None and not (whole[2] == N and all(
+            getattr(t, "_whole", (None,))[0] is whole[0] and t._whole[1] == n for n, t in enumerate(tiled_list))):
+        whole = None
+    for lane, (idxs, c0, _) in enumerate(first.groups):
+        with torch.cuda.stream(fork.lane(lane)):
+            if whole is not None:
+                comp = whole[0][lane][1]
+            else:
+                comps = [t.groups[lane][1] for t in tiled_list]
+                slot = max(c.data.shape[-1] for c in comps)
+                data = torch.cat([c.data if c.data.shape[-1] == slot else
+                                  torch.nn.functional.pad(c.data, (0, slot - c.data.shape[-1])) for c in comps])
+                comp = type(c0)(data, torch.cat([c.nbytes for c in comps]), c0.mode, c0.h, c0.w)
+            ind, masks, zq, status = codec.decompress(comp)
+        outs.append((ind, masks, zq, status))
+        statuses.append(status)
+        T = len(idxs)
+        for n in range(N):
+            for k, i in enumerate(idxs):
+                j = n * T + k
+                per_image[n][i] = (ind[j:j + 1], [m[j:j + 1] for m in masks], zq[j:j + 1])
+    fork.join(outs)
+    if not check:
+        return per_image, torch.cat(statuses)
+    if int(torch.cat(statuses).abs().max()) != 0:
+        raise RuntimeError("corrupt tile stream")
+    return per_image
 
 
 def decompress_tiled(tiled, codec, decode=None, concurrent=False, check=True):

@@ -557,3 +557,47 @@ def test_graph_lanes_run_tiled_images_on_independent_queues():
             assert int(st.abs().max()) == 0 and t.streams() == streams and t.bpp() == bpp
             for (i0, m0, z0), (i1, m1, z1) in zip(pref, p):
                 assert torch.equal(i0, i1) and torch.equal(z0, z1) and all(torch.equal(a, b) for a, b in zip(m0, m1))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("H,W", [(1000, 1800), (700, 500)])
+def test_tiled_batch_of_images_equals_the_images_one_at_a_time(H, W):
+    """highres.compress_tiled_batch: the equal-shape tiles of N images of one size as ONE batch per shape group give, image by
+    image, the streams / bpp of compress_tiled on that image alone (routing is per tile), and decompress_tiled_batch -- reading
+    the shared buffers in place, or concatenating TiledImages made one at a time -- the same indices, masks and rows"""
+    import control_gic_amd as cg
+    from control_gic_amd import highres
+    from control_gic_amd.quantize import vq_forward_route
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(H + W)
+    vq = cg.VectorQuantizer(1024, 4, beta=0.25).to(dev)
+    with torch.no_grad():
+        vq.embedding.weight.copy_(torch.from_numpy(rng.standard_normal((1024, 4)).astype(np.float32)))
+    vq.usage_counter.copy_(torch.from_numpy(rng.integers(1, 1000, 1024).astype(np.float32)))
+    codec = cg.GrainCodec(vq.embedding_counter, vq.embedding.weight.detach())
+    N = 3
+    x = torch.from_numpy((rng.integers(0, 256, (N, 3, H, W)) / 255.0).astype(np.float32)).to(dev)
+
+    def encode(tiles):                      # a stand-in encoder that is a function of each tile's own pixels
+        z = torch.nn.functional.avg_pool2d(tiles, 4)
+        z = torch.cat([z, z[:, :1] * 2 - 1], dim=1) * 3 - 1.5
+        e8, e16 = cg.entropy_maps(tiles)
+        _, _, ind, mask, _, mode = vq_forward_route(z.contiguous(), vq.embedding.weight, 0.25, True, e16, e8, 0.1, 0.8, per_image=True)
+        return ind, mask, mode
+
+    one = [highres.compress_tiled(x[n:n + 1], encode, codec) for n in range(N)]
+    for concurrent in (False, True):
+        many = highres.compress_tiled_batch(x, encode, codec, concurrent=concurrent)
+        assert len(many) == N
+        for a, b in zip(one, many):
+            assert a.tiles == b.tiles and a.streams() == b.streams() and a.bpp() == b.bpp()
+        dec = highres.decompress_tiled_batch(many, codec, concurrent=concurrent)
+        dec_cat = highres.decompress_tiled_batch(one, codec)                 # made one at a time: concatenated
+        dec_part = highres.decompress_tiled_batch(many[1:], codec)           # not the whole list: no shared-buffer shortcut
+        for n in range(N):
+            ref, _ = highres.decompress_tiled(one[n], codec)
+            for got in (dec[n], dec_cat[n]) + ((dec_part[n - 1],) if n else ()):
+                for (i0, m0, z0), (i1, m1, z1) in zip(ref, got):
+                    assert torch.equal(i0, i1) and torch.equal(z0, z1) and all(torch.equal(p, q) for p, q in zip(m0, m1))
+    with pytest.raises(ValueError):
+        highres.decompress_tiled_batch([one[0], highres.compress_tiled(x[:1, :, :512, :256], encode, codec)], codec)
