@@ -484,7 +484,9 @@ def _random_case(rng, B, h, w, c, m):
     return e16, e8, ind
 
 
-@pytest.mark.parametrize("B,h,w", [(64, 64, 64), (2, 192, 192), (3, 192, 148), (1, 4, 4)])
+@pytest.mark.parametrize("B,h,w", [(64, 64, 64), (2, 192, 192), (3, 192, 148), (1, 4, 4),
+                                   # beyond the tiling driver's sizes: a 2048x2048 image untiled, one-cell-high / -wide strips, many tiny images
+                                   (1, 512, 512), (1, 4, 4096), (1, 2048, 8), (700, 16, 16), (2, 516, 388)])
 def test_compress_batch_vs_oracle_and_roundtrip(orc, golden, B, h, w):
     """configs 2-4: B=64 256^2 and 768^2-tile grids; all modes; bytes == oracle per image (sample) and
     encode -> decode round trip for every image (size-independent property)."""
