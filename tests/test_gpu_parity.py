@@ -69,7 +69,8 @@ def test_vq_module_forward_and_counter(golden, orc):
     assert vq.embedding_counter["3"].item() == float(g["counter_cnt"][3])
 
 
-@pytest.mark.parametrize("shape,scale", [((64, 4, 64, 64), 1.0), ((3, 4, 192, 192), 1.0), ((5, 4, 20, 36), 0.002)])
+@pytest.mark.parametrize("shape,scale", [((64, 4, 64, 64), 1.0), ((3, 4, 192, 192), 1.0), ((5, 4, 20, 36), 0.002),
+                                         ((1, 4, 512, 512), 1.0), ((5, 4, 63, 65), 1.0), ((1, 4, 1, 1), 1.0), ((1, 4, 4, 4096), 1.0)])
 def test_vq_vs_oracle_and_cross_kernel(orc, shape, scale):
     """config 2 size (B=64, 256^2) and a 768^2-tile size: MFMA kernel == VALU kernel everywhere
     (size-independent property), and == the oracle on a slice the CPU finishes in seconds."""
@@ -184,7 +185,7 @@ def test_router_golden(golden, orc, shape):
 
 def test_router_batch64_and_tile_sizes(orc):
     g = np.random.default_rng(3)
-    for (B, h16, w16) in ((64, 16, 16), (2, 48, 48), (1, 48, 37)):
+    for (B, h16, w16) in ((64, 16, 16), (2, 48, 48), (1, 48, 37), (1, 128, 128), (1, 1, 1), (1, 1, 300), (2, 200, 3), (3000, 1, 1)):
         e16 = (g.random((B, h16, w16)) * 2.6).astype(np.float32)
         e8 = (g.random((B, 2 * h16, 2 * w16)) * 2.6).astype(np.float32)
         e8.ravel()[g.integers(0, e8.size, e8.size // 5)] = np.float32(1.25)      # heavy ties
@@ -335,6 +336,15 @@ def test_entropy_batch_vs_oracle_and_determinism(orc):
     a8, a16 = cg.entropy_maps(x2.to(DEV))
     assert np.abs(a8.cpu().numpy() - orc.entropy(x2.numpy(), 8)).max() < 2e-6
     assert np.abs(a16.cpu().numpy() - orc.entropy(x2.numpy(), 16)).max() < 2e-6
+
+
+@pytest.mark.parametrize("B,H,W", [(1, 2048, 2048), (1, 16, 4096), (1, 4096, 16), (300, 16, 16), (1, 16, 16)])
+def test_entropy_extreme_shapes_vs_oracle(orc, B, H, W):
+    """an untiled 2048x2048 image, one-patch-high / -wide strips, many one-patch images"""
+    x = np.random.default_rng(H + W + B).random((B, 3, H, W), dtype=np.float32)
+    e8, e16 = cg.entropy_maps(_t(x))
+    assert np.abs(e8.cpu().numpy() - orc.entropy(x, 8)).max() < 2e-6
+    assert np.abs(e16.cpu().numpy() - orc.entropy(x, 16)).max() < 2e-6
 
 
 def test_entropy_edge_pixels_vs_oracle(orc):
