@@ -155,13 +155,16 @@ def _compress_groups(x, encode, codec, tile, concurrent):
         with torch.cuda.stream(fork.lane(lane)):
             # pad + cut in ONE copy per tile (F.pad of the whole image and a stack of views would move every pixel twice): a tile
             # is the part of the image it covers, zeros where it reaches into the centred pad
-            inner = all(tiles[i][0] >= top and tiles[i][0] + th <= top + H and tiles[i][1] >= left and tiles[i][1] + tw <= left + W
-                        for i in idxs)
-            batch = (torch.empty if inner else torch.zeros)((N, len(idxs), 3, th, tw), dtype=x.dtype, device=x.device)
+            batch = torch.empty((N, len(idxs), 3, th, tw), dtype=x.dtype, device=x.device)
             for k, i in enumerate(idxs):
                 y0, x0 = tiles[i][0] - top, tiles[i][1] - left                  # in unpadded coordinates
                 sy0, sy1, sx0, sx1 = max(y0, 0), min(y0 + th, H), max(x0, 0), min(x0 + tw, W)
-                batch[:, k, :, sy0 - y0:sy1 - y0, sx0 - x0:sx1 - x0] = x[:, :, sy0:sy1, sx0:sx1]
+                dst = batch[:, k]
+                dst[:, :, sy0 - y0:sy1 - y0, sx0 - x0:sx1 - x0] = x[:, :, sy0:sy1, sx0:sx1]
+                # only the strips that reach into the pad are zeroed (a few rows / columns, not the whole batch)
+                for strip in (dst[:, :, :sy0 - y0], dst[:, :, sy1 - y0:], dst[:, :, :, :sx0 - x0], dst[:, :, :, sx1 - x0:]):
+                    if strip.numel():
+                        strip.zero_()
             ind, masks, mode = encode(batch.view(-1, 3, th, tw))
             groups.append((idxs, codec.compress(ind, masks, mode), (ind, masks, mode)))
     fork.join([(c, e) for _, c, e in groups])

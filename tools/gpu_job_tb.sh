@@ -1,5 +1,5 @@
 cd /root/repo
-timeout 900 python -m pytest tests/test_highres_container.py -q -x -m gpu 2>&1 | tail -5
+timeout 900 python -m pytest tests/test_highres_container.py -q -x -m gpu -k "tiled" 2>&1 | tail -3
 timeout 600 python - <<'PY' 2>&1 | grep "ms_per_image\|MPixels\|error\|ok"
 import json, torch, numpy as np, bench
 import control_gic_amd as cg
