@@ -821,18 +821,19 @@ __device__ __forceinline__ void vq_filter_body(const VqArgs &a, unsigned char *s
                 const int cb0 = 32 * tile_of(firstB ? B1 : A1) + (firstB ? 4 : 0);
                 const float4 *rb = cbs + rowpos(cb0);          // (a set stays inside one tile: same padding for all 16)
                 const float *eb = ees + eepos(cb0);
+                int rs = 0;                                     // the winner's offset in the set: a select between inline constants
 #pragma unroll
                 for (int r4 = 3; r4 >= 0; --r4) {
                     const float4 en = *reinterpret_cast<const float4 *>(&eb[8 * r4]);
 #pragma unroll
                     for (int r = 3; r >= 0; --r) {
-                        const int c = cb0 + 8 * r4 + r;
                         const float dd = dist_row(y0, y1, y2, y3, yy, rb[8 * r4 + r], r == 0 ? en.x : r == 1 ? en.y : r == 2 ? en.z : en.w);
                         const bool take = dd <= d;
                         d = take ? dd : d;
-                        wi = take ? c : wi;
+                        rs = take ? 8 * r4 + r : rs;
                     }
                 }
+                wi = cb0 + rs;
             }
             // ... and on the other half's best tile where it is a candidate too (lexicographic merge)
             if (__ballot(valid && other && !flag)) {
