@@ -601,3 +601,56 @@ def test_tiled_batch_of_images_equals_the_images_one_at_a_time(H, W):
                     assert torch.equal(i0, i1) and torch.equal(z0, z1) and all(torch.equal(p, q) for p, q in zip(m0, m1))
     with pytest.raises(ValueError):
         highres.decompress_tiled_batch([one[0], highres.compress_tiled(x[:1, :, :512, :256], encode, codec)], codec)
+
+
+@pytest.mark.gpu
+def test_tiled_batch_captured_as_graphs_in_flight():
+    """two batches of images (different sizes) through compress_tiled_batch + decompress_tiled_batch, each captured as one hipGraph on
+    its own hardware queue (pipeline.GraphLanes; shape groups on parallel streams inside the first), replayed side by side:
+    streams, bpp and decoded tiles of every image == the eager one-image driver"""
+    import control_gic_amd as cg
+    from control_gic_amd import highres
+    from control_gic_amd.quantize import vq_forward_route
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(77)
+    vq = cg.VectorQuantizer(1024, 4, beta=0.25).to(dev)
+    with torch.no_grad():
+        vq.embedding.weight.copy_(torch.from_numpy(rng.standard_normal((1024, 4)).astype(np.float32)))
+    vq.usage_counter.copy_(torch.from_numpy(rng.integers(1, 1000, 1024).astype(np.float32)))
+    codec = cg.GrainCodec(vq.embedding_counter, vq.embedding.weight.detach())
+    xs = [torch.from_numpy((rng.integers(0, 256, (n, 3, H, W)) / 255.0).astype(np.float32)).to(dev) for n, H, W in ((3, 1000, 1300), (2, 520, 776))]
+
+    def encode(tiles):
+        z = torch.nn.functional.avg_pool2d(tiles, 4)
+        z = torch.cat([z, z[:, :1] * 2 - 1], dim=1) * 3 - 1.5
+        e8, e16 = cg.entropy_maps(tiles)
+        _, _, ind, mask, _, mode = vq_forward_route(z.contiguous(), vq.embedding.weight, 0.25, True, e16, e8, 0.1, 0.8, per_image=True)
+        return ind, mask, mode
+
+    def make(x, concurrent):
+        def fn():
+            ts = highres.compress_tiled_batch(x, encode, codec, concurrent=concurrent)
+            per, st = highres.decompress_tiled_batch(ts, codec, concurrent=concurrent, check=False)
+            return ts, per, st
+        return fn
+
+    ref = []
+    for x in xs:
+        for n in range(x.shape[0]):
+            t = highres.compress_tiled(x[n:n + 1], encode, codec)
+            p, _ = highres.decompress_tiled(t, codec)
+            ref.append((t.streams(), t.bpp(), p))
+    gl = cg.GraphLanes(dev, [make(xs[0], True), make(xs[1], False)])
+    for _ in range(2):
+        gl.replay(2)
+        gl.join()
+        torch.cuda.synchronize()
+        k = 0
+        for ts, per, st in gl.results:
+            assert int(st.abs().max()) == 0
+            for t, p in zip(ts, per):
+                streams, bpp, pref = ref[k]
+                k += 1
+                assert t.streams() == streams and t.bpp() == bpp
+                for (i0, m0, z0), (i1, m1, z1) in zip(pref, p):
+                    assert torch.equal(i0, i1) and torch.equal(z0, z1) and all(torch.equal(a, b) for a, b in zip(m0, m1))
