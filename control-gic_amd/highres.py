@@ -28,6 +28,16 @@ def compute_padding(in_h, in_w, min_div=16):
     return (left, right, top, bottom), (-left, -right, -top, -bottom)
 
 
+def center_crop16(x, div=16):
+    """[..., H, W] -> the centred [..., div*(H//div), div*(W//div)] window: the dataset transform of both reference scripts
+    (`_resize_and_crop`, inference.py:62-68 = inference_high_resolution.py:62-68: torchvision's center_crop, whose offsets are
+    int(round((H - H') / 2.0)) with Python's round-half-to-even).  A view, no copy"""
+    H, W = x.shape[-2:]
+    th, tw = div * (H // div), div * (W // div)
+    top, left = int(round((H - th) / 2.0)), int(round((W - tw) / 2.0))
+    return x[..., top:top + th, left:left + tw]
+
+
 def tile_grid(h, w, tile=TILE):
     """row-major list of (y, x, tile_h, tile_w) -- nonoverlapping_grid_indices, :112-125 + the loop at :236-244"""
     ys = list(range(0, h, tile))

@@ -654,3 +654,20 @@ def test_tiled_batch_captured_as_graphs_in_flight():
                 assert t.streams() == streams and t.bpp() == bpp
                 for (i0, m0, z0), (i1, m1, z1) in zip(pref, p):
                     assert torch.equal(i0, i1) and torch.equal(z0, z1) and all(torch.equal(a, b) for a, b in zip(m0, m1))
+
+
+def test_center_crop16_follows_torchvision_center_crop():
+    """the dataset transform of inference.py:62-68: output [16*(H//16), 16*(W//16)], offsets int(round(d / 2.0)) with Python's
+    round-half-to-even (torchvision.transforms.functional.center_crop; torchvision is not installed here, so the formula is
+    restated: d = 1 -> 0, 3 -> 2, 5 -> 2, 7 -> 4, ...)"""
+    from control_gic_amd import highres
+    expect_off = {0: 0, 1: 0, 2: 1, 3: 2, 4: 2, 5: 2, 6: 3, 7: 4, 8: 4, 9: 4, 10: 5, 11: 6, 12: 6, 13: 6, 14: 7, 15: 8}
+    for H in range(256, 272):
+        for W in (512, 517, 527):
+            x = torch.arange(H * W, dtype=torch.float32).reshape(1, 1, H, W)
+            y = highres.center_crop16(x)
+            th, tw = 16 * (H // 16), 16 * (W // 16)
+            assert y.shape == (1, 1, th, tw)
+            top, left = expect_off[H - th], expect_off[W - tw]
+            assert float(y[0, 0, 0, 0]) == top * W + left and y.data_ptr() == x[..., top:, left:].data_ptr()
+    assert highres.center_crop16(torch.zeros(3, 1356, 2040)).shape == (3, 1344, 2032)
