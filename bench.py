@@ -174,6 +174,14 @@ def stage_breakdown(hp):
     st["vq_kernel_indices_only"] = graph_kernel_time(lambda: _vq_forward(hp.z, hp.vq.embedding.weight, 0.25, True, None, False, False, prepared=prep))
     st["compress_streams+hist"] = graph_kernel_time(lambda: hp.codec.compress(ind, mask, mode, hist=hp.hist))
     st["decompress_streams"] = graph_kernel_time(lambda: hp.codec.decompress(comp))
+    # frames that arrive as uint8 [B,H,W,3] (the datasets' PIL images): ToTensor + both maps in one pass against torch's ToTensor
+    # on the GPU followed by entropy_maps (extra data points; the timed step takes the fp32 tensor BASELINE's config names)
+    try:
+        frames = (hp.x.permute(0, 2, 3, 1) * 255).round().to(torch.uint8).contiguous()
+        st["u8_frames:totensor+entropy_maps_fused"] = graph_kernel_time(lambda: cg.entropy_maps_u8(frames))
+        st["u8_frames:torch_totensor"] = graph_kernel_time(lambda: frames.permute(0, 3, 1, 2).to(torch.float32).div(255).contiguous())
+    except Exception as e:          # noqa: BLE001 -- an extra data point never fails the bench line
+        st["u8_frames:error"] = -1.0
     return {k: round(v, 2) for k, v in st.items()}
 
 

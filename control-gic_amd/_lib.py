@@ -56,6 +56,7 @@ PROTOTYPES = {
     "cgic_index_histogram": (_int, [_vp, _i64, _int, _vp, _vp]),
     "cgic_entropy_maps_f32": (_int, [_vp, _i64, _i64, _i64, C.POINTER(_f32), _int, _f32, _vp, _vp, _vp]),
     "cgic_entropy_maps_ref_f32": (_int, [_vp, _i64, _i64, _i64, C.POINTER(_f32), _int, _f32, _vp, _vp, _vp]),
+    "cgic_entropy_maps_u8": (_int, [_vp, _i64, _i64, _i64, C.POINTER(_f32), _int, _f32, _vp, _vp, _vp, _vp]),
     "cgic_router_mode": (_int, [_f64, _f64]),
     "cgic_router_f32": (_int, [_vp, _vp, _i64, _i64, _i64, _f64, _f64, _int, _vp, _vp, _vp, _vp, C.POINTER(_int), _vp]),
     "cgic_table_create": (_int, [C.POINTER(_i64), C.POINTER(_i32), _int, C.POINTER(_vp)]),

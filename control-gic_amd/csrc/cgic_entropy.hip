@@ -99,10 +99,26 @@ __device__ __forceinline__ unsigned int cvt_round_u32(float v)
     return (unsigned int)r;
 }
 
-__global__ __launch_bounds__(kEntThreads) void entropy_maps_kernel(
-    const float *__restrict__ x, int64_t H, int64_t W, float exp2_scale, float *__restrict__ e8,
-    float *__restrict__ e16, BinsArg bins_arg, int patches_per_wave)
+// byte / 255 as torch's `.div(255)` rounds it (T.ToTensor(), inference.py:50-53): q = b * fl(1/255) corrected once by the exact
+// remainder -- equal to the IEEE quotient for all 256 bytes (checked exhaustively, tests/test_host_logic.py), three full-rate
+// instructions instead of the ~10 of a division
+__device__ __forceinline__ float unit_of_byte(float b)
 {
+    const float r = 0.00392156886f;                 // fl(1 / 255)
+    const float q = b * r;
+    return __builtin_fmaf(__builtin_fmaf(-q, 255.0f, b), r, q);
+}
+
+// U8: x is a uint8 [B, H, W, 3] frame (PIL / decoder layout) and the kernel is ToTensor + Entropy in one pass: a lane reads the
+// 12 bytes of its 4 pixels, converts them to the fp32 values T.ToTensor() produces (bit for bit) and, if x_out is given, writes
+// them as the fp32 [B, 3, H, W] tensor the conv encoder takes (inference.py:50-59 + model.py:99-101): 3 B read + 12 B written
+// per pixel instead of 3 + 12 (ToTensor) and 12 again (Entropy)
+template <bool U8>
+__global__ __launch_bounds__(kEntThreads) void entropy_maps_kernel(
+    const void *__restrict__ xin, int64_t H, int64_t W, float exp2_scale, float *__restrict__ e8,
+    float *__restrict__ e16, BinsArg bins_arg, int patches_per_wave, float *__restrict__ x_out)
+{
+    const float *__restrict__ x = reinterpret_cast<const float *>(xin);
     __shared__ __attribute__((aligned(16))) unsigned int hist_all[kEntWaves][kBins * kHistStride];
     __shared__ float bins[kBins + 4];
 
@@ -128,14 +144,22 @@ __global__ __launch_bounds__(kEntThreads) void entropy_maps_kernel(
     const int pc4 = (lane & 3) * 4;
     const int64_t plane = H * W;
     float4 pR = {0.f, 0.f, 0.f, 0.f}, pG = pR, pB = pR;
+    unsigned int raw0 = 0, raw1 = 0, raw2 = 0;      // U8: the 12 bytes R0 G0 B0 R1 | G1 B1 R2 G2 | B2 R3 G3 B3 of the lane's 4 pixels
     auto request = [&](int64_t patch) {
         if (patch < p_end) {
-            const float *p = x + (b * 3) * plane + (row0 + prow) * W + patch * 16 + pc4;
-            pR = *reinterpret_cast<const float4 *>(p);
-            pG = *reinterpret_cast<const float4 *>(p + plane);
-            pB = *reinterpret_cast<const float4 *>(p + 2 * plane);
+            if (U8) {
+                const unsigned int *q = reinterpret_cast<const unsigned int *>(
+                    reinterpret_cast<const unsigned char *>(xin) + (((b * H + row0 + prow) * W + patch * 16 + pc4) * 3));
+                raw0 = q[0]; raw1 = q[1]; raw2 = q[2];
+            } else {
+                const float *p = x + (b * 3) * plane + (row0 + prow) * W + patch * 16 + pc4;
+                pR = *reinterpret_cast<const float4 *>(p);
+                pG = *reinterpret_cast<const float4 *>(p + plane);
+                pB = *reinterpret_cast<const float4 *>(p + 2 * plane);
+            }
         }
     };
+    auto byte_f = [](unsigned int w, int k) { return (float)((w >> (8 * k)) & 0xFFu); };      // v_cvt_f32_ubyteK
     request(p_lo + wave);
 
     if (tid < kBins) bins[tid] = bins_arg.v[tid];
@@ -154,6 +178,17 @@ __global__ __launch_bounds__(kEntThreads) void entropy_maps_kernel(
 
 #pragma unroll 1
     for (int64_t patch = p_lo + wave; patch < p_end; patch += kEntWaves) {
+        if (U8) {
+            pR = {unit_of_byte(byte_f(raw0, 0)), unit_of_byte(byte_f(raw0, 3)), unit_of_byte(byte_f(raw1, 2)), unit_of_byte(byte_f(raw2, 1))};
+            pG = {unit_of_byte(byte_f(raw0, 1)), unit_of_byte(byte_f(raw1, 0)), unit_of_byte(byte_f(raw1, 3)), unit_of_byte(byte_f(raw2, 2))};
+            pB = {unit_of_byte(byte_f(raw0, 2)), unit_of_byte(byte_f(raw1, 1)), unit_of_byte(byte_f(raw2, 0)), unit_of_byte(byte_f(raw2, 3))};
+            if (x_out) {
+                float *o = x_out + (b * 3) * plane + (row0 + prow) * W + patch * 16 + pc4;
+                *reinterpret_cast<float4 *>(o) = pR;
+                *reinterpret_cast<float4 *>(o + plane) = pG;
+                *reinterpret_cast<float4 *>(o + 2 * plane) = pB;
+            }
+        }
         // gray = 0.2989 R + 0.5870 G + 0.1140 B  (:471)
         float g[4];
         g[0] = (0.2989f * pR.x + 0.5870f * pG.x) + 0.1140f * pB.x;
@@ -367,8 +402,8 @@ __global__ __launch_bounds__(256) void entropy_ref_kernel(const float *__restric
 
 using namespace cgic;
 
-extern "C" int cgic_entropy_maps_f32(const float *x, int64_t B, int64_t H, int64_t W, const float *bins,
-                                     int nbins, float sigma, float *e8, float *e16, cgic_stream_t stream)
+static int entropy_maps_launch(const void *x, bool u8, int64_t B, int64_t H, int64_t W, const float *bins, int nbins, float sigma,
+                               float *x_out, float *e8, float *e16, cgic_stream_t stream)
 {
     CGIC_REQUIRE(x && bins, CGIC_ERR_INVALID, "entropy: x and bins must not be NULL");
     CGIC_REQUIRE(nbins == kBins, CGIC_ERR_UNSUPPORTED, "entropy: nbins=%d; the reference uses 32 (model.py:480)", nbins);
@@ -382,7 +417,7 @@ extern "C" int cgic_entropy_maps_f32(const float *x, int64_t B, int64_t H, int64
     for (int i = 1; i < kBins; ++i)
         CGIC_REQUIRE(fabsf((bins[i] - bins[i - 1]) - 2.0f / 31.0f) < 1e-5f, CGIC_ERR_UNSUPPORTED,
                      "entropy: bins are not linspace(-1, 1, 32)");
-    if (B == 0 || (!e8 && !e16)) return CGIC_OK;
+    if (B == 0 || (!e8 && !e16 && !(u8 && x_out))) return CGIC_OK;
 
     BinsArg ba;
     memcpy(ba.v, bins, sizeof(ba.v));
@@ -401,13 +436,29 @@ extern "C" int cgic_entropy_maps_f32(const float *x, int64_t B, int64_t H, int64
     // dev: pad the workgroup's LDS so that fewer of them fit a CU (co-residency experiments)
     static const int pad = getenv("CGIC_ENT_PAD") ? atoi(getenv("CGIC_ENT_PAD")) : 0;
     if (pad > 0) {
-        CGIC_HIP_TRY(hipFuncSetAttribute((const void *)entropy_maps_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, pad));
-        hipLaunchKernelGGL(entropy_maps_kernel, grid, dim3(kEntThreads), (size_t)pad, s, x, H, W, exp2_scale, e8, e16, ba, ppw);
+        CGIC_HIP_TRY(hipFuncSetAttribute((const void *)entropy_maps_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, pad));
+        hipLaunchKernelGGL(entropy_maps_kernel<false>, grid, dim3(kEntThreads), (size_t)pad, s, (const void *)x, H, W, exp2_scale, e8, e16, ba, ppw, (float *)nullptr);
         return launch_check("entropy_maps_kernel");
     }
 #endif
-    hipLaunchKernelGGL(entropy_maps_kernel, grid, dim3(kEntThreads), 0, s, x, H, W, exp2_scale, e8, e16, ba, ppw);
+    if (u8)
+        hipLaunchKernelGGL(entropy_maps_kernel<true>, grid, dim3(kEntThreads), 0, s, x, H, W, exp2_scale, e8, e16, ba, ppw, x_out);
+    else
+        hipLaunchKernelGGL(entropy_maps_kernel<false>, grid, dim3(kEntThreads), 0, s, x, H, W, exp2_scale, e8, e16, ba, ppw, (float *)nullptr);
     return launch_check("entropy_maps_kernel");
+}
+
+extern "C" int cgic_entropy_maps_f32(const float *x, int64_t B, int64_t H, int64_t W, const float *bins,
+                                     int nbins, float sigma, float *e8, float *e16, cgic_stream_t stream)
+{
+    return entropy_maps_launch(x, false, B, H, W, bins, nbins, sigma, nullptr, e8, e16, stream);
+}
+
+extern "C" int cgic_entropy_maps_u8(const unsigned char *x_hwc, int64_t B, int64_t H, int64_t W, const float *bins,
+                                    int nbins, float sigma, float *x_out, float *e8, float *e16, cgic_stream_t stream)
+{
+    CGIC_REQUIRE(((uintptr_t)x_hwc & 3u) == 0, CGIC_ERR_INVALID, "entropy: the uint8 frame must be 4-byte aligned");
+    return entropy_maps_launch(x_hwc, true, B, H, W, bins, nbins, sigma, x_out, e8, e16, stream);
 }
 
 extern "C" int cgic_entropy_maps_ref_f32(const float *x, int64_t B, int64_t H, int64_t W, const float *bins,

@@ -40,6 +40,25 @@ def entropy_maps(x, want8=True, want16=True, sigma=0.01, reference_order=False):
     return e8, e16
 
 
+def entropy_maps_u8(frames, want_x=True, want8=True, want16=True, sigma=0.01):
+    """frames [B,H,W,3] uint8 on the device (PIL / decoder layout), H and W multiples of 16 -> (x, e8, e16): ToTensor and both Entropy
+    maps in ONE pass (inference.py:50-59 + model.py:99-101).  x [B,3,H,W] fp32 = frames / 255 exactly as T.ToTensor() rounds it
+    (None with want_x=False); the maps are bit-identical to entropy_maps(x)."""
+    _lib.require_device(frames)
+    if frames.dim() != 4 or frames.shape[3] != 3 or frames.dtype != torch.uint8:
+        raise ValueError(f"expected uint8 [B,H,W,3], got {frames.dtype} {tuple(frames.shape)}")
+    frames = frames.contiguous()
+    B, H, W, _ = frames.shape
+    dev = frames.device
+    x = torch.empty((B, 3, H, W), dtype=torch.float32, device=dev) if want_x else None
+    e8 = torch.empty((B, H // 8, W // 8), dtype=torch.float32, device=dev) if want8 else None
+    e16 = torch.empty((B, H // 16, W // 16), dtype=torch.float32, device=dev) if want16 else None
+    with torch.cuda.device(dev):
+        _lib.call("cgic_entropy_maps_u8", _lib.ptr(frames), B, H, W, _bins(), 32, float(sigma), _lib.ptr(x), _lib.ptr(e8), _lib.ptr(e16),
+                  _lib.current_stream(dev))
+    return x, e8, e16
+
+
 class Entropy(nn.Module):
     def __init__(self, patch_size, reference_order=False):
         super().__init__()

@@ -18,7 +18,7 @@ from typing import Optional, Tuple
 import torch
 
 from . import _lib
-from .entropy import entropy_maps as _entropy_maps
+from .entropy import entropy_maps as _entropy_maps, entropy_maps_u8 as _entropy_maps_u8
 from .quantize import _vq_forward, vq_backward as _vq_backward, vq_forward_route as _vq_forward_route
 from .router import TripleGrainFixedEntropyRouter
 
@@ -95,6 +95,21 @@ def entropy_maps_reference_order(x: torch.Tensor) -> Tuple[torch.Tensor, torch.T
 def _(x):
     B, _, H, W = x.shape
     return x.new_empty((B, H // 8, W // 8)), x.new_empty((B, H // 16, W // 16))
+
+
+@torch.library.custom_op("cgic::entropy_maps_u8", mutates_args=(), device_types=_DEV)
+def entropy_maps_u8(frames: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+    """T.ToTensor() and both Entropy maps of uint8 [B,H,W,3] frames in one pass (inference.py:50-59 + model.py:99-101):
+    (x [B,3,H,W] fp32, e8, e16)"""
+    x, e8, e16 = _entropy_maps_u8(frames)
+    return x, e8, e16
+
+
+@entropy_maps_u8.register_fake
+def _(frames):
+    B, H, W, _ = frames.shape
+    f = lambda *s: frames.new_empty(s, dtype=torch.float32)
+    return f(B, 3, H, W), f(B, H // 8, W // 8), f(B, H // 16, W // 16)
 
 
 @torch.library.custom_op("cgic::router", mutates_args=(), device_types=_DEV)

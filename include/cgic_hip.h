@@ -180,6 +180,15 @@ int cgic_entropy_maps_f32(const float *x, int64_t B, int64_t H, int64_t W, const
  * the default kernel.  Same arguments and contract as cgic_entropy_maps_f32. */
 int cgic_entropy_maps_ref_f32(const float *x, int64_t B, int64_t H, int64_t W, const float *bins,
                               int nbins, float sigma, float *e8, float *e16, cgic_stream_t stream);
+/* ToTensor + Entropy in one pass, for frames that arrive as uint8 (the datasets of both scripts: PIL image -> center crop ->
+ * T.ToTensor(), inference.py:50-59, then CGIC.encode's two Entropy calls, model.py:99-101).
+ *   x_hwc  device [B, H, W, 3] uint8 (PIL / decoder layout), 4-byte aligned, H % 16 == 0, W % 16 == 0
+ *   x_out  device [B, 3, H, W] fp32 or NULL: byte / 255 exactly as torch's `.div(255)` rounds it = what ToTensor hands to the
+ *          conv encoder (bit for bit, all 256 byte values)
+ *   e8, e16 as cgic_entropy_maps_f32 -- and bit-identical to cgic_entropy_maps_f32 run on x_out.
+ * 3 B read + 12 B written per pixel instead of ToTensor's 3 + 12 and Entropy's 12 again. */
+int cgic_entropy_maps_u8(const unsigned char *x_hwc, int64_t B, int64_t H, int64_t W, const float *bins,
+                         int nbins, float sigma, float *x_out, float *e8, float *e16, cgic_stream_t stream);
 
 /* ---------------------------------------------------------------------------
  * C. TripleGrainFixedEntropyRouter -- CGIC/modules/vqvae/RouterTriple.py:8-95

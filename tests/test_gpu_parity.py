@@ -347,6 +347,29 @@ def test_entropy_extreme_shapes_vs_oracle(orc, B, H, W):
     assert np.abs(e16.cpu().numpy() - orc.entropy(x, 16)).max() < 2e-6
 
 
+@pytest.mark.parametrize("B,H,W", [(3, 256, 256), (1, 16, 16), (2, 48, 4080), (1, 768, 592)])
+def test_uint8_frames_totensor_and_entropy_in_one_pass(orc, B, H, W):
+    """cgic_entropy_maps_u8 (inference.py:50-59 + model.py:99-101): x == what T.ToTensor() makes of the frames on the CPU
+    (permute, float, div(255)) bit for bit; the maps == entropy_maps(x) bit for bit and == the oracle within the entropy
+    tolerance; the op and the x-less call agree"""
+    rng = np.random.default_rng(B * H + W)
+    frames = rng.integers(0, 256, (B, H, W, 3), dtype=np.uint8)
+    frames[0, :16, :16] = np.arange(256, dtype=np.uint8).reshape(16, 16, 1)          # every byte value at least once
+    ref_x = torch.from_numpy(frames).permute(0, 3, 1, 2).to(torch.float32).div(255).contiguous()
+    x, e8, e16 = cg.entropy_maps_u8(_t(frames))
+    assert torch.equal(x.cpu(), ref_x)
+    f8, f16 = cg.entropy_maps(x)
+    assert torch.equal(e8, f8) and torch.equal(e16, f16)
+    assert np.abs(e8.cpu().numpy() - orc.entropy(ref_x.numpy(), 8)).max() < 2e-6
+    assert np.abs(e16.cpu().numpy() - orc.entropy(ref_x.numpy(), 16)).max() < 2e-6
+    nx, g8, g16 = cg.entropy_maps_u8(_t(frames), want_x=False)
+    assert nx is None and torch.equal(g8, e8) and torch.equal(g16, e16)
+    ox, o8, o16 = torch.ops.cgic.entropy_maps_u8(_t(frames))
+    assert torch.equal(ox, x) and torch.equal(o8, e8) and torch.equal(o16, e16)
+    with pytest.raises(ValueError):
+        cg.entropy_maps_u8(_t(frames).float())
+
+
 def test_entropy_edge_pixels_vs_oracle(orc):
     """the fixed-point deposit path on its corner cases: pixels outside [-1, 1] (no bin in reach: an all-zero histogram
     is 0 here, 2.9e-37 in the reference), exactly on bin centres / midway between two, saturated patches where all 64

@@ -152,6 +152,8 @@ def test_custom_ops_schema_and_fake_tensor_shapes():
         assert tuple(e8.shape) == (2, 8, 12) and tuple(e16.shape) == (2, 4, 6)
         masks = torch.ops.cgic.router(e16, e8, 0.1, 0.8, True)
         assert [tuple(m.shape) for m in masks] == [(2, 1, 4, 6), (2, 1, 8, 12), (2, 1, 16, 24)] and masks[0].dtype == torch.int32
+        xf, f8, f16 = torch.ops.cgic.entropy_maps_u8(torch.empty(2, 64, 96, 3, device="cuda", dtype=torch.uint8))
+        assert tuple(xf.shape) == (2, 3, 64, 96) and xf.dtype == torch.float32 and tuple(f8.shape) == (2, 8, 12) and tuple(f16.shape) == (2, 4, 6)
         out = torch.ops.cgic.vq_forward_route(z, cb, 0.25, True, torch.empty(2, 4, 6, device="cuda"), torch.empty(2, 8, 12, device="cuda"), 0.1, 0.8, True)
         assert len(out) == 6 and tuple(out[5].shape) == (2, 1, 16, 24)
         gz, gw = torch.ops.cgic.vq_backward(z, cb, idx, zq, loss, 0.25, True)
@@ -197,3 +199,20 @@ def test_codec_and_merge_custom_ops_schema_and_fake_tensor_shapes():
         assert tuple(torch.ops.cgic.decoder_blend_fine(hf, hf, mk(4), mk(2), mk(1)).shape) == (2, 8, 16, 24)
     with pytest.raises(NotImplementedError):
         torch.ops.cgic.avg_pool(torch.zeros(1, 1, 4, 4), 2)
+
+
+def test_byte_over_255_formula_of_the_uint8_entropy_kernel_is_torchs_division():
+    """cgic_entropy_maps_u8 converts a byte with q = b * fl(1/255); q = fma(fma(-q, 255, b), fl(1/255), q) (unit_of_byte,
+    cgic_entropy.hip): for every byte that is the fp32 quotient torch's `.div(255)` (T.ToTensor(), inference.py:50-53) produces.
+    The fmas are emulated in float64 (products of fp32 values and these sums are exact there)."""
+    import torch
+    b = np.arange(256, dtype=np.float32)
+    ref = torch.arange(256, dtype=torch.uint8).to(torch.float32).div(255).numpy()
+    r = np.float32(0.00392156886)
+    assert r == np.float32(1) / np.float32(255)
+    q = (b * r).astype(np.float32)
+    e = (b.astype(np.float64) - q.astype(np.float64) * 255.0)
+    assert np.array_equal(e, e.astype(np.float32).astype(np.float64))               # the remainder is an fp32 number: the fma is exact
+    q2 = (e * np.float64(r) + q.astype(np.float64)).astype(np.float32)
+    assert np.array_equal(q2, ref)
+    assert int((q != ref).sum()) > 100                                              # the plain product is NOT the quotient
