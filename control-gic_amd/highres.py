@@ -148,9 +148,14 @@ class _Fork:
 
 
 def _compress_groups(x, encode, codec, tile, concurrent):
-    """x [N,3,H,W]: the shape groups of N images of one size, each group ONE batch of N * T tiles (image-major)
+    """x [N,3,H,W] fp32 -- or uint8 frames [N,H,W,3], the tiles then reach `encode` as uint8 [T,th,tw,3] (entropy_maps_u8 makes the
+    fp32 tiles and the maps in one pass) --: the shape groups of N images of one size, each group ONE batch of N * T tiles (image-major)
     -> (H, W), pad, tiles, [(tile indices, CompressedBatch, (ind, masks, mode))]"""
-    N, _, H, W = x.shape
+    frames = x.dtype == torch.uint8
+    if frames and x.shape[-1] != 3 or not frames and x.shape[1] != 3:
+        raise ValueError(f"expected [N,3,H,W] (or uint8 [N,H,W,3]), got {x.dtype} {tuple(x.shape)}")
+    N = x.shape[0]
+    H, W = (x.shape[1], x.shape[2]) if frames else (x.shape[2], x.shape[3])
     pad, _ = compute_padding(H, W)
     left, right, top, bottom = pad
     tiles = tile_grid(H + top + bottom, W + left + right, tile)
@@ -161,21 +166,23 @@ def _compress_groups(x, encode, codec, tile, concurrent):
     # the largest group first: it is the long pole, and lane 0 (no fork latency) is its stream
     order = sorted(by_shape.items(), key=lambda kv: -len(kv[1]) * kv[0][0] * kv[0][1])
     fork = _Fork(x.device, concurrent)
+    xv = x.permute(0, 3, 1, 2) if frames else x              # [N,3,H,W] view either way
     for lane, ((th, tw), idxs) in enumerate(order):
         with torch.cuda.stream(fork.lane(lane)):
             # pad + cut in ONE copy per tile (F.pad of the whole image and a stack of views would move every pixel twice): a tile
             # is the part of the image it covers, zeros where it reaches into the centred pad
-            batch = torch.empty((N, len(idxs), 3, th, tw), dtype=x.dtype, device=x.device)
+            batch = torch.empty((N, len(idxs), th, tw, 3) if frames else (N, len(idxs), 3, th, tw), dtype=x.dtype, device=x.device)
+            bv = batch.permute(0, 1, 4, 2, 3) if frames else batch
             for k, i in enumerate(idxs):
                 y0, x0 = tiles[i][0] - top, tiles[i][1] - left                  # in unpadded coordinates
                 sy0, sy1, sx0, sx1 = max(y0, 0), min(y0 + th, H), max(x0, 0), min(x0 + tw, W)
-                dst = batch[:, k]
-                dst[:, :, sy0 - y0:sy1 - y0, sx0 - x0:sx1 - x0] = x[:, :, sy0:sy1, sx0:sx1]
+                dst = bv[:, k]
+                dst[:, :, sy0 - y0:sy1 - y0, sx0 - x0:sx1 - x0] = xv[:, :, sy0:sy1, sx0:sx1]
                 # only the strips that reach into the pad are zeroed (a few rows / columns, not the whole batch)
                 for strip in (dst[:, :, :sy0 - y0], dst[:, :, sy1 - y0:], dst[:, :, :, :sx0 - x0], dst[:, :, :, sx1 - x0:]):
                     if strip.numel():
                         strip.zero_()
-            ind, masks, mode = encode(batch.view(-1, 3, th, tw))
+            ind, masks, mode = encode(batch.view(-1, th, tw, 3) if frames else batch.view(-1, 3, th, tw))
             groups.append((idxs, codec.compress(ind, masks, mode), (ind, masks, mode)))
     fork.join([(c, e) for _, c, e in groups])
     return (H, W), pad, tiles, groups
@@ -186,19 +193,20 @@ def compress_tiled(x, encode, codec, tile=TILE, concurrent=False):
     with per-tile routing (the reference's per-tile B=1 call); codec: GrainCodec.  -> TiledImage.
     concurrent: the shape groups run on parallel streams (same results; see _Fork)"""
     if x.dim() != 4 or x.shape[0] != 1:
-        raise ValueError("compress_tiled takes one image [1,3,H,W] (the reference script uses batch 1); "
+        raise ValueError("compress_tiled takes one image [1,3,H,W] (or one uint8 frame [1,H,W,3]; the reference script uses batch 1); "
                          "compress_tiled_batch takes several of one size")
     return TiledImage(*_compress_groups(x, encode, codec, tile, concurrent))
 
 
 def compress_tiled_batch(x, encode, codec, tile=TILE, concurrent=False):
-    """x [N,3,H,W]: N images of ONE size (a folder of camera frames, a DIV2K bucket) -> list of N TiledImage, each what
+    """x [N,3,H,W] (or uint8 frames [N,H,W,3]: `encode` then gets uint8 tiles [T,th,tw,3] for entropy_maps_u8 -- a pad of zero
+    bytes is the pad of zeros ToTensor would have produced): N images of ONE size (a folder of camera frames, a DIV2K bucket) -> list of N TiledImage, each what
     compress_tiled gives for that image alone (routing is per tile, so batching across images changes no byte).  The tiles
     of equal shape of ALL the images go through the kernels as one batch: a 2040x1356 image alone is four launch chains of one or
     two tiles each (a handful of workgroups per launch); eight images are chains of 8-16 tiles.  The TiledImages hold views
     of the shared per-group buffers"""
     if x.dim() != 4:
-        raise ValueError("compress_tiled_batch takes [N,3,H,W]")
+        raise ValueError("compress_tiled_batch takes [N,3,H,W] or uint8 [N,H,W,3]")
     N = x.shape[0]
     hw, pad, tiles, groups = _compress_groups(x, encode, codec, tile, concurrent)
     out = []

@@ -671,3 +671,46 @@ def test_center_crop16_follows_torchvision_center_crop():
             top, left = expect_off[H - th], expect_off[W - tw]
             assert float(y[0, 0, 0, 0]) == top * W + left and y.data_ptr() == x[..., top:, left:].data_ptr()
     assert highres.center_crop16(torch.zeros(3, 1356, 2040)).shape == (3, 1344, 2032)
+
+
+@pytest.mark.gpu
+def test_tiling_driver_takes_uint8_frames():
+    """uint8 frames [N,H,W,3] through compress_tiled / compress_tiled_batch (tiles cut as bytes, entropy_maps_u8 makes the fp32
+    tiles + both maps in one pass inside `encode`) give the streams and bpp of the fp32 images T.ToTensor() makes of them"""
+    import control_gic_amd as cg
+    from control_gic_amd import highres
+    from control_gic_amd.quantize import vq_forward_route
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(5)
+    vq = cg.VectorQuantizer(1024, 4, beta=0.25).to(dev)
+    with torch.no_grad():
+        vq.embedding.weight.copy_(torch.from_numpy(rng.standard_normal((1024, 4)).astype(np.float32)))
+    vq.usage_counter.copy_(torch.from_numpy(rng.integers(1, 1000, 1024).astype(np.float32)))
+    codec = cg.GrainCodec(vq.embedding_counter, vq.embedding.weight.detach())
+    N, H, W = 2, 1000, 1300
+    frames = torch.from_numpy(rng.integers(0, 256, (N, H, W, 3), dtype=np.uint8)).to(dev)
+    x = frames.permute(0, 3, 1, 2).float().div(255).contiguous()
+
+    def latent(tiles):
+        z = torch.nn.functional.avg_pool2d(tiles, 4)
+        return (torch.cat([z, z[:, :1] * 2 - 1], dim=1) * 3 - 1.5).contiguous()
+
+    def encode(tiles):
+        if tiles.dtype == torch.uint8:
+            tiles, e8, e16 = cg.entropy_maps_u8(tiles)
+        else:
+            e8, e16 = cg.entropy_maps(tiles)
+        _, _, ind, mask, _, mode = vq_forward_route(latent(tiles), vq.embedding.weight, 0.25, True, e16, e8, 0.1, 0.8, per_image=True)
+        return ind, mask, mode
+
+    ref = highres.compress_tiled_batch(x, encode, codec)
+    got = highres.compress_tiled_batch(frames, encode, codec)
+    one = highres.compress_tiled(frames[:1], encode, codec)
+    for a, b in zip(ref, got):
+        assert a.tiles == b.tiles and a.image_hw == b.image_hw and a.streams() == b.streams() and a.bpp() == b.bpp()
+    assert one.streams() == ref[0].streams()
+    dec = highres.decompress_tiled_batch(got, codec)
+    refd = highres.decompress_tiled_batch(ref, codec)
+    for pa, pb in zip(dec, refd):
+        for (i0, m0, z0), (i1, m1, z1) in zip(pa, pb):
+            assert torch.equal(i0, i1) and torch.equal(z0, z1)

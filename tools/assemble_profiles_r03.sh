@@ -36,8 +36,11 @@ echo
 cat $O/pmc_hbm.md
 echo
 echo "Algorithmic bytes per launch at B=64 of 256x256: entropy maps 50.33 MB read (the image, once); VQ + router 4.2 MB read (latent) + 0.33 MB (entropy maps)"
-echo "and 2.1 MB (int64 indices) + 4.2 MB (z_q) + 1.38 MB (int32 masks) written = 12.2 MB; the counted 13.57 MB (r02: 14.85) carry ~1.1 MB of scratch"
-echo "stores from the 128-VGPR cap (the 54 KB prepared codebook image read by 256 workgroups is served by L2)."
+echo "and 2.1 MB (int64 indices) + 4.2 MB (z_q) + 1.38 MB (int32 masks) written = 12.2 MB; counted 13.57 MB (r02: 14.85) = 1.11x.  Of the 1.4 MB"
+echo "over the algorithmic bytes, the ISA of the final build accounts for ~0.5 MB: the 128-VGPR cap leaves ONE spilled dword per lane, stored once per"
+echo "workgroup before the group loop (256 workgroups x 512 lanes x 4 B; round 2 spilled 4-10 registers inside the loop); the rest (loss partials,"
+echo "ticket words, partial cache lines of the mask writes) was not attributed by a separate measurement.  The 54 KB prepared codebook image read by"
+echo "256 workgroups is served by L2."
 } > profiles/r03_pmc_hbm.md
 {
 echo "# SQ instruction counters, round 3"
