@@ -478,7 +478,7 @@ __global__ __launch_bounds__(kEncThreads) CGIC_VGPR_CAP_COMPRESS void compress_s
     const int64_t b = jobs_fastest ? blockIdx.y : blockIdx.x;
     CGIC_STAMP2(0);
     CGIC_SPAN_BEGIN();
-#ifdef CGIC_PHASE_CLOCKS      // dev: per-workgroup (start, end) for tools/probe_compress_blocks.py
+#ifdef CGIC_PHASE_CLOCKS      // dev: per-workgroup (start, end) for tools/probes/probe_compress_blocks.py
     const unsigned int dbg_lin = (unsigned int)b * 16 + (jobs_fastest ? blockIdx.x : blockIdx.y);      // (image, job in launch order) like the probe expects
     if (threadIdx.x == 0 && dbg_lin < 4096) g_blk_t[2 * dbg_lin] = wall_clock64();
     struct DbgEnd { unsigned int lin; __device__ ~DbgEnd() { if (threadIdx.x == 0 && lin < 4096) g_blk_t[2 * lin + 1] = wall_clock64(); } } dbg_end{dbg_lin};

@@ -107,7 +107,7 @@ __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & (kWave - 1
 // the VALU, no LDS round trip.  Called with a == b == x they return
 //   swap16: a = x of rows (0,0,2,2), b = x of rows (1,1,3,3)      swap32: a = (lower half, lower half), b = (upper, upper)
 // Inline asm on purpose: through __builtin_amdgcn_permlane16_swap hipcc (ROCm 7.2) was seen to fold r[0] + r[1]
-// of one swap into 2 * r[0] (tools/probe_dpp.hip).  s_nop 1 = the wait states after the VALU write of an operand.
+// of one swap into 2 * r[0] (tools/probes/probe_dpp.hip).  s_nop 1 = the wait states after the VALU write of an operand.
 __device__ __forceinline__ void swap16(unsigned int &a, unsigned int &b)
 {
     asm("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));

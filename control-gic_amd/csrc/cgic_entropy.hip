@@ -50,7 +50,7 @@ __device__ __forceinline__ float dpp_add(float v)
 // 48..63).  Offsets 1, 2, 4, 8 are DPP operands of the adds (quad_perm / row_half_mirror / row_mirror on values that
 // are already uniform inside the smaller group = xor butterfly), then row_bcast:15 hands row 0's total to row 1 and
 // row 2's to row 3.  Fixed association => deterministic.  (The all-lanes form needs a v_permlane16_swap instead of
-// the last step: 4x the issue time of a DPP add, tools/probe_valu2.)
+// the last step: 4x the issue time of a DPP add, tools/probes/probe_valu2.)
 __device__ __forceinline__ float sum32_upper(float v)
 {
     v = dpp_add<0xB1>(v);        // quad_perm [1,0,3,2]: xor 1
@@ -133,7 +133,7 @@ __global__ __launch_bounds__(kEntThreads) void entropy_maps_kernel(
     const int64_t p_end = p_lo + kEntWaves * patches_per_wave < npx ? p_lo + kEntWaves * patches_per_wave : npx;
 
     CGIC_STAMP(16);
-#ifdef CGIC_PHASE_CLOCKS      // dev: per-workgroup (start, end) for tools/probe_entropy.py
+#ifdef CGIC_PHASE_CLOCKS      // dev: per-workgroup (start, end) for tools/probes/probe_entropy.py
     const unsigned int dbg_lin = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
     if (threadIdx.x == 0 && dbg_lin < 4096) g_blk_t[2 * dbg_lin] = wall_clock64();
     struct DbgEnd { unsigned int lin; __device__ ~DbgEnd() { if (threadIdx.x == 0 && lin < 4096) g_blk_t[2 * lin + 1] = wall_clock64(); } } dbg_end{dbg_lin};

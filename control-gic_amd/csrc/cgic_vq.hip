@@ -1316,7 +1316,7 @@ static int vq_dispatch(const float *z, int64_t hw, int64_t N, const float *codeb
 #undef CGIC_VQF_LAUNCH
     }
     CGIC_REQUIRE(!qc, CGIC_ERR_UNSUPPORTED, "vq: the fused quant_conv needs K %% 64 == 0 and K <= %d (K=%d): apply the 1x1 convolution separately", kVqfMaxK, K);
-    // exact loop; per-wave tile: measured on MI355X (tools/probe_vq.hip) ZT=4 at 4 waves/SIMD is the fastest
+    // exact loop; per-wave tile: measured on MI355X (tools/probes/probe_vq.hip) ZT=4 at 4 waves/SIMD is the fastest
     // for large N; smaller N shrinks the tile so that all 256 CUs get work
 #define CGIC_VQ_LAUNCH(ZT) launch_mfma<ZT>(z, hw, N, codebook, K, indices, z_q, ws, beta, legacy, loss, s, router, router_blocks, router_lds)
     if (force_zt == 8) return CGIC_VQ_LAUNCH(8);

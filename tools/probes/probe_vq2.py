@@ -1,7 +1,7 @@
 """GPU probe (round 2): the VQ kernel alone, timed from a hipGraph of 20 launches (no host-bound gaps), with the
 dbg build's phase clocks and workgroup end times when CGIC_LIB points at libcgic_hip_dbg.so; checks the filter path
 against the VALU restatement on the same inputs.
-usage: python tools/probe_vq2.py [B] [size]"""
+usage: python tools/probes/probe_vq2.py [B] [size]"""
 import sys, os, ctypes
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
