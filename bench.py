@@ -12,7 +12,7 @@ synthetic N(0,1) latent standing in for the encoder output.
 The K timed steps are K successive, DISTINCT batches: the inputs rotate through enough slots to exceed the
 256 MiB Infinity Cache, so the image bytes of every step come from HBM.  The whole rotation of batches is captured
 back to back in ONE hipGraph on one stream (successive graph launches are ~7 us apart on the device; `--no-ring`: one
-hipGraph per batch; what is left of K after whole rotations always runs as per-batch graphs) (`--schedule pipelined`: control_gic_amd.pipeline.BatchStream, encode side of batch i+1 next to the
+hipGraph per batch; what is left of K after whole rotations always runs as per-batch graphs) (`--schedule pipelined`: control_gic_amd.experimental.BatchStream, encode side of batch i+1 next to the
 decode side of batch i on two HIP streams -- measured no faster).  `value` = all pixels of the K
 steps / wall time between two barrier + synchronize brackets, max over ranks.
 
@@ -167,9 +167,11 @@ def stage_breakdown(hp):
     st["entropy_maps"] = graph_kernel_time(lambda: cg.entropy_maps(hp.x))
     st["router_alone"] = graph_kernel_time(lambda: hp.router(e16, e8, want_gate=False))
     st["vq+router_fused_launch"] = graph_kernel_time(lambda: vq_forward_route(
+        hp.z, hp.vq.embedding.weight, 0.25, True, e16, e8, hp.router.coarse_grain_ratio, hp.router.medium_grain_ratio, prepared=prep, pixels=hp.x))
+    st["vq+router_fused_launch_no_refinement"] = graph_kernel_time(lambda: vq_forward_route(
         hp.z, hp.vq.embedding.weight, 0.25, True, e16, e8, hp.router.coarse_grain_ratio, hp.router.medium_grain_ratio, prepared=prep))
     st["vq+router_fused_launch_unprepared"] = graph_kernel_time(lambda: vq_forward_route(
-        hp.z, hp.vq.embedding.weight, 0.25, True, e16, e8, hp.router.coarse_grain_ratio, hp.router.medium_grain_ratio))
+        hp.z, hp.vq.embedding.weight, 0.25, True, e16, e8, hp.router.coarse_grain_ratio, hp.router.medium_grain_ratio, pixels=hp.x))
     st["vq_kernel_alone"] = graph_kernel_time(lambda: _vq_forward(hp.z, hp.vq.embedding.weight, 0.25, True, None, prepared=prep))
     st["vq_kernel_indices_only"] = graph_kernel_time(lambda: _vq_forward(hp.z, hp.vq.embedding.weight, 0.25, True, None, False, False, prepared=prep))
     st["compress_streams+hist"] = graph_kernel_time(lambda: hp.codec.compress(ind, mask, mode, hist=hp.hist))
@@ -198,7 +200,7 @@ def saturated_launch_time(hp, lanes=4, per_graph=20, reps=6):
             out = None
             for _ in range(per_graph):
                 out = vq_forward_route(z, hp.vq.embedding.weight, 0.25, True, e16, e8, hp.router.coarse_grain_ratio, hp.router.medium_grain_ratio,
-                                       prepared=hp.pipe.prepared)
+                                       prepared=hp.pipe.prepared, pixels=hp.x)
             return out
         return fn
     gl = GraphLanes(hp.x.device, [make(z) for z in zs])
@@ -273,8 +275,10 @@ def cpu_baseline(x, z, cb, ratio, budget_s=12.0, threads=None):
 
 def check_against_oracle(out, x, z, cb, ratio, images=None):
     """bitstream / index / mask parity of a finished step with the oracle, on EVERY image of the batch (outside the
-    timed region).  Masks are checked given the GPU's own entropy maps (the bit-exact contract of SURVEY.md section 7);
-    pixels -> masks is the `mask_mismatch` report.  Returns (all equal, list of per-image bpp)."""
+    timed region).  Round 4: the masks -- hence every byte -- are checked FROM THE PIXELS: oracle entropy maps in the
+    reference's own arithmetic (cgic_oracle_entropy_ref) -> oracle router -> oracle coder against what the timed step's
+    default kernels left (entropy_maps -> router with its threshold-band refinement).  The maps themselves: <= 2e-6.
+    Returns (all equal, list of per-image bpp)."""
     from oracle import cgic_oracle as orc
     e8, e16, mask, mode, zq, ind, comp, dind, dmask, dq, status = out
     torch.cuda.synchronize()
@@ -295,7 +299,9 @@ def check_against_oracle(out, x, z, cb, ratio, images=None):
         _, _, oidx = orc.vq(z[b:b + 1], cb)
         oidx = oidx.reshape(h, w)
         ok = ok and bool(np.array_equal(ind_h[b], oidx))
-        omc, omm, omf, _, omode = orc.router(e16_h[b:b + 1], e8_h[b:b + 1], ratio[0], ratio[1])
+        o8, o16 = orc.entropy_ref(x[b:b + 1], 8), orc.entropy_ref(x[b:b + 1], 16)
+        ok = ok and float(np.abs(o8 - e8_h[b:b + 1]).max()) < 2e-6 and float(np.abs(o16 - e16_h[b:b + 1]).max()) < 2e-6
+        omc, omm, omf, _, omode = orc.router(o16, o8, ratio[0], ratio[1])
         ok = ok and omode == mode and all(np.array_equal(mk[g][b, 0], o[0, 0]) for g, o in enumerate((omc, omm, omf)))
         ref = orc.compress_image(oidx, omc[0, 0], omm[0, 0], omf[0, 0], mode, htab)
         ok = ok and host[b] == ref
@@ -307,9 +313,10 @@ def check_against_oracle(out, x, z, cb, ratio, images=None):
 
 # ------------------------------------------------------------------------------------------------ extras (rank 0, N=1)
 def mask_mismatch(hp, x, z, cb, ratio):
-    """pixels -> masks -> bytes on the GPU against the CPU oracle from the SAME pixels: the GPU's
-    entropy maps differ from the CPU's by ~1e-6 (exp/log implementations), thresholds are k-th smallest values, so a
-    near-tie can flip a mask element and with it every byte behind it."""
+    """pixels -> masks -> bytes on the GPU against the CPU oracle from the SAME pixels, on the benchmark
+    batch as the timed step left it.  Oracle side: entropy maps in the reference's own arithmetic (cgic_oracle_entropy_ref: torch's
+    operation order, exp / log correctly rounded) -> oracle router -> oracle coder.  (Round 3 compared against the libm / sequential-
+    sum oracle maps: both sides were ~1e-6 off the reference's arithmetic and agreed on noise only because noise has no ties.)"""
     from oracle import cgic_oracle as orc
     e8, e16, mask, mode, zq, ind, comp = hp.out[:7]
     torch.cuda.synchronize()
@@ -322,7 +329,7 @@ def mask_mismatch(hp, x, z, cb, ratio):
     diff_elems = diff_images = diff_files = files = 0
     max_de = 0.0
     for b in range(B):
-        o8, o16 = orc.entropy(x[b:b + 1], 8), orc.entropy(x[b:b + 1], 16)
+        o8, o16 = orc.entropy_ref(x[b:b + 1], 8), orc.entropy_ref(x[b:b + 1], 16)
         max_de = max(max_de, float(np.abs(o8 - e8[b:b + 1].cpu().numpy()).max()), float(np.abs(o16 - e16[b:b + 1].cpu().numpy()).max()))
         omc, omm, omf, _, omode = orc.router(o16, o8, ratio[0], ratio[1])
         d = sum(int((mk[g][b, 0] != o[0, 0]).sum()) for g, o in enumerate((omc, omm, omf)))
@@ -334,7 +341,7 @@ def mask_mismatch(hp, x, z, cb, ratio):
     n_elems = B * (h * w + h * w // 4 + h * w // 16)
     return {"images": B, "mask_elements": n_elems, "differing_mask_elements": diff_elems, "images_with_a_difference": int(diff_images),
             "bin_files": files, "differing_bin_files": int(diff_files), "max_abs_entropy_diff": max_de,
-            "note": "GPU entropy -> GPU router vs oracle entropy -> oracle router on the same pixels; given equal masks every byte is identical (bpp_match)"}
+            "note": "GPU entropy maps -> GPU router (threshold-band refinement) vs oracle reference-arithmetic maps -> oracle router on the same pixels; given equal masks every byte is identical (bpp_match)"}
 
 
 def mask_flip_families(dev, z, cb, vq, codec, ratio):
@@ -348,12 +355,13 @@ def mask_flip_families(dev, z, cb, vq, codec, ratio):
     from control_gic_amd.quantize import vq_forward_route
     htab = orc.HuffmanTable(zipf_freq())
 
-    def run(x, zz, reference_order=False):
+    def run(x, zz, reference_order=False, refine=True):
         B, H, W = x.shape[0], x.shape[2], x.shape[3]
         h, w = H // 4, W // 4
         xd, zd = torch.from_numpy(x).to(dev), torch.from_numpy(zz).to(dev)
         e8, e16 = cg_entropy(xd, reference_order=reference_order)
-        _, _, ind, mask, _, mode = vq_forward_route(zd, vq.embedding.weight, 0.25, True, e16, e8, ratio[0], ratio[1], per_image=True)
+        _, _, ind, mask, _, mode = vq_forward_route(zd, vq.embedding.weight, 0.25, True, e16, e8, ratio[0], ratio[1], per_image=True,
+                                                    pixels=xd if refine else None)
         host = codec.compress(ind, mask, mode).to_host()
         torch.cuda.synchronize()
         mk = [m.cpu().numpy() for m in mask]
@@ -379,25 +387,40 @@ def mask_flip_families(dev, z, cb, vq, codec, ratio):
 
     from control_gic_amd import entropy_maps as cg_entropy
     out = {}
-    ref_mode = {}
+    alone = {}
     short = lambda r: {k: r[k] for k in ("images", "differing_mask_elements", "images_with_a_difference", "differing_bin_files", "max_abs_entropy_diff")}
-    for name, x in families(n=64).items():
+
+    def launch_us(x, zz):
+        """the fused VQ + router launch on this content, with and without the refinement (what the band costs)"""
+        xd, zd = torch.from_numpy(x).to(dev), torch.from_numpy(zz).to(dev)
+        e8, e16 = cg_entropy(xd)
+        f = lambda px: graph_kernel_time(lambda: vq_forward_route(zd, vq.embedding.weight, 0.25, True, e16, e8, ratio[0], ratio[1], per_image=True,
+                                                                  pixels=px), per_graph=5, reps=3)
+        return {"vq+router_us": round(f(xd), 2), "vq+router_no_refinement_us": round(f(None), 2)}
+
+    fam = families(n=64)
+    for name, x in fam.items():
         out[name] = run(x, z)
-        ref_mode[name] = short(run(x, z, reference_order=True))
+        out[name].update(launch_us(x, z))
+        alone[name] = short(run(x, z, refine=False))
     t = families(n=2, H=768, W=768, seed=11)
     tiles = np.concatenate([t[k] for k in ("noise8", "smooth8", "flat_edges", "blocky8")])
     zt = np.random.default_rng(5).standard_normal((tiles.shape[0], 4, 192, 192), dtype=np.float32)
     out["tiles_768"] = run(tiles, zt)
-    ref_mode["tiles_768"] = short(run(tiles, zt, reference_order=True))
-    xd = torch.from_numpy(families(n=64)["smooth8"]).to(dev)
-    ref_mode["us_per_launch_B64_256x256"] = round(graph_kernel_time(lambda: cg_entropy(xd, reference_order=True), per_graph=5, reps=3), 2)
-    ref_mode["default_kernel_us_per_launch"] = round(graph_kernel_time(lambda: cg_entropy(xd), per_graph=5, reps=3), 2)
-    ref_mode["note"] = ("entropy_maps(reference_order=True) = cgic_entropy_maps_ref_f32: torch's CPU operation sequence and summation order, exp / log "
-                        "correctly rounded (opt-in; the timed step uses the default kernel)")
-    out["reference_order_mode"] = ref_mode
-    out["note"] = ("reference side = the reference's torch-CPU entropy arithmetic evaluated on this host (oracle/entropy_torch.py) -> oracle router; "
-                   "a differing mask element is a patch whose entropy lies within ~1e-6 of a threshold (k-th smallest value, strict '<'); the masks are "
-                   "part of the bitstream, so every stream decodes either way")
+    out["tiles_768"].update(launch_us(tiles, zt))
+    alone["tiles_768"] = short(run(tiles, zt, refine=False))
+    alone["note"] = "the same launches WITHOUT the pixels (round 3's default): the maps of the default kernel decide as given"
+    out["maps_alone"] = alone
+    xd = torch.from_numpy(fam["smooth8"]).to(dev)
+    out["reference_order_kernel"] = {
+        "smooth8": short(run(fam["smooth8"], z, reference_order=True, refine=False)),
+        "us_per_launch_B64_256x256": round(graph_kernel_time(lambda: cg_entropy(xd, reference_order=True), per_graph=5, reps=3), 2),
+        "default_kernel_us_per_launch": round(graph_kernel_time(lambda: cg_entropy(xd), per_graph=5, reps=3), 2),
+        "note": "entropy_maps(reference_order=True) = cgic_entropy_maps_ref_f32: every patch in the reference's arithmetic (opt-in; the "
+                "timed step evaluates only the patches inside a threshold band that way)"}
+    out["note"] = ("DEFAULT path = what the timed step runs: entropy_maps -> [VQ + router with the pixels: patches within 4e-6 of a threshold "
+                   "(k-th smallest value, strict '<') are re-evaluated in the reference's own arithmetic inside the router].  Reference side = the "
+                   "reference's torch-CPU entropy arithmetic evaluated on this host (oracle/entropy_torch.py) -> oracle router -> oracle coder")
     return out
 
 
@@ -456,7 +479,7 @@ def div2k_image(dev, cb, vq, codec, iters=8):
         if key not in zs:
             zs[key] = torch.from_numpy(np.random.default_rng(th * 7 + tw).standard_normal((T, 4, th // 4, tw // 4), dtype=np.float32)).to(dev)
         e8, e16 = cg.entropy_maps(tiles)
-        _, _, ind, mask, _, mode = vq_forward_route(zs[key], vq.embedding.weight, 0.25, True, e16, e8, 0.1, 0.8, per_image=True)
+        _, _, ind, mask, _, mode = vq_forward_route(zs[key], vq.embedding.weight, 0.25, True, e16, e8, 0.1, 0.8, per_image=True, pixels=tiles)
         return ind, mask, mode
 
     def once():
@@ -575,7 +598,7 @@ def div2k_image(dev, cb, vq, codec, iters=8):
             if key not in zs:
                 zs[key] = torch.from_numpy(np.random.default_rng(th * 7 + tw).standard_normal((T, 4, th // 4, tw // 4), dtype=np.float32)).to(dev)
             _, e8, e16 = cg.entropy_maps_u8(tiles)
-            _, _, ind, mask, _, mode = vq_forward_route(zs[key], vq.embedding.weight, 0.25, True, e16, e8, 0.1, 0.8, per_image=True)
+            _, _, ind, mask, _, mode = vq_forward_route(zs[key], vq.embedding.weight, 0.25, True, e16, e8, 0.1, 0.8, per_image=True, pixels=tiles)
             return ind, mask, mode
 
         def once_u8():
@@ -765,7 +788,7 @@ def run_rank(a, rank, world, local):
         hist = torch.zeros(1024, dtype=torch.int64, device=dev)
         slots_dev = [(torch.from_numpy(x).to(dev), torch.from_numpy(z).to(dev)) for x, z, _ in slots_np]
         if a.schedule == "pipelined" and not a.no_graph:
-            stream = cg.pipeline.BatchStream(vq, ratio[0], ratio[1], slots_dev, frequency=codec.huffman, hist=hist)
+            stream = cg.experimental.BatchStream(vq, ratio[0], ratio[1], slots_dev, frequency=codec.huffman, hist=hist)
             stream.capture()
         else:
             # control_gic_amd.pipeline.LaneStream: batch t on HIP stream t % lanes, one ring graph per stream, no

@@ -13,10 +13,10 @@ from .entropy import Entropy, entropy_maps, entropy_maps_u8
 from .indices_coding import HuffmanCoding
 from .mask_coding import BinaryCoding
 from .codec import GrainCodec, CompressedBatch, mode_streams, STREAM_NAMES, decoder_mode
-from . import pipeline, highres, container, model, ops
-from .pipeline import HotPathPipeline, BatchStream, LaneStream, GraphLanes, capture_graph
+from . import pipeline, highres, container, model, ops, experimental
+from .pipeline import HotPathPipeline, LaneStream, GraphLanes, capture_graph
 from .model import install, compress_batch, grain_merge, avg_pool, decoder_blend_medium, decoder_blend_fine
 
 __all__ = ["VectorQuantize2", "VectorQuantizer", "TripleGrainFixedEntropyRouter", "Entropy", "entropy_maps", "entropy_maps_u8",
            "HuffmanCoding", "BinaryCoding", "GrainCodec", "CompressedBatch", "mode_streams", "STREAM_NAMES",
-           "HotPathPipeline", "BatchStream", "LaneStream", "GraphLanes", "capture_graph", "decoder_mode", "install", "compress_batch", "grain_merge", "avg_pool", "decoder_blend_medium", "decoder_blend_fine", "highres", "container", "CgicError", "LIB_PATH"]
+           "HotPathPipeline", "LaneStream", "GraphLanes", "capture_graph", "decoder_mode", "install", "compress_batch", "grain_merge", "avg_pool", "decoder_blend_medium", "decoder_blend_fine", "highres", "container", "CgicError", "LIB_PATH"]

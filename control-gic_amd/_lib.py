@@ -32,13 +32,21 @@ class Conv1x1(C.Structure):
 
 _cv = C.POINTER(Conv1x1)
 
+
+class Pixels(C.Structure):
+    """struct cgic_pixels (include/cgic_hip.h): the image batch behind a pair of entropy maps, for the router's refinement"""
+    _fields_ = [("x", _vp), ("is_u8", _int), ("bins", C.POINTER(_f32)), ("nbins", _int), ("sigma", _f32), ("flat8", _vp)]
+
+
+_px = C.POINTER(Pixels)
+
 # name -> (restype, argtypes); every function include/cgic_hip.h declares
 PROTOTYPES = {
     "cgic_last_error": (C.c_char_p, []),
     "cgic_abi_version": (_int, []),
     "cgic_set_decode_mode": (_int, [_int]),
     "cgic_device_count": (_int, []),
-    "cgic_launch_graphs": (_int, [C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_int), _int, _int]),
+    "cgic_launch_graphs": (_int, [C.POINTER(_vp), C.POINTER(_vp), _int]),
     "cgic_ticket_scope_begin": (_int, []),
     "cgic_ticket_scope_end": (_int, []),
     "cgic_ticket_scope_release": (_int, [_int]),
@@ -50,15 +58,16 @@ PROTOTYPES = {
     "cgic_vq_forward_f32": (_int, [_vp, _i64, _i64, _vp, _int, _int, _f32, _int, _vp, _vp, _vp, _vp, _vp, _cv, _vp, _vp]),
     "cgic_vq_forward_valu_f32": (_int, [_vp, _i64, _i64, _vp, _int, _int, _f32, _int, _vp, _vp, _vp, _vp, _vp, _cv, _vp]),
     "cgic_vq_forward_route_f32": (_int, [_vp, _i64, _i64, _vp, _int, _int, _f32, _int, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64,
-                                         _f64, _f64, _int, _vp, _vp, _vp, _vp, C.POINTER(_int), _cv, _vp, _vp]),
+                                         _f64, _f64, _int, _vp, _vp, _vp, _vp, C.POINTER(_int), _cv, _vp, _px, _vp]),
     "cgic_vq_backward_workspace_bytes": (_sz, [_i64, _int]),
     "cgic_vq_backward_f32": (_int, [_vp, _i64, _i64, _vp, _int, _int, _vp, _vp, _vp, _f32, _int, _vp, _vp, _vp, _vp]),
     "cgic_index_histogram": (_int, [_vp, _i64, _int, _vp, _vp]),
-    "cgic_entropy_maps_f32": (_int, [_vp, _i64, _i64, _i64, C.POINTER(_f32), _int, _f32, _vp, _vp, _vp]),
+    "cgic_entropy_maps_f32": (_int, [_vp, _i64, _i64, _i64, C.POINTER(_f32), _int, _f32, _vp, _vp, _vp, _vp]),
     "cgic_entropy_maps_ref_f32": (_int, [_vp, _i64, _i64, _i64, C.POINTER(_f32), _int, _f32, _vp, _vp, _vp]),
-    "cgic_entropy_maps_u8": (_int, [_vp, _i64, _i64, _i64, C.POINTER(_f32), _int, _f32, _vp, _vp, _vp, _vp]),
+    "cgic_entropy_maps_u8": (_int, [_vp, _i64, _i64, _i64, C.POINTER(_f32), _int, _f32, _vp, _vp, _vp, _vp, _vp]),
     "cgic_router_mode": (_int, [_f64, _f64]),
-    "cgic_router_f32": (_int, [_vp, _vp, _i64, _i64, _i64, _f64, _f64, _int, _vp, _vp, _vp, _vp, C.POINTER(_int), _vp]),
+    "cgic_router_refine_supported": (_int, [_i64, _i64, _i64, _int]),
+    "cgic_router_f32": (_int, [_vp, _vp, _i64, _i64, _i64, _f64, _f64, _int, _vp, _vp, _vp, _vp, C.POINTER(_int), _px, _vp]),
     "cgic_table_create": (_int, [C.POINTER(_i64), C.POINTER(_i32), _int, C.POINTER(_vp)]),
     "cgic_table_binary": (_int, [C.POINTER(_vp)]),
     "cgic_table_destroy": (None, [_vp]),
@@ -136,6 +145,45 @@ def conv_arg(conv, bias_first=False):
     return C.byref(st), (st, w, b)
 
 
+_BINS = None
+
+
+def linspace_bins():
+    """torch.linspace(-1, 1, 32) evaluated on the CPU like the reference's CPU path (model.py:480), as a ctypes float[32]"""
+    global _BINS
+    if _BINS is None:
+        import torch
+        _BINS = (C.c_float * 32)(*torch.linspace(-1, 1, 32, dtype=torch.float32).tolist())
+    return _BINS
+
+
+def pixels_arg(pixels, B, h16, w16, per_image, sigma=0.01, flat8=None):
+    """(ctypes pointer or None, keep-alive) for the router's `refine` argument.  pixels: None, the fp32 [B,3,16 h16,16 w16] image
+    batch the maps were made from, or the uint8 [B,16 h16,16 w16,3] frames; flat8: the constant-patch map the same entropy call
+    made (entropy_maps(...) attaches it to its maps as `_cgic_flat8`), optional.  None is also returned (no refinement, the maps
+    decide as given) when the routing segment does not fit the workgroup's LDS (cgic_router_refine_supported: flattened
+    batches / images beyond ~768x768 routed as one segment)."""
+    if pixels is None:
+        return None, ()
+    import torch
+    require_device(pixels)
+    u8 = pixels.dtype == torch.uint8
+    want = (B, 16 * h16, 16 * w16, 3) if u8 else (B, 3, 16 * h16, 16 * w16)
+    if tuple(pixels.shape) != want or (not u8 and pixels.dtype != torch.float32):
+        raise ValueError(f"pixels {pixels.dtype} {tuple(pixels.shape)} do not belong to entropy maps of {B} x {h16} x {w16} "
+                         f"(expected fp32 [B,3,16 h16,16 w16] or uint8 [B,16 h16,16 w16,3])")
+    if not lib().cgic_router_refine_supported(B, h16, w16, int(bool(per_image))):
+        return None, ()
+    px = pixels.contiguous()
+    if flat8 is not None:
+        require_device(flat8)
+        if tuple(flat8.shape) != (B, 2 * h16, 2 * w16) or flat8.dtype != torch.float32:
+            raise ValueError(f"flat8 {flat8.dtype} {tuple(flat8.shape)} does not belong to these maps")
+        flat8 = flat8.contiguous()
+    st = Pixels(px.data_ptr(), int(u8), linspace_bins(), 32, float(sigma), ptr(flat8))
+    return C.byref(st), (st, px, flat8)
+
+
 class ticket_scope:
     """`with ticket_scope() as sc:` around the capture of a hipGraph (on this thread): the ticket slots its launches take are
     tagged; `sc.release()` -- or `sc.release_with(obj)`: when `obj`, the graph object, is garbage-collected -- returns them
@@ -158,9 +206,32 @@ class ticket_scope:
             self.id = 0
 
     def release_with(self, obj):
+        """give the slots back once `obj` (the graph object) is gone AND its last replay has finished.  Destroying a graph does
+        not wait for a replay that is still in flight, and a slot handed to a new launch while the old graph's kernels still
+        use it corrupts the shared ticket: the finalizer therefore only QUEUES the scope; flush_released() -- called by
+        pipeline.capture_graph before every capture, the only consumer of pool slots -- synchronises the device and
+        releases what is queued."""
         import weakref
-        weakref.finalize(obj, lib().cgic_ticket_scope_release, self.id)
+        f = weakref.finalize(obj, _released.append, self.id)
+        f.atexit = False
         return obj
+
+
+_released = []          # scope ids whose graph object died (list.append is atomic; drained by flush_released)
+
+
+def flush_released(device=None):
+    """return the ticket slots of graphs that were garbage-collected since the last call.  Synchronises `device` first if there
+    is anything to return (a replay of a dead graph may still be running); must not be called while a stream is capturing."""
+    if not _released:
+        return 0
+    import torch
+    torch.cuda.synchronize(device)
+    n = 0
+    while _released:
+        r = lib().cgic_ticket_scope_release(_released.pop())
+        n += max(r, 0)
+    return n
 
 
 def current_stream(device=None):

@@ -26,7 +26,7 @@
 // lane only, was measured 5x less accurate -- 5.9e-6 against the CPU reference -- because the two terms cancel.)
 // This op cannot be bit-exact against the CPU reference anyway (SLEEF vs GPU transcendentals, torch.mean's
 // summation tree); it is held to 2e-5 absolute, and measures ~1e-6.
-#include "cgic_common.h"
+#include "cgic_entropy_dev.h"
 
 #include <stdlib.h>
 
@@ -34,12 +34,9 @@ namespace cgic {
 
 constexpr int kEntThreads = 256;
 constexpr int kEntWaves = kEntThreads / kWave;
-constexpr int kBins = 32;
 constexpr int kWin = 2;            // bins evaluated per pixel: the two that bracket it
 constexpr int kHistStride = 36;    // dwords per bin: 4 sub-patches x 8 replicas + 4 pad (conflict-free b128 rows)
 constexpr float kFixScale = 67108864.f;           // 2^26: a replica collects <= 8 pixels with values <= 1, four replicas < 2^31
-
-struct BinsArg { float v[kBins]; };   // passed by value in the kernarg segment
 
 template <int CTRL, int ROW_MASK = 0xF>
 __device__ __forceinline__ float dpp_add(float v)
@@ -99,16 +96,6 @@ __device__ __forceinline__ unsigned int cvt_round_u32(float v)
     return (unsigned int)r;
 }
 
-// byte / 255 as torch's `.div(255)` rounds it (T.ToTensor(), inference.py:50-53): q = b * fl(1/255) corrected once by the exact
-// remainder -- equal to the IEEE quotient for all 256 bytes (checked exhaustively, tests/test_host_logic.py), three full-rate
-// instructions instead of the ~10 of a division
-__device__ __forceinline__ float unit_of_byte(float b)
-{
-    const float r = 0.00392156886f;                 // fl(1 / 255)
-    const float q = b * r;
-    return __builtin_fmaf(__builtin_fmaf(-q, 255.0f, b), r, q);
-}
-
 // U8: x is a uint8 [B, H, W, 3] frame (PIL / decoder layout) and the kernel is ToTensor + Entropy in one pass: a lane reads the
 // 12 bytes of its 4 pixels, converts them to the fp32 values T.ToTensor() produces (bit for bit) and, if x_out is given, writes
 // them as the fp32 [B, 3, H, W] tensor the conv encoder takes (inference.py:50-59 + model.py:99-101): 3 B read + 12 B written
@@ -116,7 +103,7 @@ __device__ __forceinline__ float unit_of_byte(float b)
 template <bool U8>
 __global__ __launch_bounds__(kEntThreads) void entropy_maps_kernel(
     const void *__restrict__ xin, int64_t H, int64_t W, float exp2_scale, float *__restrict__ e8,
-    float *__restrict__ e16, BinsArg bins_arg, int patches_per_wave, float *__restrict__ x_out)
+    float *__restrict__ e16, BinsArg bins_arg, int patches_per_wave, float *__restrict__ x_out, float *__restrict__ flat8)
 {
     const float *__restrict__ x = reinterpret_cast<const float *>(xin);
     __shared__ __attribute__((aligned(16))) unsigned int hist_all[kEntWaves][kBins * kHistStride];
@@ -197,6 +184,20 @@ __global__ __launch_bounds__(kEntThreads) void entropy_maps_kernel(
         g[3] = (0.2989f * pR.w + 0.5870f * pG.w) + 0.1140f * pB.w;
         request(patch + kEntWaves);            // in flight during this patch's arithmetic
         CGIC_STAMP(17);
+        if (flat8) {
+            // flat8[sub-patch] = its gray value if all 64 pixels of the 8x8 sub-patch carry the SAME gray (bit for bit), else NaN:
+            // lets the router's refinement evaluate constant patches -- blown-out sky, letterbox bars, flat graphics: the big tie
+            // groups of real content -- once per distinct gray instead of once per patch (cgic_router_dev.h).  Sub-patch (sy, sx) =
+            // the lanes with bit 5 == sy and bit 1 == sx; its first lane is lane & 0x22.
+            const float first = __shfl(g[0], lane & 0x22, kWave);
+            const bool same = (g[0] == first) & (g[1] == first) & (g[2] == first) & (g[3] == first);      // (NaN: never)
+            const unsigned long long eq = __ballot(same);
+            const unsigned long long m = (0x33333333ull << ((lane >> 1 & 1) * 2)) << (lane & 32);        // my sub-patch's lanes
+            if ((lane & ~0x22) == 0) {
+                const int64_t h8 = H / 8, w8 = W / 8;
+                flat8[(b * h8 + (row0 / 8 + (lane >> 5))) * w8 + (patch * 2 + ((lane >> 1) & 1))] = (eq & m) == m ? first : __builtin_nanf("");
+            }
+        }
 
         unsigned long long nan_lanes = 0;      // lanes that hold a NaN pixel (the reference's histogram turns NaN)
         // candidate window: the two bins that bracket the pixel.  Every other bin is at least one bin width = 6.45 sigma away
@@ -299,19 +300,6 @@ __global__ __launch_bounds__(kEntThreads) void entropy_maps_kernel(
 // combine them, 160 finalise.  ~8x the instructions of the kernel above: an option for when bit-level agreement of the
 // masks with the CPU reference is wanted, not the default.
 // =====================================================================================================
-constexpr int kRefWin = 5;
-
-__device__ __forceinline__ float sum32_lanes8(const float *v)
-{
-    float p[8];
-#pragma unroll
-    for (int k = 0; k < 8; ++k) p[k] = ((v[k] + v[8 + k]) + v[16 + k]) + v[24 + k];
-    float s = 0.f;
-#pragma unroll
-    for (int k = 0; k < 8; ++k) s = s + p[k];
-    return s;
-}
-
 __global__ __launch_bounds__(256) void entropy_ref_kernel(const float *__restrict__ x, int64_t H, int64_t W, float sigma,
                                                           float *__restrict__ e8, float *__restrict__ e16, BinsArg bins_arg)
 {
@@ -326,27 +314,16 @@ __global__ __launch_bounds__(256) void entropy_ref_kernel(const float *__restric
     const int r = tid >> 4, c = tid & 15;
     const int64_t o = ((b * 3) * H + by * 16 + r) * W + bx * 16 + c;
     const float R = x[o], G = x[o + H * W], Bc = x[o + 2 * H * W];
-    const float gray = (0.2989f * R + 0.5870f * G) + 0.1140f * Bc;
+    const float gray = ref_gray_of(R, G, Bc);
     __syncthreads();
     {
-        // the window: the first bin that is not below gray - 0.1445 (14.42 sigma = 0.1442: exp is exactly 0 in fp32 beyond)
-        // and the four after it; found by comparing against the bin values themselves (no division, NaN-safe: a NaN pixel
-        // selects window 0 and poisons it)
-        int j0 = 0;
-#pragma unroll 8
-        for (int j = 0; j < kBins; ++j) j0 += (s_bins[j] < gray - 0.1445f) ? 1 : 0;
-        j0 = j0 > kBins - kRefWin ? kBins - kRefWin : j0;
+        int j0;
+        float v[kRefWin];
+        ref_pixel(s_bins, sigma, gray, j0, v);                                  // cgic_entropy_dev.h: the window and its five values
 #pragma unroll
         for (int j = 0; j < kBins; ++j) s_val[tid][j] = 0.f;                    // (exactly what exp rounds to out there)
 #pragma unroll
-        for (int k = 0; k < kRefWin; ++k) {
-            const float res = gray - s_bins[j0 + k];
-            const float t = res / sigma;
-            const float t2 = t * t;
-            const float a = -0.5f * t2;
-            // exp(a) < 2^-150 rounds to 0 in fp32 (a < -103.98); NaN takes the exp
-            if (!(a < -104.0f)) s_val[tid][j0 + k] = (float)exp((double)a);      // correctly rounded but for ~1e-9 of the arguments
-        }
+        for (int k = 0; k < kRefWin; ++k) s_val[tid][j0 + k] = v[k];
     }
     __syncthreads();
     // chunk sums: task = (patch, bin, chunk): 4 x 32 x 4 for the 8x8 patches (chunk = two rows of 8), 32 x 16 for the 16x16
@@ -403,7 +380,7 @@ __global__ __launch_bounds__(256) void entropy_ref_kernel(const float *__restric
 using namespace cgic;
 
 static int entropy_maps_launch(const void *x, bool u8, int64_t B, int64_t H, int64_t W, const float *bins, int nbins, float sigma,
-                               float *x_out, float *e8, float *e16, cgic_stream_t stream)
+                               float *x_out, float *e8, float *e16, float *flat8, cgic_stream_t stream)
 {
     CGIC_REQUIRE(x && bins, CGIC_ERR_INVALID, "entropy: x and bins must not be NULL");
     CGIC_REQUIRE(nbins == kBins, CGIC_ERR_UNSUPPORTED, "entropy: nbins=%d; the reference uses 32 (model.py:480)", nbins);
@@ -417,7 +394,7 @@ static int entropy_maps_launch(const void *x, bool u8, int64_t B, int64_t H, int
     for (int i = 1; i < kBins; ++i)
         CGIC_REQUIRE(fabsf((bins[i] - bins[i - 1]) - 2.0f / 31.0f) < 1e-5f, CGIC_ERR_UNSUPPORTED,
                      "entropy: bins are not linspace(-1, 1, 32)");
-    if (B == 0 || (!e8 && !e16 && !(u8 && x_out))) return CGIC_OK;
+    if (B == 0 || (!e8 && !e16 && !flat8 && !(u8 && x_out))) return CGIC_OK;
 
     BinsArg ba;
     memcpy(ba.v, bins, sizeof(ba.v));
@@ -437,28 +414,28 @@ static int entropy_maps_launch(const void *x, bool u8, int64_t B, int64_t H, int
     static const int pad = getenv("CGIC_ENT_PAD") ? atoi(getenv("CGIC_ENT_PAD")) : 0;
     if (pad > 0) {
         CGIC_HIP_TRY(hipFuncSetAttribute((const void *)entropy_maps_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, pad));
-        hipLaunchKernelGGL(entropy_maps_kernel<false>, grid, dim3(kEntThreads), (size_t)pad, s, (const void *)x, H, W, exp2_scale, e8, e16, ba, ppw, (float *)nullptr);
+        hipLaunchKernelGGL(entropy_maps_kernel<false>, grid, dim3(kEntThreads), (size_t)pad, s, (const void *)x, H, W, exp2_scale, e8, e16, ba, ppw, (float *)nullptr, flat8);
         return launch_check("entropy_maps_kernel");
     }
 #endif
     if (u8)
-        hipLaunchKernelGGL(entropy_maps_kernel<true>, grid, dim3(kEntThreads), 0, s, x, H, W, exp2_scale, e8, e16, ba, ppw, x_out);
+        hipLaunchKernelGGL(entropy_maps_kernel<true>, grid, dim3(kEntThreads), 0, s, x, H, W, exp2_scale, e8, e16, ba, ppw, x_out, flat8);
     else
-        hipLaunchKernelGGL(entropy_maps_kernel<false>, grid, dim3(kEntThreads), 0, s, x, H, W, exp2_scale, e8, e16, ba, ppw, (float *)nullptr);
+        hipLaunchKernelGGL(entropy_maps_kernel<false>, grid, dim3(kEntThreads), 0, s, x, H, W, exp2_scale, e8, e16, ba, ppw, (float *)nullptr, flat8);
     return launch_check("entropy_maps_kernel");
 }
 
 extern "C" int cgic_entropy_maps_f32(const float *x, int64_t B, int64_t H, int64_t W, const float *bins,
-                                     int nbins, float sigma, float *e8, float *e16, cgic_stream_t stream)
+                                     int nbins, float sigma, float *e8, float *e16, float *flat8, cgic_stream_t stream)
 {
-    return entropy_maps_launch(x, false, B, H, W, bins, nbins, sigma, nullptr, e8, e16, stream);
+    return entropy_maps_launch(x, false, B, H, W, bins, nbins, sigma, nullptr, e8, e16, flat8, stream);
 }
 
 extern "C" int cgic_entropy_maps_u8(const unsigned char *x_hwc, int64_t B, int64_t H, int64_t W, const float *bins,
-                                    int nbins, float sigma, float *x_out, float *e8, float *e16, cgic_stream_t stream)
+                                    int nbins, float sigma, float *x_out, float *e8, float *e16, float *flat8, cgic_stream_t stream)
 {
     CGIC_REQUIRE(((uintptr_t)x_hwc & 3u) == 0, CGIC_ERR_INVALID, "entropy: the uint8 frame must be 4-byte aligned");
-    return entropy_maps_launch(x_hwc, true, B, H, W, bins, nbins, sigma, x_out, e8, e16, stream);
+    return entropy_maps_launch(x_hwc, true, B, H, W, bins, nbins, sigma, x_out, e8, e16, flat8, stream);
 }
 
 extern "C" int cgic_entropy_maps_ref_f32(const float *x, int64_t B, int64_t H, int64_t W, const float *bins,

@@ -24,7 +24,7 @@ __global__ __launch_bounds__(kRouterThreads) void router_kernel(RouterArgs a)
 
 int router_prepare(const float *e16, const float *e8, int64_t B, int64_t h16, int64_t w16, double c_ratio,
                    double m_ratio, int per_image, int32_t *mask_c, int32_t *mask_m, int32_t *mask_f, float *gate,
-                   RouterArgs *out, int64_t *nseg_out, size_t *lds_out, size_t lds_budget)
+                   RouterArgs *out, int64_t *nseg_out, size_t *lds_out, size_t lds_budget, const cgic_pixels *refine)
 {
     CGIC_REQUIRE(e16 && e8 && mask_c && mask_m && mask_f, CGIC_ERR_INVALID, "router: NULL tensor");
     CGIC_REQUIRE(B > 0 && h16 > 0 && w16 > 0, CGIC_ERR_INVALID, "router: bad shape");
@@ -46,7 +46,31 @@ int router_prepare(const float *e16, const float *e8, int64_t B, int64_t h16, in
     a.per = per; a.h16 = h16; a.w16 = w16; a.mode = mode;
     a.rank_c = (unsigned int)(k_c != 0 ? k_c - 1 : 0);      // sorted[k-1 if k != 0 else k]
     a.rank_m = (unsigned int)(k_m != 0 ? k_m - 1 : 0);
-    const size_t lds = router_lds_bytes(N16, N8, &a.stage, lds_budget);
+    a.rf.x = nullptr;
+    if (refine && refine->x && (mode <= 3)) {          // (modes 4-6 compare nothing)
+        CGIC_REQUIRE(refine->bins && refine->nbins == kBins, CGIC_ERR_UNSUPPORTED, "router: refinement needs the 32 bin centres (model.py:480)");
+        CGIC_REQUIRE(refine->sigma > 0.f && refine->sigma <= 0.0105f, CGIC_ERR_UNSUPPORTED,
+                     "router: sigma=%g; the five-bin window assumes the reference's sigma=0.01 (model.py:481)", refine->sigma);
+        for (int i = 0; i < kBins; ++i)        // the kernel recomputes them (24-byte RefineSrc): they must be THE linspace, to the bit
+            CGIC_REQUIRE(refine->bins[i] == linspace_bin(i), CGIC_ERR_UNSUPPORTED,
+                         "router: bins[%d]=%.9g is not torch.linspace(-1, 1, 32)[%d]=%.9g", i, refine->bins[i], i, linspace_bin(i));
+        CGIC_REQUIRE(!refine->is_u8 || ((uintptr_t)refine->x & 3u) == 0, CGIC_ERR_INVALID, "router: the uint8 frame must be 4-byte aligned");
+        a.rf.x = refine->x;
+        a.rf.u8 = refine->is_u8 ? 1 : 0;
+        CGIC_REQUIRE(16 * h16 < ((int64_t)1 << 30) && 16 * w16 < ((int64_t)1 << 30), CGIC_ERR_UNSUPPORTED, "router: image too large");
+        a.rf.H = (int)(16 * h16);
+        a.rf.W = (int)(16 * w16);
+        a.rf.sigma = refine->sigma;
+        a.rf.flat8 = refine->flat8;
+    }
+    // (with refinement every segment must fit the FUSED launch's budget, so that the stand-alone and the fused launch accept
+    // the same shapes)
+    const size_t lds = router_lds_bytes(N16, N8, &a.stage, a.rf.x ? (lds_budget < kRouterFusedLds ? lds_budget : kRouterFusedLds) : lds_budget,
+                                        a.rf.x != nullptr);
+    CGIC_REQUIRE(a.stage >= 0, CGIC_ERR_UNSUPPORTED,
+                 "router: threshold refinement needs a segment whose maps fit the workgroup's LDS (%lld + %lld patches here; "
+                 "cgic_router_refine_supported): route per image / per tile of at most 768x768, or pass no pixels",
+                 (long long)N16, (long long)N8);
     // large per-image segments: several workgroups per image share the mask writing (every one repeats the selects, which
     // costs nothing while most CUs are idle): up to 8, while the launch stays within ~a quarter of the chip
     a.bands = 1;
@@ -75,10 +99,19 @@ extern "C" int cgic_router_mode(double c, double m)
     return c != 0 ? 4 : (m != 0 ? 5 : 6);
 }
 
+extern "C" int cgic_router_refine_supported(int64_t B, int64_t h16, int64_t w16, int per_image)
+{
+    if (B <= 0 || h16 <= 0 || w16 <= 0) return 0;
+    const int64_t N16 = (per_image ? 1 : B) * h16 * w16;
+    int st = 0;
+    router_lds_bytes(N16, 4 * N16, &st, kRouterFusedLds, true);
+    return st == 1 ? 1 : 0;
+}
+
 extern "C" int cgic_router_f32(const float *e16, const float *e8, int64_t B, int64_t h16, int64_t w16,
                                double c_ratio, double m_ratio, int per_image, int32_t *mask_c,
                                int32_t *mask_m, int32_t *mask_f, float *gate, int *mode_out,
-                               cgic_stream_t stream)
+                               const cgic_pixels *refine, cgic_stream_t stream)
 {
     if (mode_out) *mode_out = cgic_router_mode(c_ratio, m_ratio);
     CGIC_REQUIRE(B >= 0, CGIC_ERR_INVALID, "router: bad shape");
@@ -86,7 +119,8 @@ extern "C" int cgic_router_f32(const float *e16, const float *e8, int64_t B, int
     RouterArgs a;
     int64_t nseg;
     size_t lds;
-    int rc = router_prepare(e16, e8, B, h16, w16, c_ratio, m_ratio, per_image, mask_c, mask_m, mask_f, gate, &a, &nseg, &lds);
+    int rc = router_prepare(e16, e8, B, h16, w16, c_ratio, m_ratio, per_image, mask_c, mask_m, mask_f, gate, &a, &nseg, &lds,
+                            96 * 1024, refine);
     if (rc) return rc;
     if (lds > 64 * 1024)
         { int rc_ = ensure_dynamic_lds((const void *)router_kernel, (size_t)lds); if (rc_) return rc_; }

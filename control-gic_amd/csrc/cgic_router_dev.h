@@ -2,6 +2,7 @@
 // stand-alone launch (cgic_router.hip) and the horizontally fused VQ+router launch (cgic_vq.hip).
 #pragma once
 #include "cgic_common.h"
+#include "cgic_entropy_dev.h"
 
 #include <math.h>
 
@@ -99,7 +100,231 @@ struct RouterArgs {
     int stage;             // 1: the segment's e16/e8 are copied to LDS once (all select passes read LDS); 2: only e8 (router_lds_bytes)
     int bands;             // workgroups per segment (per-image segments only): every one finds the thresholds, each writes
                            // only its band of rows of the masks (one CU per 768x768 tile spent 10 us writing 200 KB of masks)
+    RefineSrc rf;          // rf.x != nullptr (stage 1 only): threshold-band refinement from the pixels, see refine_select
 };
+
+// ---- threshold-band refinement -------------------------------------------------------------------------------------------
+// The thresholds are k-th smallest entropies compared with a strict '<' (RouterTriple.py:21-34), and the maps the default
+// entropy kernel hands over are within delta ~ 1e-6 of the reference's arithmetic, not equal to it: on tie-heavy content the
+// last bits decide masks, hence bytes.  An order statistic is 1-Lipschitz in the sup norm, so with t_a the k-th smallest of
+// the approximate values and `band` >= 2 delta: every element below t_a - band is below the true threshold t*, every element
+// above t_a + band is above it, and t* is the k-th smallest of the array in which the elements INSIDE the band carry their
+// exact values (the others keep their approximations: they stay on their side).  So: count the band; if it holds more than
+// the threshold element itself, re-evaluate its patches from the pixels in the reference's own arithmetic
+// (cgic_entropy_dev.h), write the values into the LDS copy of the map and select again.  Typical images: band of one, nothing
+// to do.  8-bit smooth content: a handful of patches per image.
+constexpr float kRefineBand = 4e-6f;       // >= 2 x the default entropy kernel's error (measured <= 1.1e-6, held to 2e-6 by the tests)
+constexpr int kRefWavesMax = 8;            // waves of a router workgroup that evaluate patches (LDS scratch is sized for them)
+constexpr int kRefListCap = 1024;          // band elements listed per sweep (a longer band is swept range by range)
+constexpr int kRefFlatSlots = 128;         // distinct grays of constant patches per select (more: the rest go patch by patch)
+constexpr unsigned int kRefEmpty = 0xFFFFFFFFu;      // (a NaN pattern: never the gray of a constant patch)
+struct RefineShared {
+    unsigned int cnt[8];                                   // band size | of which not exactly known | list length | below the band | small list length
+    unsigned int list[kRefListCap];
+    float T[kRefWavesMax][kRefUnitRows * kRefRow];         // chunk sums: the four units of a 16x16 patch are four consecutive waves'
+    float rec[kRefWavesMax][kRefRecFloats];
+    float P[kRefWavesMax][2 * kBins];
+    float bins[kBins];
+    unsigned int flat_key[kRefFlatSlots];                  // open-addressing set of the constant patches' grays (bit patterns)
+    float flat_val[kRefFlatSlots];
+    unsigned int small[64];                                // all band elements, when there are at most 64 (the final pick)
+    unsigned char lead[64];                                // ... and for each the first member with the same constant gray
+    float thr;
+};
+
+__device__ __forceinline__ unsigned int flat_hash(unsigned int key) { return (key * 2654435761u) >> 25; }      // 7 bits
+// slot of `key` in the set, or -1
+__device__ __forceinline__ int flat_find(const unsigned int *keys, unsigned int key)
+{
+    unsigned int s = flat_hash(key);
+    for (int t = 0; t < kRefFlatSlots; ++t, s = (s + 1) & (kRefFlatSlots - 1)) {
+        const unsigned int k = keys[s];
+        if (k == key) return (int)s;
+        if (k == kRefEmpty) return -1;
+    }
+    return -1;
+}
+__device__ __forceinline__ void flat_insert(unsigned int *keys, unsigned int key)
+{
+    unsigned int s = flat_hash(key);
+    for (int t = 0; t < kRefFlatSlots; ++t, s = (s + 1) & (kRefFlatSlots - 1)) {
+        const unsigned int old = atomicCAS(&keys[s], kRefEmpty, key);
+        if (old == kRefEmpty || old == key) return;
+    }       // (full: the element is evaluated patch by patch)
+}
+
+// One select's refinement.  arr: the LDS copy of the map (n values; element i = patch i of the segment's images in order),
+// t_a: its rank-th smallest value as found, is_exact(i): the value is exact already (a gated zero of the masked medium map).
+// Returns the threshold to use; arr is patched in place.  All NT threads call; contains barriers.
+//   1. count the band (and note its members while they are few); the threshold element alone -> done.
+//   FEW (<= 64 members, the usual case): evaluate the members, then pick the (rank - below)-th smallest among them with one wave.
+//   MANY (flat / smooth content): constant patches first (flat8 says so without touching a pixel): one evaluation per DISTINCT
+//        gray, handed out lane-parallel; the others range by range; then a full select over the patched copy.
+// A patch is 64 pixels per wave and step: an 8x8 patch is one step, a 16x16 one four (quarters of four rows), by four waves side by
+// side when there are at most two patches, else by one wave each (no workgroup barrier inside the sweep).
+template <int NT, int P, typename EX>
+__device__ float refine_select(float *arr, int n, unsigned int rank, float t_a, EX is_exact, const RefineSrc &rf, int64_t img0,
+                               int wP, int nP, RefineShared *rs, RouterShared *sh)
+{
+    constexpr int NW = NT / 64, NWR = NW < kRefWavesMax ? NW : kRefWavesMax;
+    constexpr int UPP = P == 16 ? 4 : 1;              // units (64 pixels, one wave and step) per patch
+    const int tid = threadIdx.x, lane = lane_id(), wave = tid >> 6;
+    const float w = kRefineBand;
+    if (tid < 8) rs->cnt[tid] = 0;
+    if (tid < kBins) rs->bins[tid] = linspace_bin(tid);
+    __syncthreads();
+    {
+        unsigned int minx = 0, below = 0;
+        for (int i = tid; i < n; i += NT) {
+            const float d = arr[i] - t_a;
+            if (fabsf(d) <= w) {                                  // (NaN: false)
+                const unsigned int s = atomicAdd(&rs->cnt[0], 1u);
+                if (s < 64) rs->small[s] = (unsigned int)i;
+                minx += is_exact(i) ? 0u : 1u;
+            }
+            below += d < -w ? 1u : 0u;
+        }
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) below += __shfl_xor(below, d, kWave);
+        if (lane == 0 && below) atomicAdd(&rs->cnt[3], below);
+        if (minx) atomicAdd(&rs->cnt[1], minx);
+    }
+    __syncthreads();
+    const unsigned int m_all = rs->cnt[0], m_inexact = rs->cnt[1], c_below = rs->cnt[3];
+    if (m_all < 2 || m_inexact == 0) return t_a;          // (workgroup-uniform) the threshold element alone: nothing can change
+    // From here on this workgroup is the launch's critical path (in the fused launch it shares its CU with an issue-bound VQ
+    // workgroup): its instructions go first.  Measured, 64 images of 256x256, fused launch: routers at priority 3 throughout
+    // 25.4 -> 27.4 us when no image refines (the VQ workgroups pay), refining images 35.5 -> 30.3 us; raised only here: both.
+    __builtin_amdgcn_s_setprio(3);
+
+    // one unit: lane = pixel `lane` of quarter q of patch e (an 8x8 patch is its own single quarter) -> chunk sums in T
+    auto unit = [&](int e, int q, float *T) {
+        const int bi = e / nP, r = e - bi * nP;
+        const int py = r / wP, px = r - py * wP;
+        int64_t y, x;
+        if (P == 16) { y = 16 * (int64_t)py + 4 * q + (lane >> 4); x = 16 * (int64_t)px + (lane & 15); }
+        else         { y = 8 * (int64_t)py + (lane >> 3);          x = 8 * (int64_t)px + (lane & 7); }
+        const float gray = ref_gray_at(rf, img0 + bi, y, x);
+        int j0;
+        float v[kRefWin];
+        ref_pixel(rs->bins, rf.sigma, gray, j0, v);
+        ref_unit_chunks(rs->rec[wave], j0, v, T);
+    };
+    // evaluate the patches lst[0..L) that `todo` accepts and write their entropies into arr
+    auto sweep = [&](const unsigned int *lst, int L, auto todo) {
+        if (P == 16 && L * UPP <= NWR) {
+            // a couple of 16x16 patches: four waves each, side by side
+            const int e = wave < L * UPP ? (int)lst[wave / UPP] : -1;
+            const bool go = e >= 0 && todo(wave / UPP, e);
+            if (go) unit(e, wave % UPP, rs->T[wave]);
+            __syncthreads();
+            if (go && wave % UPP == 0) {
+                float acc = 0.f;
+                for (int q = 0; q < UPP; ++q) acc = ref_add_rows(acc, rs->T[wave + q]);
+                const float ent = ref_finalize(acc, P * P, rs->P[wave]);
+                if (lane == 0) arr[e] = ent;
+            }
+        } else if (wave < NWR) {
+            for (int k = wave; k < L; k += NWR) {
+                const int e = (int)lst[k];
+                if (!todo(k, e)) continue;                            // (wave-uniform)
+                float acc = 0.f;
+                for (int q = 0; q < UPP; ++q) {
+                    unit(e, q, rs->T[wave]);
+                    acc = ref_add_rows(acc, rs->T[wave]);
+                }
+                const float ent = ref_finalize(acc, P * P, rs->P[wave]);
+                if (lane == 0) arr[e] = ent;
+            }
+        }
+        __syncthreads();
+    };
+
+    const float *flat = rf.flat8 ? rf.flat8 + img0 * (P == 16 ? 4 * (int64_t)nP : (int64_t)nP) : nullptr;     // this segment's 8x8 flags
+    auto flat_key_of = [&](int i) -> unsigned int {        // gray bits of constant patch i, or kRefEmpty
+        if (P == 8) { const float f = flat[i]; return f == f ? __float_as_uint(f) : kRefEmpty; }
+        const int bi = i / nP, r = i - bi * nP, py = r / wP, px = r - py * wP;
+        const float *q = flat + (int64_t)bi * 4 * nP + (int64_t)(2 * py) * (2 * wP) + 2 * px;
+        const float f = q[0];
+        return (f == q[1] && f == q[2 * wP] && f == q[2 * wP + 1]) ? __float_as_uint(f) : kRefEmpty;           // (NaN: never equal)
+    };
+
+    if (m_all <= 64 && rank >= c_below && rank - c_below < m_all) {
+        // constant patches of one gray are one evaluation: member k is evaluated only if it is the first of its gray (lead[k] == k)
+        if (wave == 0) {
+            unsigned int key = kRefEmpty;
+            if (flat && lane < (int)m_all && !is_exact((int)rs->small[lane])) key = flat_key_of((int)rs->small[lane]);
+            int lead = lane;
+            for (int j = (int)m_all - 1; j >= 0; --j) {
+                const unsigned int kj = __shfl(key, j, kWave);
+                if (kj == key && key != kRefEmpty) lead = j;              // ends at the smallest j of this gray
+            }
+            rs->lead[lane] = (unsigned char)lead;
+        }
+        __syncthreads();
+        sweep(rs->small, (int)m_all, [&](int k, int e) { return !is_exact(e) && rs->lead[k] == k; });
+        if (wave == 0 && lane < (int)m_all && rs->lead[lane] != lane) arr[rs->small[lane]] = arr[rs->small[rs->lead[lane]]];
+        __syncthreads();
+        // everything below the band is below the true threshold, everything above it above: it is the band's (rank - below)-th
+        if (wave == 0) {
+            const float v = lane < (int)m_all ? arr[rs->small[lane]] : __builtin_inff();
+            unsigned int less = 0, leq = 0;
+            for (unsigned int j = 0; j < m_all; ++j) {
+                const float vj = __shfl(v, (int)j, kWave);
+                less += vj < v ? 1u : 0u;
+                leq += vj <= v ? 1u : 0u;
+            }
+            const unsigned int r = rank - c_below;
+            if (lane < (int)m_all && less <= r && r < leq) rs->thr = v;       // (lanes holding equal values write the same bits)
+        }
+        __syncthreads();
+        __builtin_amdgcn_s_setprio(0);
+        return rs->thr;
+    }
+
+    // ---- MANY.  Membership of the band is decided on the values as they were when the select ran: every element is tested
+    // before it is written, and written once.
+    auto in_band = [&](int i) { return fabsf(arr[i] - t_a) <= w && !is_exact(i); };
+    if (flat) {
+        for (int i = tid; i < kRefFlatSlots; i += NT) rs->flat_key[i] = kRefEmpty;
+        __syncthreads();
+        for (int i = tid; i < n; i += NT)
+            if (in_band(i)) { const unsigned int k = flat_key_of(i); if (k != kRefEmpty) flat_insert(rs->flat_key, k); }
+        __syncthreads();
+        if (wave < NWR) {
+            for (int s = wave; s < kRefFlatSlots; s += NWR) {
+                const unsigned int k = rs->flat_key[s];              // (wave-uniform)
+                if (k == kRefEmpty) continue;
+                int j0;
+                float v[kRefWin];
+                ref_pixel(rs->bins, rf.sigma, __uint_as_float(k), j0, v);        // every pixel of the patch is this one
+                ref_unit_chunks(rs->rec[wave], j0, v, rs->T[wave]);
+                float acc = 0.f;
+                for (int q = 0; q < UPP; ++q) acc = ref_add_rows(acc, rs->T[wave]);
+                const float ent = ref_finalize(acc, P * P, rs->P[wave]);
+                if (lane == 0) rs->flat_val[s] = ent;
+            }
+        }
+        __syncthreads();
+    }
+    for (int base = 0; base < n; base += kRefListCap) {
+        if (tid == 0) rs->cnt[2] = 0;
+        __syncthreads();
+        const int hi = base + kRefListCap < n ? base + kRefListCap : n;
+        for (int i = base + tid; i < hi; i += NT) {
+            if (!in_band(i)) continue;
+            int slot = -1;
+            if (flat) { const unsigned int k = flat_key_of(i); if (k != kRefEmpty) slot = flat_find(rs->flat_key, k); }
+            if (slot >= 0) arr[i] = rs->flat_val[slot];
+            else rs->list[atomicAdd(&rs->cnt[2], 1u)] = (unsigned int)i;
+        }
+        __syncthreads();
+        sweep(rs->list, (int)rs->cnt[2], [](int, int) { return true; });
+    }
+    const float thr = radix_select<NT>([&](int64_t i) { return arr[i]; }, n, rank, sh);
+    __builtin_amdgcn_s_setprio(0);
+    return thr;
+}
 
 // The whole router for segment `seg`, executed by a block of NT threads; `dyn` = dynamic LDS of at least
 // router_lds_bytes() bytes.
@@ -120,6 +345,7 @@ __device__ __forceinline__ void router_body(const RouterArgs &a, int64_t blk, un
     const int64_t N16 = a.per * n16, N8 = a.per * n8, N4 = a.per * n4;
     const float *e16 = a.e16 + seg * N16;
     const float *e8 = a.e8 + seg * N8;
+    RefineShared *rs = nullptr;
     if (a.stage) {
         // one round trip to HBM/L2 instead of one per radix pass (8 passes + 3 elementwise sweeps)
         float *l16 = reinterpret_cast<float *>(gc_bits + ((N16 + 63) >> 6));
@@ -130,8 +356,10 @@ __device__ __forceinline__ void router_body(const RouterArgs &a, int64_t blk, un
         }
         for (int64_t i = tid; i < N8; i += NT) l8[i] = e8[i];
         e8 = l8;
+        if (a.rf.x) rs = reinterpret_cast<RefineShared *>((reinterpret_cast<uintptr_t>(l8 + N8) + 15) & ~(uintptr_t)15);
         __syncthreads();
     }
+    const bool refine = rs != nullptr;          // (the host only asks for it at stage 1: both maps in LDS)
     CGIC_STAMP(1);
     int32_t *mc = a.mask_c + seg * N16;
     int32_t *mm = a.mask_m + seg * N8;
@@ -141,7 +369,12 @@ __device__ __forceinline__ void router_body(const RouterArgs &a, int64_t blk, un
 
     // ---- coarse gate (RouterTriple.py:21-25 / 52-56 / 63-66)
     float thr_c = 0.f;
-    if (has_thr_c) thr_c = radix_select<NT>([&](int64_t i) { return e16[i]; }, N16, a.rank_c, sh);
+    if (has_thr_c) {
+        thr_c = radix_select<NT>([&](int64_t i) { return e16[i]; }, N16, a.rank_c, sh);
+        if (refine)
+            thr_c = refine_select<NT, 16>(const_cast<float *>(e16), (int)N16, a.rank_c, thr_c, [](int) { return false; }, a.rf,
+                                          seg * a.per, (int)w16, (int)n16, rs, sh);
+    }
     CGIC_STAMP(2);
     const int64_t N16r = (N16 + 63) & ~(int64_t)63;
     for (int64_t i = tid; i < N16r; i += NT) {
@@ -180,22 +413,31 @@ __device__ __forceinline__ void router_body(const RouterArgs &a, int64_t blk, un
     float thr_m = 0.f;
     if (mode == 0) {      // :27-31: sort e8 * (1 - up2(gate_coarse))
         if (a.stage) {
-            // materialise the masked values once (LDS), so the four radix passes are plain LDS sweeps
-            float *l8m = const_cast<float *>(e8) + N8;
+            // mask the LDS copy IN PLACE, once, so the four radix passes are plain LDS sweeps.  (A second, masked copy used to
+            // sit beside the plain one; the plain value of a gated element is never needed again: its medium gate is
+            // (v < thr) && !gate_coarse whatever v is -- 4 N8 bytes of LDS less.)
+            float *l8m = const_cast<float *>(e8);
             if (rows2d) {
                 for (int y = wv; y < (int)h8; y += NWV)
-                    for (int x = lane; x < w8i; x += 64) l8m[y * w8i + x] = e8[y * w8i + x] * (1.0f - (gc_at(0, y, x) ? 1.0f : 0.0f));
+                    for (int x = lane; x < w8i; x += 64) l8m[y * w8i + x] = l8m[y * w8i + x] * (1.0f - (gc_at(0, y, x) ? 1.0f : 0.0f));
             } else {
-                for (int64_t i = tid; i < N8; i += NT) l8m[i] = e8[i] * (1.0f - (gc_of8(i) ? 1.0f : 0.0f));
+                for (int64_t i = tid; i < N8; i += NT) l8m[i] = l8m[i] * (1.0f - (gc_of8(i) ? 1.0f : 0.0f));
             }
             __syncthreads();
             thr_m = radix_select<NT>([&](int64_t i) { return l8m[i]; }, N8, a.rank_m, sh);
+            if (refine)       // (a gated element's 0 is exact: never re-evaluated, never overwritten)
+                thr_m = refine_select<NT, 8>(l8m, (int)N8, a.rank_m, thr_m, [&](int i) { return gc_of8(i); }, a.rf, seg * a.per, w8i,
+                                             n8i, rs, sh);
         } else {
             thr_m = radix_select<NT>([&](int64_t i) { return e8[i] * (1.0f - (gc_of8(i) ? 1.0f : 0.0f)); }, N8, a.rank_m, sh);
         }
     }
-    if (mode == 1)        // :40-43
+    if (mode == 1) {      // :40-43
         thr_m = radix_select<NT>([&](int64_t i) { return e8[i]; }, N8, a.rank_m, sh);
+        if (refine)
+            thr_m = refine_select<NT, 8>(const_cast<float *>(e8), (int)N8, a.rank_m, thr_m, [](int) { return false; }, a.rf, seg * a.per,
+                                         w8i, n8i, rs, sh);
+    }
     auto gm_rule = [&](float v, bool gc) -> bool {
         switch (mode) {
         case 0: return (v < thr_m) && !gc;                  // :32
@@ -259,15 +501,19 @@ __device__ __forceinline__ void router_body(const RouterArgs &a, int64_t blk, un
 }
 
 
-// stage 1: e16, e8 and the masked copy of e8 live in LDS; stage 2: only e8 and its masked copy (e16 is read from global memory
-// by the coarse select's four passes); 0: nothing staged.  `budget`: the fused VQ + router launch keeps a router workgroup
-// under half a CU's LDS so that it can share the CU with a VQ workgroup (a 768x768 tile: 86 KB full, 77 KB at stage 2).
-__host__ __device__ inline size_t router_lds_bytes(int64_t N16, int64_t N8, int *stage, size_t budget = 96 * 1024)
+// stage 1: e16 and e8 live in LDS (e8 is masked in place for the medium select); stage 2: only e8 (e16 is read from global
+// memory by the coarse select's four passes); 0: nothing staged.  `budget`: the fused VQ + router launch keeps a router
+// workgroup under half a CU's LDS so that it can share the CU with a VQ workgroup.  `refine`: room for RefineShared behind
+// the maps (stage 1 only; *stage = -1 if that does not fit the budget).
+__host__ __device__ inline size_t router_lds_bytes(int64_t N16, int64_t N8, int *stage, size_t budget = 96 * 1024, bool refine = false)
 {
     size_t lds = 3072 + 8 * (size_t)((N16 + 63) / 64);
     int st = 0;
-    if (lds + 4 * (size_t)(N16 + 2 * N8) <= budget) { st = 1; lds += 4 * (size_t)(N16 + 2 * N8); }
-    else if (lds + 4 * (size_t)(2 * N8) <= budget) { st = 2; lds += 4 * (size_t)(2 * N8); }
+    if (refine) {
+        const size_t need = lds + 4 * (size_t)(N16 + N8) + 16 + sizeof(RefineShared);
+        if (need <= budget) { st = 1; lds = need; } else st = -1;
+    } else if (lds + 4 * (size_t)(N16 + N8) <= budget) { st = 1; lds += 4 * (size_t)(N16 + N8); }
+    else if (lds + 4 * (size_t)N8 <= budget) { st = 2; lds += 4 * (size_t)N8; }
     if (stage) *stage = st;
     return lds;
 }
@@ -275,6 +521,10 @@ __host__ __device__ inline size_t router_lds_bytes(int64_t N16, int64_t N8, int 
 // host-side argument preparation shared by the stand-alone and the VQ-fused launch
 int router_prepare(const float *e16, const float *e8, int64_t B, int64_t h16, int64_t w16, double c_ratio,
                    double m_ratio, int per_image, int32_t *mask_c, int32_t *mask_m, int32_t *mask_f, float *gate,
-                   RouterArgs *out, int64_t *nseg, size_t *lds, size_t lds_budget = 96 * 1024);
+                   RouterArgs *out, int64_t *nseg, size_t *lds, size_t lds_budget = 96 * 1024, const cgic_pixels *refine = nullptr);
+
+// LDS budget of a router workgroup in the fused VQ + router launch (two allocations per 160 KB CU); refinement is offered
+// for segments that fit THIS budget, in the stand-alone launch too, so that one answer holds for both
+constexpr size_t kRouterFusedLds = (size_t)78 * 1024;
 
 }  // namespace cgic

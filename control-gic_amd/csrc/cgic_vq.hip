@@ -521,6 +521,7 @@ __host__ __device__ constexpr size_t vqf_lds_bytes(int K) { return vqf_ees_off(K
 
 // The codebook's LDS image of the filter path: fp32 rows (at rowpos()), row norms (at eepos()), the split fp16 A operands
 // and, in s_max[0..1], the bit patterns of max |e_kj| and max ee_k (they fix the fp16 scaling).  Ends with a barrier.
+constexpr unsigned int kPreparedMagic = 0x43474951u;      // "CGIQ": last word of a prepared codebook image, after (Emax, EEmax, K)
 template <int NT>
 __device__ __forceinline__ void vqf_stage(const float *__restrict__ cb, const int K, unsigned char *smem, unsigned int *s_max)
 {
@@ -601,7 +602,7 @@ __device__ __forceinline__ void vq_filter_body(const VqArgs &a, unsigned char *s
     uint4 *ldsA = reinterpret_cast<uint4 *>(smem);                                  // [K/32][64]
     float4 *cbs = reinterpret_cast<float4 *>(smem + vqf_rows_off(K));               // fp32 rows, at rowpos()
     float *ees = reinterpret_cast<float *>(smem + vqf_ees_off(K));                  // their squared norms, at eepos()
-    __shared__ unsigned int s_max[2];
+    __shared__ unsigned int s_max[4];        // [2..3]: the prepared image's (K, magic) tag
     __shared__ double s_wsum[NT / 64];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -682,8 +683,14 @@ __device__ __forceinline__ void vq_filter_body(const VqArgs &a, unsigned char *s
         const int n16 = (int)(vqf_lds_bytes(K) / 16);
 #pragma unroll 8
         for (int i = tid; i < n16; i += NT) dst[i] = src[i];
-        if (tid < 2) s_max[tid] = reinterpret_cast<const unsigned int *>(src + n16)[tid];
+        if (tid < 4) s_max[tid] = reinterpret_cast<const unsigned int *>(src + n16)[tid];
         __syncthreads();
+        // the image carries (K, magic) behind the two maxima: an image of another K, or memory that is not an image at all,
+        // is not trusted -- the workgroup derives its own from the fp32 rows (workgroup-uniform branch)
+        if (s_max[2] != (unsigned int)K || s_max[3] != kPreparedMagic) {
+            __syncthreads();
+            vqf_stage<NT>(a.cb, K, smem, s_max);
+        }
     } else {
         vqf_stage<NT>(a.cb, K, smem, s_max);
     }
@@ -1042,14 +1049,14 @@ __global__ CGIC_VQF_BOUNDS void vq_filter_router_kernel(VqArgs a, RouterArgs r, 
 __global__ __launch_bounds__(kVqfThreads) void vq_prepare_kernel(const float *__restrict__ cb, int K, uint4 *__restrict__ out)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_f[];
-    __shared__ unsigned int s_max[2];
+    __shared__ unsigned int s_max[4];
     const int n16 = (int)(vqf_lds_bytes(K) / 16);
     uint4 *img = reinterpret_cast<uint4 *>(smem_f);
     for (int i = threadIdx.x; i < n16; i += kVqfThreads) img[i] = make_uint4(0u, 0u, 0u, 0u);      // the padding rows: defined bytes
     __syncthreads();
     vqf_stage<kVqfThreads>(cb, K, smem_f, s_max);
     for (int i = threadIdx.x; i < n16; i += kVqfThreads) out[i] = img[i];
-    if (threadIdx.x == 0) out[n16] = make_uint4(s_max[0], s_max[1], (unsigned int)K, 0x43474951u);
+    if (threadIdx.x == 0) out[n16] = make_uint4(s_max[0], s_max[1], (unsigned int)K, kPreparedMagic);
 }
 
 // Plain-VALU restatement: one latent vector per thread, codebook broadcast from
@@ -1386,7 +1393,8 @@ extern "C" int cgic_vq_forward_route_f32(const float *z, int64_t B, int64_t hw, 
                                          void *workspace, const float *e16, const float *e8, int64_t h16, int64_t w16,
                                          double coarse_ratio, double medium_ratio, int per_image, int32_t *mask_c,
                                          int32_t *mask_m, int32_t *mask_f, float *gate, int *mode_out,
-                                         const cgic_conv1x1 *quant_conv, const void *prepared, cgic_stream_t stream)
+                                         const cgic_conv1x1 *quant_conv, const void *prepared, const cgic_pixels *refine,
+                                         cgic_stream_t stream)
 {
     int rc = vq_check(z, B, hw, codebook, K, e_dim, loss, workspace, false);
     if (rc) return rc;
@@ -1402,7 +1410,7 @@ extern "C" int cgic_vq_forward_route_f32(const float *z, int64_t B, int64_t hw, 
     size_t rlds;
     // (78 KB: a router workgroup of the fused launch shares its CU with a VQ workgroup -- two allocations per 160 KB)
     rc = router_prepare(e16, e8, B, h16, w16, coarse_ratio, medium_ratio, per_image, mask_c, mask_m, mask_f, gate, &r, &nseg, &rlds,
-                        (size_t)78 * 1024);
+                        kRouterFusedLds, refine);
     if (rc) return rc;
     hipStream_t s = (hipStream_t)stream;
     VqWs ws;

@@ -10,20 +10,20 @@ from torch import nn
 
 from . import _lib
 
-_BINS = None
+_bins = _lib.linspace_bins         # torch.linspace(-1, 1, 32) evaluated on the CPU, like the CPU reference path (model.py:480)
 
 
-def _bins():
-    # torch.linspace(-1, 1, 32) evaluated on the CPU, like the CPU reference path (model.py:480)
-    global _BINS
-    if _BINS is None:
-        vals = torch.linspace(-1, 1, 32, dtype=torch.float32).tolist()
-        _BINS = (ctypes.c_float * 32)(*vals)
-    return _BINS
+def _tag(maps, pixels, flat8):
+    """the maps carry what the router's refinement wants (plain attributes: gone after any arithmetic on a map)"""
+    for e in maps:
+        if e is not None:
+            e._cgic_pixels, e._cgic_flat8 = pixels, flat8
 
 
-def entropy_maps(x, want8=True, want16=True, sigma=0.01, reference_order=False):
+def entropy_maps(x, want8=True, want16=True, sigma=0.01, reference_order=False, want_flat=True):
     """x [B,3,H,W] fp32 on the device, H and W multiples of 16 -> (e8 [B,H/8,W/8], e16 [B,H/16,W/16]).
+    The maps come back tagged with the pixels they were made from and (want_flat) the by-product map of constant 8x8 patches:
+    control_gic_amd's router finds both there (TripleGrainFixedEntropyRouter.forward) for its threshold-band refinement.
     reference_order=True: the reference's own fp32 operation sequence and summation order with correctly rounded exp / log
     (cgic_entropy_maps_ref_f32): bit-identical to the CPU reference in ~99 % of the values and no flipped mask element on
     tie-heavy content, at ~8x the instructions -- for when the masks must agree with the CPU reference's to the bit."""
@@ -35,12 +35,18 @@ def entropy_maps(x, want8=True, want16=True, sigma=0.01, reference_order=False):
     e8 = torch.empty((B, H // 8, W // 8), dtype=torch.float32, device=x.device) if want8 else None
     e16 = torch.empty((B, H // 16, W // 16), dtype=torch.float32, device=x.device) if want16 else None
     with torch.cuda.device(x.device):
-        _lib.call("cgic_entropy_maps_ref_f32" if reference_order else "cgic_entropy_maps_f32", _lib.ptr(x), B, H, W, _bins(), 32, float(sigma), _lib.ptr(e8),
-                  _lib.ptr(e16), _lib.current_stream(x.device))
+        if reference_order:
+            _lib.call("cgic_entropy_maps_ref_f32", _lib.ptr(x), B, H, W, _bins(), 32, float(sigma), _lib.ptr(e8), _lib.ptr(e16),
+                      _lib.current_stream(x.device))
+        else:
+            flat8 = torch.empty((B, H // 8, W // 8), dtype=torch.float32, device=x.device) if want_flat else None
+            _lib.call("cgic_entropy_maps_f32", _lib.ptr(x), B, H, W, _bins(), 32, float(sigma), _lib.ptr(e8), _lib.ptr(e16), _lib.ptr(flat8),
+                      _lib.current_stream(x.device))
+            _tag((e8, e16), x, flat8)
     return e8, e16
 
 
-def entropy_maps_u8(frames, want_x=True, want8=True, want16=True, sigma=0.01):
+def entropy_maps_u8(frames, want_x=True, want8=True, want16=True, sigma=0.01, want_flat=True):
     """frames [B,H,W,3] uint8 on the device (PIL / decoder layout), H and W multiples of 16 -> (x, e8, e16): ToTensor and both Entropy
     maps in ONE pass (inference.py:50-59 + model.py:99-101).  x [B,3,H,W] fp32 = frames / 255 exactly as T.ToTensor() rounds it
     (None with want_x=False); the maps are bit-identical to entropy_maps(x)."""
@@ -53,9 +59,11 @@ def entropy_maps_u8(frames, want_x=True, want8=True, want16=True, sigma=0.01):
     x = torch.empty((B, 3, H, W), dtype=torch.float32, device=dev) if want_x else None
     e8 = torch.empty((B, H // 8, W // 8), dtype=torch.float32, device=dev) if want8 else None
     e16 = torch.empty((B, H // 16, W // 16), dtype=torch.float32, device=dev) if want16 else None
+    flat8 = torch.empty((B, H // 8, W // 8), dtype=torch.float32, device=dev) if want_flat else None
     with torch.cuda.device(dev):
         _lib.call("cgic_entropy_maps_u8", _lib.ptr(frames), B, H, W, _bins(), 32, float(sigma), _lib.ptr(x), _lib.ptr(e8), _lib.ptr(e16),
-                  _lib.current_stream(dev))
+                  _lib.ptr(flat8), _lib.current_stream(dev))
+    _tag((e8, e16), frames, flat8)
     return x, e8, e16
 
 
@@ -71,4 +79,8 @@ class Entropy(nn.Module):
 
     def forward(self, inputs):
         e8, e16 = entropy_maps(inputs, want8=self.psize == 8, want16=self.psize == 16, reference_order=self.reference_order)
+        # The router is reached through the reference's own Encoder.forward(x, x_entropy_p16, x_entropy_p8)
+        # (vqvae_blocks.py:303,355), which hands it the maps and nothing else: entropy_maps tags the map with the pixels it was
+        # made from, and control_gic_amd's router uses them for its threshold-band refinement (masks equal to the CPU
+        # reference's from PIXELS).  A plain attribute: it does not survive arithmetic on the map, and then the maps decide.
         return e8 if self.psize == 8 else e16

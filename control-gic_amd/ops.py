@@ -113,15 +113,17 @@ def _(frames):
 
 
 @torch.library.custom_op("cgic::router", mutates_args=(), device_types=_DEV)
-def router(e16: torch.Tensor, e8: torch.Tensor, coarse_ratio: float, medium_ratio: float, per_image: bool) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+def router(e16: torch.Tensor, e8: torch.Tensor, coarse_ratio: float, medium_ratio: float, per_image: bool,
+           pixels: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
     """TripleGrainFixedEntropyRouter.forward masks (RouterTriple.py:15-95): int32 [B,1,h16,w16], [B,1,2h16,2w16], [B,1,4h16,4w16];
-    the mode is a function of the ratios alone: control_gic_amd.TripleGrainFixedEntropyRouter(c, m).mode"""
-    mask, _, _, _ = TripleGrainFixedEntropyRouter(coarse_ratio, medium_ratio, per_image=per_image)(e16, e8, want_gate=False)
+    the mode is a function of the ratios alone: control_gic_amd.TripleGrainFixedEntropyRouter(c, m).mode.
+    pixels: the image batch behind the maps -> threshold-band refinement (masks equal to the CPU reference's from pixels)"""
+    mask, _, _, _ = TripleGrainFixedEntropyRouter(coarse_ratio, medium_ratio, per_image=per_image)(e16, e8, want_gate=False, pixels=pixels)
     return mask[0], mask[1], mask[2]
 
 
 @router.register_fake
-def _(e16, e8, coarse_ratio, medium_ratio, per_image):
+def _(e16, e8, coarse_ratio, medium_ratio, per_image, pixels=None):
     B, h16, w16 = e16.shape
     mk = lambda s: e16.new_empty((B, 1, s * h16, s * w16), dtype=torch.int32)
     return mk(1), mk(2), mk(4)
@@ -129,14 +131,16 @@ def _(e16, e8, coarse_ratio, medium_ratio, per_image):
 
 @torch.library.custom_op("cgic::vq_forward_route", mutates_args=(), device_types=_DEV)
 def vq_forward_route(z: torch.Tensor, codebook: torch.Tensor, beta: float, legacy: bool, e16: torch.Tensor, e8: torch.Tensor,
-                     coarse_ratio: float, medium_ratio: float, per_image: bool) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor]:
-    """vq_forward and router in ONE launch: (z_q, loss, indices, mask_c, mask_m, mask_f)"""
-    z_q, loss, idx, mask, _, _ = _vq_forward_route(z, codebook, beta, legacy, e16, e8, coarse_ratio, medium_ratio, per_image=per_image)
+                     coarse_ratio: float, medium_ratio: float, per_image: bool,
+                     pixels: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor]:
+    """vq_forward and router in ONE launch: (z_q, loss, indices, mask_c, mask_m, mask_f); pixels: see router"""
+    z_q, loss, idx, mask, _, _ = _vq_forward_route(z, codebook, beta, legacy, e16, e8, coarse_ratio, medium_ratio, per_image=per_image,
+                                                   pixels=pixels)
     return z_q, loss, idx, mask[0], mask[1], mask[2]
 
 
 @vq_forward_route.register_fake
-def _(z, codebook, beta, legacy, e16, e8, coarse_ratio, medium_ratio, per_image):
+def _(z, codebook, beta, legacy, e16, e8, coarse_ratio, medium_ratio, per_image, pixels=None):
     B, C, h, w = z.shape
     _, h16, w16 = e16.shape
     mk = lambda s: e16.new_empty((B, 1, s * h16, s * w16), dtype=torch.int32)
@@ -325,10 +329,16 @@ def _grain_merge_setup(ctx, inputs, output):
 def _grain_merge_bwd(ctx, g):
     mc, mm, mf = ctx.saved_tensors
     g = g.contiguous()
+    B, _, h, w = g.shape
+    # masks arrive as [B,1,.,.] or squeezed [B,.,.] (the forward only needs their element count): broadcast over channels
+    # explicitly -- a squeezed [B,h,w] mask with B == C would otherwise line up with the CHANNEL axis and scale silently wrong
+    mc = mc.reshape(B, 1, h // 4, w // 4).to(g.dtype)
+    mm = mm.reshape(B, 1, h // 2, w // 2).to(g.dtype)
+    mf = mf.reshape(B, 1, h, w).to(g.dtype)
     # d/dh_coarse = mask_c * (sum of g over the 4x4 cell): the window sum is the library's average pool x 16 (exact)
-    g_c = torch.ops.cgic.avg_pool(g, 4) * 16.0 * mc.to(g.dtype)
-    g_m = torch.ops.cgic.avg_pool(g, 2) * 4.0 * mm.to(g.dtype)
-    return g_c, g_m, g * mf.to(g.dtype), None, None, None
+    g_c = torch.ops.cgic.avg_pool(g, 4) * 16.0 * mc
+    g_m = torch.ops.cgic.avg_pool(g, 2) * 4.0 * mm
+    return g_c, g_m, g * mf, None, None, None
 
 
 grain_merge.register_autograd(_grain_merge_bwd, setup_context=_grain_merge_setup)

@@ -1,12 +1,5 @@
-"""HotPathPipeline -- the whole hot path over a batch, scheduled for throughput.
-
-VQ and the entropy maps are throughput-bound kernels that fill all 256 CUs; the router, the
-stream coder and the decoder are one-workgroup-per-image kernels that are latency-bound and
-occupy a quarter of the chip.  Images are independent (per-image routing), so the batch is cut
-into `chunks` and each chunk runs the full chain on its own HIP stream: the latency-bound
-kernels of one chunk overlap the throughput-bound kernels of another.  Results are identical to
-the unchunked path (same kernels, same per-image semantics); the fork/join uses stream events
-only, so a step can be captured in a hipGraph and replayed.
+"""The hot path over batches: HotPathPipeline (one batch, five dependent launches), LaneStream (successive batches on
+independent hardware queues, hipGraphs), GraphLanes (arbitrary captured work on independent queues).
 """
 import torch
 
@@ -18,8 +11,12 @@ from .router import TripleGrainFixedEntropyRouter
 
 
 class HotPathPipeline:
-    def __init__(self, quantizer, coarse_ratio, medium_ratio, chunks=1, frequency=None, fork_vq=False, fuse_router=True,
-                 prepare=False):
+    """One batch through the hot path on the current stream: entropy maps -> [VQ + per-image router, one launch] -> stream
+    coder (+ usage histogram) -> prefix decoder -> scatter / merge / gather: five launches, each depending on the one before.
+    (Cutting a batch into chunks on several streams and forking VQ next to entropy -> router were measured slower, NOTES.md;
+    what overlaps well is WHOLE batches on independent queues: LaneStream.)"""
+
+    def __init__(self, quantizer, coarse_ratio, medium_ratio, frequency=None, fuse_router=True, prepare=False, refine=True):
         self.vq = quantizer
         # prepare=True: inference against a codebook that does not change -- the VQ kernel's codebook image is made once
         # (quantize.prepare_codebook, a snapshot of the weights NOW; refresh_codebook() after changing them) instead of by
@@ -28,91 +25,41 @@ class HotPathPipeline:
         self.router = TripleGrainFixedEntropyRouter(coarse_ratio, medium_ratio, per_image=True)
         self.codec = GrainCodec(frequency if frequency is not None else quantizer.embedding_counter,
                                 quantizer.embedding.weight)
-        self.chunks = max(1, int(chunks))
-        self.fork_vq = int(fork_vq)       # 1: VQ(+hist) on a side stream next to entropy -> router; 2: router on a side stream next to VQ
         # True: the per-image router workgroups ride in the VQ launch (best for ONE batch at a time).  False: a launch
-        # of its own in front of the VQ kernel -- a small-footprint kernel that shares CUs with the kernels of OTHER
-        # batches when several independent streams of batches are in flight (bench.py --lanes).
+        # of its own in front of the VQ kernel.
         self.fuse_router = bool(fuse_router)
-        self._streams = None
-        self._side = None
+        # refine: the router re-evaluates, in the reference's own arithmetic, the patches whose entropy lies within the
+        # default kernel's error of a threshold (cgic_router_refined_f32): masks -- hence bytes -- equal to the CPU
+        # reference's from PIXELS, also on tie-heavy content
+        self.refine = bool(refine)
 
     def refresh_codebook(self):
+        """after changing embedding.weight: rewrite the codebook image IN PLACE (same device buffer), so that hipGraphs
+        captured with it (LaneStream, GraphLanes) read the new weights on their next replay instead of a freed snapshot"""
         if self.prepared is not None:
-            self.prepared = prepare_codebook(self.vq.embedding.weight)
-
-    def _get_streams(self, device):
-        if self._streams is None or self._streams[0].device != device:
-            self._streams = [torch.cuda.Stream(device) for _ in range(self.chunks)]
-        return self._streams
+            self.prepared = prepare_codebook(self.vq.embedding.weight, out=self.prepared)
 
     def _chain(self, x, z, hist, decode, decoder=None):
-        if self.fork_vq == 2:
-            # entropy, then the router on a side stream next to the VQ kernel
-            cur = torch.cuda.current_stream(x.device)
-            if self._side is None or self._side.device != x.device:
-                self._side = torch.cuda.Stream(x.device)
-            e8, e16 = entropy_maps(x)
-            fork = torch.cuda.Event()
-            fork.record(cur)
-            self._side.wait_event(fork)
-            with torch.cuda.stream(self._side):
-                mask, _, _, mode = self.router(e16, e8, want_gate=False)
-                join = torch.cuda.Event()
-                join.record(self._side)
-            zq, loss, ind = _vq_forward(z, self.vq.embedding.weight, self.vq.beta, self.vq.legacy, None, prepared=self.prepared)
-            cur.wait_event(join)
-        elif self.fork_vq:
-            cur = torch.cuda.current_stream(x.device)
-            if self._side is None or self._side.device != x.device:
-                self._side = torch.cuda.Stream(x.device)
-            fork = torch.cuda.Event()
-            fork.record(cur)
-            self._side.wait_event(fork)
-            with torch.cuda.stream(self._side):
-                zq, loss, ind = _vq_forward(z, self.vq.embedding.weight, self.vq.beta, self.vq.legacy, None, prepared=self.prepared)
-                join = torch.cuda.Event()
-                join.record(self._side)
-            e8, e16 = entropy_maps(x)
-            mask, _, _, mode = self.router(e16, e8, want_gate=False)
-            cur.wait_event(join)
-        elif not self.fuse_router:
-            e8, e16 = entropy_maps(x)
-            mask, _, _, mode = self.router(e16, e8, want_gate=False)
+        e8, e16 = entropy_maps(x)
+        px = x if self.refine else None
+        if not self.fuse_router:
+            mask, _, _, mode = self.router(e16, e8, want_gate=False, pixels=px)
             zq, loss, ind = _vq_forward(z, self.vq.embedding.weight, self.vq.beta, self.vq.legacy, None, prepared=self.prepared)
         else:
-            e8, e16 = entropy_maps(x)
             # VQ and the per-image router share one launch (the router rides in the VQ kernel's shadow)
             zq, loss, ind, mask, _, mode = vq_forward_route(
                 z, self.vq.embedding.weight, self.vq.beta, self.vq.legacy, e16, e8,
-                self.router.coarse_grain_ratio, self.router.medium_grain_ratio, per_image=True, prepared=self.prepared)
+                self.router.coarse_grain_ratio, self.router.medium_grain_ratio, per_image=True, prepared=self.prepared,
+                pixels=px)
         comp = self.codec.compress(ind, mask, mode, hist=hist)      # usage histogram rides on the coder launch
         dec = self.codec.decompress(comp, decoder=decoder) if decode else None
         return {"e8": e8, "e16": e16, "mask": mask, "mode": mode, "z_q": zq, "loss": loss, "ind": ind,
                 "comp": comp, "dec": dec}
 
     def run(self, x, z, hist=None, decode=True):
-        """x [B,3,H,W], z [B,4,H/4,W/4] on the device -> list of per-chunk result dicts (views of the
-        batch in order).  `hist` (int64 [n_e], optional) accumulates the usage histogram."""
-        B = x.shape[0]
-        n = min(self.chunks, B)
-        if n == 1:
-            return [self._chain(x, z, hist, decode)]
-        cur = torch.cuda.current_stream(x.device)
-        streams = self._get_streams(x.device)
-        bounds = [(B * i) // n for i in range(n + 1)]
-        fork = torch.cuda.Event()
-        fork.record(cur)
-        out = []
-        for i in range(n):
-            s = streams[i]
-            s.wait_event(fork)
-            with torch.cuda.stream(s):
-                out.append(self._chain(x[bounds[i]:bounds[i + 1]], z[bounds[i]:bounds[i + 1]], hist, decode))
-            done = torch.cuda.Event()
-            done.record(s)
-            cur.wait_event(done)
-        return out
+        """x [B,3,H,W], z [B,4,H/4,W/4] on the device -> [result dict] (a list for compatibility with round 1's chunked form).
+        `hist` (int64 [n_e], optional) accumulates the usage histogram."""
+        return [self._chain(x, z, hist, decode)]
 
 
 class BatchSlot:
@@ -127,103 +74,12 @@ class BatchSlot:
         self.used = False
 
 
-class BatchStream:
-    """Successive batches through the hot path, software-pipelined over TWO HIP streams.
-
-    The three latency-bound kernels of a step (stream coder, prefix decoder, scatter/merge) keep at most a quarter
-    of the CUs busy and the two throughput kernels (entropy maps, VQ) cannot use that idle time inside ONE batch --
-    every kernel of a batch depends on the previous one.  Across batches nothing depends on anything: the encode side
-    of batch i+1 (entropy -> VQ + router -> stream coder) runs on one stream while the decode side of batch i
-    (prefix decode -> merge + gather) runs on the other.  Each side of each slot is one captured hipGraph; slots
-    rotate, an event per slot and side carries the only two dependencies (decode i after encode i; encode i + R after
-    decode i, because they share the slot's buffers).  Results are bit-identical to the one-stream order: same
-    kernels, same inputs, no shared scratch between slots (per-launch tickets are library-owned).
-
-    slots: list of (x [B,3,H,W], z [B,4,H/4,W/4]) device tensors -- the caller refills a slot's tensors in place
-    (on `enc_stream`, after `slot.ev_dec`) to feed new data.
-    """
-
-    def __init__(self, quantizer, coarse_ratio, medium_ratio, slots, frequency=None, hist=None, decode=True):
-        if len(slots) < 2:
-            raise ValueError("BatchStream needs at least 2 slots (batch i+1 encodes while batch i decodes)")
-        self.pipe = HotPathPipeline(quantizer, coarse_ratio, medium_ratio, frequency=frequency)
-        self.hist = hist
-        self.decode = bool(decode)
-        self.slots = [BatchSlot(x, z) for x, z in slots]
-        dev = self.slots[0].x.device
-        self.device = dev
-        self.enc_stream = torch.cuda.Stream(dev)
-        self.dec_stream = torch.cuda.Stream(dev)
-        self._next = 0
-        self._captured = False
-
-    # the two halves of HotPathPipeline._chain
-    def _encode(self, s):
-        p = self.pipe
-        e8, e16 = entropy_maps(s.x)
-        zq, loss, ind, mask, _, mode = vq_forward_route(
-            s.z, p.vq.embedding.weight, p.vq.beta, p.vq.legacy, e16, e8,
-            p.router.coarse_grain_ratio, p.router.medium_grain_ratio, per_image=True)
-        comp = p.codec.compress(ind, mask, mode, hist=self.hist)
-        s.enc = {"e8": e8, "e16": e16, "mask": mask, "mode": mode, "z_q": zq, "loss": loss, "ind": ind, "comp": comp}
-
-    def _decode(self, s):
-        s.dec = self.pipe.codec.decompress(s.enc["comp"])
-
-    def capture(self, warmup=2):
-        """run every slot eagerly (uploads tables, sets function attributes), then capture its two graphs"""
-        cur = torch.cuda.current_stream(self.device)
-        self.enc_stream.wait_stream(cur)
-        with torch.cuda.stream(self.enc_stream):
-            for s in self.slots:
-                for _ in range(warmup):
-                    self._encode(s)
-                    if self.decode:
-                        self._decode(s)
-            for s in self.slots:
-                s.g_enc, _ = capture_graph(lambda s=s: self._encode(s), self.enc_stream)
-                if self.decode:
-                    s.g_dec, _ = capture_graph(lambda s=s: self._decode(s), self.enc_stream)
-        cur.wait_stream(self.enc_stream)
-        self.dec_stream.wait_stream(cur)
-        self._captured = True
-
-    def submit(self, n=1):
-        """enqueue the next n batches (slots in rotation); returns immediately"""
-        if not self._captured:
-            self.capture()
-        for _ in range(n):
-            s = self.slots[self._next]
-            self._next = (self._next + 1) % len(self.slots)
-            with torch.cuda.stream(self.enc_stream):
-                if s.used and self.decode:
-                    self.enc_stream.wait_event(s.ev_dec)        # the slot's previous decode still reads its streams
-                s.g_enc.replay()
-                s.ev_enc.record(self.enc_stream)
-            if self.decode:
-                with torch.cuda.stream(self.dec_stream):
-                    self.dec_stream.wait_event(s.ev_enc)
-                    s.g_dec.replay()
-                    s.ev_dec.record(self.dec_stream)
-            s.used = True
-
-    def join(self, stream=None):
-        """make `stream` (default: the current one) wait for everything submitted so far"""
-        stream = torch.cuda.current_stream(self.device) if stream is None else stream
-        stream.wait_stream(self.enc_stream)
-        stream.wait_stream(self.dec_stream)
-
-    def fork(self, stream=None):
-        """make both pipeline streams wait for `stream` (default: the current one), e.g. after refilling slots"""
-        stream = torch.cuda.current_stream(self.device) if stream is None else stream
-        self.enc_stream.wait_stream(stream)
-        self.dec_stream.wait_stream(stream)
-
-
 def capture_graph(fn, stream):
     """capture `fn()` (which only enqueues work on the current stream) into a hipGraph on `stream` -> (graph, fn's result).
-    The ticket slots the captured launches take from the library's pool are returned when the graph object is
-    garbage-collected (_lib.ticket_scope), so a long-lived process can capture per image shape for as long as it likes."""
+    The ticket slots the captured launches take from the library's pool go back to it after the graph object has been
+    garbage-collected -- at the next capture, behind a device synchronisation (_lib.flush_released) -- so a long-lived process
+    can capture per image shape for as long as it likes."""
+    _lib.flush_released(stream.device)              # slots of graphs that died since the last capture (waits for their last replay)
     g = torch.cuda.CUDAGraph()
     sc = _lib.ticket_scope()
     try:
@@ -303,18 +159,17 @@ class LaneStream:
 
     slots: list of (x [B,3,H,W], z [B,4,H/4,W/4]) device tensors; the caller refills a slot's tensors in place after
     `join()` to feed new data.  `hist` (int64 [n_e], optional) accumulates the usage histogram of everything submitted.
-    `launch_threads=True` hands each lane's replays to a thread of its own (graph launches release the GIL): the lanes
-    start together instead of one host launch after the other.
     """
 
     def __init__(self, quantizer, coarse_ratio, medium_ratio, slots, lanes=4, frequency=None, hist=None, decode=True,
-                 graph=True, ring=True, fuse_router=True, decoder=None, max_ring=8, launch_threads=False, quick_start=False,
-                 prepare=True, native_launch=1):
+                 graph=True, ring=True, fuse_router=True, decoder=None, max_ring=8, prepare=True, native_launch=True,
+                 refine=True):
         if not slots:
             raise ValueError("LaneStream needs at least one slot")
         # prepare: a stream of batches is inference against ONE codebook -- its image is made once, when capture() runs
         # (a captured launch holds a snapshot of the codebook either way: HotPathPipeline.prepare)
-        self.pipe = HotPathPipeline(quantizer, coarse_ratio, medium_ratio, frequency=frequency, fuse_router=fuse_router, prepare=prepare)
+        self.pipe = HotPathPipeline(quantizer, coarse_ratio, medium_ratio, frequency=frequency, fuse_router=fuse_router, prepare=prepare,
+                                    refine=refine)
         self.hist = hist
         self.decode = bool(decode)
         self.graph = bool(graph)
@@ -328,18 +183,9 @@ class LaneStream:
         with torch.cuda.device(self.device):
             streams = distinct_queue_streams(self.device, nl)          # one hardware queue per lane, measured
         self.lanes = [{"slots": self.slots[j::nl], "pos": 0, "stream": streams[j], "graphs": {}} for j in range(nl)]
-        # quick_start: a lane's first run of a submit is split into (1 step) + (the rest): a graph launch costs the host
-        # ~12 us + ~0.55 us per kernel node, and lane j only starts after the launches of lanes 0..j-1 (measured: no gain at
-        # K=20 -- the window is bound by resources, not by the last lane's start -- hence off by default)
-        self.quick_start = bool(quick_start) and nl > 1
-        # native_launch: 1 (default) = all graph launches of a submit in ONE C call (cgic_launch_graphs: no interpreter between
-        # them: host time of a K=20 submit 115 -> 93 us, the window 777 -> 756 us), 2 = ... each lane's launches on its own
-        # persistent C thread (host 60 us, the window no shorter: the runtime serialises the launches), 0 = replay() from Python
-        self.native_launch = int(native_launch) if self.graph and hasattr(torch.cuda.CUDAGraph, "raw_cuda_graph_exec") else 0
-        self._pool = None
-        if launch_threads and nl > 1:
-            from concurrent.futures import ThreadPoolExecutor
-            self._pool = ThreadPoolExecutor(max_workers=nl, thread_name_prefix="cgic-lane")
+        # native_launch (default): all graph launches of a submit in ONE C call (cgic_launch_graphs: no interpreter between
+        # them: host time of a K=20 submit 115 -> 93 us, the window 777 -> 756 us); False = replay() from Python
+        self.native_launch = bool(native_launch) and self.graph and hasattr(torch.cuda.CUDAGraph, "raw_cuda_graph_exec")
         self._t = 0
         self._captured = False
 
@@ -403,8 +249,6 @@ class LaneStream:
             c = todo[j]
             while c:
                 k = min(c, self.max_ring)
-                if self.quick_start and not runs and k > 2:
-                    k = 1                                  # every lane starts after one short launch
                 runs.append((pos, k))
                 pos = (pos + k) % m
                 c -= k
@@ -428,28 +272,22 @@ class LaneStream:
         key = tuple(tuple(r) for r in plans)
         cached = getattr(self, "_native_args", {}).get(key)
         if cached is None:
-            execs, streams, lane_of = [], [], []
+            execs, streams = [], []
             depth = max(len(r) for r in plans)
             for i in range(depth):                                       # one launch per lane and turn, like the Python loop
-                for j, (lane, runs) in enumerate(zip(self.lanes, plans)):
+                for lane, runs in zip(self.lanes, plans):
                     if i < len(runs):
                         execs.append(self._graph(lane, *runs[i])[0].raw_cuda_graph_exec())
                         streams.append(lane["stream"].cuda_stream)
-                        lane_of.append(j)
             n = len(execs)
-            cached = ((ctypes.c_void_p * n)(*execs), (ctypes.c_void_p * n)(*streams), (ctypes.c_int * n)(*lane_of), n)
+            cached = ((ctypes.c_void_p * n)(*execs), (ctypes.c_void_p * n)(*streams), n)
             self.__dict__.setdefault("_native_args", {})[key] = cached
         return cached
 
     def _launch_native(self, plans):
-        e, s, l, n = self._native_args_for(plans)
+        e, s, n = self._native_args_for(plans)
         with torch.cuda.device(self.device):
-            _lib.call("cgic_launch_graphs", e, s, l, n, len(self.lanes) if self.native_launch >= 2 else 1)
-
-    def _run_lane(self, lane, runs):
-        with torch.cuda.device(self.device), torch.cuda.stream(lane["stream"]):
-            for start, count in runs:
-                self._graph(lane, start, count)[0].replay()
+            _lib.call("cgic_launch_graphs", e, s, n)
 
     def submit(self, n=1):
         """enqueue the next n batches (batch t on lane t % lanes, slots of a lane in rotation); returns immediately"""
@@ -463,9 +301,6 @@ class LaneStream:
                     self._graph(lane, start, count)
             if self.native_launch:
                 self._launch_native(plans)
-            elif self._pool is not None:
-                for f in [self._pool.submit(self._run_lane, lane, runs) for lane, runs in zip(self.lanes, plans) if runs]:
-                    f.result()
             else:
                 depth = max(len(r) for r in plans)
                 for i in range(depth):                                  # one launch per lane and turn keeps every queue fed

@@ -91,11 +91,12 @@ def vq_backward(z, weight, idx, g_zq, g_loss, beta, legacy, want_gz=True, want_g
     return gz, gw
 
 
-def prepare_codebook(weight):
+def prepare_codebook(weight, out=None):
     """The codebook image cgic_vq_prepare_f32 makes for the filter path (uint8 tensor; None if this K has no filter path):
     row norms, the maxima that fix the fp16 scaling and the split MFMA operands -- what every workgroup of every launch
     otherwise derives from `weight` (torch.sum(embedding.weight**2) of quantize.py:73-75 is per call in the reference too).
-    A SNAPSHOT: pass it only to launches against the same, unchanged weights."""
+    A SNAPSHOT: pass it only to launches against the same, unchanged weights.  `out`: an image made earlier for a codebook of
+    the same K -- it is rewritten IN PLACE (same device pointer), so hipGraphs captured with it see the new weights."""
     _lib.require_device(weight)
     wt = weight.detach().contiguous()
     if wt.dtype != torch.float32 or wt.dim() != 2:
@@ -103,7 +104,9 @@ def prepare_codebook(weight):
     nbytes = int(_lib.lib().cgic_vq_prepared_bytes(wt.shape[0]))
     if nbytes == 0:
         return None
-    img = torch.empty(nbytes, dtype=torch.uint8, device=wt.device)
+    if out is not None and (out.numel() != nbytes or out.device != wt.device or out.dtype != torch.uint8):
+        raise ValueError("prepare_codebook: `out` is not an image of a codebook of this size on this device")
+    img = out if out is not None else torch.empty(nbytes, dtype=torch.uint8, device=wt.device)
     with torch.cuda.device(wt.device):
         _lib.call("cgic_vq_prepare_f32", _lib.ptr(wt), wt.shape[0], wt.shape[1], _lib.ptr(img), _lib.current_stream(wt.device))
     return img
@@ -140,12 +143,18 @@ def _vq_forward(z, weight, beta, legacy, hist, want_zq=True, want_loss=True, ker
 
 
 def vq_forward_route(z, weight, beta, legacy, e16, e8, coarse_ratio, medium_ratio, per_image=True, want_gate=False,
-                     want_zq=True, want_loss=True, quant_conv=None, conv_bias_first=False, prepared=None):
+                     want_zq=True, want_loss=True, quant_conv=None, conv_bias_first=False, prepared=None, pixels=None, flat8=None):
     """VectorQuantize2.forward and TripleGrainFixedEntropyRouter.forward in ONE launch (the router's per-image
     workgroups ride behind the VQ workgroups; see cgic_vq_forward_route_f32).  Returns
-    (z_q, loss, indices, [mask_c, mask_m, mask_f], gate, mode) -- identical to the two separate calls."""
+    (z_q, loss, indices, [mask_c, mask_m, mask_f], gate, mode) -- identical to the two separate calls.
+    pixels: the image batch the maps were made from (fp32 [B,3,H,W] or uint8 [B,H,W,3]) -> the router's threshold-band
+    refinement (router.TripleGrainFixedEntropyRouter.forward); flat8: its constant-patch map (default: the one entropy_maps
+    left on the maps)."""
     import ctypes
     _lib.require_device(z, weight, e16, e8)
+    if flat8 is None and pixels is not None:
+        from .router import _flat_of
+        flat8 = _flat_of(pixels, e8, e16)
     B, C, h, w = z.shape
     z = z.contiguous()
     weight = weight.detach().contiguous()
@@ -166,12 +175,13 @@ def vq_forward_route(z, weight, beta, legacy, e16, e8, coarse_ratio, medium_rati
     gate = torch.empty((B, 1, 4 * h16, 12 * w16), dtype=torch.float32, device=dev) if want_gate else None
     mode = ctypes.c_int(0)
     qc, keep = _lib.conv_arg(quant_conv, conv_bias_first)
+    px, keep_px = _lib.pixels_arg(pixels, B, h16, w16, per_image, flat8=flat8)
     with torch.cuda.device(dev):
         _lib.call("cgic_vq_forward_route_f32", _lib.ptr(z), B, h * w, _lib.ptr(weight), weight.shape[0], C, float(beta),
                   int(bool(legacy)), _lib.ptr(idx), _lib.ptr(z_q), _lib.ptr(loss), _lib.ptr(ws), _lib.ptr(e16), _lib.ptr(e8),
                   h16, w16, float(coarse_ratio), float(medium_ratio), int(bool(per_image)), _lib.ptr(mc), _lib.ptr(mm),
-                  _lib.ptr(mf), _lib.ptr(gate), ctypes.byref(mode), qc, _lib.ptr(prepared), _lib.current_stream(dev))
-    del keep
+                  _lib.ptr(mf), _lib.ptr(gate), ctypes.byref(mode), qc, _lib.ptr(prepared), px, _lib.current_stream(dev))
+    del keep, keep_px
     return z_q, loss, idx, [mc, mm, mf], gate, mode.value
 
 
@@ -274,13 +284,19 @@ class VectorQuantize2(nn.Module):
 
     def _load_counter(self, state, prefix, local_metadata, strict, missing, unexpected, errors):
         self._prepared = None                       # new weights are coming in: the snapshot is stale
+        loaded = False
         for k in list(state.keys()):
             if k.startswith(prefix + "embedding_counter."):
                 i = int(k[len(prefix) + len("embedding_counter."):])
                 if 0 <= i < self.n_e:
                     with torch.no_grad():
                         self.usage_counter[i] = state[k].reshape(-1)[0].to(self.usage_counter)
+                    loaded = True
                 del state[k]
+        if loaded:
+            # counters that come out of a checkpoint are the whole job's (every rank loads the same file): they are the base
+            # that sync_usage_counter_now() must not add up again over the ranks
+            self._usage_synced = self.usage_counter.detach().to(torch.float64).round().to(torch.int64)
 
     @property
     def embedding_counter(self):
@@ -309,8 +325,16 @@ class VectorQuantize2(nn.Module):
     def prepare(self):
         """Inference: snapshot the codebook image of the HIP kernel once (prepare_codebook) instead of deriving it at the head
         of every launch.  Used by forward() / indices() while the module is in eval mode and autograd is off; dropped by
-        train() and load_state_dict().  Call it again after changing embedding.weight by hand."""
-        self._prepared = prepare_codebook(self.embedding.weight)
+        train() and load_state_dict().  The snapshot is keyed on the weight tensor and its autograd version counter: an
+        in-place update of embedding.weight that autograd sees (optimizer step, `with no_grad(): w.copy_()`, EMA) is noticed by
+        the next forward(), which rewrites the image in place.  Writes through `weight.data` bypass the version counter: call
+        prepare() again after those."""
+        w = self.embedding.weight
+        old = getattr(self, "_prepared", None)
+        if old is not None and (old.device != w.device or self._prepared_key[0] is not w):
+            old = None
+        self._prepared = prepare_codebook(w, out=old)
+        self._prepared_key = (w, w._version)
         return self
 
     def train(self, mode=True):
@@ -321,17 +345,36 @@ class VectorQuantize2(nn.Module):
     def _prepared_image(self):
         if self.training or torch.is_grad_enabled():
             return None
-        return getattr(self, "_prepared", None)
+        img = getattr(self, "_prepared", None)
+        if img is not None:
+            w = self.embedding.weight
+            if self._prepared_key[0] is not w or self._prepared_key[1] != w._version:
+                self.prepare()                      # the weights changed under the snapshot
+                img = self._prepared
+        return img
 
     def sync_usage_counter_now(self):
-        """sum the fp32 usage counters over the process group, once (checkpoint / epoch end): every rank then holds the
-        counts of the whole data set, like sync_usage_counter=True would have accumulated step by step (exact while the totals
-        stay below 2^24, the fp32 counter's own limit).  Collective: call it on every rank."""
+        """Sum over the process group what every rank has counted SINCE THE LAST SYNC (or since the counters were loaded from a
+        checkpoint: those are the whole job's already) and add it to that common base: every rank then holds the counts of the
+        whole data set, like sync_usage_counter=True would have accumulated step by step (exact while the totals stay below
+        2^24, the fp32 counter's own limit).  Safe to call at every checkpoint / epoch end: only the per-rank delta is reduced,
+        so earlier counts are never multiplied by the world size.  Collective: call it on every rank.  Counters filled by hand
+        identically on every rank are a common base too: say so with mark_usage_counter_synced()."""
         from . import dist as cdist
         with torch.no_grad():
             total = self.usage_counter.to(torch.float64).round().to(torch.int64)
-            cdist.all_reduce_histogram(total)
+            base = getattr(self, "_usage_synced", None)
+            if base is None or base.shape != total.shape or base.device != total.device:
+                base = torch.zeros_like(total)
+            delta = total - base
+            cdist.all_reduce_histogram(delta)
+            total = base + delta
             self.usage_counter.copy_(total.to(self.usage_counter.dtype))
+            self._usage_synced = total
+
+    def mark_usage_counter_synced(self):
+        """declare the current counters common to all ranks (e.g. after filling them by hand on every rank)"""
+        self._usage_synced = self.usage_counter.detach().to(torch.float64).round().to(torch.int64)
 
     def forward(self, z):
         if not isinstance(z, PendingQuantConv) and z.dtype != torch.float32:

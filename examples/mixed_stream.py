@@ -50,7 +50,7 @@ def run(rank, world, expect_world=None):
         e8, e16 = cg.entropy_maps(tiles)
         z = torch.nn.functional.avg_pool2d(torch.cat([tiles, tiles[:, :1]], 1), 4) * 4 - 2     # stand-in latent [T,4,h,w]
         _, _, ind, mask, _, mode = vq_forward_route(z, vq.embedding.weight, 0.25, True, e16, e8, 0.1, 0.8,
-                                                    per_image=True, want_zq=False, want_loss=False)
+                                                    per_image=True, want_zq=False, want_loss=False, pixels=tiles)
         cg._lib.call("cgic_index_histogram", ind.data_ptr(), ind.numel(), 1024, hist.data_ptr(), cg._lib.current_stream(dev))
         return ind, mask, mode
 

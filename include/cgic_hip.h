@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define CGIC_ABI_VERSION 4
+#define CGIC_ABI_VERSION 5
 
 #define CGIC_OK 0
 #define CGIC_ERR_INVALID (-1)     /* bad argument (shape, ratio, NULL pointer ...) */
@@ -63,11 +63,10 @@ int cgic_ticket_scope_begin(void);
 int cgic_ticket_scope_end(void);
 int cgic_ticket_scope_release(int scope);
 int cgic_ticket_slots_in_use(void);
-/* Launch n captured hipGraphs in one call: graph_execs[i] (hipGraphExec_t) on streams[i] (hipStream_t), in order.  threads <= 1 (or
- * lane_of == NULL): back to back on the calling thread.  threads > 1: the launches with the same lane_of[i] (0..63) keep their order on
- * one persistent worker thread per lane, different lanes are launched concurrently.  For runtimes of several independent streams of
- * batches (pipeline.LaneStream): from Python every launch is an interpreter round trip and the last lane starts ~100 us after the first. */
-int cgic_launch_graphs(void *const *graph_execs, void *const *streams, const int *lane_of, int n, int threads);
+/* Launch n captured hipGraphs in one call: graph_execs[i] (hipGraphExec_t) on streams[i] (hipStream_t), in order, back to back on the
+ * calling thread.  For runtimes of several independent streams of batches (pipeline.LaneStream): from Python every launch is an
+ * interpreter round trip and the last lane starts ~100 us after the first. */
+int cgic_launch_graphs(void *const *graph_execs, void *const *streams, int n);
 const char *cgic_last_error(void);
 int cgic_abi_version(void);
 /* number of visible HIP devices, or CGIC_ERR_HIP; never throws, never aborts */
@@ -105,6 +104,19 @@ int cgic_device_count(void);
  * channels in order.  oneDNN seeds the accumulator with the bias or adds it at the end depending on shape and
  * thread count (measured with torch 2.10: 1 thread, or a 64x64 latent -> bias last; 8 threads and >= 96x96 ->
  * bias first); `bias_first` selects which of the two sequences to reproduce. */
+/* The pixels behind a pair of entropy maps, for the router's threshold-band refinement (cgic_router_f32 below). */
+typedef struct cgic_pixels {
+    const void *x;      /* device: the image batch the maps were computed from -- [B, 3, 16 h16, 16 w16] fp32, or, with
+                         * is_u8, the uint8 frames [B, 16 h16, 16 w16, 3] of cgic_entropy_maps_u8 (4-byte aligned) */
+    int is_u8;
+    const float *bins;  /* host [32] fp32: torch.linspace(-1, 1, 32) (model.py:480) */
+    int nbins;          /* 32 */
+    float sigma;        /* 0.01 (model.py:481) */
+    const float *flat8; /* device [B, 2 h16, 2 w16] fp32 or NULL: the flat8 output of the entropy call that made the maps.
+                         * Without it constant patches are re-evaluated one by one like any other (same result, slower on
+                         * flat content) */
+} cgic_pixels;
+
 typedef struct cgic_conv1x1 {
     const float *weight;   /* device [4, 4] fp32 = Conv2d.weight[:, :, 0, 0], row = output channel */
     const float *bias;     /* device [4] fp32 or NULL */
@@ -123,13 +135,14 @@ int cgic_vq_forward_f32(const float *z, int64_t B, int64_t hw, const float *code
                         cgic_stream_t stream);
 /* cgic_vq_forward_f32 and cgic_router_f32 in ONE launch: the router's per-image workgroups share the grid with
  * the VQ workgroups (neither needs the other's output; both need what precedes them, i.e. the latent and
- * the entropy maps).  Same contracts as the two separate calls. */
+ * the entropy maps).  Same contracts as the two separate calls (`refine`: see cgic_router_f32). */
 int cgic_vq_forward_route_f32(const float *z, int64_t B, int64_t hw, const float *codebook, int K, int e_dim,
                               float beta, int legacy, int64_t *indices, float *z_q, float *loss,
                               void *workspace, const float *e16, const float *e8, int64_t h16, int64_t w16,
                               double coarse_ratio, double medium_ratio, int per_image, int32_t *mask_c,
                               int32_t *mask_m, int32_t *mask_f, float *gate, int *mode_out,
-                              const cgic_conv1x1 *quant_conv, const void *prepared, cgic_stream_t stream);
+                              const cgic_conv1x1 *quant_conv, const void *prepared, const cgic_pixels *refine,
+                              cgic_stream_t stream);
 /* same contract, plain-VALU kernel (no MFMA); kept as an independent
  * implementation for cross-checking the MFMA kernel's rounding */
 int cgic_vq_forward_valu_f32(const float *z, int64_t B, int64_t hw, const float *codebook, int K,
@@ -162,13 +175,16 @@ int cgic_index_histogram(const int64_t *indices, int64_t n, int K, int64_t *hist
  *   bins  host   [32] fp32  (torch.linspace(-1, 1, 32), model.py:480)
  *   e8    device [B, H/8,  W/8 ] fp32 or NULL
  *   e16   device [B, H/16, W/16] fp32 or NULL
+ *   flat8 device [B, H/8,  W/8 ] fp32 or NULL: per 8x8 patch its gray value (0.2989 R + 0.5870 G + 0.1140 B, model.py:471) if
+ *         all 64 pixels carry the same one, else NaN -- by-product of the pass, consumed by the router's refinement
+ *         (cgic_pixels.flat8): constant patches are the large tie groups of real content
  * fp32 throughout; exp / log / reciprocal are the GPU's (v_exp_f32, v_log_f32, v_rcp_f32) and only the 2 bins
  * that bracket a pixel are evaluated (the rest is <= 9e-10 per pixel), so results match the CPU reference to
  * ~1e-6 (measured <= 1.1e-6; tests hold it to 2e-6), not bit-for-bit (SURVEY.md section 7 "hard parts"); see
  * cgic_entropy_maps_ref_f32 below for the variant that follows the reference's rounding.
  * ------------------------------------------------------------------------- */
 int cgic_entropy_maps_f32(const float *x, int64_t B, int64_t H, int64_t W, const float *bins,
-                          int nbins, float sigma, float *e8, float *e16, cgic_stream_t stream);
+                          int nbins, float sigma, float *e8, float *e16, float *flat8, cgic_stream_t stream);
 /* The same maps in the REFERENCE'S OWN ARITHMETIC (opt-in): torch's CPU operation sequence and summation order -- gray as three
  * products and two sums, IEEE divide by sigma, the mean over a patch's pixels as torch's cascade sum (chunks of 16 pixels in
  * row-major order, then the chunk sums), both sums over the 32 bins as torch's eight strided partials -- with exp / log
@@ -188,7 +204,7 @@ int cgic_entropy_maps_ref_f32(const float *x, int64_t B, int64_t H, int64_t W, c
  *   e8, e16 as cgic_entropy_maps_f32 -- and bit-identical to cgic_entropy_maps_f32 run on x_out.
  * 3 B read + 12 B written per pixel instead of ToTensor's 3 + 12 and Entropy's 12 again. */
 int cgic_entropy_maps_u8(const unsigned char *x_hwc, int64_t B, int64_t H, int64_t W, const float *bins,
-                         int nbins, float sigma, float *x_out, float *e8, float *e16, cgic_stream_t stream);
+                         int nbins, float sigma, float *x_out, float *e8, float *e16, float *flat8, cgic_stream_t stream);
 
 /* ---------------------------------------------------------------------------
  * C. TripleGrainFixedEntropyRouter -- CGIC/modules/vqvae/RouterTriple.py:8-95
@@ -205,12 +221,26 @@ int cgic_entropy_maps_u8(const unsigned char *x_hwc, int64_t B, int64_t H, int64
  *   mode_out host int or NULL
  * k = round(n*ratio) uses Python's round-half-even on the float64 product.
  * CGIC_ERR_INVALID if k > n (the reference raises IndexError there).
+ *
+ *   refine NULL: the masks are exactly the reference router's for the maps AS GIVEN (bit-exact integer / compare work).
+ *          Non-NULL (round 4; what the pipeline passes by default): the masks are the reference's from the PIXELS.  The
+ *          thresholds are k-th smallest entropies compared with a strict '<' (:21-34) and the maps of cgic_entropy_maps_f32
+ *          are within ~1e-6 of the reference's arithmetic, not equal to it, so on tie-heavy content (8-bit, smooth, flat
+ *          images) the last bits decide masks and hence .bin bytes.  With the pixels, every patch whose entropy lies within
+ *          4e-6 (>= twice the kernel's error) of a threshold is re-evaluated inside the router in the reference's own fp32
+ *          operation order (the arithmetic of cgic_entropy_maps_ref_f32), and the k-th smallest is taken again: the result
+ *          equals routing on cgic_entropy_maps_ref_f32's maps (tested), at the default kernel's cost whenever the band holds
+ *          only the threshold element itself -- the typical image.  Needs a segment whose maps fit the workgroup's LDS:
+ *          per-image routing of images / tiles up to 768x768 (cgic_router_refine_supported); otherwise
+ *          CGIC_ERR_UNSUPPORTED.  The maps themselves are not modified.
  * ------------------------------------------------------------------------- */
 int cgic_router_mode(double coarse_ratio, double medium_ratio);
+/* 1 if cgic_router_f32 / cgic_vq_forward_route_f32 accept `refine` for this shape, else 0 */
+int cgic_router_refine_supported(int64_t B, int64_t h16, int64_t w16, int per_image);
 int cgic_router_f32(const float *e16, const float *e8, int64_t B, int64_t h16, int64_t w16,
                     double coarse_ratio, double medium_ratio, int per_image, int32_t *mask_c,
                     int32_t *mask_m, int32_t *mask_f, float *gate, int *mode_out,
-                    cgic_stream_t stream);
+                    const cgic_pixels *refine, cgic_stream_t stream);
 
 /* ---------------------------------------------------------------------------
  * D. HuffmanCoding.__init__ / make_heap / merge_nodes / make_codes --

@@ -245,6 +245,32 @@ int cgic_oracle_entropy_ref(const float *x, long B, long H, long W, int p,
     return 0;
 }
 
+/* The GPU's division by sigma = 0.01f in its reference-arithmetic code (cgic_entropy_dev.h: div_by_sigma001: q = x * 100,
+ * corrected once by the exact remainder) against the IEEE quotient the reference computes (model.py:454, `residuals / sigma`):
+ * number of fp32 magnitudes u in [lo_bits, hi_bits), stepping by `stride`, for which +x or -x differs in any bit.
+ * tests/test_oracle_golden.py samples it; tools/check_fast_div.py runs it exhaustively over 2^-100 <= |x| <= 8 (0 mismatches). */
+long cgic_oracle_check_fast_div(unsigned int lo_bits, unsigned int hi_bits, unsigned int stride, unsigned int *first_bad)
+{
+    const float sigma = 0.01f, r = 100.0f;
+    long bad = 0;
+    if (stride == 0) stride = 1;
+    for (unsigned long long u = lo_bits; u < hi_bits; u += stride) {
+        for (int sgn = 0; sgn < 2; ++sgn) {
+            const unsigned int bits = (unsigned int)u | (sgn ? 0x80000000u : 0u);
+            float x;
+            memcpy(&x, &bits, 4);
+            const float q = x * r;
+            const float q1 = fmaf(fmaf(-q, sigma, x), r, q);
+            const float ref = x / sigma;
+            if (memcmp(&q1, &ref, 4)) {
+                if (!bad && first_bad) *first_bad = bits;
+                ++bad;
+            }
+        }
+    }
+    return bad;
+}
+
 /* ------------------------------------------------------------------------- *
  * C. Router: CGIC/modules/vqvae/RouterTriple.py:8-95
  * ------------------------------------------------------------------------- */

@@ -700,7 +700,7 @@ def test_tiling_driver_takes_uint8_frames():
             tiles, e8, e16 = cg.entropy_maps_u8(tiles)
         else:
             e8, e16 = cg.entropy_maps(tiles)
-        _, _, ind, mask, _, mode = vq_forward_route(latent(tiles), vq.embedding.weight, 0.25, True, e16, e8, 0.1, 0.8, per_image=True)
+        _, _, ind, mask, _, mode = vq_forward_route(latent(tiles), vq.embedding.weight, 0.25, True, e16, e8, 0.1, 0.8, per_image=True, pixels=tiles)
         return ind, mask, mode
 
     ref = highres.compress_tiled_batch(x, encode, codec)

@@ -21,7 +21,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(l, name), f"{name} declared in cgic_hip.h but not exported"
     assert declared == set(_lib.PROTOTYPES), "ctypes prototype table out of sync with the header"
-    assert _lib.lib().cgic_abi_version() == 4
+    assert _lib.lib().cgic_abi_version() == 5
 
 
 def test_device_count_does_not_abort_without_gpu():
@@ -121,11 +121,24 @@ def test_argument_validation_happens_before_any_launch():
     assert l.cgic_vq_backward_f32(one, 1, 16, one, 1024, 4, None, None, None, 0.25, 1, None, None, None, None) == _lib.ERR_INVALID
     assert l.cgic_vq_backward_f32(one, 1, 16, one, 1024, 4, one, None, None, 0.25, 1, None, one, None, None) == _lib.ERR_INVALID          # codebook gradient without workspace
     # router: k > n is an IndexError in the reference
-    assert l.cgic_router_f32(one, one, 1, 4, 4, 1.5, 0.0, 0, one, one, one, None, None, None) == _lib.ERR_INVALID
+    assert l.cgic_router_f32(one, one, 1, 4, 4, 1.5, 0.0, 0, one, one, one, None, None, None, None) == _lib.ERR_INVALID
     assert b"IndexError" in l.cgic_last_error()
     bins = (ctypes.c_float * 32)(*np.linspace(-1, 1, 32, dtype=np.float32))
-    assert l.cgic_entropy_maps_f32(one, 1, 24, 32, bins, 32, 0.01, one, one, None) == _lib.ERR_INVALID
-    assert l.cgic_entropy_maps_f32(one, 1, 32, 32, bins, 32, 0.05, one, one, None) == _lib.ERR_UNSUPPORTED
+    # router refinement (round 4): the kernel recomputes torch.linspace(-1, 1, 32) itself, so the caller's bins must be THE
+    # linspace to the bit (numpy's differs from torch's in the second half); segments that do not fit the LDS are refused
+    tb = _lib.linspace_bins()
+    px = _lib.Pixels(16, 0, tb, 32, 0.01, None)
+    assert l.cgic_router_f32(one, one, 1, 4, 4, 0.1, 0.8, 1, one, one, one, None, None, ctypes.byref(px), None) in (_lib.ERR_HIP, _lib.OK)  # passes validation (no GPU here: the launch fails)
+    bad = (ctypes.c_float * 32)(*[v + (1e-7 if i == 20 else 0.0) for i, v in enumerate(tb)])
+    assert l.cgic_router_f32(one, one, 1, 4, 4, 0.1, 0.8, 1, one, one, one, None, None, ctypes.byref(_lib.Pixels(16, 0, bad, 32, 0.01, None)), None) == _lib.ERR_UNSUPPORTED
+    assert b"linspace" in l.cgic_last_error()
+    assert l.cgic_router_f32(one, one, 64, 16, 16, 0.1, 0.8, 0, one, one, one, None, None, ctypes.byref(px), None) == _lib.ERR_UNSUPPORTED   # flattened batch of 64
+    assert b"refine_supported" in l.cgic_last_error()
+    assert l.cgic_router_refine_supported(64, 16, 16, 1) == 1 and l.cgic_router_refine_supported(8, 48, 48, 1) == 1
+    assert l.cgic_router_refine_supported(64, 16, 16, 0) == 0 and l.cgic_router_refine_supported(1, 128, 85, 1) == 0
+    assert l.cgic_router_f32(one, one, 1, 4, 4, 1.0, 0.0, 1, one, one, one, None, None, ctypes.byref(_lib.Pixels(16, 0, bad, 32, 0.01, None)), None) in (_lib.ERR_HIP, _lib.OK)  # mode 4 compares nothing: pixels ignored
+    assert l.cgic_entropy_maps_f32(one, 1, 24, 32, bins, 32, 0.01, one, one, None, None) == _lib.ERR_INVALID
+    assert l.cgic_entropy_maps_f32(one, 1, 32, 32, bins, 32, 0.05, one, one, None, None) == _lib.ERR_UNSUPPORTED
 
 
 def test_slot_and_workspace_sizes():

@@ -15,7 +15,7 @@ hp = bench.HotPath(dev, x, z, cb, (0.1, 0.8))
 e8, e16 = cg.entropy_maps(hp.x)
 w, prep = hp.vq.embedding.weight, hp.pipe.prepared
 which = sys.argv[1] if len(sys.argv) > 1 else "fused"
-fn = (lambda: vq_forward_route(hp.z, w, 0.25, True, e16, e8, 0.1, 0.8, prepared=prep)) if which == "fused" else \
+fn = (lambda: vq_forward_route(hp.z, w, 0.25, True, e16, e8, 0.1, 0.8, prepared=prep, pixels=hp.x)) if which == "fused" else \
      (lambda: _vq_forward(hp.z, w, 0.25, True, None, prepared=prep))
 t = bench.graph_kernel_time(fn)
 print(f"{which}: HIP events, 20 launches per graph x 5 replays: {t:.2f} us per launch", flush=True)
