@@ -461,6 +461,83 @@ def ratio_sweep(dev, x, z, cb, vq, codec, steps=30):
     return out
 
 
+def input_regimes(dev, x, ratio, steps=30):
+    """SURVEY.md 8(d) config 2 beyond N(0,1) latents against an N(0,1) codebook -- the regimes in which the candidate filter has
+    near-ties to resolve and the streams are short: the reference's INIT codebook U(+-1/1024) (quantize.py:26) with latents of
+    the same scale, a clustered codebook of near-duplicate rows, and latents whose index histogram follows the Huffman table
+    (Zipf): same step, same kernels, parity of a sample of images checked against the oracle for each.  Telemetry per variant:
+    vectors that needed the all-K exact scan, groups rerun on the exact loop, groups with a second candidate set (cgic_vq_stats),
+    the self-synchronising decoder's sweeps per image (cgic_decode_stats), bits per coded symbol."""
+    import control_gic_amd as cg
+    B, H, W = x.shape[0], x.shape[2], x.shape[3]
+    N = B * (H // 4) * (W // 4)
+    rng = np.random.default_rng(77)
+    cb_n = np.random.default_rng(12345).standard_normal((1024, 4), dtype=np.float32)
+    u = lambda shape: ((rng.random(shape, dtype=np.float32) * 2 - 1) / np.float32(1024)).astype(np.float32)
+    centres = rng.standard_normal((64, 4), dtype=np.float32)
+    cb_cl = (centres[rng.integers(0, 64, 1024)] + np.float32(1e-4) * rng.standard_normal((1024, 4), dtype=np.float32)).astype(np.float32)
+    p = zipf_freq().astype(np.float64); p /= p.sum()
+    pick = rng.choice(1024, size=(B, H // 4, W // 4), p=p)
+    z_zipf = (cb_n[pick] + np.float32(0.02) * rng.standard_normal((B, H // 4, W // 4, 4), dtype=np.float32)).transpose(0, 3, 1, 2).copy()
+    variants = [
+        ("normal", rng.standard_normal((B, 4, H // 4, W // 4), dtype=np.float32), cb_n, "z ~ N(0,1), codebook ~ N(0,1): the timed step's inputs"),
+        ("init_uniform", u((B, 4, H // 4, W // 4)), u((1024, 4)), "z, codebook ~ U(+-1/1024): the reference's codebook at initialisation (quantize.py:26)"),
+        ("clustered_codebook", rng.standard_normal((B, 4, H // 4, W // 4), dtype=np.float32), cb_cl,
+         "codebook = 64 centres ~ N(0,1), 16 near-duplicates each (1e-4 apart): many runner-up tiles inside the margin"),
+        ("zipf_matched", z_zipf, cb_n, "z = codebook rows drawn from the Huffman table's own distribution + 0.02 N(0,1): short streams"),
+    ]
+    xd = torch.from_numpy(x).to(dev)
+    lib = cg._lib.lib()
+    out = {}
+    base = None
+    for name, z, cb, what in variants:
+        vq = make_quantizer(dev, cb)
+        codec = cg.GrainCodec(vq.embedding_counter, vq.embedding.weight)
+        zd = torch.from_numpy(z).to(dev)
+        hp = HotPath(dev, xd, zd, cb, ratio, vq=vq, codec=codec)
+        g = hp.capture()
+        for _ in range(3):
+            g.replay()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            g.replay()
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / steps
+        ok, bpp = check_against_oracle(hp.out, x, z, cb, ratio, images=range(0, B, 16))
+        dt4, _ = lanes_rate(vq, codec, ratio, [(xd, zd)], 4, 4 * steps, copies=4)
+        # telemetry: one eager step with the counters on (throughput decoder = what the lanes run)
+        cnt = torch.zeros(8, dtype=torch.int32, device=dev)
+        lib.cgic_vq_stats(cnt.data_ptr()); lib.cgic_decode_stats(cnt.data_ptr() + 16)
+        try:
+            with cg.decoder_mode("throughput"):
+                r = hp.pipe.run(hp.x, hp.z, None, decode=True)[0]
+            torch.cuda.synchronize()
+        finally:
+            lib.cgic_vq_stats(None); lib.cgic_decode_stats(None)
+        c = cnt.cpu().numpy().astype(np.int64)
+        nsym = int(sum((m.sum() for m in r["mask"])))
+        nbits = float(np.sum(r["comp"].bpp(H * W))) * H * W          # all five streams of all images, headers and mask streams included
+        fused = graph_kernel_time(lambda: vq_route_call(hp), per_graph=10, reps=3)
+        out[name] = {"what": what, "MPixels/s": round(B * H * W / dt / 1e6, 1), "ms_per_step": round(dt * 1e3, 5),
+                     "MPixels/s_4_in_flight": round(B * H * W / dt4 / 1e6, 1), "vq+router_us": round(fused, 2),
+                     "flagged_vector_fraction": round(float(c[0]) / N, 6), "fallback_groups": int(c[1]), "second_set_groups": int(c[2]),
+                     "groups": N // 64, "decoder_sweeps_mean": round(float(c[4]) / max(int(c[5]), 1), 2), "decoder_sweeps_max": int(c[6]),
+                     "bits_per_symbol_incl_masks": round(nbits / max(nsym, 1), 2), "bpp_mean": round(float(np.mean(bpp)), 6), "bpp_match": ok}
+        if base is None:
+            base = out[name]
+        else:
+            out[name]["slowdown_vs_normal_4_in_flight"] = round(base["MPixels/s_4_in_flight"] / out[name]["MPixels/s_4_in_flight"], 3)
+    return out
+
+
+def vq_route_call(hp):
+    from control_gic_amd.quantize import vq_forward_route
+    e8, e16 = hp.out[0], hp.out[1]
+    return vq_forward_route(hp.z, hp.vq.embedding.weight, 0.25, True, e16, e8, hp.router.coarse_grain_ratio, hp.router.medium_grain_ratio,
+                            prepared=hp.pipe.prepared, pixels=hp.x)
+
+
 def div2k_image(dev, cb, vq, codec, iters=8):
     """one 2040x1356 image (DIV2K-typical) through the tiling driver of inference_high_resolution.py: zero-pad to x16,
     768-px grid (6 tiles in 4 shape groups), per-tile routing, same-shape tiles batched, pad / stack copies included;
@@ -966,6 +1043,10 @@ def report(a, dev, world, stream, slots_np, vq, codec, ratio):
         except Exception as e:                                   # an extra data point: never fail the bench line
             res["mask_mismatch"]["tie_heavy_content"] = {"error": str(e)[:200]}
         res["ratio_sweep"] = ratio_sweep(dev, x, z, cb, vq, codec)
+        try:
+            res["input_regimes"] = input_regimes(dev, x, ratio)
+        except Exception as e:                                   # an extra data point: never fail the bench line
+            res["input_regimes"] = {"error": str(e)[:300]}
         res["b1_latency"] = b1_latency(dev, cb, vq, codec)
         res["div2k_image"] = div2k_image(dev, cb, vq, codec)
         res["div2k_tiles"] = [tiles_768(dev, cb, vq, codec, 8, 60), tiles_768(dev, cb, vq, codec, 32, 30)]

@@ -45,12 +45,14 @@ PROTOTYPES = {
     "cgic_last_error": (C.c_char_p, []),
     "cgic_abi_version": (_int, []),
     "cgic_set_decode_mode": (_int, [_int]),
+    "cgic_decode_stats": (_int, [_vp]),
     "cgic_device_count": (_int, []),
     "cgic_launch_graphs": (_int, [C.POINTER(_vp), C.POINTER(_vp), _int]),
     "cgic_ticket_scope_begin": (_int, []),
     "cgic_ticket_scope_end": (_int, []),
     "cgic_ticket_scope_release": (_int, [_int]),
     "cgic_ticket_slots_in_use": (_int, []),
+    "cgic_vq_stats": (_int, [_vp]),
     "cgic_vq_workspace_bytes": (_sz, [_i64]),
     "cgic_conv1x1_rows_f32": (_int, [_vp, _i64, _cv, _vp, _vp]),
     "cgic_vq_prepared_bytes": (_sz, [_int]),

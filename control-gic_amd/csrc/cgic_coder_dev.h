@@ -68,6 +68,8 @@ struct DecodeArgs {
     int32_t *status;         // [B] zeroed here for the merge kernel's atomicMin
     uint32_t *bf;            // [B, 3, parts, 64] range functions exchanged by the parts of decode_split_kernel
     unsigned int *tick;      // [B, 3] ticket slots of decode_split_kernel
+    unsigned int *stats;     // telemetry of the self-synchronising decoder (cgic_decode_stats) or NULL: [0] sweeps summed over the
+                             // images, [1] images, [2] most sweeps of one image
 };
 
 // the self-synchronising one-workgroup-per-image decoder (cgic_decode_ss.hip); launched by cgic_decompress_streams

@@ -1159,6 +1159,13 @@ extern "C" int cgic_decode_stream(const cgic_table *t, const uint8_t *in, int64_
 static const size_t kLdsBudget = 150 * 1024;
 
 static std::atomic<int> g_decode_mode{CGIC_DECODE_AUTO};
+static std::atomic<unsigned int *> g_decode_stats{nullptr};
+extern "C" int cgic_decode_stats(unsigned int *device_counters)
+{
+    CGIC_REQUIRE(((uintptr_t)device_counters & 3u) == 0, CGIC_ERR_INVALID, "decode_stats: the counters must be 4-byte aligned");
+    g_decode_stats.store(device_counters, std::memory_order_relaxed);
+    return CGIC_OK;
+}
 extern "C" int cgic_set_decode_mode(int mode)
 {
     CGIC_REQUIRE(mode == CGIC_DECODE_AUTO || mode == CGIC_DECODE_LATENCY || mode == CGIC_DECODE_THROUGHPUT, CGIC_ERR_INVALID,
@@ -1220,6 +1227,7 @@ extern "C" int cgic_decompress_streams(const cgic_table *t, const uint8_t *in, i
     if (lds_d > 48 * 1024)
         { int rc_ = ensure_dynamic_lds((const void *)decode_streams_kernel, (size_t)lds_d); if (rc_) return rc_; }
     d.tick = nullptr;
+    d.stats = g_decode_stats.load(std::memory_order_relaxed);
     // The self-synchronising one-workgroup-per-image decoder when the worst case of the grid fits its LDS: bits <= symbols
     // the three grids can hold x the longest code.  (Longer inputs are an overflow on any path.)
     bool ss = false;

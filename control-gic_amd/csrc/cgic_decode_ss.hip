@@ -238,7 +238,7 @@ __global__ __launch_bounds__(kDecThreads) void decode_image_kernel(DecodeArgs a,
     }
     __syncthreads();
     CGIC_STAMP3(3);
-    [[maybe_unused]] int dbg_sweeps = 0;
+    int dbg_sweeps = 0;
 #ifdef CGIC_PHASE_CLOCKS
     if (blockIdx.x == 0 && tid == 0) { g_phase_clk[23] = C; g_phase_clk[24] = R; int mx = 0; for (int g = 0; g < C; ++g) mx = cnt[g] > mx ? cnt[g] : mx; g_phase_clk[25] = mx; }
 #endif
@@ -257,6 +257,11 @@ __global__ __launch_bounds__(kDecThreads) void decode_image_kernel(DecodeArgs a,
         if (!__syncthreads_or(changed)) break;
     }
     CGIC_STAMP3(4);
+    if (a.stats && tid == 0) {
+        atomicAdd(&a.stats[0], (unsigned int)dbg_sweeps);
+        atomicAdd(&a.stats[1], 1u);
+        atomicMax(&a.stats[2], (unsigned int)dbg_sweeps);
+    }
 #ifdef CGIC_PHASE_CLOCKS
     if (blockIdx.x == 0 && tid == 0) g_phase_clk[9] = dbg_sweeps;
 #endif

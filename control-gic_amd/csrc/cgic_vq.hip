@@ -16,6 +16,8 @@
 // Compiled with -ffp-contract=off; every fused op is an explicit fmaf / MFMA.
 #include "cgic_router_dev.h"
 
+#include <atomic>
+
 #include <stdlib.h>
 
 #include <map>
@@ -211,6 +213,10 @@ struct VqArgs {
     // filter path: the LDS image of the codebook (split fp16 A operands, padded fp32 rows, row norms, maxima) as
     // vq_prepare_kernel left it, or NULL: every workgroup then derives it from `cb` itself
     const void *prep;
+    // telemetry (cgic_vq_stats; NULL = off): [0] vectors that took the all-K exact scan ("flagged"), [1] 64-vector groups that
+    // reran the exact fp32-MFMA loop, [2] groups that evaluated a second candidate set, [3] groups seen -- touched only
+    // inside the rare branches, so a launch without near-ties executes nothing for it
+    unsigned int *stats;
 };
 
 // The reference's quant_conv is a torch.nn.Conv2d(4, 4, 1) on the CPU.  Its fp32 rounding sequence is an fma chain over
@@ -845,6 +851,7 @@ __device__ __forceinline__ void vq_filter_body(const VqArgs &a, unsigned char *s
             // ... and on the other half's best tile where it is a candidate too (lexicographic merge)
             if (__ballot(valid && other && !flag)) {
                 CGIC_DBG_COUNT(1, 1);
+                if (a.stats && lane == 0) atomicAdd(&a.stats[2], 1u);
                 const int cb1 = 32 * tile_of(firstB ? A1 : B1) + (firstB ? 0 : 4);
                 const float4 *rb = cbs + rowpos(cb1);
                 const float *eb = ees + eepos(cb1);
@@ -865,6 +872,7 @@ __device__ __forceinline__ void vq_filter_body(const VqArgs &a, unsigned char *s
             const unsigned long long fmask = __ballot(flag);               // one bit per vector, wave-uniform
             const int nflag = __builtin_popcountll(fmask);
             CGIC_DBG_COUNT(0, nflag);
+            if (a.stats && nflag != 0 && lane == 0) { atomicAdd(&a.stats[0], (unsigned int)nflag); if (nflag > kVqfBulk) atomicAdd(&a.stats[1], 1u); }
             if (nflag != 0 && nflag <= kVqfBulk) {
                 // a few near-ties: the whole wave scans all K codes exactly for each such vector
                 unsigned long long todo = fmask;
@@ -1174,6 +1182,9 @@ static int vq_check(const float *z, int64_t B, int64_t hw, const float *cb, int 
     return CGIC_OK;
 }
 
+// telemetry target of the filter path's launches (cgic_vq_stats): process-wide, read when a launch is enqueued / captured
+static std::atomic<unsigned int *> g_vq_stats{nullptr};
+
 static int prepared_check(const void *prepared, int K)
 {
     CGIC_REQUIRE(!prepared || (((uintptr_t)prepared & 15) == 0 && K % 64 == 0 && K <= 1024), CGIC_ERR_INVALID,
@@ -1210,7 +1221,7 @@ static int launch_mfma(const float *z, int64_t hw, int64_t N, const float *cb, i
     a.z = z; a.hw = hw; a.N = N; a.cb = cb; a.K = K; a.idx_out = idx; a.zq_out = zq;
     a.sq_partial = loss ? ws.partial : nullptr; a.ticket = ws.ticket; a.beta = beta; a.legacy = legacy; a.loss = loss;
     a.nblk = (unsigned int)((N + per_block - 1) / per_block);
-    a.n_early = a.g_early = a.g_late = 0; a.conv_w = a.conv_b = nullptr; a.conv_bias_first = 0; a.prep = nullptr;
+    a.n_early = a.g_early = a.g_late = 0; a.conv_w = a.conv_b = nullptr; a.conv_bias_first = 0; a.prep = nullptr; a.stats = nullptr;
     size_t lds = sizeof(float) * (size_t)K * 5;
     if (!router) {
         int rc = ensure_dynamic_lds((const void *)vq_mfma_kernel<ZT>, lds);
@@ -1267,6 +1278,7 @@ static int launch_filter(const float *z, int64_t hw, int64_t N, const float *cb,
     a.nblk = (unsigned int)nblk;
     a.conv_w = CONV ? qc->weight : nullptr; a.conv_b = CONV ? qc->bias : nullptr; a.conv_bias_first = CONV ? qc->bias_first : 0;
     a.prep = prepared;
+    a.stats = g_vq_stats.load(std::memory_order_relaxed);
     // groups per workgroup.  Router workgroups in front: the `late` VQ workgroups that must wait for a router's CU
     // (~11 us at 256x256, ~`delta` groups of VQ work) own `g_late` groups, the others `g_early`, a multiple of 4
     int64_t per = (ngroups + nblk - 1) / nblk, g_early = per, g_late = per, n_early = nblk;
@@ -1345,6 +1357,13 @@ extern "C" size_t cgic_vq_workspace_bytes(int64_t n_vectors)
 {
     // one double per workgroup; (n / 16 + 1) covers every tiling of both paths
     return sizeof(double) * (size_t)((n_vectors + 15) / 16 + 1);
+}
+
+extern "C" int cgic_vq_stats(unsigned int *device_counters)
+{
+    CGIC_REQUIRE(((uintptr_t)device_counters & 3u) == 0, CGIC_ERR_INVALID, "vq_stats: the counters must be 4-byte aligned");
+    g_vq_stats.store(device_counters, std::memory_order_relaxed);
+    return CGIC_OK;
 }
 
 extern "C" size_t cgic_vq_prepared_bytes(int K)

@@ -125,6 +125,12 @@ typedef struct cgic_conv1x1 {
 /* out[n] = conv(rows[n]) for n rows of 4 floats (post_quant_conv applied to the codebook, model.py:52,115) */
 int cgic_conv1x1_rows_f32(const float *rows, int64_t n, const cgic_conv1x1 *conv, float *out, cgic_stream_t stream);
 
+/* Telemetry of the candidate-filter path (K % 64 == 0, K <= 1024): launches enqueued (or captured) after this call add to
+ * device_counters[0..3] (uint32, device memory, zeroed by the caller): [0] vectors whose runner-up tile was inside the
+ * margin, so that the wave scanned all K codes exactly for them; [1] 64-vector groups with more than 12 such vectors, rerun
+ * on the exact fp32-MFMA loop; [2] groups that evaluated a second 16-code candidate set exactly.  NULL switches it off (the
+ * default).  Process-wide; the counters are only touched inside those rare branches.  Results never depend on it. */
+int cgic_vq_stats(unsigned int *device_counters);
 size_t cgic_vq_workspace_bytes(int64_t n_vectors);
 /* bytes of the prepared codebook image (0: this K only has the exact loop, which needs none) / make it (one small launch) */
 size_t cgic_vq_prepared_bytes(int K);
@@ -350,6 +356,10 @@ size_t cgic_decompress_workspace_bytes(int64_t B, int64_t h, int64_t w);
 #define CGIC_DECODE_LATENCY 1
 #define CGIC_DECODE_THROUGHPUT 2
 int cgic_set_decode_mode(int mode);
+/* Telemetry of the self-synchronising decoder (CGIC_DECODE_THROUGHPUT): launches enqueued (or captured) after this call add to
+ * device_counters[0..2] (uint32, device memory, zeroed by the caller): [0] fix-point sweeps summed over the images, [1] images,
+ * [2] the most sweeps one image needed.  NULL switches it off (the default).  Process-wide; results never depend on it. */
+int cgic_decode_stats(unsigned int *device_counters);
 int cgic_decompress_streams(const cgic_table *t, const uint8_t *in, int64_t slot, const int32_t *nbytes,
                             int64_t B, int64_t h, int64_t w, int mode, int64_t *ind_out,
                             int32_t *mask_c_out, int32_t *mask_m_out, int32_t *mask_f_out,

@@ -464,3 +464,54 @@ def test_split_decode_tiny_and_huge_streams_round_trip(orc, golden, ratio, shape
     assert int(status.abs().max()) == 0 and np.array_equal(dind.cpu().numpy(), exp)
     assert all(torch.equal(a, b_) for a, b_ in zip(dmask, mask))
     assert torch.equal(zq, codec.codebook[dind].permute(0, 3, 1, 2))
+
+
+def test_telemetry_counters_do_not_change_results(orc):
+    """cgic_vq_stats / cgic_decode_stats: device counters of the rare branches (flagged vectors, groups rerun exactly, second
+    candidate sets; the self-synchronising decoder's sweeps).  Same outputs with and without them; a clustered codebook of
+    near-duplicate rows drives every group onto the exact loop and says so; N(0,1) inputs flag well under 1 % of the vectors."""
+    from control_gic_amd.quantize import _vq_forward
+    lib = cg._lib.lib()
+    rng = np.random.default_rng(3)
+    z = torch.from_numpy(rng.standard_normal((8, 4, 64, 64), dtype=np.float32)).to(DEV)
+    cb_n = rng.standard_normal((1024, 4), dtype=np.float32)
+    cb_c = (rng.standard_normal((64, 4), dtype=np.float32)[rng.integers(0, 64, 1024)] + np.float32(1e-4) * rng.standard_normal((1024, 4), dtype=np.float32)).astype(np.float32)
+    N = 8 * 64 * 64
+    for cb, clustered in ((cb_n, False), (cb_c, True)):
+        w = torch.from_numpy(cb).to(DEV)
+        ref = _vq_forward(z, w, 0.25, True, None)
+        cnt = torch.zeros(4, dtype=torch.int32, device=DEV)
+        assert lib.cgic_vq_stats(cnt.data_ptr()) == 0
+        try:
+            got = _vq_forward(z, w, 0.25, True, None)
+            torch.cuda.synchronize()
+        finally:
+            lib.cgic_vq_stats(None)
+        assert torch.equal(ref[2], got[2]) and torch.equal(ref[0], got[0]) and float(ref[1]) == float(got[1])
+        _, _, oidx = orc.vq(z[:1].cpu().numpy(), cb)
+        assert np.array_equal(got[2][:4096].cpu().numpy(), oidx)
+        c = cnt.cpu().numpy()
+        if clustered:
+            assert c[1] == N // 64 and c[0] > N // 2, c            # every group reran the exact loop
+        else:
+            assert c[1] == 0 and 0 < c[0] < N // 100, c
+    # decoder sweeps
+    vq = cg.VectorQuantizer(1024, 4, beta=0.25).to(DEV).eval()
+    vq.usage_counter.copy_(torch.arange(1024, 0, -1, dtype=torch.float32))
+    codec = cg.GrainCodec(vq.embedding_counter, vq.embedding.weight)
+    ind = torch.from_numpy(rng.integers(0, 1024, (6, 64, 64))).to(DEV)
+    e16 = torch.from_numpy((rng.random((6, 16, 16)) * 2.6).astype(np.float32)).to(DEV)
+    e8 = torch.from_numpy((rng.random((6, 32, 32)) * 2.6).astype(np.float32)).to(DEV)
+    mask, _, _, mode = cg.TripleGrainFixedEntropyRouter(0.1, 0.8, per_image=True)(e16, e8)
+    comp = codec.compress(ind, mask, mode)
+    a = codec.decompress(comp, decoder="throughput")
+    cnt = torch.zeros(4, dtype=torch.int32, device=DEV)
+    assert lib.cgic_decode_stats(cnt.data_ptr()) == 0
+    try:
+        b = codec.decompress(comp, decoder="throughput")
+        torch.cuda.synchronize()
+    finally:
+        lib.cgic_decode_stats(None)
+    assert torch.equal(a[0], b[0]) and int(b[3].abs().max()) == 0
+    c = cnt.cpu().numpy()
+    assert c[1] == 6 and 6 <= c[0] <= 6 * 40 and 1 <= c[2] <= 40, c
