@@ -798,6 +798,170 @@ class StubStream:
         pass
 
 
+MIXED_KODAK, MIXED_DIV2K = (512, 768), (1356, 2040)      # (H, W): BASELINE config 5
+
+
+def mixed_sizes(n_div2k):
+    """the stream of BASELINE config 5: 24 Kodak-sized images and n DIV2K-sized ones"""
+    return [MIXED_KODAK] * 24 + [MIXED_DIV2K] * n_div2k
+
+
+def mixed_share(sizes, rank, world):
+    """(Kodak images, DIV2K images, pixels, latent vectors) of a rank: round-robin per size class -- the Kodak-sized images are
+    dealt from rank 0 upwards, the DIV2K-sized ones (5.9 times the pixels each) from the last rank downwards, so that a remainder
+    of one class lands where the other class left room"""
+    nk_all, nd_all = sizes.count(MIXED_KODAK), sizes.count(MIXED_DIV2K)
+    nk = len(range(rank, nk_all, world))
+    nd = len(range(world - 1 - rank, nd_all, world))
+    vec = lambda H, W: (-(-H // 16) * 4) * (-(-W // 16) * 4)                 # latent vectors of an image (DIV2K: padded to x16)
+    return nk, nd, nk * MIXED_KODAK[0] * MIXED_KODAK[1] + nd * MIXED_DIV2K[0] * MIXED_DIV2K[1], nk * vec(*MIXED_KODAK) + nd * vec(*MIXED_DIV2K)
+
+
+class StubMixed:
+    """CPU stand-in for MixedStream (launcher / reduction tests only)"""
+
+    def __init__(self, vectors):
+        self.hist = torch.zeros(1024, dtype=torch.int64)
+        self.vectors = vectors
+
+    def submit(self, n=1, collective=None):
+        for _ in range(n):
+            self.hist[3] += self.vectors
+        self.work = collective(self.hist) if collective is not None else None
+
+    def join(self):
+        if getattr(self, "work", None) is not None:
+            self.work.wait()
+
+
+class MixedStream:
+    """One rank's share of BASELINE config 5 (Kodak 768x512 + DIV2K 2040x1356 images, round-robin over the ranks) as two
+    independent chains on two hardware queues: the Kodak-sized images as ONE batch through the hot path, the DIV2K-sized ones
+    through the tiling driver with the equal-shape tiles of all of them batched (highres.compress_tiled_batch).  Each chain is
+    an encode hipGraph and a decode hipGraph; on the LAST step of a submit the histogram all-reduce -- the path's only
+    collective -- is issued as soon as both encode graphs are enqueued and runs under the decode side."""
+
+    def __init__(self, dev, rank, nk, nd, vq, codec, ratio, hist):
+        import control_gic_amd as cg
+        from control_gic_amd import highres
+        from control_gic_amd.quantize import vq_forward_route
+        self.dev, self.hist = dev, hist
+        rng = np.random.default_rng(500 + rank)
+        st = cg.pipeline.distinct_queue_streams(dev, 2)
+        self.chains = []
+        lib = cg._lib
+        if nk:
+            H, W = MIXED_KODAK
+            xk = torch.from_numpy(rng.random((nk, 3, H, W), dtype=np.float32)).to(dev)
+            zk = torch.from_numpy(rng.standard_normal((nk, 4, H // 4, W // 4), dtype=np.float32)).to(dev)
+            pipe = cg.pipeline.HotPathPipeline(vq, ratio[0], ratio[1], frequency=codec.huffman, prepare=True)
+            box = {}
+
+            def k_enc():
+                e8, e16 = cg.entropy_maps(xk)
+                zq, loss, ind, mask, _, mode = vq_forward_route(zk, vq.embedding.weight, vq.beta, vq.legacy, e16, e8, ratio[0], ratio[1],
+                                                              per_image=True, prepared=pipe.prepared, pixels=xk)
+                box["comp"] = codec.compress(ind, mask, mode, hist=hist)
+                return box["comp"]
+
+            def k_dec():
+                box["dec"] = codec.decompress(box["comp"], decoder="throughput")
+                return box["dec"]
+            self.chains.append((st[0], k_enc, k_dec, box))
+        if nd:
+            H, W = MIXED_DIV2K
+            xd = torch.from_numpy(rng.random((nd, 3, H, W), dtype=np.float32)).to(dev)
+            zs = {}
+            box2 = {}
+
+            def encode(tiles):
+                T, _, th, tw = tiles.shape
+                key = (T, th, tw)
+                if key not in zs:
+                    zs[key] = torch.from_numpy(np.random.default_rng(th * 7 + tw).standard_normal((T, 4, th // 4, tw // 4), dtype=np.float32)).to(dev)
+                e8, e16 = cg.entropy_maps(tiles)
+                _, _, ind, mask, _, mode = vq_forward_route(zs[key], vq.embedding.weight, 0.25, True, e16, e8, ratio[0], ratio[1], per_image=True,
+                                                            pixels=tiles)
+                lib.call("cgic_index_histogram", ind.data_ptr(), ind.numel(), 1024, hist.data_ptr(), lib.current_stream(dev))
+                return ind, mask, mode
+
+            def d_enc():
+                box2["tiled"] = highres.compress_tiled_batch(xd, encode, codec)
+                return box2["tiled"]
+
+            def d_dec():
+                with cg.decoder_mode("throughput"):
+                    box2["dec"] = highres.decompress_tiled_batch(box2["tiled"], codec, check=False)
+                return box2["dec"]
+            self.chains.append((st[1], d_enc, d_dec, box2))
+        self.graphs = []
+        cur = torch.cuda.current_stream(dev)
+        for stream, enc, dec, _ in self.chains:
+            stream.wait_stream(cur)
+            with torch.cuda.stream(stream):
+                for _ in range(2):
+                    enc(); dec()
+            torch.cuda.synchronize(dev)
+            ge, _ = cg.capture_graph(enc, stream)
+            gd, _ = cg.capture_graph(dec, stream)
+            self.graphs.append((stream, ge, gd))
+        torch.cuda.synchronize(dev)
+        self.work = None
+
+    def submit(self, n=1, collective=None):
+        cur = torch.cuda.current_stream(self.dev)
+        for k in range(n):
+            last = k == n - 1 and collective is not None
+            for stream, ge, gd in self.graphs:
+                with torch.cuda.stream(stream):
+                    ge.replay()
+                    if not last:
+                        gd.replay()
+            if last:
+                for stream, _, _ in self.graphs:
+                    cur.wait_stream(stream)
+                self.work = collective(self.hist)          # async: RCCL's stream, ordered after the encode sides
+                for stream, _, gd in self.graphs:
+                    with torch.cuda.stream(stream):
+                        gd.replay()
+
+    def join(self):
+        cur = torch.cuda.current_stream(self.dev)
+        for stream, _, _ in self.graphs:
+            cur.wait_stream(stream)
+        if self.work is not None:
+            self.work.wait()
+            self.work = None
+
+    def round_trip_ok(self):
+        """decoded indices == encoded ones wherever the fine grain kept them, statuses zero (after a join + synchronize)"""
+        ok = True
+        for _, _, _, box in self.chains:
+            if "comp" in box:
+                ok = ok and int(box["dec"][3].abs().max()) == 0
+            else:
+                per, status = box["dec"]
+                ok = ok and int(status.abs().max()) == 0
+        return bool(ok)
+
+
+def mixed_extra(dev, vq, codec, ratio, n_div2k=8, steps=10):
+    """BASELINE config 5 on this one GPU (`python bench.py --workload mixed [--gpus N]` is the same as a bench line of its own)"""
+    sizes = mixed_sizes(n_div2k)
+    nk, nd, pix, vec = mixed_share(sizes, 0, 1)
+    hist = torch.zeros(1024, dtype=torch.int64, device=dev)
+    ms = MixedStream(dev, 0, nk, nd, vq, codec, ratio, hist)
+    ms.submit(2); ms.join(); torch.cuda.synchronize()
+    hist.zero_()
+    t0 = time.perf_counter()
+    ms.submit(steps); ms.join(); torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    ok = ms.round_trip_ok() and int(hist.sum()) == steps * vec
+    return {"workload": f"{nk} images of 768x512 (one batch) + {nd} of 2040x1356 (per-shape tile batches), two independent queues, encode + decode hipGraphs",
+            "MPixels/s": round(pix / dt / 1e6, 1), "ms_per_pass": round(dt * 1e3, 4), "round_trip_and_histogram_ok": bool(ok),
+            "note": "python bench.py --workload mixed --gpus N shards the same stream over N ranks (strong scaling) with the histogram all-reduce under the last decode"}
+
+
 def run_rank(a, rank, world, local):
     stub = bool(a.stub)
     dist = None
@@ -848,7 +1012,28 @@ def run_rank(a, rank, world, local):
     B, H, W = a.batch, a.size, a.size
     ratio = (0.1, 0.8)
     h, w = H // 4, W // 4
-    if stub:
+    mixed = a.workload == "mixed"
+    if mixed:
+        sizes = mixed_sizes(a.div2k)
+        nk, nd, pix_rank, vec_rank = mixed_share(sizes, rank, world)
+        pix_all = sum(hh * ww for hh, ww in sizes)
+        vec_all = sum(mixed_share(sizes, r, world)[3] for r in range(world))
+        n_slots, slots_np = 1, []
+        if stub:
+            stream = StubMixed(vec_rank)
+            hist = stream.hist
+        else:
+            import control_gic_amd as cg
+            cb = make_inputs(1, 16, 16, 0)[2]
+            vq = make_quantizer(dev, cb)
+            codec = cg.GrainCodec(vq.embedding_counter, vq.embedding.weight)
+            hist = torch.zeros(1024, dtype=torch.int64, device=dev)
+            stream = MixedStream(dev, rank, nk, nd, vq, codec, ratio, hist)
+            stream.submit(a.warmup)
+            stream.join()
+            sync()
+            hist.zero_()
+    elif stub:
         stream, slots_np, n_slots = StubStream(B, h, w), [], 2
         hist = stream.hist
     else:
@@ -885,11 +1070,17 @@ def run_rank(a, rank, world, local):
 
     barrier()
     t0 = time.perf_counter()
-    stream.submit(a.steps)                                  # exactly K steps
-    stream.join()
-    if dist is not None and world > 1:
-        # the path's only exchange: global usage histogram (int64, exact) -- once per stream of batches
-        dist.all_reduce(hist, op=dist.ReduceOp.SUM)
+    if mixed:
+        # the path's only exchange goes out as soon as the last pass's encode side is enqueued and runs under its decode side
+        coll = (lambda hh: dist.all_reduce(hh, op=dist.ReduceOp.SUM, async_op=True)) if dist is not None and world > 1 else None
+        stream.submit(a.steps, collective=coll)
+        stream.join()
+    else:
+        stream.submit(a.steps)                              # exactly K steps
+        stream.join()
+        if dist is not None and world > 1:
+            # the path's only exchange: global usage histogram (int64, exact) -- once per stream of batches
+            dist.all_reduce(hist, op=dist.ReduceOp.SUM)
     barrier()
     dt = time.perf_counter() - t0
     if dist is not None and world == 1:
@@ -914,8 +1105,32 @@ def run_rank(a, rank, world, local):
             best = min(best, time.perf_counter() - ta)
         allreduce_us = round(best * 1e6, 1)
     hist_total = int(hist.sum().item())
-    if hist_total != world * a.steps * B * h * w:
-        raise SystemExit(f"bench.py: usage histogram lost counts ({hist_total} != {world * a.steps * B * h * w})")
+    want_total = a.steps * vec_all if mixed else world * a.steps * B * h * w
+    if hist_total != want_total:
+        raise SystemExit(f"bench.py: usage histogram lost counts ({hist_total} != {want_total})")
+    if mixed:
+        if rank == 0:
+            ok = True if stub else stream.round_trip_ok()
+            pix = [mixed_share(sizes, r, world)[2] for r in range(world)]
+            res = {
+                "metric": "encode+decode MPixels/s at fixed granularity ratio; bpp match vs reference",
+                "value": round(a.steps * pix_all / dt / 1e6, 2), "unit": "MPixels/s",
+                "n_gpus": world, "rccl_ranks": ranks_seen, "steps": a.steps, "warmup": a.warmup,
+                "per_rank_MPixels/s": [round(a.steps * p / t / 1e6, 2) for p, t in zip(pix, per_rank)],
+                "histogram_allreduce_us": allreduce_us, "ms_per_step": round(dt / a.steps * 1e3, 5),
+                "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                "round_trip_ok": ok,
+                "config": {"workload": f"mixed stream (BASELINE config 5): 24 images of 768x512 + {a.div2k} of 2040x1356 (tiled 768, 6 tiles each), "
+                                       "sharded round-robin over the ranks; one step = one pass over the whole stream; hot path only, latent synthetic",
+                           "launch": "stub" if stub else "per rank: the Kodak-sized images as one batch and the DIV2K-sized ones as per-shape tile batches, two "
+                                     "independent hardware queues, an encode and a decode hipGraph each; the int64[1024] histogram all-reduce is issued "
+                                     "async once the last pass's encode graphs are enqueued",
+                           "sharding": f"images per rank: {[mixed_share(sizes, r, world)[:2] for r in range(world)]} (Kodak, DIV2K)"}}
+            print(json.dumps(res), flush=True)
+        if dist is not None:
+            barrier()
+            dist.destroy_process_group()
+        return
 
     if rank == 0:
         res = {
@@ -1051,6 +1266,10 @@ def report(a, dev, world, stream, slots_np, vq, codec, ratio):
         res["div2k_image"] = div2k_image(dev, cb, vq, codec)
         res["div2k_tiles"] = [tiles_768(dev, cb, vq, codec, 8, 60), tiles_768(dev, cb, vq, codec, 32, 30)]
         try:
+            res["mixed_stream"] = mixed_extra(dev, vq, codec, ratio)
+        except Exception as e:                                   # an extra data point: never fail the bench line
+            res["mixed_stream"] = {"error": str(e)[:300]}
+        try:
             res["end_to_end_estimate"] = end_to_end_estimate(dev, res["single_batch"]["ms_per_step"], B, H, W)
         except Exception as e:                                   # (MIOpen missing / out of memory: the estimate is optional)
             res["end_to_end_estimate"] = {"error": str(e)[:200]}
@@ -1080,6 +1299,9 @@ def parse_args(argv=None):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--workload", choices=["batch", "mixed"], default="batch",
+                    help="batch: BASELINE config 2 (the headline); mixed: config 5, a Kodak + DIV2K stream sharded over the ranks (total work fixed: strong scaling)")
+    ap.add_argument("--div2k", type=int, default=8, help="--workload mixed: DIV2K-sized images in the stream (next to 24 Kodak-sized ones)")
     ap.add_argument("--batch", type=int, default=64)
     ap.add_argument("--size", type=int, default=256)
     ap.add_argument("--schedule", choices=["pipelined", "sequential"], default="sequential",

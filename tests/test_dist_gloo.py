@@ -132,6 +132,31 @@ def test_bench_spawns_its_own_ranks():
     assert solo["rccl_ranks"] is None and solo["histogram_allreduce_us"] is None
 
 
+def test_bench_mixed_workload_shards_the_stream():
+    """`bench.py --workload mixed` (BASELINE config 5: 24 Kodak-sized + N DIV2K-sized images, round-robin over the ranks, ONE
+    histogram all-reduce issued async under the last decode side): launcher, sharding and reduction logic over gloo with the CPU
+    stand-in for the kernels -- strong scaling (the stream is fixed), exact histogram total, per-rank rates"""
+    import json
+    import bench
+    sizes = bench.mixed_sizes(8)
+    assert len(sizes) == 32 and sizes.count(bench.MIXED_DIV2K) == 8
+    shares = [bench.mixed_share(sizes, r, 2) for r in range(2)]
+    assert sum(s[0] for s in shares) == 24 and sum(s[1] for s in shares) == 8 and shares[0][:2] == shares[1][:2] == (12, 4)
+    for world in (3, 4, 8):
+        sh = [bench.mixed_share(sizes, r, world) for r in range(world)]
+        assert sum(v[0] for v in sh) == 24 and sum(v[1] for v in sh) == 8 and max(v[2] for v in sh) <= 1.35 * min(v[2] for v in sh)
+    assert bench.mixed_share(sizes, 0, 1)[3] == 24 * 128 * 192 + 8 * 340 * 512          # latent vectors (DIV2K padded to 1360 x 2048)
+    for gpus in (1, 2):
+        r = _bench(["--gpus", str(gpus), "--stub", "--workload", "mixed", "--steps", "3", "--warmup", "1"])
+        assert r.returncode == 0, r.stdout + r.stderr
+        lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+        assert len(lines) == 1, r.stdout
+        d = json.loads(lines[0])
+        assert d["n_gpus"] == gpus and d["rccl_ranks"] == gpus and d["scaling"] == "strong" and "mixed stream" in d["config"]["workload"]
+        pix = 24 * 512 * 768 + 8 * 1356 * 2040
+        assert abs(d["value"] - 3 * pix / (d["ms_per_step"] * 3 * 1e-3) / 1e6) / d["value"] < 1e-3 and len(d["per_rank_MPixels/s"]) == gpus
+
+
 def test_bench_refuses_a_mismatched_world():
     """under a launcher whose WORLD_SIZE differs from --gpus, or without enough GPUs, bench.py exits non-zero instead of
     silently benchmarking fewer GPUs than it reports"""
