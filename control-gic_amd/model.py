@@ -68,11 +68,29 @@ def decoder_blend_fine(h, h_fine, mask, out=None):
 
 
 def _codec_for(model, h_indices=None):
+    """the model's GrainCodec, rebuilt when what it was built from changed: the codebook tensor, the usage counters (the
+    Huffman table IS the counters: a train() step between two compress() calls changes it -- round 3 kept a stale table), or the
+    coder object the caller hands in.  `h_indices` (model.py:206): a control_gic_amd HuffmanCoding is used as it is; a FOREIGN
+    coder (the reference's own class, whose codes the GPU coder cannot take over) must describe the same code as the counters
+    do, otherwise its files would not be what this compress() writes: that raises instead of being ignored."""
+    q = model.quantize
+    own = h_indices if isinstance(h_indices, HuffmanCoding) else None
+    counter = q.usage_counter if hasattr(q, "usage_counter") else None
     c = getattr(model, "_cgic_codec", None)
-    if c is None or c.codebook is not model.quantize.embedding.weight:
-        huff = h_indices if isinstance(h_indices, HuffmanCoding) else HuffmanCoding(model.quantize.embedding_counter)
-        c = GrainCodec(huff, model.quantize.embedding.weight)
+    key = getattr(model, "_cgic_codec_key", None)
+    fresh = (c is not None and key is not None and c.codebook is q.embedding.weight and key[0] is own
+             and (counter is None or (key[1].device == counter.device and torch.equal(key[1], counter))))
+    if not fresh:
+        huff = own if own is not None else HuffmanCoding(q.embedding_counter)
+        c = GrainCodec(huff, q.embedding.weight)
         model._cgic_codec = c
+        model._cgic_codec_key = (own, None if counter is None else counter.detach().clone())
+    if h_indices is not None and own is None:
+        theirs = getattr(h_indices, "codes", None)
+        if not isinstance(theirs, dict) or {int(k): v for k, v in theirs.items()} != c.huffman.codes:
+            raise ValueError("compress(h_indices=...): the coder handed in does not carry the code table of this model's "
+                             "embedding_counter (or is not a Huffman coder with .codes); build it from "
+                             "model.quantize.embedding_counter like inference.py:150, or pass a control_gic_amd.HuffmanCoding")
     return c
 
 
@@ -127,8 +145,25 @@ def compress(self, input, path, h_indices=None, h_mask=None, save_img=False):
     return dec, bpp[0], None
 
 
-def install(model, per_image=False, fuse_convs=True):
+class AvgPool(torch.nn.Module):
+    """torch.nn.AvgPool2d(k, k, 0) on the library's kernel (decoder.py:304-305): bit-identical to the CPU kernel, differentiable"""
+
+    def __init__(self, k):
+        super().__init__()
+        self.k = int(k)
+
+    def forward(self, x):
+        if not x.is_cuda or x.dtype != torch.float32 or x.dim() != 4 or x.shape[2] % self.k or x.shape[3] % self.k:
+            return torch.nn.functional.avg_pool2d(x, self.k, self.k, 0)
+        return torch.ops.cgic.avg_pool(x, self.k)
+
+
+def install(model, per_image=False, fuse_convs=True, patch_pools=True):
     """swap VectorQuantize2 / Entropy / router target / compress of a reference CGIC instance in place.
+    patch_pools: the decoder's two average pools in front of its masked blends (decoder.avgpool_layer1 / _layer2,
+    decoder.py:304-305,366-367) become control_gic_amd.model.AvgPool -- they are modules, so they can be swapped.  The three
+    masked-blend EXPRESSIONS (vqvae_blocks.py:364-366, decoder.py:372-378) are inline arithmetic of the reference's forward
+    methods: using grain_merge / decoder_blend_medium / decoder_blend_fine there takes the two source edits INTEGRATION.md shows.
     per_image=False keeps the reference's routing for encode() / forward() / training (thresholds over the flattened
     batch, RouterTriple.py:21-31); compress_batch / compress / the tiling driver always route per image.
     fuse_convs: move quant_conv into the VQ kernel and post_quant_conv into the decode-side gather (under no_grad).  The
@@ -154,7 +189,14 @@ def install(model, per_image=False, fuse_convs=True):
             and tuple(model.quant_conv.weight.shape) == (4, 4, 1, 1) and q.n_e % 64 == 0 and q.n_e <= 1024:
         model.quant_conv = FusedQuantConv.adopt(model.quant_conv)          # hands its input to the quantiser as a PendingQuantConv
     model._cgic_fuse_post_quant_conv = bool(fuse_convs)
+    dec = getattr(model, "decoder", None)
+    if patch_pools and dec is not None:
+        for name, k in (("avgpool_layer1", 4), ("avgpool_layer2", 2)):
+            m = getattr(dec, name, None)
+            if isinstance(m, torch.nn.AvgPool2d) and m.kernel_size in (k, (k, k)) and m.stride in (k, (k, k)) and m.padding in (0, (0, 0)):
+                setattr(dec, name, AvgPool(k))
     model.compress = types.MethodType(compress, model)
     model.compress_batch = types.MethodType(compress_batch, model)
     model._cgic_codec = None
+    model._cgic_codec_key = None
     return model

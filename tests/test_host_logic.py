@@ -229,3 +229,31 @@ def test_byte_over_255_formula_of_the_uint8_entropy_kernel_is_torchs_division():
     q2 = (e * np.float64(r) + q.astype(np.float64)).astype(np.float32)
     assert np.array_equal(q2, ref)
     assert int((q != ref).sum()) > 100                                              # the plain product is NOT the quotient
+
+
+def test_codec_follows_the_counters_and_refuses_a_foreign_table():
+    """model._codec_for (behind compress / compress_batch): the Huffman table is rebuilt when embedding_counter changed (a
+    training step between two compress() calls; round 3 kept the stale table), and a coder handed in as h_indices must carry
+    the code of these counters -- a foreign coder with another table raises instead of being silently ignored"""
+    import types
+    from control_gic_amd import model as cm
+    vq = cg.VectorQuantizer(1024, 4, beta=0.25)
+    vq.usage_counter.copy_(torch.arange(1024, 0, -1, dtype=torch.float32))
+    m = types.SimpleNamespace(quantize=vq)
+    c1 = cm._codec_for(m)
+    assert cm._codec_for(m) is c1                                   # unchanged counters: cached
+    codes1 = dict(c1.huffman.codes)
+    with torch.no_grad():
+        vq.usage_counter[5] += 4000.0                              # (what fold_usage_hist does in training)
+    c2 = cm._codec_for(m)
+    assert c2 is not c1 and c2.huffman.codes != codes1
+    assert c2.huffman.codes == cg.HuffmanCoding(vq.embedding_counter).codes
+    own = cg.HuffmanCoding(vq.embedding_counter)
+    assert cm._codec_for(m, own).huffman is own                     # a control_gic_amd coder is used as it is
+    same = types.SimpleNamespace(codes={k: v for k, v in c2.huffman.codes.items()})     # the reference's class: .codes {symbol: bits}
+    cm._codec_for(m, same)
+    other = types.SimpleNamespace(codes=codes1)
+    with pytest.raises(ValueError, match="code table"):
+        cm._codec_for(m, other)
+    with pytest.raises(ValueError, match="code table"):
+        cm._codec_for(m, object())
