@@ -130,6 +130,23 @@ __device__ __forceinline__ T wave_inclusive_scan(T v)
     return v;
 }
 
+// The same for 32-bit integers on DPP operands: four row_shr steps inside the rows of 16 lanes, then row_bcast:15 / row_bcast:31
+// carry the row totals over -- six dependent VALU instructions instead of six LDS-crossbar round trips (ds_bpermute) with a
+// compare and a select each.  Matters where ONE wave's dependent chain is the critical path (the router's histogram scans in the
+// fused VQ + router launch, whose waves only get the issue slots the VQ workgroup leaves over).
+__device__ __forceinline__ unsigned int wave_inclusive_scan_u32(unsigned int v)
+{
+#define CGIC_DPP_ADD(ctrl, rmask) v += (unsigned int)__builtin_amdgcn_update_dpp(0, (int)v, ctrl, rmask, 0xF, false)
+    CGIC_DPP_ADD(0x111, 0xF);        // row_shr:1
+    CGIC_DPP_ADD(0x112, 0xF);        // row_shr:2
+    CGIC_DPP_ADD(0x114, 0xF);        // row_shr:4
+    CGIC_DPP_ADD(0x118, 0xF);        // row_shr:8
+    CGIC_DPP_ADD(0x142, 0xA);        // row_bcast:15 into rows 1 and 3
+    CGIC_DPP_ADD(0x143, 0xC);        // row_bcast:31 into rows 2 and 3
+#undef CGIC_DPP_ADD
+    return v;
+}
+
 // Block-wide exclusive scan of one value per thread (blockDim.x multiple of 64,
 // <= 1024).  `smem` needs blockDim.x/64 + 1 elements.  Returns the exclusive
 // prefix; *total receives the block total.  Contains three __syncthreads().

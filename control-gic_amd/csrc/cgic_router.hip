@@ -46,6 +46,15 @@ int router_prepare(const float *e16, const float *e8, int64_t B, int64_t h16, in
     a.per = per; a.h16 = h16; a.w16 = w16; a.mode = mode;
     a.rank_c = (unsigned int)(k_c != 0 ? k_c - 1 : 0);      // sorted[k-1 if k != 0 else k]
     a.rank_m = (unsigned int)(k_m != 0 ? k_m - 1 : 0);
+    {
+        // magic multipliers of the index divisions (cgic_router_dev.h: fdiv): exact while (largest dividend) x (divisor) < 2^32
+        const int64_t n8 = 4 * h16 * w16, n4 = 16 * h16 * w16, w8 = 2 * w16, w4 = 4 * w16;
+        auto magic = [](int64_t nmax, int64_t d) -> unsigned int {
+            return (d > 1 && nmax * d < ((int64_t)1 << 32)) ? (unsigned int)((((uint64_t)1 << 32) + (uint64_t)d - 1) / (uint64_t)d) : 0u;
+        };
+        a.mg_n8 = magic(N8, n8); a.mg_w8 = magic(n8, w8);
+        a.mg_n4 = magic(4 * N8, n4); a.mg_w4 = magic(n4, w4);
+    }
     a.rf.x = nullptr;
     if (refine && refine->x && (mode <= 3)) {          // (modes 4-6 compare nothing)
         CGIC_REQUIRE(refine->bins && refine->nbins == kBins, CGIC_ERR_UNSUPPORTED, "router: refinement needs the 32 bin centres (model.py:480)");

@@ -33,8 +33,15 @@ struct RouterShared {
 // histogram of pass p+1 was cleared during pass p (three rotating buffers: a slow wave may still be reading
 // pass p-1's while a fast one clears).  The previous 3-barriers-per-pass version cost 2.8 + 5.8 us for the two
 // selects of a 256x256 image.
+// what the last pass of a select knew (every wave computes it): the counts of the low key byte among the elements that share
+// the threshold's upper 24 key bits, the threshold's own byte, and how many elements with the threshold's key sort before it
+struct SelInfo {
+    const unsigned int *h;      // [256], valid until the next select clears it
+    unsigned int digit, before;
+};
+
 template <int NT, typename F>
-__device__ float radix_select(F val, int64_t n, unsigned int rank0, RouterShared *sh)
+__device__ float radix_select(F val, int64_t n, unsigned int rank0, RouterShared *sh, SelInfo *info = nullptr)
 {
     const int tid = threadIdx.x;
     const int lane = lane_id();
@@ -68,20 +75,24 @@ __device__ float radix_select(F val, int64_t n, unsigned int rank0, RouterShared
         }
         __syncthreads();
         // every wave: lane handles 4 consecutive digits; find the digit holding `rank`
-        const unsigned int c0 = h[4 * lane], c1 = h[4 * lane + 1], c2 = h[4 * lane + 2], c3 = h[4 * lane + 3];
-        const unsigned int s = c0 + c1 + c2 + c3;
-        const unsigned int incl = wave_inclusive_scan(s);
+        // (a router wave of the fused launch only gets the issue slots the VQ workgroup on its CU leaves over: what counts below is
+        // the length of the dependent chain -- one 16-byte LDS read, a DPP scan, mask arithmetic, v_readlane -- not the lane count)
+        const uint4 c4 = *reinterpret_cast<const uint4 *>(h + 4 * lane);
+        const unsigned int p1 = c4.x, p2 = p1 + c4.y, p3 = p2 + c4.z, s = p3 + c4.w;
+        const unsigned int incl = wave_inclusive_scan_u32(s);
         const unsigned int excl = incl - s;
         const bool mine = excl <= rank && rank < incl;
-        unsigned int r = rank - excl, d = 4 * lane;
-        if (r >= c0) { r -= c0; ++d; if (r >= c1) { r -= c1; ++d; if (r >= c2) { r -= c2; ++d; } } }
+        const unsigned int rl = rank - excl;                        // (meaningful in the lane that holds the rank)
+        const unsigned int k = (rl >= p1 ? 1u : 0u) + (rl >= p2 ? 1u : 0u) + (rl >= p3 ? 1u : 0u);
+        const unsigned int dl = 4u * lane + k, rr = rl - (k == 0 ? 0u : k == 1 ? p1 : k == 2 ? p2 : p3);
         const unsigned long long who = __ballot(mine);
         const int src = who ? __builtin_ctzll(who) : 0;            // (rank >= n cannot happen: checked on the host)
-        d = __shfl(d, src, kWave);
-        r = __shfl(r, src, kWave);
+        const unsigned int d = (unsigned int)__builtin_amdgcn_readlane((int)dl, src);
+        const unsigned int r = (unsigned int)__builtin_amdgcn_readlane((int)rr, src);
         prefix |= d << shift;
         rank = r;
         himask |= 0xFFu << shift;
+        if (shift == 0 && info) { info->h = h; info->digit = d; info->before = r; }
     }
     __syncthreads();   // all waves are done with the histograms before a later call clears them
     return key2f(prefix);
@@ -101,6 +112,7 @@ struct RouterArgs {
     int bands;             // workgroups per segment (per-image segments only): every one finds the thresholds, each writes
                            // only its band of rows of the masks (one CU per 768x768 tile spent 10 us writing 200 KB of masks)
     RefineSrc rf;          // rf.x != nullptr (stage 1 only): threshold-band refinement from the pixels, see refine_select
+    unsigned int mg_n8, mg_w8, mg_n4, mg_w4;      // ceil(2^32 / d) for d = n8, w8, n4, w4, or 0: divide (router_prepare)
 };
 
 // ---- threshold-band refinement -------------------------------------------------------------------------------------------
@@ -164,12 +176,35 @@ __device__ __forceinline__ void flat_insert(unsigned int *keys, unsigned int key
 // side when there are at most two patches, else by one wave each (no workgroup barrier inside the sweep).
 template <int NT, int P, typename EX>
 __device__ float refine_select(float *arr, int n, unsigned int rank, float t_a, EX is_exact, const RefineSrc &rf, int64_t img0,
-                               int wP, int nP, RefineShared *rs, RouterShared *sh)
+                               int wP, int nP, RefineShared *rs, RouterShared *sh, const SelInfo &si)
 {
     constexpr int NW = NT / 64, NWR = NW < kRefWavesMax ? NW : kRefWavesMax;
     constexpr int UPP = P == 16 ? 4 : 1;              // units (64 pixels, one wave and step) per patch
     const int tid = threadIdx.x, lane = lane_id(), wave = tid >> 6;
     const float w = kRefineBand;
+    // 0. The usual image leaves here WITHOUT a pass over the map and without a barrier: the select's last pass counted the low
+    // key byte of everything that shares the threshold's upper 24 key bits, and a band of +-4e-6 around a value in [0.13, 4) is
+    // at most +-250 such steps -- when both band edges share those 24 bits with the threshold (most of the time for values
+    // above 1), the band's size and the number of its members sorting before the threshold element are sums over that
+    // histogram, which every wave still has in LDS.  (Measured on the timed batch: the counting pass below cost the router's
+    // critical path +1.6 us per select whether or not anything was in the band.)
+    {
+        const uint32_t kt = f2key(t_a), klo = f2key(t_a - w), khi = f2key(t_a + w);
+        if (t_a == t_a && ((klo ^ kt) >> 8) == 0 && ((khi ^ kt) >> 8) == 0) {          // (wave-uniform: t_a is)
+            const unsigned int dlo = klo & 255u, dhi = khi & 255u, dt = si.digit;
+            unsigned int mall = 0, before = 0;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const unsigned int d = 4u * lane + j, c = si.h[d];
+                mall += (d >= dlo && d <= dhi) ? c : 0u;
+                before += (d >= dlo && d < dt) ? c : 0u;
+            }
+#pragma unroll
+            for (int o = 32; o >= 1; o >>= 1) { mall += __shfl_xor(mall, o, kWave); before += __shfl_xor(before, o, kWave); }
+            before += si.before;                       // elements EQUAL to the threshold that sort before it
+            if (mall < 2u || before == 0u) return t_a;      // the threshold element alone / nothing of the band below it (see 1.)
+        }
+    }
     if (tid < 8) rs->cnt[tid] = 0;
     if (tid < kBins) rs->bins[tid] = linspace_bin(tid);
     __syncthreads();
@@ -192,6 +227,11 @@ __device__ float refine_select(float *arr, int n, unsigned int rank, float t_a, 
     __syncthreads();
     const unsigned int m_all = rs->cnt[0], m_inexact = rs->cnt[1], c_below = rs->cnt[3];
     if (m_all < 2 || m_inexact == 0) return t_a;          // (workgroup-uniform) the threshold element alone: nothing can change
+    // The band's members all rank at or above the threshold element (nothing of the band sorts before it): the true threshold is
+    // the SMALLEST exact value of the band, and under the strict '<' no member of the band lies below that -- every one of them
+    // gets 0 whatever the exact values are, everything outside the band keeps its side: t_a already gives the reference's mask.
+    // (Half of the two-member bands of noise-like content.)
+    if (rank == c_below) return t_a;
     // From here on this workgroup is the launch's critical path (in the fused launch it shares its CU with an issue-bound VQ
     // workgroup): its instructions go first.  Measured, 64 images of 256x256, fused launch: routers at priority 3 throughout
     // 25.4 -> 27.4 us when no image refines (the VQ workgroups pay), refining images 35.5 -> 30.3 us; raised only here: both.
@@ -329,7 +369,29 @@ __device__ float refine_select(float *arr, int n, unsigned int rank, float t_a, 
 // The whole router for segment `seg`, executed by a block of NT threads; `dyn` = dynamic LDS of at least
 // router_lds_bytes() bytes.
 template <int NT>
+__device__ __forceinline__ void router_team(const RouterArgs &a, int64_t blk, unsigned char *dyn);
+
+// The router of workgroup `blk`, executed by a block of NT threads.  A small segment (a 256x256 image: 256 + 1024 map values) is
+// routed by a TEAM of CGIC_ROUTER_TEAM threads; the other waves of the workgroup leave at once (they take no part in barriers any
+// more): every wave repeats the histogram scans, and in the fused launch the router's waves only get the issue slots the VQ
+// workgroup on the same CU leaves over -- what counts there is the number of instructions, not the number of lanes.
+#ifndef CGIC_ROUTER_TEAM
+#define CGIC_ROUTER_TEAM 0
+#endif
+template <int NT>
 __device__ __forceinline__ void router_body(const RouterArgs &a, int64_t blk, unsigned char *dyn)
+{
+    constexpr int TEAM = CGIC_ROUTER_TEAM;
+    if (TEAM > 0 && TEAM < NT && a.per * a.h16 * a.w16 * 4 <= 2048) {
+        if ((int)threadIdx.x >= TEAM) return;
+        router_team<(TEAM > 0 && TEAM < NT) ? TEAM : NT>(a, blk, dyn);
+        return;
+    }
+    router_team<NT>(a, blk, dyn);
+}
+
+template <int NT>
+__device__ __forceinline__ void router_team(const RouterArgs &a, int64_t blk, unsigned char *dyn)
 {
     const int nb = a.bands > 1 ? a.bands : 1;
     const int64_t seg = blk / nb;
@@ -340,6 +402,12 @@ __device__ __forceinline__ void router_body(const RouterArgs &a, int64_t blk, un
     const int tid = threadIdx.x;
     const int lane = lane_id();
     CGIC_STAMP(0);
+#ifdef CGIC_PHASE_CLOCKS      // dev: (start, after coarse select, after medium select, end) of the first 64 router workgroups: g_blk_t slots 1024 + 2 blk ..
+#define CGIC_RT_STAMP(k) do { if (threadIdx.x == 0 && blk < 64) g_blk_t[2 * (1024 + 2 * blk) + (k)] = wall_clock64(); } while (0)
+#else
+#define CGIC_RT_STAMP(k) do {} while (0)
+#endif
+    CGIC_RT_STAMP(0);
     const int64_t h16 = a.h16, w16 = a.w16, h8 = 2 * h16, w8 = 2 * w16, h4 = 4 * h16, w4 = 4 * w16;
     const int64_t n16 = h16 * w16, n8 = h8 * w8, n4 = h4 * w4;
     const int64_t N16 = a.per * n16, N8 = a.per * n8, N4 = a.per * n4;
@@ -370,12 +438,14 @@ __device__ __forceinline__ void router_body(const RouterArgs &a, int64_t blk, un
     // ---- coarse gate (RouterTriple.py:21-25 / 52-56 / 63-66)
     float thr_c = 0.f;
     if (has_thr_c) {
-        thr_c = radix_select<NT>([&](int64_t i) { return e16[i]; }, N16, a.rank_c, sh);
+        SelInfo si;
+        thr_c = radix_select<NT>([&](int64_t i) { return e16[i]; }, N16, a.rank_c, sh, &si);
         if (refine)
             thr_c = refine_select<NT, 16>(const_cast<float *>(e16), (int)N16, a.rank_c, thr_c, [](int) { return false; }, a.rf,
-                                          seg * a.per, (int)w16, (int)n16, rs, sh);
+                                          seg * a.per, (int)w16, (int)n16, rs, sh, si);
     }
     CGIC_STAMP(2);
+    CGIC_RT_STAMP(1);
     const int64_t N16r = (N16 + 63) & ~(int64_t)63;
     for (int64_t i = tid; i < N16r; i += NT) {
         bool g = false;
@@ -387,14 +457,18 @@ __device__ __forceinline__ void router_body(const RouterArgs &a, int64_t blk, un
     __syncthreads();
     // 32-bit index math throughout (N8 < 2^31 is checked on the host): a 64-bit divide is ~100 instructions
     const int n8i = (int)n8, w8i = (int)w8, n16i = (int)n16, w16i = (int)w16;
+    // n / d as one v_mul_hi_u32 with m = ceil(2^32 / d): exact while n * d < 2^32 (n < 2^31 / 4 here, d <= 2^13: the host checks);
+    // a 32-bit divide is ~25 instructions, and the sweeps below do two per element
+    const unsigned int mg_n8 = a.mg_n8, mg_w8 = a.mg_w8, mg_n4 = a.mg_n4, mg_w4 = a.mg_w4;
+    auto fdiv = [](int n, unsigned int m, int d) -> int { return m ? (int)__umulhi((unsigned int)n, m) : n / d; };
     auto gc_at = [&](int b, int y8, int x8) -> bool {   // coarse gate of the parent of medium element (y8, x8) of image b
         const int c = b * n16i + (y8 >> 1) * w16i + (x8 >> 1);
         return (gc_bits[c >> 6] >> (c & 63)) & 1ull;
     };
     auto gc_of8 = [&](int64_t i) -> bool {
         const int ii = (int)i;
-        const int b = ii / n8i, r = ii - b * n8i;
-        const int y = r / w8i, x = r - y * w8i;
+        const int b = fdiv(ii, mg_n8, n8i), r = ii - b * n8i;
+        const int y = fdiv(r, mg_w8, w8i), x = r - y * w8i;
         return gc_at(b, y, x);
     };
     // One image per segment (per-image routing: every batched compress): walk rows by wave and columns by lane -- the
@@ -424,19 +498,21 @@ __device__ __forceinline__ void router_body(const RouterArgs &a, int64_t blk, un
                 for (int64_t i = tid; i < N8; i += NT) l8m[i] = l8m[i] * (1.0f - (gc_of8(i) ? 1.0f : 0.0f));
             }
             __syncthreads();
-            thr_m = radix_select<NT>([&](int64_t i) { return l8m[i]; }, N8, a.rank_m, sh);
+            SelInfo si;
+            thr_m = radix_select<NT>([&](int64_t i) { return l8m[i]; }, N8, a.rank_m, sh, &si);
             if (refine)       // (a gated element's 0 is exact: never re-evaluated, never overwritten)
                 thr_m = refine_select<NT, 8>(l8m, (int)N8, a.rank_m, thr_m, [&](int i) { return gc_of8(i); }, a.rf, seg * a.per, w8i,
-                                             n8i, rs, sh);
+                                             n8i, rs, sh, si);
         } else {
             thr_m = radix_select<NT>([&](int64_t i) { return e8[i] * (1.0f - (gc_of8(i) ? 1.0f : 0.0f)); }, N8, a.rank_m, sh);
         }
     }
     if (mode == 1) {      // :40-43
-        thr_m = radix_select<NT>([&](int64_t i) { return e8[i]; }, N8, a.rank_m, sh);
+        SelInfo si;
+        thr_m = radix_select<NT>([&](int64_t i) { return e8[i]; }, N8, a.rank_m, sh, &si);
         if (refine)
             thr_m = refine_select<NT, 8>(const_cast<float *>(e8), (int)N8, a.rank_m, thr_m, [](int) { return false; }, a.rf, seg * a.per,
-                                         w8i, n8i, rs, sh);
+                                         w8i, n8i, rs, sh, si);
     }
     auto gm_rule = [&](float v, bool gc) -> bool {
         switch (mode) {
@@ -449,6 +525,7 @@ __device__ __forceinline__ void router_body(const RouterArgs &a, int64_t blk, un
     };
     auto gm_of8 = [&](int64_t i) -> bool { return gm_rule(e8[i], (mode == 0 || mode == 3) ? gc_of8(i) : false); };
     CGIC_STAMP(4);
+    CGIC_RT_STAMP(2);
     if (rows2d) {
         for (int y = 2 * cy0 + wv; y < 2 * cy1; y += NWV)
             for (int x = lane; x < w8i; x += 64)
@@ -492,12 +569,13 @@ __device__ __forceinline__ void router_body(const RouterArgs &a, int64_t blk, un
     } else {
         for (int q = tid; q < NQ; q += NT) {
             const int i = q << 2;
-            const int b = i / n4i, r = i - b * n4i;
-            const int y = r / W4, x = r - y * W4;
+            const int b = fdiv(i, mg_n4, n4i), r = i - b * n4i;
+            const int y = fdiv(r, mg_w4, W4), x = r - y * W4;
             fine_quad(b, y, x);
         }
     }
     CGIC_STAMP(6);
+    CGIC_RT_STAMP(3);
 }
 
 

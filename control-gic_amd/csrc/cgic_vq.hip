@@ -710,7 +710,24 @@ __device__ __forceinline__ void vq_filter_body(const VqArgs &a, unsigned char *s
     const int a_cap = 15 + sbe - sb, a_min = -14 + sbe - sb;
 
     double sq = 0.0;                    // this lane's share of the loss, over all groups of the wave
+#ifdef CGIC_PHASE_CLOCKS      // dev: per-wave (loop start, loop end) of the first 64 workgroups, slots 512 + 8 wg + wave of g_blk_t
+    if (lane == 0 && vblk < 64 && wave < 8) g_blk_t[2 * (512 + 8 * vblk + wave)] = wall_clock64();
+#endif
+#ifndef CGIC_VQF_TURN_PRIO
+#define CGIC_VQF_TURN_PRIO 1
+#endif
+#ifndef CGIC_VQF_NO_TURNS
+    // Two waves share a SIMD (wave w and w + NW/2), and the arbiter serves the OLDER one first: waves 0..NW/2-1 ran their two
+    // groups in 11.6 us and left, their younger mates then ran alone -- a lone wave's MFMAs and VALU work do not overlap -- until
+    // 14.6 us (per-wave loop clocks, tools/probes/probe_vq_phases.py waves).  The mates take turns instead: group by group the one
+    // that is behind gets the issue priority, so both have work until the end.
+    int turn = wave >= NW / 2 ? 1 : 0;
+#endif
     while (cur < blk_hi) {
+#ifndef CGIC_VQF_NO_TURNS
+        if (turn & 1) __builtin_amdgcn_s_setprio(CGIC_VQF_TURN_PRIO); else __builtin_amdgcn_s_setprio(0);
+        ++turn;
+#endif
         const int64_t grp = cur;
         const int64_t base = grp * G;
         float zv[2][4];
@@ -989,6 +1006,12 @@ __device__ __forceinline__ void vq_filter_body(const VqArgs &a, unsigned char *s
         }
     }
 
+#ifndef CGIC_VQF_NO_TURNS
+    __builtin_amdgcn_s_setprio(0);
+#endif
+#ifdef CGIC_PHASE_CLOCKS
+    if (lane == 0 && vblk < 64 && wave < 8) g_blk_t[2 * (512 + 8 * vblk + wave) + 1] = wall_clock64();
+#endif
     CGIC_STAMP(5);
     if (a.sq_partial) {
         // Only wave 0 stays for the hand-off: the other waves leave at the barrier WITHOUT draining their z_q /
@@ -1045,6 +1068,9 @@ __global__ CGIC_VQF_BOUNDS void vq_filter_router_kernel(VqArgs a, RouterArgs r, 
     // (every VQ workgroup gets a CU at once and the router workgroups move in beside them)
     const unsigned int rb = router_behind ? a.nblk : 0u, vb = router_behind ? 0u : nrouter;
     if (blockIdx.x - rb < nrouter) {
+#ifdef CGIC_ROUTER_PRIO
+        __builtin_amdgcn_s_setprio(CGIC_ROUTER_PRIO);
+#endif
         router_body<kVqfThreads>(r, (int64_t)(blockIdx.x - rb), smem_f);
         return;
     }

@@ -2,7 +2,7 @@
 latents -- workgroup start / end distribution and the phase stamps of workgroup 0 (waves 0 and 3)."""
 import sys, os, ctypes
 import numpy as np, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import control_gic_amd as cg
 from control_gic_amd import _lib
 from control_gic_amd.quantize import _vq_forward, prepare_codebook
@@ -46,3 +46,28 @@ w0 = [(p[i] - p[0]) / ghz / 1e3 for i in range(7)]
 print("wg0 wave0 stamps (us from start; stamps 2-4 are of the LAST group of the wave):", " | ".join(f"{n} {v:.2f}" for n, v in zip(names, w0)))
 w3 = [(p[8 + i] - p[0]) / ghz / 1e3 for i in range(2, 8)]
 print("wg0 wave3 stamps:", " ".join(f"{v:.2f}" for v in w3))
+if "starts" in sys.argv:
+    print("start by workgroup (us):", " ".join(f"{v:.1f}" for v in st))
+    print("end by workgroup (us):", " ".join(f"{v:.1f}" for v in en))
+if "events" in sys.argv:
+    # is the start stagger by XCD real, or are the XCDs' clocks offset?  kernel time by HIP events (isolated launches) vs the device span
+    ts = []
+    for _ in range(20):
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(); f(); e1.record(); torch.cuda.synchronize()
+        ts.append(e0.elapsed_time(e1) * 1e3)
+    print("isolated launch by HIP events: min %.2f med %.2f us; device span (max end - min start) %.2f us" % (min(ts), sorted(ts)[10], en.max() - st.min()))
+    import bench
+    print("back to back in a graph: %.2f us per launch" % bench.graph_kernel_time(f))
+if "waves" in sys.argv:
+    f(); torch.cuda.synchronize()
+    l.cgic_debug_block_times(big, 4096)
+    a = np.array(list(big), dtype=np.int64).reshape(4096, 2)
+    wv = a[512:512 + 512].reshape(64, 8, 2)
+    wg = a[:64]
+    for g in (0, 1, 2, 3, 8, 9, 16, 40):
+        t0g = wg[g, 0]
+        print(f"wg {g}: loop start per wave " + " ".join(f"{(wv[g, w, 0] - t0g) / 100:.1f}" for w in range(8)) + " | loop end " + " ".join(f"{(wv[g, w, 1] - t0g) / 100:.1f}" for w in range(8)) + f" | wg end {(wg[g, 1] - t0g) / 100:.1f}")
+    le = (wv[:, :, 1] - wg[:, :1]) / 100.0
+    print("loop end by wave index, median over 64 workgroups:", " ".join(f"{np.median(le[:, w]):.2f}" for w in range(8)), "| max over waves, median:", f"{np.median(le.max(1)):.2f}", "| min:", f"{np.median(le.min(1)):.2f}")
