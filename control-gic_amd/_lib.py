@@ -53,6 +53,7 @@ PROTOTYPES = {
     "cgic_ticket_scope_release": (_int, [_int]),
     "cgic_ticket_slots_in_use": (_int, []),
     "cgic_vq_stats": (_int, [_vp]),
+    "cgic_vq_filter_probe_f32": (_int, [_vp, _i64, _i64, _vp, _int, _vp, _vp, _vp, _vp]),
     "cgic_vq_workspace_bytes": (_sz, [_i64]),
     "cgic_conv1x1_rows_f32": (_int, [_vp, _i64, _cv, _vp, _vp]),
     "cgic_vq_prepared_bytes": (_sz, [_int]),

@@ -131,7 +131,8 @@ constexpr int kRefListCap = 1024;          // band elements listed per sweep (a 
 constexpr int kRefFlatSlots = 128;         // distinct grays of constant patches per select (more: the rest go patch by patch)
 constexpr unsigned int kRefEmpty = 0xFFFFFFFFu;      // (a NaN pattern: never the gray of a constant patch)
 struct RefineShared {
-    unsigned int cnt[8];                                   // band size | of which not exactly known | list length | below the band | small list length
+    unsigned int cnt[16];                                  // two banks of 8 (coarse / medium select; zeroed once, when the router starts): band size | of
+                                                           // which not exactly known | list length | below the band
     unsigned int list[kRefListCap];
     float T[kRefWavesMax][kRefUnitRows * kRefRow];         // chunk sums: the four units of a 16x16 patch are four consecutive waves'
     float rec[kRefWavesMax][kRefRecFloats];
@@ -140,7 +141,6 @@ struct RefineShared {
     unsigned int flat_key[kRefFlatSlots];                  // open-addressing set of the constant patches' grays (bit patterns)
     float flat_val[kRefFlatSlots];
     unsigned int small[64];                                // all band elements, when there are at most 64 (the final pick)
-    unsigned char lead[64];                                // ... and for each the first member with the same constant gray
     float thr;
 };
 
@@ -176,8 +176,10 @@ __device__ __forceinline__ void flat_insert(unsigned int *keys, unsigned int key
 // side when there are at most two patches, else by one wave each (no workgroup barrier inside the sweep).
 template <int NT, int P, typename EX>
 __device__ float refine_select(float *arr, int n, unsigned int rank, float t_a, EX is_exact, const RefineSrc &rf, int64_t img0,
-                               int wP, int nP, RefineShared *rs, RouterShared *sh, const SelInfo &si)
+                               int wP, int nP, RefineShared *rs_, RouterShared *sh, const SelInfo &si, int bank)
 {
+    RefineShared *rs = rs_;
+    unsigned int *cnt = rs->cnt + 8 * bank;
     constexpr int NW = NT / 64, NWR = NW < kRefWavesMax ? NW : kRefWavesMax;
     constexpr int UPP = P == 16 ? 4 : 1;              // units (64 pixels, one wave and step) per patch
     const int tid = threadIdx.x, lane = lane_id(), wave = tid >> 6;
@@ -205,15 +207,12 @@ __device__ float refine_select(float *arr, int n, unsigned int rank, float t_a, 
             if (mall < 2u || before == 0u) return t_a;      // the threshold element alone / nothing of the band below it (see 1.)
         }
     }
-    if (tid < 8) rs->cnt[tid] = 0;
-    if (tid < kBins) rs->bins[tid] = linspace_bin(tid);
-    __syncthreads();
-    {
+    {       // (cnt and the bin centres were set up when the router started: no barrier in front of the count)
         unsigned int minx = 0, below = 0;
         for (int i = tid; i < n; i += NT) {
             const float d = arr[i] - t_a;
             if (fabsf(d) <= w) {                                  // (NaN: false)
-                const unsigned int s = atomicAdd(&rs->cnt[0], 1u);
+                const unsigned int s = atomicAdd(&cnt[0], 1u);
                 if (s < 64) rs->small[s] = (unsigned int)i;
                 minx += is_exact(i) ? 0u : 1u;
             }
@@ -221,11 +220,11 @@ __device__ float refine_select(float *arr, int n, unsigned int rank, float t_a, 
         }
 #pragma unroll
         for (int d = 32; d >= 1; d >>= 1) below += __shfl_xor(below, d, kWave);
-        if (lane == 0 && below) atomicAdd(&rs->cnt[3], below);
-        if (minx) atomicAdd(&rs->cnt[1], minx);
+        if (lane == 0 && below) atomicAdd(&cnt[3], below);
+        if (minx) atomicAdd(&cnt[1], minx);
     }
     __syncthreads();
-    const unsigned int m_all = rs->cnt[0], m_inexact = rs->cnt[1], c_below = rs->cnt[3];
+    const unsigned int m_all = cnt[0], m_inexact = cnt[1], c_below = cnt[3];
     if (m_all < 2 || m_inexact == 0) return t_a;          // (workgroup-uniform) the threshold element alone: nothing can change
     // The band's members all rank at or above the threshold element (nothing of the band sorts before it): the true threshold is
     // the SMALLEST exact value of the band, and under the strict '<' no member of the band lies below that -- every one of them
@@ -290,27 +289,26 @@ __device__ float refine_select(float *arr, int n, unsigned int rank, float t_a, 
     };
 
     if (m_all <= 64 && rank >= c_below && rank - c_below < m_all) {
-        // constant patches of one gray are one evaluation: member k is evaluated only if it is the first of its gray (lead[k] == k)
-        if (wave == 0) {
-            unsigned int key = kRefEmpty;
-            if (flat && lane < (int)m_all && !is_exact((int)rs->small[lane])) key = flat_key_of((int)rs->small[lane]);
-            int lead = lane;
-            for (int j = (int)m_all - 1; j >= 0; --j) {
-                const unsigned int kj = __shfl(key, j, kWave);
-                if (kj == key && key != kRefEmpty) lead = j;              // ends at the smallest j of this gray
-            }
-            rs->lead[lane] = (unsigned char)lead;
+        // constant patches of one gray are one evaluation: member k is evaluated only if it is the first of its gray.  Every wave
+        // works that out for itself (lane = member): no LDS, no barrier
+        unsigned int key = kRefEmpty;
+        const int my = lane < (int)m_all ? (int)rs->small[lane] : 0;
+        const bool exact_l = lane < (int)m_all ? is_exact(my) : true;
+        if (flat && lane < (int)m_all && !exact_l) key = flat_key_of(my);
+        int lead = lane;
+        for (int j = (int)m_all - 1; j >= 0; --j) {
+            const unsigned int kj = (unsigned int)__builtin_amdgcn_readlane((int)key, j);
+            if (kj == key && key != kRefEmpty) lead = j;                  // ends at the smallest j of this gray
         }
-        __syncthreads();
-        sweep(rs->small, (int)m_all, [&](int k, int e) { return !is_exact(e) && rs->lead[k] == k; });
-        if (wave == 0 && lane < (int)m_all && rs->lead[lane] != lane) arr[rs->small[lane]] = arr[rs->small[rs->lead[lane]]];
-        __syncthreads();
+        const unsigned long long work = __ballot(lane < (int)m_all && !exact_l && lead == lane);      // bit k: member k is evaluated
+        sweep(rs->small, (int)m_all, [&](int k, int) { return (work >> k) & 1ull; });
         // everything below the band is below the true threshold, everything above it above: it is the band's (rank - below)-th
         if (wave == 0) {
-            const float v = lane < (int)m_all ? arr[rs->small[lane]] : __builtin_inff();
+            float v = lane < (int)m_all ? arr[rs->small[lead]] : __builtin_inff();        // (a follower takes its leader's value)
+            if (lane < (int)m_all && lead != lane) arr[my] = v;
             unsigned int less = 0, leq = 0;
             for (unsigned int j = 0; j < m_all; ++j) {
-                const float vj = __shfl(v, (int)j, kWave);
+                const float vj = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), (int)j));
                 less += vj < v ? 1u : 0u;
                 leq += vj <= v ? 1u : 0u;
             }
@@ -348,7 +346,7 @@ __device__ float refine_select(float *arr, int n, unsigned int rank, float t_a, 
         __syncthreads();
     }
     for (int base = 0; base < n; base += kRefListCap) {
-        if (tid == 0) rs->cnt[2] = 0;
+        if (tid == 0) cnt[2] = 0;
         __syncthreads();
         const int hi = base + kRefListCap < n ? base + kRefListCap : n;
         for (int i = base + tid; i < hi; i += NT) {
@@ -356,10 +354,10 @@ __device__ float refine_select(float *arr, int n, unsigned int rank, float t_a, 
             int slot = -1;
             if (flat) { const unsigned int k = flat_key_of(i); if (k != kRefEmpty) slot = flat_find(rs->flat_key, k); }
             if (slot >= 0) arr[i] = rs->flat_val[slot];
-            else rs->list[atomicAdd(&rs->cnt[2], 1u)] = (unsigned int)i;
+            else rs->list[atomicAdd(&cnt[2], 1u)] = (unsigned int)i;
         }
         __syncthreads();
-        sweep(rs->list, (int)rs->cnt[2], [](int, int) { return true; });
+        sweep(rs->list, (int)cnt[2], [](int, int) { return true; });
     }
     const float thr = radix_select<NT>([&](int64_t i) { return arr[i]; }, n, rank, sh);
     __builtin_amdgcn_s_setprio(0);
@@ -424,7 +422,11 @@ __device__ __forceinline__ void router_team(const RouterArgs &a, int64_t blk, un
         }
         for (int64_t i = tid; i < N8; i += NT) l8[i] = e8[i];
         e8 = l8;
-        if (a.rf.x) rs = reinterpret_cast<RefineShared *>((reinterpret_cast<uintptr_t>(l8 + N8) + 15) & ~(uintptr_t)15);
+        if (a.rf.x) {
+            rs = reinterpret_cast<RefineShared *>((reinterpret_cast<uintptr_t>(l8 + N8) + 15) & ~(uintptr_t)15);
+            if (tid < 16) rs->cnt[tid] = 0;
+            if (tid < kBins) rs->bins[tid] = linspace_bin(tid);
+        }
         __syncthreads();
     }
     const bool refine = rs != nullptr;          // (the host only asks for it at stage 1: both maps in LDS)
@@ -442,7 +444,7 @@ __device__ __forceinline__ void router_team(const RouterArgs &a, int64_t blk, un
         thr_c = radix_select<NT>([&](int64_t i) { return e16[i]; }, N16, a.rank_c, sh, &si);
         if (refine)
             thr_c = refine_select<NT, 16>(const_cast<float *>(e16), (int)N16, a.rank_c, thr_c, [](int) { return false; }, a.rf,
-                                          seg * a.per, (int)w16, (int)n16, rs, sh, si);
+                                          seg * a.per, (int)w16, (int)n16, rs, sh, si, 0);
     }
     CGIC_STAMP(2);
     CGIC_RT_STAMP(1);
@@ -502,7 +504,7 @@ __device__ __forceinline__ void router_team(const RouterArgs &a, int64_t blk, un
             thr_m = radix_select<NT>([&](int64_t i) { return l8m[i]; }, N8, a.rank_m, sh, &si);
             if (refine)       // (a gated element's 0 is exact: never re-evaluated, never overwritten)
                 thr_m = refine_select<NT, 8>(l8m, (int)N8, a.rank_m, thr_m, [&](int i) { return gc_of8(i); }, a.rf, seg * a.per, w8i,
-                                             n8i, rs, sh, si);
+                                             n8i, rs, sh, si, 1);
         } else {
             thr_m = radix_select<NT>([&](int64_t i) { return e8[i] * (1.0f - (gc_of8(i) ? 1.0f : 0.0f)); }, N8, a.rank_m, sh);
         }
@@ -512,7 +514,7 @@ __device__ __forceinline__ void router_team(const RouterArgs &a, int64_t blk, un
         thr_m = radix_select<NT>([&](int64_t i) { return e8[i]; }, N8, a.rank_m, sh, &si);
         if (refine)
             thr_m = refine_select<NT, 8>(const_cast<float *>(e8), (int)N8, a.rank_m, thr_m, [](int) { return false; }, a.rf, seg * a.per,
-                                         w8i, n8i, rs, sh, si);
+                                         w8i, n8i, rs, sh, si, 1);
     }
     auto gm_rule = [&](float v, bool gc) -> bool {
         switch (mode) {

@@ -217,6 +217,9 @@ struct VqArgs {
     // reran the exact fp32-MFMA loop, [2] groups that evaluated a second candidate set, [3] groups seen -- touched only
     // inside the rare branches, so a launch without near-ties executes nothing for it
     unsigned int *stats;
+    // margin telemetry (cgic_vq_filter_probe_f32 only; the product instantiations never read them): every approximate score
+    // the filter saw, [N, K], and per vector (f_min, margin M, threshold, flagged, scale exponent q, S) in unscaled score units
+    float *probe_scores, *probe_aux;
 };
 
 // The reference's quant_conv is a torch.nn.Conv2d(4, 4, 1) on the CPU.  Its fp32 rounding sequence is an fma chain over
@@ -596,7 +599,7 @@ __device__ __forceinline__ void vqf_stage(const float *__restrict__ cb, const in
 
 // ALIGNED: hw % 64 == 0 -- a group of 64 consecutive vectors never straddles two images, so (image, position) of a
 // group is wave-uniform and every address is a scalar base plus a per-lane offset that is computed once.
-template <int NT, bool ALIGNED, bool CONV>
+template <int NT, bool ALIGNED, bool CONV, bool PROBE = false>
 __device__ __forceinline__ void vq_filter_body(const VqArgs &a, unsigned char *smem, const unsigned int vblk)
 {
     constexpr int NW = NT / 64, G = kVqfGroup;
@@ -784,6 +787,12 @@ __device__ __forceinline__ void vq_filter_body(const VqArgs &a, unsigned char *s
             auto digest = [&](int T, const f32x16 (&D)[2]) {
 #pragma unroll
                 for (int t = 0; t < 2; ++t) {
+                    if (PROBE && T < ntile && base + 32 * t + j < N) {
+                        // register r of this lane = row 8 (r / 4) + 4 hf + r % 4 of the tile = code 32 T + that row, column j = vector 32 t + j
+#pragma unroll
+                        for (int r = 0; r < 16; ++r)
+                            a.probe_scores[(base + 32 * t + j) * K + 32 * T + 8 * (r >> 2) + 4 * hf + (r & 3)] = ldexpf(D[t][r], -qs[t]);
+                    }
                     float u = __builtin_inff();        // seeded with a constant: a two-operand fminf() canonicalises both operands first
 #pragma unroll
                     for (int r = 0; r < 16; r += 2) u = __builtin_fminf(__builtin_fminf(u, D[t][r]), D[t][r + 1]);     // v_min3_f32 on the raw MFMA outputs
@@ -840,6 +849,10 @@ __device__ __forceinline__ void vq_filter_body(const VqArgs &a, unsigned char *s
             const bool deep = !(A2 > thr) || !(B2 > thr);       // a second tile of one half is a candidate: a third may be too
             const bool other = !(B1 < A1) ? cB1 : cA1;           // the half that does not hold the minimum has one as well
             const bool flag = valid && (deep || (hf ? unscalable[1] : unscalable[0]) || !(cA1 || cB1));
+            if (PROBE && valid) {
+                float *ax = a.probe_aux + (base + lane) * 6;
+                ax[0] = mt; ax[1] = M; ax[2] = ldexpf(thr, -q); ax[3] = flag ? 1.f : 0.f; ax[4] = (float)q; ax[5] = S;
+            }
             const bool firstB = B1 < A1;                        // which half holds the minimum
             auto tile_of = [&](float v) -> int {
                 int T = __float_as_int(v) & 31;
@@ -1056,6 +1069,15 @@ __global__ CGIC_VQF_BOUNDS void vq_filter_kernel(VqArgs a)
     vq_filter_body<kVqfThreads, ALIGNED, CONV>(a, smem_f, blockIdx.x);
 }
 
+// Telemetry instantiation (cgic_vq_filter_probe_f32): the SAME body, with every approximate score and every decision threshold
+// written out -- what tools/stress_vq.py --telemetry and tests/test_gpu_stress.py compare with the budgeted error bound.
+template <bool ALIGNED>
+__global__ CGIC_VQF_BOUNDS void vq_filter_probe_kernel(VqArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_f[];
+    vq_filter_body<kVqfThreads, ALIGNED, false, true>(a, smem_f, blockIdx.x);
+}
+
 // The fused launch of the filter path (see vq_router_kernel).  A VQ workgroup takes most of a CU's register file, and
 // dynamic LDS / the VGPR budget are per launch, so a router workgroup does not share a CU with one: behind the VQ
 // workgroups it only starts when the VQ is over.  The router workgroups therefore come FIRST (`nrouter` of them, one CU
@@ -1247,7 +1269,7 @@ static int launch_mfma(const float *z, int64_t hw, int64_t N, const float *cb, i
     a.z = z; a.hw = hw; a.N = N; a.cb = cb; a.K = K; a.idx_out = idx; a.zq_out = zq;
     a.sq_partial = loss ? ws.partial : nullptr; a.ticket = ws.ticket; a.beta = beta; a.legacy = legacy; a.loss = loss;
     a.nblk = (unsigned int)((N + per_block - 1) / per_block);
-    a.n_early = a.g_early = a.g_late = 0; a.conv_w = a.conv_b = nullptr; a.conv_bias_first = 0; a.prep = nullptr; a.stats = nullptr;
+    a.n_early = a.g_early = a.g_late = 0; a.conv_w = a.conv_b = nullptr; a.conv_bias_first = 0; a.prep = nullptr; a.stats = nullptr; a.probe_scores = a.probe_aux = nullptr;
     size_t lds = sizeof(float) * (size_t)K * 5;
     if (!router) {
         int rc = ensure_dynamic_lds((const void *)vq_mfma_kernel<ZT>, lds);
@@ -1305,6 +1327,7 @@ static int launch_filter(const float *z, int64_t hw, int64_t N, const float *cb,
     a.conv_w = CONV ? qc->weight : nullptr; a.conv_b = CONV ? qc->bias : nullptr; a.conv_bias_first = CONV ? qc->bias_first : 0;
     a.prep = prepared;
     a.stats = g_vq_stats.load(std::memory_order_relaxed);
+    a.probe_scores = a.probe_aux = nullptr;
     // groups per workgroup.  Router workgroups in front: the `late` VQ workgroups that must wait for a router's CU
     // (~11 us at 256x256, ~`delta` groups of VQ work) own `g_late` groups, the others `g_early`, a multiple of 4
     int64_t per = (ngroups + nblk - 1) / nblk, g_early = per, g_late = per, n_early = nblk;
@@ -1383,6 +1406,40 @@ extern "C" size_t cgic_vq_workspace_bytes(int64_t n_vectors)
 {
     // one double per workgroup; (n / 16 + 1) covers every tiling of both paths
     return sizeof(double) * (size_t)((n_vectors + 15) / 16 + 1);
+}
+
+extern "C" int cgic_vq_filter_probe_f32(const float *z, int64_t B, int64_t hw, const float *codebook, int K, int64_t *indices,
+                                        float *scores, float *aux, cgic_stream_t stream)
+{
+    int rc = vq_check(z, B, hw, codebook, K, 4, nullptr, nullptr, false);
+    if (rc) return rc;
+    CGIC_REQUIRE(K % 64 == 0 && K <= kVqfMaxK, CGIC_ERR_UNSUPPORTED, "vq_filter_probe: K=%d has no filter path", K);
+    CGIC_REQUIRE(indices && scores && aux, CGIC_ERR_INVALID, "vq_filter_probe: NULL output");
+    const int64_t N = B * hw;
+    if (N == 0) return CGIC_OK;
+    int cus = 0;
+    rc = device_cu_count(&cus);
+    if (rc) return rc;
+    const int64_t ngroups = (N + kVqfGroup - 1) / kVqfGroup;
+    const int64_t nblk = ngroups < cus ? ngroups : cus, per = (ngroups + nblk - 1) / nblk;
+    VqArgs a;
+    a.z = z; a.hw = hw; a.N = N; a.cb = codebook; a.K = K; a.idx_out = indices; a.zq_out = nullptr;
+    a.sq_partial = nullptr; a.ticket = nullptr; a.beta = 0.f; a.legacy = 1; a.loss = nullptr;
+    a.nblk = (unsigned int)nblk; a.n_early = (unsigned int)nblk; a.g_early = a.g_late = (unsigned int)per;
+    a.conv_w = a.conv_b = nullptr; a.conv_bias_first = 0; a.prep = nullptr; a.stats = nullptr;
+    a.probe_scores = scores; a.probe_aux = aux;
+    const size_t lds = vqf_lds_bytes(K);
+    hipStream_t s = (hipStream_t)stream;
+    if (hw % kVqfGroup == 0) {
+        rc = ensure_dynamic_lds((const void *)vq_filter_probe_kernel<true>, lds);
+        if (rc) return rc;
+        hipLaunchKernelGGL((vq_filter_probe_kernel<true>), dim3(a.nblk), dim3(kVqfThreads), lds, s, a);
+    } else {
+        rc = ensure_dynamic_lds((const void *)vq_filter_probe_kernel<false>, lds);
+        if (rc) return rc;
+        hipLaunchKernelGGL((vq_filter_probe_kernel<false>), dim3(a.nblk), dim3(kVqfThreads), lds, s, a);
+    }
+    return launch_check("vq_filter_probe_kernel");
 }
 
 extern "C" int cgic_vq_stats(unsigned int *device_counters)

@@ -131,6 +131,17 @@ int cgic_conv1x1_rows_f32(const float *rows, int64_t n, const cgic_conv1x1 *conv
  * on the exact fp32-MFMA loop; [2] groups that evaluated a second 16-code candidate set exactly.  NULL switches it off (the
  * default).  Process-wide; the counters are only touched inside those rare branches.  Results never depend on it. */
 int cgic_vq_stats(unsigned int *device_counters);
+/* Margin telemetry of the candidate filter: the SAME kernel body as cgic_vq_forward_f32's filter path (K % 64 == 0, K <= 1024),
+ * instantiated so that it also writes out what it decided on:
+ *   scores device [B*hw, K] fp32: the approximate score f_k = ee_k - 2 z.e_k of every code as the fp16 matrix cores delivered it
+ *          (scaled back to score units) -- the exactness argument bounds |f_k - F_k| <= 1.8e-6 (ee_k + 2 sum|z_j e_kj|) + floor
+ *   aux    device [B*hw, 6]  fp32: per vector (f_min, the margin M, the candidate threshold f_min + M + floor, 1 if the vector was
+ *          sent to the all-K exact scan, the exponent q of its score scaling 2^q, the bound S on ee_k + 2 sum|z_j e_kj|)
+ *   indices device [B*hw] int64: the result (identical to cgic_vq_forward_f32's)
+ * tools/stress_vq.py --telemetry and tests/test_gpu_stress.py compare the observed error and the margin actually consumed by
+ * the reference's winners with the budget.  Not a product path: B*hw*K*4 bytes of output. */
+int cgic_vq_filter_probe_f32(const float *z, int64_t B, int64_t hw, const float *codebook, int K, int64_t *indices,
+                             float *scores, float *aux, cgic_stream_t stream);
 size_t cgic_vq_workspace_bytes(int64_t n_vectors);
 /* bytes of the prepared codebook image (0: this K only has the exact loop, which needs none) / make it (one small launch) */
 size_t cgic_vq_prepared_bytes(int K);

@@ -515,3 +515,86 @@ def test_telemetry_counters_do_not_change_results(orc):
     assert torch.equal(a[0], b[0]) and int(b[3].abs().max()) == 0
     c = cnt.cpu().numpy()
     assert c[1] == 6 and 6 <= c[0] <= 6 * 40 and 1 <= c[2] <= 40, c
+
+
+def filter_margin_telemetry(orc, z, cb):
+    """cgic_vq_filter_probe_f32 on z [1,4,hw] / cb [K,4] -> dict of what the exactness argument of the candidate filter budgets
+    against what was observed: (a) |f_k - F_k| against 1.8e-6 (ee_k + 2 sum|z_j e_kj|) + the fp16-subnormal floor of 0.02 scaled
+    units; (b) how much of the candidate margin thr - f_min the REFERENCE'S winners (argmin set of the oracle's distance row)
+    actually used; (c) indices == oracle."""
+    import ctypes
+    lib = cg._lib.lib()
+    zt = torch.from_numpy(z).to(DEV).contiguous()
+    w = torch.from_numpy(cb).to(DEV).contiguous()
+    _, C, hw = z.shape
+    K = cb.shape[0]
+    N = hw
+    scores = torch.empty((N, K), dtype=torch.float32, device=DEV)
+    aux = torch.zeros((N, 6), dtype=torch.float32, device=DEV)
+    idx = torch.empty(N, dtype=torch.int64, device=DEV)
+    cg._lib.call("cgic_vq_filter_probe_f32", zt.data_ptr(), 1, hw, w.data_ptr(), K, idx.data_ptr(), scores.data_ptr(), aux.data_ptr(), None)
+    torch.cuda.synchronize()
+    f = scores.cpu().numpy().astype(np.float64)
+    ax = aux.cpu().numpy().astype(np.float64)
+    zv = z[0].T.astype(np.float32)                                   # [N,4]
+    e32 = cb.astype(np.float32)
+    ee = (((e32[:, 0] * e32[:, 0] + e32[:, 1] * e32[:, 1]).astype(np.float32) + e32[:, 2] * e32[:, 2]).astype(np.float32) + e32[:, 3] * e32[:, 3]).astype(np.float32)
+    z64, e64 = zv.astype(np.float64), e32.astype(np.float64)
+    F = ee.astype(np.float64)[None, :] - 2.0 * z64 @ e64.T
+    T = ee.astype(np.float64)[None, :] + 2.0 * np.abs(z64) @ np.abs(e64).T
+    flagged = ax[:, 3] != 0
+    ok = ~flagged
+    floor = 0.02 * np.exp2(-ax[:, 4])[:, None]
+    over = np.maximum(np.abs(f - F) - floor, 0.0) / (1.8e-6 * T)
+    err_ratio = float(over[ok].max()) if ok.any() else 0.0
+    plain = float((np.abs(f - F) / T)[ok].max()) if ok.any() else 0.0
+    used = 0.0
+    got = idx.cpu().numpy()
+    bad = 0
+    for n in range(N):
+        d = orc.vq_distances(zv[n], e32)
+        win = np.flatnonzero(d == d.min())
+        bad += int(got[n] != win[0])
+        if ok[n]:
+            span = ax[n, 2] - f[n].min()
+            if span > 0:
+                used = max(used, float((f[n, win] - f[n].min()).max() / span))
+    return {"vectors": N, "flagged": int(flagged.sum()), "max_err_over_budget": err_ratio, "max_err_over_T": plain,
+            "max_margin_used_by_reference_winners": used, "wrong_indices": bad}
+
+
+def telemetry_families(rng, hw=1024):
+    cb_n = rng.standard_normal((1024, 4)).astype(np.float32)
+    u = lambda shape: ((rng.random(shape) * 2 - 1) / 1024).astype(np.float32)
+    fam = {}
+    fam["normal"] = (rng.standard_normal((1, 4, hw)).astype(np.float32), cb_n)
+    fam["scale_1e-3"] = (fam["normal"][0] * np.float32(1e-3), cb_n * np.float32(1e-3))
+    fam["scale_37"] = (fam["normal"][0] * np.float32(37), cb_n * np.float32(37))
+    fam["init_uniform"] = (u((1, 4, hw)), u((1024, 4)))
+    fam["z_small_next_to_codebook"] = (fam["normal"][0] * np.float32(1e-3), cb_n)
+    fam["z_large_next_to_codebook"] = (fam["normal"][0] * np.float32(50), cb_n)
+    on = cb_n[rng.integers(0, 1024, hw)].T[None].copy() + np.float32(1e-6) * rng.standard_normal((1, 4, hw)).astype(np.float32)
+    fam["on_code"] = (on.astype(np.float32), cb_n)
+    dup = cb_n.copy()
+    dup[512:] = dup[:512]
+    dup[512:, 1] = np.nextafter(dup[512:, 1], np.float32(4))          # every code has a twin one ulp away, 16 tiles further on
+    fam["twin_rows_one_ulp_apart"] = ((dup[rng.integers(0, 512, hw)].T[None] + np.float32(0.05) * rng.standard_normal((1, 4, hw))).astype(np.float32), dup)
+    spread = (cb_n * np.exp(rng.uniform(-6, 2, (1024, 1)))).astype(np.float32)
+    fam["codebook_of_mixed_norms"] = (rng.standard_normal((1, 4, hw)).astype(np.float32), spread)
+    return fam
+
+
+def test_filter_margin_telemetry(orc):
+    """the exactness of the fp16 candidate filter rested on an analytic margin plus sampling; here the kernel
+    itself (cgic_vq_filter_probe_f32: the production body, instantiated to write its scores and thresholds out) is held against
+    the budget on the stress families: the observed |f - F| stays under HALF of 1.8e-6 T_k (+ the subnormal floor), the
+    reference's winners use less than half of the candidate margin, and every index equals the oracle's."""
+    rng = np.random.default_rng(12)
+    worst = {}
+    for name, (z, cb) in telemetry_families(rng).items():
+        t = filter_margin_telemetry(orc, z, cb)
+        worst[name] = t
+        assert t["wrong_indices"] == 0, (name, t)
+        assert t["max_err_over_budget"] <= 0.5, (name, t)
+        assert t["max_margin_used_by_reference_winners"] <= 0.5, (name, t)
+    assert worst["normal"]["flagged"] < 16

@@ -5,6 +5,18 @@ import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import control_gic_amd as cg
 from control_gic_amd.quantize import _vq_forward
+if "--telemetry" in sys.argv:
+    # margin telemetry of the candidate filter (cgic_vq_filter_probe_f32): worst observed |f - F| against the budget and the share
+    # of the candidate margin the reference's winners used, over the stress families (tests/test_gpu_stress.py holds both under 0.5)
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+    import test_gpu_stress as tgs
+    from oracle import cgic_oracle as orc
+    orc.build()
+    seed = int(sys.argv[sys.argv.index("--telemetry") + 1]) if len(sys.argv) > sys.argv.index("--telemetry") + 1 else 12
+    for rep in range(3):
+        for name, (z, cb) in tgs.telemetry_families(np.random.default_rng(seed + rep), hw=2048).items():
+            print(rep, name, tgs.filter_margin_telemetry(orc, z, cb), flush=True)
+    sys.exit(0)
 rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 0)
 t0 = time.time(); n = 0; nvec = 0
 while time.time() - t0 < float(sys.argv[2] if len(sys.argv) > 2 else 60):
