@@ -1211,14 +1211,14 @@ def report(a, dev, world, stream, slots_np, vq, codec, ratio):
     flops = 2.0 * N * 1024 * 4                        # 2*N*K*D per launch (0.512 kFLOP/pixel)
     t_live = stages["vq+router_fused_launch"] * 1e-6  # HIP events around 20 launches in a hipGraph, on the stream they run on
     prof = None
-    pj = os.path.join(ROOT, "profiles", "r03_roofline.json")
+    pj = os.path.join(ROOT, "profiles", "r04_roofline.json")
     if os.path.exists(pj) and (B, H) == (64, 256):
         try:
             prof = json.load(open(pj))
         except Exception:                             # noqa: BLE001
             prof = None
     # `frac` is priced with the PROFILER's average duration of the kernel for the same command (tools/run_roofline_cmd.py = this
-    # measurement under rocprofv3 --kernel-trace --stats; profiles/r03_roofline.json, made by tools/gpu_profile_r03.sh): the number a
+    # measurement under rocprofv3 --kernel-trace --stats; profiles/r04_roofline.json, made by tools/gpu_profile_r04.sh): the number a
     # reader can recompute from profiles/.  The live HIP-event figure of this run stays next to it.
     t_dom = prof["rocprof_avg_us_alone_graph"] * 1e-6 if prof else t_live
     achieved = flops / t_dom / 1e12
@@ -1228,17 +1228,20 @@ def report(a, dev, world, stream, slots_np, vq, codec, ratio):
         "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4),
         "traffic": prof.get("hbm_bytes_per_launch") if prof else None,
         "duration_us": round(t_dom * 1e6, 3),
-        "duration_source": ("profiles/r03_roofline.json: rocprofv3 --kernel-trace average over the 100 timed launches of tools/run_roofline_cmd.py "
+        "duration_source": ("profiles/r04_roofline.json: rocprofv3 --kernel-trace average over the 100 timed launches of tools/run_roofline_cmd.py "
                             "(the same 20-launches-per-hipGraph command as the live measurement)") if prof else "live HIP events (no profile JSON found)",
         "frac_hip_events": round(flops / t_live / 1e12 / PEAK_F32_MFMA_TFLOPS, 4), "hip_events_us": round(t_live * 1e6, 3),
         "frac_one_lane_loop": prof.get("frac_lanes1_loop") if prof else None,
         "one_lane_loop_us": prof.get("rocprof_avg_us_lanes1_loop") if prof else None,
         "in_step_us": prof.get("rocprof_avg_us_lanes4_loop") if prof else None,
         "vq_alone_frac": round(flops / (stages["vq_kernel_alone"] * 1e-6) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
+        "mfma_busy_frac": (prof.get("mfma") or {}).get("mfma_busy_frac") if prof else None,
+        "mfma_counters": {k: v for k, v in (prof.get("mfma") or {}).items() if k.startswith("SQ_")} if prof else None,
         "note": "algorithmic flops = 2*N*K*D of the fp32 distance contraction per launch / the kernel's average duration, priced against the dense "
                 "fp32 MFMA peak (results are bit-identical to the fp32 sequence); the kernel issues fp16 MFMAs with 16 K-slots per 4-dim contraction "
                 f"({2.0 * N * 1024 * 16 / 1e9:.1f} GFLOP per launch = {2.0 * N * 1024 * 16 / t_dom / 2.5e15:.2f} of the 2.5 PFLOP/s fp16 peak) "
-                "and is bound by VALU + MFMA issue (one half-rate v_min3 per two scores), not by the matrix cores alone.  frac: the launch by itself, "
+                "and is bound by VALU + MFMA issue (one v_min3 per two scores), not by the matrix cores alone: mfma_busy_frac = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x "
+                "the launch's cycles), from the counter passes of the same command (profiles/r04_pmc_sq_vq.md).  frac: the launch by itself, "
                 "back to back; frac_one_lane_loop: the same kernel inside the one-batch-in-flight step (behind the entropy kernel's 50 MB: cold "
                 "L2); in_step_us: its duration while the kernels of three other batches share the GPU (not a kernel property; under the "
                 "profiler, which serialises part of the overlap); vq_alone_frac: the VQ kernel without the router workgroups, live"}

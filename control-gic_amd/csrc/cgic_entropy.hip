@@ -162,6 +162,10 @@ __global__ __launch_bounds__(kEntThreads) void entropy_maps_kernel(
     own0[0] = zero4; own0[1] = zero4; own1[0] = zero4; own1[1] = zero4;
     __syncthreads();                                      // bins[]; the only workgroup-wide barrier
     const float k0 = -bins[0] * 15.5f;                    // floor((g - bins[0]) * 15.5) = the bin below the pixel
+    // flat8 by-product: crossbar source of a lane (first lane of its 8x8 sub-patch) and where the sub-patch's flag goes
+    const int flat_src = (lane & 0x22) * 4;
+    const int64_t flat_off = (int64_t)(lane >> 5) * (W / 8) + ((lane >> 1) & 1);
+    float *__restrict__ flat_row = flat8 ? flat8 + (b * (H / 8) + row0 / 8) * (W / 8) : nullptr;
 
 #pragma unroll 1
     for (int64_t patch = p_lo + wave; patch < p_end; patch += kEntWaves) {
@@ -188,17 +192,17 @@ __global__ __launch_bounds__(kEntThreads) void entropy_maps_kernel(
             // flat8[sub-patch] = its gray value if all 64 pixels of the 8x8 sub-patch carry the SAME gray (bit for bit), else NaN:
             // lets the router's refinement evaluate constant patches -- blown-out sky, letterbox bars, flat graphics: the big tie
             // groups of real content -- once per distinct gray instead of once per patch (cgic_router_dev.h).  Sub-patch (sy, sx) =
-            // the lanes with bit 5 == sy and bit 1 == sx; its first lane is lane & 0x22.
-            const float first = __shfl(g[0], lane & 0x22, kWave);
-            const bool same = (g[0] == first) & (g[1] == first) & (g[2] == first) & (g[3] == first);      // (NaN: never)
-            const unsigned long long eq = __ballot(same);
-            const unsigned long long m = (0x33333333ull << ((lane >> 1 & 1) * 2)) << (lane & 32);        // my sub-patch's lanes
-            if ((lane & ~0x22) == 0) {
-                const int64_t h8 = H / 8, w8 = W / 8;
-                flat8[(b * h8 + (row0 / 8 + (lane >> 5))) * w8 + (patch * 2 + ((lane >> 1) & 1))] = (eq & m) == m ? first : __builtin_nanf("");
-            }
+            // the lanes with bit 5 == sy and bit 1 == sx; its first lane is lane & 0x22.  Alone this kernel is bound by VALU issue,
+            // so the test is kept to one crossbar read, four compares and one select per lane: everything else is 64-bit mask
+            // arithmetic on the scalar unit (the first version -- per-lane masks and shifts -- cost 2 of 14 us in the one-lane loop).
+            const float first = __int_as_float(__builtin_amdgcn_ds_bpermute(flat_src, __float_as_int(g[0])));
+            const unsigned long long eq = __ballot((g[0] == first) & (g[1] == first) & (g[2] == first) & (g[3] == first));   // (NaN: never)
+            constexpr unsigned long long M00 = 0x0000000033333333ull, M01 = 0x00000000CCCCCCCCull, M10 = M00 << 32, M11 = M01 << 32;
+            const unsigned long long ok = ((eq & M00) == M00 ? 1ull << 0 : 0ull) | ((eq & M01) == M01 ? 1ull << 2 : 0ull) |
+                                          ((eq & M10) == M10 ? 1ull << 32 : 0ull) | ((eq & M11) == M11 ? 1ull << 34 : 0ull);
+            if (__builtin_amdgcn_inverse_ballot_w64(0x0000000500000005ull))       // lanes 0, 2, 32, 34: one per sub-patch
+                flat_row[patch * 2 + flat_off] = __builtin_amdgcn_inverse_ballot_w64(ok) ? first : __builtin_nanf("");
         }
-
         unsigned long long nan_lanes = 0;      // lanes that hold a NaN pixel (the reference's histogram turns NaN)
         // candidate window: the two bins that bracket the pixel.  Every other bin is at least one bin width = 6.45 sigma away
         // and holds <= exp(-0.5 * 6.45^2) = 9e-10 (6.5e-9 at the largest sigma accepted): nonzero in fp32 and summed by the

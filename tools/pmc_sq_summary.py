@@ -3,6 +3,9 @@ usage: python tools/pmc_sq_summary.py [--match SUBSTR] db1 [db2 ...]
 Counters are summed over all instances (XCDs/SEs/dimensions) of one dispatch, then averaged over dispatches."""
 import sqlite3, sys, collections
 args = sys.argv[1:]
+as_json = False
+if args and args[0] == "--json":
+    as_json = True; args = args[1:]
 match = "cgic::"
 if args and args[0] == "--match":
     match = args[1]; args = args[2:]
@@ -24,6 +27,10 @@ for path in args:
         for k, c, v, n in db.execute(q):
             k = k.split("(")[0].replace("void ", "")
             res[k][c] = (v, n)
+if as_json:
+    import json
+    print(json.dumps({k: {c: v[0] for c, v in d.items()} for k, d in res.items() if match in k}))
+    sys.exit(0)
 for k, d in res.items():
     if match not in k:
         continue

@@ -1,4 +1,4 @@
-"""profiles/r03_roofline.json from the round-3 profiling passes (tools/gpu_profile_r03.sh): the ONE table bench.py's roofline line is
+"""profiles/r04_roofline.json from the round-4 profiling passes (tools/gpu_profile_r04.sh): the ONE table bench.py's roofline line is
 computed from.  usage: python tools/roofline_json.py OUTDIR  (reads OUTDIR/loop_lanes1.json, loop_lanes4.json, alone.db, pmc_hbm.json)"""
 import json, os, sqlite3, sys
 O = sys.argv[1]
@@ -26,9 +26,24 @@ if os.path.exists(pm):
     out.update({k: v for k, v in json.load(open(pm)).items() if k in ("hbm_bytes_per_launch", "read_bytes_x2", "write_bytes")})
 out["frac_lanes1_loop"] = round(out["flops_per_launch"] / (out["rocprof_avg_us_lanes1_loop"] * 1e-6) / 1e12 / 157.3, 4)
 out["frac_alone_graph"] = round(out["flops_per_launch"] / (out["rocprof_avg_us_alone_graph"] * 1e-6) / 1e12 / 157.3, 4)
+# matrix-core counters of the same command (tools/gpu_profile_r04.sh, pmcf_* passes): busy fraction of the 1024 SIMDs' MFMA pipes
+pj = os.path.join(O, "pmc_sq_vq_fused.json")
+if os.path.exists(pj):
+    try:
+        c = next(iter(json.load(open(pj)).values()))
+        busy, insts = c.get("SQ_VALU_MFMA_BUSY_CYCLES"), c.get("SQ_INSTS_MFMA")
+        dur_cycles = out["rocprof_avg_us_alone_graph"] * 1e-6 * 2.4e9
+        out["mfma"] = {"SQ_INSTS_MFMA": insts, "SQ_VALU_MFMA_BUSY_CYCLES": busy, "SQ_VALU_MFMA_COEXEC_CYCLES": c.get("SQ_VALU_MFMA_COEXEC_CYCLES"),
+                       "SQ_INSTS_VALU": c.get("SQ_INSTS_VALU"), "SQ_WAVE_CYCLES": c.get("SQ_WAVE_CYCLES"), "SQ_WAIT_ANY": c.get("SQ_WAIT_ANY"),
+                       "SQ_LDS_BANK_CONFLICT": c.get("SQ_LDS_BANK_CONFLICT"), "SQ_LDS_IDX_ACTIVE": c.get("SQ_LDS_IDX_ACTIVE"),
+                       "mfma_busy_frac": round(busy / 1024.0 / dur_cycles, 4) if busy else None,
+                       "note": "SQ_VALU_MFMA_BUSY_CYCLES summed over the chip / 1024 SIMDs / (launch duration x 2.4 GHz): the share of the launch "
+                               "during which a SIMD's matrix pipe was busy; 32 cycles per v_mfma_f32_32x32x16_f16"}
+    except Exception as e:                      # noqa: BLE001
+        out["mfma"] = {"error": str(e)[:200]}
 out["commands"] = {
     "lanes L loop": "rocprofv3 --kernel-trace --stats -- python bench.py --steps 96 --warmup 16 --no-report --lanes L   (tools/trace_concurrency.py: the last 96 five-launch chains)",
     "alone graph": "rocprofv3 --kernel-trace --stats -- python tools/run_roofline_cmd.py fused   (bench.graph_kernel_time: 20 launches per hipGraph, the last 100 launches)",
     "hbm": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE --kernel-trace -- python bench.py --steps 40 --warmup 10 --no-report --lanes 1 --no-graph   (tools/pmc_summary.py)"}
-json.dump(out, open(os.path.join(O, "r03_roofline.json"), "w"), indent=1)
+json.dump(out, open(os.path.join(O, "r04_roofline.json"), "w"), indent=1)
 print(json.dumps(out, indent=1))
