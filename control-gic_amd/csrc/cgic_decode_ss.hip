@@ -134,11 +134,126 @@ __device__ __forceinline__ int ss_walk(const TableDev &t, const uint32_t *lut, c
     return pos - 64;
 }
 
+
+// -------------------------------------------------------------------------------------------
+// Round 4: ALL entry offsets at once instead of guessing.  A codeword that starts before bit 64 of a chunk ends at most
+// max_len - 1 bits into the next one, so a chunk can only be entered at offsets 0 .. max_len - 1 (or not at all: the stream ended).
+// For tables whose codes all fit the LUT window and max_len <= 15 (the Zipf-like table of a trained model: 13) a lane walks its
+// chunk from EVERY such offset, the walks interleaved in one instruction stream: a single walk is a chain of dependent LUT
+// lookups (~400 cycles per codeword for a lone wave), fifteen independent chains fill those gaps, so the pass costs about what
+// three guessing walks cost.  The result is the chunk's entry -> exit FUNCTION (16 bytes: exit offset per entry, 15 = "stream
+// ended"); functions compose (v_perm_b32 looks eight entries up at once), a wave scan + one cross-wave step give every chunk its
+// true entry -- no fix-point sweeps (8.3 on the benchmark's streams, one per chunk on a stream built never to re-synchronise),
+// no data-dependent running time.
+// -------------------------------------------------------------------------------------------
+constexpr int kSsMaxSweeps = 32;        // fix-point sweeps before the all-entries pass takes over (ordinary streams: 4-10, seen up to 16)
+constexpr int kMeEntries = 15;          // entry offsets 0..14; code 15 = kMeEnd
+constexpr uint32_t kMeEnd = 15;
+
+struct MeFn { uint32_t r[4]; };         // byte e = exit code of entry e
+
+__device__ __forceinline__ MeFn me_identity() { return MeFn{{0x03020100u, 0x07060504u, 0x0B0A0908u, 0x0F0E0D0Cu}}; }
+__device__ __forceinline__ MeFn me_const0() { return MeFn{{0u, 0u, 0u, 0u}}; }      // every entry, "ended" included, -> 0: the next chunk starts a stream
+// (cur o prev)[e] = cur[prev[e]]: prev's bytes are the selectors into cur's 16-byte table
+__device__ __forceinline__ MeFn me_compose(const MeFn &prev, const MeFn &cur)
+{
+    MeFn o;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const uint32_t sel = prev.r[k];
+        const uint32_t s7 = sel & 0x07070707u;
+        const uint32_t lo = __builtin_amdgcn_perm(cur.r[1], cur.r[0], s7);      // entries 0..7
+        const uint32_t hi = __builtin_amdgcn_perm(cur.r[3], cur.r[2], s7);      // entries 8..15
+        const uint32_t m = ((sel >> 3) & 0x01010101u) * 0xFFu;
+        o.r[k] = (hi & m) | (lo & ~m);
+    }
+    return o;
+}
+__device__ __forceinline__ uint32_t me_apply(const MeFn &f, uint32_t e)
+{
+    const uint32_t w = e < 8 ? (e < 4 ? f.r[0] : f.r[1]) : (e < 12 ? f.r[2] : f.r[3]);
+    return (w >> (8 * (e & 3))) & 0xFFu;
+}
+__device__ __forceinline__ MeFn me_shfl_up(const MeFn &f, int d)
+{
+    MeFn o;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) o.r[k] = (uint32_t)__shfl_up((int)f.r[k], d, kWave);
+    return o;
+}
+// inclusive scan of function composition over the lanes of a wave (lane i: f_i o ... o f_0)
+__device__ __forceinline__ MeFn me_wave_scan(MeFn f)
+{
+    const int lane = lane_id();
+#pragma unroll
+    for (int d = 1; d < kWave; d <<= 1) {
+        const MeFn p = me_shfl_up(f, d);
+        const MeFn c = me_compose(p, f);
+        if (lane >= d) f = c;
+    }
+    return f;
+}
+
+// The entry -> (exit, count) maps of chunk g for all entry offsets: returns the function; cnt_lo / cnt_hi get the codeword counts
+// of entries 0..7 / 8..14, one byte each (a chunk holds at most 64 codewords).  Requires t.max_len <= t.lut_bits (every code in the
+// staged LUT, "no such prefix" staged as length 255) and t.max_len <= 15.
+__device__ __forceinline__ MeFn me_walk_all(const TableDev &t, const uint32_t *lut, const uint8_t *stage, const SsLayout &L, int g,
+                                            unsigned long long *cnt_lo, unsigned long long *cnt_hi)
+{
+    const int s = (g >= L.c[1]) + (g >= L.c[2]);
+    const int ch = g - sel3(s, L.c[0], L.c[1], L.c[2]);
+    const int rem = sel3(s, L.nbits[0], L.nbits[1], L.nbits[2]) - 64 * ch;
+    const uint32_t *q = reinterpret_cast<const uint32_t *>(stage + sel3(s, L.off[0], L.off[1], L.off[2]) + 8 * ch);
+    const uint32_t r0 = __builtin_bswap32(q[0]), r1 = __builtin_bswap32(q[1]), r2 = __builtin_bswap32(q[2]), r3 = __builtin_bswap32(q[3]);
+    const uint32_t d0 = __builtin_amdgcn_alignbit(r0, r1, 24), d1 = __builtin_amdgcn_alignbit(r1, r2, 24), d2 = __builtin_amdgcn_alignbit(r2, r3, 24);
+    const int LB = t.lut_bits;
+    const int remc = rem < 128 ? rem : 128, lim = rem < 64 ? rem : 64;
+    const uint32_t ish = 30u - (uint32_t)LB, imask = ((1u << LB) - 1u) << 2;
+    const char *lutb = reinterpret_cast<const char *>(lut);
+    const int E = t.max_len < kMeEntries ? t.max_len : kMeEntries;
+    int pos[kMeEntries], n[kMeEntries];
+#pragma unroll
+    for (int e = 0; e < kMeEntries; ++e) { pos[e] = e < E ? e : 1 << 20; n[e] = 0; }       // (entries beyond max_len - 1 cannot occur: parked)
+    for (;;) {
+        bool any = false;
+#pragma unroll
+        for (int e = 0; e < kMeEntries; ++e) any |= pos[e] < lim;
+        if (__builtin_amdgcn_ballot_w64(any) == 0) break;
+#pragma unroll
+        for (int e = 0; e < kMeEntries; ++e) {
+            const int p = pos[e];
+            const bool go = p < lim;
+            const uint32_t bits = ss_bits(d0, d1, d2, p & 63);
+            const uint32_t ent = *reinterpret_cast<const uint32_t *>(lutb + ((bits >> ish) & imask));
+            const int np = p + (int)(ent & 0xFF);
+            const bool ok = go && np <= remc;                       // a code of this table that ends inside the stream
+            pos[e] = go ? np : p;
+            n[e] += ok ? 1 : 0;
+        }
+    }
+    MeFn f;
+    unsigned long long lo = 0, hi = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) f.r[k] = 0;
+#pragma unroll
+    for (int e = 0; e < kMeEntries; ++e) {
+        const int p = pos[e];
+        const uint32_t x = (e >= E || p < 64 || p > remc) ? kMeEnd : (uint32_t)(p - 64);     // the stream ended inside (or before) this chunk
+        f.r[e >> 2] |= x << (8 * (e & 3));
+        if (e < 8) lo |= (unsigned long long)(uint32_t)n[e] << (8 * e);
+        else hi |= (unsigned long long)(uint32_t)n[e] << (8 * (e - 8));
+    }
+    f.r[3] |= kMeEnd << 24;
+    *cnt_lo = lo; *cnt_hi = hi;
+    return f;
+}
+
 __global__ __launch_bounds__(kDecThreads) void decode_image_kernel(DecodeArgs a, int stage_cap, int chunk_cap)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t sm[];
     __shared__ int s_scan[kDecWaves + 1];
     __shared__ int s_base[4];
+    __shared__ MeFn s_fn[kDecWaves];
     uint32_t *lut = sm;                                             // [1 << lut_bits]
     uint8_t *stage = reinterpret_cast<uint8_t *>(lut + (1 << a.tab.lut_bits));
     uint8_t *ent = stage + stage_cap, *ext = ent + chunk_cap, *cnt = ext + chunk_cap;
@@ -218,6 +333,13 @@ __global__ __launch_bounds__(kDecThreads) void decode_image_kernel(DecodeArgs a,
     const int g0 = tid * R < C ? tid * R : C, g1 = g0 + R < C ? g0 + R : C;
     auto is_first = [&](int g) { return g == L.c[0] || g == L.c[1] || g == L.c[2]; };
     auto nop = [](int, int, int) {};
+    int dbg_sweeps = 0;
+    const bool all_entries = a.tab.max_len <= a.tab.lut_bits && a.tab.max_len <= kMeEntries;       // (wave-uniform)
+    // Guessing first: on ordinary streams it converges in a handful of sweeps and costs less than walking every entry offset
+    // (measured, 64 images of 256x256: 30.3 vs 32.2 us decode + merge; all-fine grids 33.7 vs 57.1).  A stream that does not
+    // re-synchronise -- one 13-bit codeword repeated: one sweep per chunk, 207 sweeps, 852 us -- is cut off after kSsMaxSweeps
+    // and finished by the all-entries pass, whose running time does not depend on the data (56 us for that batch).
+    bool stuck = false;
     {
         int prev = 0;
         for (int g = g0; g < g1; ++g) {
@@ -238,10 +360,6 @@ __global__ __launch_bounds__(kDecThreads) void decode_image_kernel(DecodeArgs a,
     }
     __syncthreads();
     CGIC_STAMP3(3);
-    int dbg_sweeps = 0;
-#ifdef CGIC_PHASE_CLOCKS
-    if (blockIdx.x == 0 && tid == 0) { g_phase_clk[23] = C; g_phase_clk[24] = R; int mx = 0; for (int g = 0; g < C; ++g) mx = cnt[g] > mx ? cnt[g] : mx; g_phase_clk[25] = mx; }
-#endif
     for (;;) {
         ++dbg_sweeps;
         int changed = 0;
@@ -255,6 +373,45 @@ __global__ __launch_bounds__(kDecThreads) void decode_image_kernel(DecodeArgs a,
             }
         }
         if (!__syncthreads_or(changed)) break;
+        if (all_entries && dbg_sweeps >= kSsMaxSweeps) { stuck = true; break; }
+    }
+    if (stuck) {
+        // ---- every entry offset at once; the chunks' entry -> exit functions composed by a scan
+        MeFn mine = me_identity();
+        unsigned long long c_lo = 0, c_hi = 0;
+        for (int g = g0; g < g1; ++g) {
+            MeFn f = me_walk_all(a.tab, lut, stage, L, g, &c_lo, &c_hi);
+            if (is_first(g + 1)) f = me_const0();                 // whatever this chunk's exit is, the next chunk starts a stream at 0
+            mine = me_compose(mine, f);
+        }
+        const MeFn incl = me_wave_scan(mine);
+        if (lane == kWave - 1) s_fn[wave] = incl;
+        __syncthreads();
+        // (few waves: every lane composes the totals of the waves before its own)
+        MeFn before = me_identity();
+        for (int w2 = 0; w2 < wave; ++w2) before = me_compose(before, s_fn[w2]);
+        MeFn prev = me_shfl_up(incl, 1);
+        if (lane == 0) prev = me_identity();
+        uint32_t e = me_apply(prev, me_apply(before, 0u));         // this lane's first chunk is entered here (0 at a stream start by construction)
+        if (g0 < g1 && is_first(g0)) e = 0;
+        if (R == 1) {
+            if (g0 < g1) {
+                const unsigned long long cw = e < 8 ? c_lo : c_hi;
+                ent[g0] = (uint8_t)(e == kMeEnd ? kSsEnd : (int)e);
+                cnt[g0] = e == kMeEnd ? (uint8_t)0 : (uint8_t)((cw >> (8 * (e & 7))) & 0xFFull);
+            }
+        } else {
+            int en = e == kMeEnd ? kSsEnd : (int)e;
+            for (int g = g0; g < g1; ++g) {
+                if (is_first(g)) en = 0;
+                int n;
+                const int x = ss_walk<false>(a.tab, lut, stage, L, g, en, &n, nop);
+                ent[g] = (uint8_t)en; cnt[g] = (uint8_t)n;
+                en = x;
+            }
+        }
+        dbg_sweeps += 1;
+        __syncthreads();
     }
     CGIC_STAMP3(4);
     if (a.stats && tid == 0) {
