@@ -24,19 +24,20 @@ __device__ __forceinline__ float key2f(uint32_t k)
 }
 
 struct RouterShared {
-    unsigned int hist[3][256];      // rotating: pass p counts into [p % 3] while [(p + 1) % 3] is being cleared
+    unsigned int hist[4][256];      // pass p counts into [p]; [p + 1] is cleared meanwhile ([0] of the next select during pass 3)
 };
+constexpr size_t kRouterSharedBytes = sizeof(RouterShared);      // gc_bits follow
 
 // k-th smallest (0-based rank) of n values produced by val(i); all NT threads of the block call.
-// 4 passes of 8 bits, ONE barrier per pass: every wave finds the digit holding the rank by itself from the
-// finished histogram (a 256-bin scan is 4 loads + one wave scan), so there is nothing to broadcast, and the
-// histogram of pass p+1 was cleared during pass p (three rotating buffers: a slow wave may still be reading
-// pass p-1's while a fast one clears).  The previous 3-barriers-per-pass version cost 2.8 + 5.8 us for the two
-// selects of a 256x256 image.
+// 4 passes of 8 bits, ONE barrier per pass and none around them: every wave finds the digit holding the rank by itself from the
+// finished histogram (a 256-bin scan is one 16-byte load + one wave scan), so there is nothing to broadcast; pass p counts into
+// buffer p while buffer p + 1 is cleared (the last pass clears buffer 0 for the NEXT select: the caller zeroes hist[0] once,
+// with a barrier, before the first one -- router_team's staging), and a wave that is still scanning buffer p - 1 disturbs nobody.
+// The previous versions: 3 barriers per pass 2.8 + 5.8 us for the two selects of a 256x256 image; a barrier in front and behind.
 // what the last pass of a select knew (every wave computes it): the counts of the low key byte among the elements that share
 // the threshold's upper 24 key bits, the threshold's own byte, and how many elements with the threshold's key sort before it
 struct SelInfo {
-    const unsigned int *h;      // [256], valid until the next select clears it
+    const unsigned int *h;      // [256], valid until pass 2 of the next select clears it
     unsigned int digit, before;
 };
 
@@ -45,18 +46,15 @@ __device__ float radix_select(F val, int64_t n, unsigned int rank0, RouterShared
 {
     const int tid = threadIdx.x;
     const int lane = lane_id();
-    for (int i = tid; i < 512; i += NT) (&sh->hist[0][0])[i] = 0;      // buffers 0 and 1
-    __syncthreads();
     unsigned int prefix = 0, rank = rank0, himask = 0;
     int pass = 0;
 #pragma unroll 1
     for (int shift = 24; shift >= 0; shift -= 8, ++pass) {
-        unsigned int *h = sh->hist[pass % 3];
+        unsigned int *h = sh->hist[pass];
         // Same-address LDS atomics serialise across the whole workgroup, and entropy values crowd into 2-3 bins of a pass
         // (all of them in the exponent byte): at 9216 values per 768x768 tile a pass spent ~4 us incrementing ONE
         // counter.  Every lane therefore merges equal digits of its own consecutive slots before it touches LDS: a
         // hot pass costs one or two atomics per lane instead of n / NT, a spread-out pass the same as before.
-        // (Ballot-based wave aggregation was measured no faster: its ~25 extra instructions per slot cost what it saved.)
         {
             unsigned int run_d = 0, run_n = 0;
             for (int64_t i = tid; i < n; i += NT) {
@@ -67,10 +65,27 @@ __device__ float radix_select(F val, int64_t n, unsigned int rank0, RouterShared
                 run_d = digit;
                 ++run_n;
             }
+            // The exponent byte (pass 0): nearly every lane of the workgroup is left holding the SAME digit, one atomic each on
+            // one counter (~1 cycle apiece, 512-1024 of them per select of a 256x256 image).  The lanes that share the first
+            // pending lane's digit hand their counts to it, twice (a masked map has two hot digits: the gated zeros and the rest).
+            if (pass == 0) {
+#pragma unroll 1
+                for (int round = 0; round < 2; ++round) {
+                    const unsigned long long pend = __ballot(run_n != 0);
+                    if (!pend) break;
+                    const int first = __builtin_ctzll(pend);
+                    const unsigned int d0 = (unsigned int)__builtin_amdgcn_readlane((int)run_d, first);
+                    const bool same = run_n != 0 && run_d == d0;
+                    const unsigned int tot = wave_inclusive_scan_u32(same ? run_n : 0u);
+                    const unsigned int all = (unsigned int)__builtin_amdgcn_readlane((int)tot, 63);
+                    if (lane == first) atomicAdd(&h[d0], all);
+                    if (same) run_n = 0;
+                }
+            }
             if (run_n) atomicAdd(&h[run_d], run_n);
         }
-        if (pass >= 1) {
-            unsigned int *hz = sh->hist[(pass + 1) % 3];
+        {
+            unsigned int *hz = sh->hist[(pass + 1) & 3];
             for (int i = tid; i < 256; i += NT) hz[i] = 0;
         }
         __syncthreads();
@@ -94,7 +109,6 @@ __device__ float radix_select(F val, int64_t n, unsigned int rank0, RouterShared
         himask |= 0xFFu << shift;
         if (shift == 0 && info) { info->h = h; info->digit = d; info->before = r; }
     }
-    __syncthreads();   // all waves are done with the histograms before a later call clears them
     return key2f(prefix);
 }
 
@@ -201,9 +215,11 @@ __device__ float refine_select(float *arr, int n, unsigned int rank, float t_a, 
                 mall += (d >= dlo && d <= dhi) ? c : 0u;
                 before += (d >= dlo && d < dt) ? c : 0u;
             }
-#pragma unroll
-            for (int o = 32; o >= 1; o >>= 1) { mall += __shfl_xor(mall, o, kWave); before += __shfl_xor(before, o, kWave); }
-            before += si.before;                       // elements EQUAL to the threshold that sort before it
+            // both sums in one DPP scan (a segment that is refined has < 2^16 elements: it fits the fused launch's LDS budget):
+            // twelve dependent ds_bpermute round trips were ~0.4 us of every select's tail
+            const unsigned int both = (unsigned int)__builtin_amdgcn_readlane((int)wave_inclusive_scan_u32((mall << 16) | before), 63);
+            mall = both >> 16;
+            before = (both & 0xFFFFu) + si.before;     // + the elements EQUAL to the threshold that sort before it
             if (mall < 2u || before == 0u) return t_a;      // the threshold element alone / nothing of the band below it (see 1.)
         }
     }
@@ -395,7 +411,7 @@ __device__ __forceinline__ void router_team(const RouterArgs &a, int64_t blk, un
     const int64_t seg = blk / nb;
     const int band = (int)(blk - seg * nb);
     RouterShared *sh = reinterpret_cast<RouterShared *>(dyn);
-    unsigned long long *gc_bits = reinterpret_cast<unsigned long long *>(dyn + 3072);  // [ceil(N16/64)]
+    unsigned long long *gc_bits = reinterpret_cast<unsigned long long *>(dyn + kRouterSharedBytes);  // [ceil(N16/64)]
 
     const int tid = threadIdx.x;
     const int lane = lane_id();
@@ -412,6 +428,8 @@ __device__ __forceinline__ void router_team(const RouterArgs &a, int64_t blk, un
     const float *e16 = a.e16 + seg * N16;
     const float *e8 = a.e8 + seg * N8;
     RefineShared *rs = nullptr;
+    for (int i = tid; i < 256; i += NT) sh->hist[0][i] = 0;        // (radix_select: the first select's first buffer)
+    if (!a.stage) __syncthreads();
     if (a.stage) {
         // one round trip to HBM/L2 instead of one per radix pass (8 passes + 3 elementwise sweeps)
         float *l16 = reinterpret_cast<float *>(gc_bits + ((N16 + 63) >> 6));
@@ -587,7 +605,7 @@ __device__ __forceinline__ void router_team(const RouterArgs &a, int64_t blk, un
 // the maps (stage 1 only; *stage = -1 if that does not fit the budget).
 __host__ __device__ inline size_t router_lds_bytes(int64_t N16, int64_t N8, int *stage, size_t budget = 96 * 1024, bool refine = false)
 {
-    size_t lds = 3072 + 8 * (size_t)((N16 + 63) / 64);
+    size_t lds = kRouterSharedBytes + 8 * (size_t)((N16 + 63) / 64);
     int st = 0;
     if (refine) {
         const size_t need = lds + 4 * (size_t)(N16 + N8) + 16 + sizeof(RefineShared);
