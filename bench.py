@@ -1059,14 +1059,16 @@ def run_rank(a, rank, world, local):
                                             graph=not a.no_graph, ring=not a.no_ring, fuse_router=not a.split_router, max_ring=a.max_ring,
                                             )
             stream.capture()
+            # every graph of the W warm-up steps AND of the K timed steps is captured before the warm-up runs: nothing but the
+            # barrier lies between the last warm-up step and the first timed one (a capture in between left the GPU idle for
+            # milliseconds and the timed window started from its idle clocks)
             stream.prepare(a.warmup)
+            stream.prepare(a.steps, after=a.warmup)
+            sync()
         stream.submit(a.warmup)
         stream.join()
-        sync()
-        if hasattr(stream, "prepare"):
-            stream.prepare(a.steps)                         # captures the graphs the timed submit replays (outside the timed region)
-            sync()
         hist.zero_()
+        sync()
 
     barrier()
     t0 = time.perf_counter()

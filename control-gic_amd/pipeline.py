@@ -237,15 +237,17 @@ class LaneStream:
         lane["graphs"][key] = (g, outs)
         return g, outs
 
-    def _plan(self, n):
-        """[(lane, start, count), ...] per lane for the next n batches, without advancing"""
+    def _plan(self, n, after=0):
+        """[(lane, start, count), ...] per lane for the n batches that follow the next `after` ones, without advancing"""
         L = len(self.lanes)
-        todo = [0] * L
-        for t in range(self._t, self._t + n):
+        skip, todo = [0] * L, [0] * L
+        for t in range(self._t, self._t + after):
+            skip[t % L] += 1
+        for t in range(self._t + after, self._t + after + n):
             todo[t % L] += 1
         plans = []
         for j, lane in enumerate(self.lanes):
-            m, pos, runs = len(lane["slots"]), lane["pos"], []
+            m, pos, runs = len(lane["slots"]), (lane["pos"] + skip[j]) % len(lane["slots"]), []
             c = todo[j]
             while c:
                 k = min(c, self.max_ring)
@@ -255,12 +257,13 @@ class LaneStream:
             plans.append(runs)
         return plans
 
-    def prepare(self, n):
-        """capture (outside any timed region) every graph the next submit(n) will replay"""
+    def prepare(self, n, after=0):
+        """capture (outside any timed region) every graph submit(n) will replay once the next `after` batches have been
+        submitted: prepare(W); prepare(K, after=W); submit(W); submit(K) leaves no capture between the warm-up and the run"""
         if not self._captured:
             self.capture()
         if self.graph:
-            plans = self._plan(n)
+            plans = self._plan(n, after)
             for lane, runs in zip(self.lanes, plans):
                 for start, count in runs:
                     self._graph(lane, start, count)
