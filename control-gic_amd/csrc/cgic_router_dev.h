@@ -23,6 +23,12 @@ __device__ __forceinline__ float key2f(uint32_t k)
     return __uint_as_float(u);
 }
 
+// A pointer the compiler KNOWS points into LDS: the maps' copies are reached through pointers that may as well be global (the
+// unstaged cases), so plain reads compile to flat_load + a full s_waitcnt per element -- a 768x768 tile's selects spent most of
+// their 22 us there.  Reads through this type are ds_read_b32.
+typedef const __attribute__((address_space(3))) float *lds_cf32;
+__device__ __forceinline__ lds_cf32 as_lds(const float *p) { return (lds_cf32)p; }
+
 struct RouterShared {
     unsigned int hist[4][256];      // pass p counts into [p]; [p + 1] is cleared meanwhile ([0] of the next select during pass 3)
 };
@@ -57,14 +63,25 @@ __device__ float radix_select(F val, int64_t n, unsigned int rank0, RouterShared
         // hot pass costs one or two atomics per lane instead of n / NT, a spread-out pass the same as before.
         {
             unsigned int run_d = 0, run_n = 0;
-            for (int64_t i = tid; i < n; i += NT) {
-                const uint32_t key = f2key(val(i));
-                if ((key & himask) != prefix) continue;
+            auto take = [&](float v) {
+                const uint32_t key = f2key(v);
+                if ((key & himask) != prefix) return;
                 const unsigned int digit = (key >> shift) & 0xFF;
                 if (digit != run_d && run_n) { atomicAdd(&h[run_d], run_n); run_n = 0; }
                 run_d = digit;
                 ++run_n;
+            };
+            // full trips of four elements per lane: all four loads in front of the first atomic (the compiler does not move a
+            // load across one; one load per trip was one LDS round trip per element, 9-18 of them per lane and pass for a tile)
+            int64_t base = 0;
+            for (; base + 4 * NT <= n; base += 4 * NT) {
+                float v[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) v[u] = val(base + u * NT + tid);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) take(v[u]);
             }
+            for (int64_t i = base + tid; i < n; i += NT) take(val(i));
             // The exponent byte (pass 0): nearly every lane of the workgroup is left holding the SAME digit, one atomic each on
             // one counter (~1 cycle apiece, 512-1024 of them per select of a 256x256 image).  The lanes that share the first
             // pending lane's digit hand their counts to it, twice (a masked map has two hot digits: the gated zeros and the rest).
@@ -375,36 +392,26 @@ __device__ float refine_select(float *arr, int n, unsigned int rank, float t_a, 
         __syncthreads();
         sweep(rs->list, (int)cnt[2], [](int, int) { return true; });
     }
-    const float thr = radix_select<NT>([&](int64_t i) { return arr[i]; }, n, rank, sh);
+    const lds_cf32 arr_l = as_lds(arr);                  // (refinement only runs on staged maps)
+    const float thr = radix_select<NT>([&](int64_t i) { return arr_l[i]; }, n, rank, sh);
     __builtin_amdgcn_s_setprio(0);
     return thr;
 }
 
-// The whole router for segment `seg`, executed by a block of NT threads; `dyn` = dynamic LDS of at least
-// router_lds_bytes() bytes.
-template <int NT>
+// The whole router for segment `seg`, executed by a block of NT threads; `dyn` = dynamic LDS of at least router_lds_bytes() bytes.
+// ST: both maps are staged in LDS (a.stage == 1: every segment that fits -- per-image routing up to 768x768 tiles): the copy the
+// launches of the timed paths run, all element reads ds_read; the other copy serves the unstaged / half-staged segments.
+template <int NT, bool ST>
 __device__ __forceinline__ void router_team(const RouterArgs &a, int64_t blk, unsigned char *dyn);
 
-// The router of workgroup `blk`, executed by a block of NT threads.  A small segment (a 256x256 image: 256 + 1024 map values) is
-// routed by a TEAM of CGIC_ROUTER_TEAM threads; the other waves of the workgroup leave at once (they take no part in barriers any
-// more): every wave repeats the histogram scans, and in the fused launch the router's waves only get the issue slots the VQ
-// workgroup on the same CU leaves over -- what counts there is the number of instructions, not the number of lanes.
-#ifndef CGIC_ROUTER_TEAM
-#define CGIC_ROUTER_TEAM 0
-#endif
 template <int NT>
 __device__ __forceinline__ void router_body(const RouterArgs &a, int64_t blk, unsigned char *dyn)
 {
-    constexpr int TEAM = CGIC_ROUTER_TEAM;
-    if (TEAM > 0 && TEAM < NT && a.per * a.h16 * a.w16 * 4 <= 2048) {
-        if ((int)threadIdx.x >= TEAM) return;
-        router_team<(TEAM > 0 && TEAM < NT) ? TEAM : NT>(a, blk, dyn);
-        return;
-    }
-    router_team<NT>(a, blk, dyn);
+    if (a.stage == 1) router_team<NT, true>(a, blk, dyn);
+    else router_team<NT, false>(a, blk, dyn);
 }
 
-template <int NT>
+template <int NT, bool ST>
 __device__ __forceinline__ void router_team(const RouterArgs &a, int64_t blk, unsigned char *dyn)
 {
     const int nb = a.bands > 1 ? a.bands : 1;
@@ -448,6 +455,9 @@ __device__ __forceinline__ void router_team(const RouterArgs &a, int64_t blk, un
         __syncthreads();
     }
     const bool refine = rs != nullptr;          // (the host only asks for it at stage 1: both maps in LDS)
+    // element reads: ds_read in the staged copy (see lds_cf32)
+    auto rd16 = [&](int64_t i) -> float { if constexpr (ST) return as_lds(e16)[i]; else return e16[i]; };
+    auto rd8 = [&](int64_t i) -> float { if constexpr (ST) return as_lds(e8)[i]; else return e8[i]; };
     CGIC_STAMP(1);
     int32_t *mc = a.mask_c + seg * N16;
     int32_t *mm = a.mask_m + seg * N8;
@@ -459,7 +469,7 @@ __device__ __forceinline__ void router_team(const RouterArgs &a, int64_t blk, un
     float thr_c = 0.f;
     if (has_thr_c) {
         SelInfo si;
-        thr_c = radix_select<NT>([&](int64_t i) { return e16[i]; }, N16, a.rank_c, sh, &si);
+        thr_c = radix_select<NT>(rd16, N16, a.rank_c, sh, &si);
         if (refine)
             thr_c = refine_select<NT, 16>(const_cast<float *>(e16), (int)N16, a.rank_c, thr_c, [](int) { return false; }, a.rf,
                                           seg * a.per, (int)w16, (int)n16, rs, sh, si, 0);
@@ -469,7 +479,7 @@ __device__ __forceinline__ void router_team(const RouterArgs &a, int64_t blk, un
     const int64_t N16r = (N16 + 63) & ~(int64_t)63;
     for (int64_t i = tid; i < N16r; i += NT) {
         bool g = false;
-        if (i < N16) g = has_thr_c ? (e16[i] < thr_c) : (mode == 4);
+        if (i < N16) g = has_thr_c ? (rd16(i) < thr_c) : (mode == 4);
         unsigned long long bal = __ballot(g);
         if (lane == 0) gc_bits[i >> 6] = bal;
         if (i < N16 && band == 0) mc[i] = g ? 1 : 0;
@@ -511,15 +521,16 @@ __device__ __forceinline__ void router_team(const RouterArgs &a, int64_t blk, un
             // sit beside the plain one; the plain value of a gated element is never needed again: its medium gate is
             // (v < thr) && !gate_coarse whatever v is -- 4 N8 bytes of LDS less.)
             float *l8m = const_cast<float *>(e8);
+            __attribute__((address_space(3))) float *l8w = (__attribute__((address_space(3))) float *)l8m;
             if (rows2d) {
                 for (int y = wv; y < (int)h8; y += NWV)
-                    for (int x = lane; x < w8i; x += 64) l8m[y * w8i + x] = l8m[y * w8i + x] * (1.0f - (gc_at(0, y, x) ? 1.0f : 0.0f));
+                    for (int x = lane; x < w8i; x += 64) l8w[y * w8i + x] = l8w[y * w8i + x] * (1.0f - (gc_at(0, y, x) ? 1.0f : 0.0f));
             } else {
-                for (int64_t i = tid; i < N8; i += NT) l8m[i] = l8m[i] * (1.0f - (gc_of8(i) ? 1.0f : 0.0f));
+                for (int64_t i = tid; i < N8; i += NT) l8w[i] = l8w[i] * (1.0f - (gc_of8(i) ? 1.0f : 0.0f));
             }
             __syncthreads();
             SelInfo si;
-            thr_m = radix_select<NT>([&](int64_t i) { return l8m[i]; }, N8, a.rank_m, sh, &si);
+            thr_m = radix_select<NT>(rd8, N8, a.rank_m, sh, &si);        // (stage 2: the masked copy through the generic pointer)
             if (refine)       // (a gated element's 0 is exact: never re-evaluated, never overwritten)
                 thr_m = refine_select<NT, 8>(l8m, (int)N8, a.rank_m, thr_m, [&](int i) { return gc_of8(i); }, a.rf, seg * a.per, w8i,
                                              n8i, rs, sh, si, 1);
@@ -529,7 +540,7 @@ __device__ __forceinline__ void router_team(const RouterArgs &a, int64_t blk, un
     }
     if (mode == 1) {      // :40-43
         SelInfo si;
-        thr_m = radix_select<NT>([&](int64_t i) { return e8[i]; }, N8, a.rank_m, sh, &si);
+        thr_m = radix_select<NT>(rd8, N8, a.rank_m, sh, &si);
         if (refine)
             thr_m = refine_select<NT, 8>(const_cast<float *>(e8), (int)N8, a.rank_m, thr_m, [](int) { return false; }, a.rf, seg * a.per,
                                          w8i, n8i, rs, sh, si, 1);
@@ -543,13 +554,13 @@ __device__ __forceinline__ void router_team(const RouterArgs &a, int64_t blk, un
         default: return false;
         }
     };
-    auto gm_of8 = [&](int64_t i) -> bool { return gm_rule(e8[i], (mode == 0 || mode == 3) ? gc_of8(i) : false); };
+    auto gm_of8 = [&](int64_t i) -> bool { return gm_rule(rd8(i), (mode == 0 || mode == 3) ? gc_of8(i) : false); };
     CGIC_STAMP(4);
     CGIC_RT_STAMP(2);
     if (rows2d) {
         for (int y = 2 * cy0 + wv; y < 2 * cy1; y += NWV)
             for (int x = lane; x < w8i; x += 64)
-                mm[y * w8i + x] = gm_rule(e8[y * w8i + x], (mode == 0 || mode == 3) ? gc_at(0, y, x) : false) ? 1 : 0;
+                mm[y * w8i + x] = gm_rule(rd8(y * w8i + x), (mode == 0 || mode == 3) ? gc_at(0, y, x) : false) ? 1 : 0;
     } else {
         for (int64_t i = tid; i < N8; i += NT) mm[i] = gm_of8(i) ? 1 : 0;
     }
@@ -565,7 +576,7 @@ __device__ __forceinline__ void router_team(const RouterArgs &a, int64_t blk, un
         const bool gc = (gc_bits[c >> 6] >> (c & 63)) & 1ull;
         const int64_t m0 = (int64_t)b * n8 + (y >> 1) * W8 + (x >> 1);
         const bool gcm = (mode == 0 || mode == 3) ? gc : false;          // (the medium pair's coarse parent is this quad's)
-        const bool gm0 = gm_rule(e8[m0], gcm), gm1 = gm_rule(e8[m0 + 1], gcm);
+        const bool gm0 = gm_rule(rd8(m0), gcm), gm1 = gm_rule(rd8(m0 + 1), gcm);
         bool gf0, gf1;
         switch (mode) {
         case 0: gf0 = !gc && !gm0; gf1 = !gc && !gm1; break;
