@@ -34,6 +34,7 @@ stages = {
     "vq alone": lambda: _vq_forward(hp.z, hp.vq.embedding.weight, 0.25, True, None, prepared=prep),
     "compress": lambda: hp.codec.compress(ind, mask, mode, hist=hp.hist),
     "decompress": lambda: hp.codec.decompress(comp),
+    "decompress (throughput decoder)": lambda: hp.codec.decompress(comp, decoder="throughput"),
 }
 for name, f in stages.items():
     for _ in range(3): f()
