@@ -606,6 +606,40 @@ def div2k_image(dev, cb, vq, codec, iters=8):
                                "note": "whole image captured once, shape groups on parallel streams"}
     except Exception as e:      # an extra data point: never fail the bench line
         res["graph_replay"] = {"error": str(e)[:200]}
+    # the same image as ONE launch chain: the four shape groups through one launch per kernel (launch groups, cgic_group_begin /
+    # _launch; highres chain=True): entropy | VQ + router | compress | decode | merge = 5 launches for the six tiles
+    try:
+        import control_gic_amd as cg
+
+        def once_chain(check=True):
+            t = highres.compress_tiled(x, encode, codec, chain=True)
+            p, st = highres.decompress_tiled(t, codec, check=check, chain=True)
+            return t, p, st
+        tc, pc, _ = once_chain(); torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(iters):
+            tc, pc, _ = once_chain()
+        torch.cuda.synchronize()
+        dtc = (time.perf_counter() - t0) / iters
+        same_c = tc.streams() == tiled.streams() and all(torch.equal(a[0], b[0]) and torch.equal(a[2], b[2]) for a, b in zip(pc, per_tile))
+        res["chain"] = {"eager_ms_per_image": round(dtc * 1e3, 4), "eager_MPixels/s": round(H * W / dtc / 1e6, 1), "streams_equal_eager": bool(same_c),
+                        "note": "all shape groups through ONE launch per kernel (cgic_group_*): 5 launches + the pad / cut copies"}
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        gc_, (tgc, pgc, stgc) = cg.capture_graph(lambda: once_chain(False), side)
+        torch.cuda.current_stream().wait_stream(side)
+        for _ in range(3):
+            gc_.replay()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(4 * iters):
+            gc_.replay()
+        torch.cuda.synchronize()
+        dtgc = (time.perf_counter() - t0) / (4 * iters)
+        res["chain"].update({"graph_replay_ms_per_image": round(dtgc * 1e3, 4), "graph_replay_MPixels/s": round(H * W / dtgc / 1e6, 1),
+                             "graph_streams_equal_eager": bool(int(stgc.abs().max()) == 0 and tgc.streams() == tiled.streams())})
+    except Exception as e:
+        res["chain"] = {"error": str(e)[:300]}
     # four such images in flight: one hipGraph per image (its shape groups one after the other) on four independent HIP streams,
     # the small-footprint decoder -- the tiling driver under pipeline.LaneStream's schedule
     try:

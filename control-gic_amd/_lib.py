@@ -6,6 +6,7 @@ different code path.
 """
 import ctypes as C
 import os
+import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # CGIC_LIB lets dev tools load an instrumented build of the SAME sources (make -C csrc dbg)
@@ -48,6 +49,11 @@ PROTOTYPES = {
     "cgic_decode_stats": (_int, [_vp]),
     "cgic_device_count": (_int, []),
     "cgic_launch_graphs": (_int, [C.POINTER(_vp), C.POINTER(_vp), _int]),
+    "cgic_group_max": (_int, []),
+    "cgic_group_begin": (_int, [_int, C.POINTER(C.c_double)]),
+    "cgic_group_select": (_int, [_int]),
+    "cgic_group_launch": (_int, [_vp]),
+    "cgic_group_abort": (None, []),
     "cgic_ticket_scope_begin": (_int, []),
     "cgic_ticket_scope_end": (_int, []),
     "cgic_ticket_scope_release": (_int, [_int]),
@@ -127,9 +133,57 @@ def call(name, *args):
     return check(getattr(lib(), name)(*args))
 
 
+class launch_group:
+    """`with launch_group(n, shares) as g:` -- independent sub-batches of different shapes through ONE launch per kernel
+    (cgic_group_begin / _select / _launch, include/cgic_hip.h): inside the block the entropy / VQ+router / compress / decompress
+    calls of this thread record their launches; `g.select(k)` names the group the following calls belong to; leaving the block
+    issues the recorded launches position by position on `device`'s current stream.  Outputs are valid (in stream order) after the
+    block; no torch work may consume them inside it."""
+
+    def __init__(self, n, shares=None, device=None):
+        self.n, self.shares, self.device, self.launches = int(n), shares, device, None
+
+    def __enter__(self):
+        arr = None
+        if self.shares is not None:
+            tot = float(sum(self.shares))
+            arr = (C.c_double * self.n)(*[max(float(v) / tot, 1e-6) for v in self.shares])
+        call("cgic_group_begin", self.n, arr)
+        _group_tls.keep = []
+        return self
+
+    def select(self, k):
+        call("cgic_group_select", int(k))
+
+    def __exit__(self, et, ev, tb):
+        try:
+            if et is not None:
+                lib().cgic_group_abort()
+                return False
+            import torch
+            with torch.cuda.device(self.device):
+                self.launches = call("cgic_group_launch", current_stream(self.device))
+        except BaseException:
+            lib().cgic_group_abort()
+            raise
+        finally:
+            _group_tls.keep = None          # (released in stream order: after the launches just enqueued)
+        return False
+
+
+_group_tls = threading.local()
+
+
 def ptr(t):
-    """device/host pointer of a torch tensor (None -> NULL)"""
-    return None if t is None else t.data_ptr()
+    """device/host pointer of a torch tensor (None -> NULL).  Inside a launch_group block the tensor is also kept alive until the
+    group has been launched: the launches are deferred, and a temporary released before them (a workspace, an output the caller
+    drops) would be handed out again by the caching allocator while a recorded launch still points at it"""
+    if t is None:
+        return None
+    keep = getattr(_group_tls, "keep", None)
+    if keep is not None:
+        keep.append(t)
+    return t.data_ptr()
 
 
 def conv_arg(conv, bias_first=False):
@@ -183,7 +237,7 @@ def pixels_arg(pixels, B, h16, w16, per_image, sigma=0.01, flat8=None):
         if tuple(flat8.shape) != (B, 2 * h16, 2 * w16) or flat8.dtype != torch.float32:
             raise ValueError(f"flat8 {flat8.dtype} {tuple(flat8.shape)} does not belong to these maps")
         flat8 = flat8.contiguous()
-    st = Pixels(px.data_ptr(), int(u8), linspace_bins(), 32, float(sigma), ptr(flat8))
+    st = Pixels(ptr(px), int(u8), linspace_bins(), 32, float(sigma), ptr(flat8))
     return C.byref(st), (st, px, flat8)
 
 

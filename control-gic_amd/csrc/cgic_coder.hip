@@ -461,7 +461,7 @@ constexpr int kLdsTable = 1024;          // tables up to this many single-word c
 // table) when no grid of the launch has more positions than that -- a 256x256 image -- because what such a latency-bound workgroup
 // costs the kernels of OTHER batches in flight is the LDS it holds: 33.6 -> 32.7 us per step at four lanes (round 3).
 template <int LP>
-__global__ __launch_bounds__(kEncThreads) CGIC_VGPR_CAP_COMPRESS void compress_streams_kernel(CompressArgs a)
+__device__ __forceinline__ void compress_streams_body(const CompressArgs &a, const Blk blk)
 {
     __shared__ __attribute__((aligned(16))) uint32_t lds_end[LP];
     __shared__ uint16_t lds_sym[LP];
@@ -475,11 +475,11 @@ __global__ __launch_bounds__(kEncThreads) CGIC_VGPR_CAP_COMPRESS void compress_s
     // Split streams wait for each other: their launch is (jobs, B) -- the parts of a stream are neighbours in dispatch order,
     // so a workgroup never holds a CU waiting for one that is hundreds of workgroups behind it in the queue.
     const bool jobs_fastest = a.tick != nullptr;
-    const int64_t b = jobs_fastest ? blockIdx.y : blockIdx.x;
+    const int64_t b = jobs_fastest ? blk.y : blk.x;
     CGIC_STAMP2(0);
     CGIC_SPAN_BEGIN();
 #ifdef CGIC_PHASE_CLOCKS      // dev: per-workgroup (start, end) for tools/probes/probe_compress_blocks.py
-    const unsigned int dbg_lin = (unsigned int)b * 16 + (jobs_fastest ? blockIdx.x : blockIdx.y);      // (image, job in launch order) like the probe expects
+    const unsigned int dbg_lin = (unsigned int)b * 16 + (jobs_fastest ? blk.x : blk.y);      // (image, job in launch order) like the probe expects
     if (threadIdx.x == 0 && dbg_lin < 4096) g_blk_t[2 * dbg_lin] = wall_clock64();
     struct DbgEnd { unsigned int lin; __device__ ~DbgEnd() { if (threadIdx.x == 0 && lin < 4096) g_blk_t[2 * lin + 1] = wall_clock64(); } } dbg_end{dbg_lin};
 #endif
@@ -557,7 +557,7 @@ __global__ __launch_bounds__(kEncThreads) CGIC_VGPR_CAP_COMPRESS void compress_s
         }
         if (threadIdx.x == 0 && part == nparts - 1) *nb = rc < 0 ? rc - 10 : rc;     // errors are CGIC_ERR_* - 10 (-1 means "not written")
     };
-    int y = (int)(jobs_fastest ? blockIdx.x : blockIdx.y);
+    int y = (int)(jobs_fastest ? blk.x : blk.y);
     if (a.combine) {
         // unsplit streams (grids up to kLdsPos positions): the fine stream, the medium stream, ONE workgroup for the three short
         // streams one after the other (coarse indices, the two masks), and the histogram if asked for.  As six workgroups per
@@ -584,6 +584,20 @@ __global__ __launch_bounds__(kEncThreads) CGIC_VGPR_CAP_COMPRESS void compress_s
         run_job(s, part, nparts);
     }
     CGIC_SPAN_END();
+}
+
+template <int LP>
+__global__ __launch_bounds__(kEncThreads) CGIC_VGPR_CAP_COMPRESS void compress_streams_kernel(CompressArgs a)
+{
+    compress_streams_body<LP>(a, own_blk());
+}
+
+// several shape groups in one launch (cgic_common.h: launch groups); split streams keep their own ticket slots per group
+__global__ __launch_bounds__(kEncThreads) CGIC_VGPR_CAP_COMPRESS void compress_streams_grouped_kernel(Grouped<CompressArgs> g)
+{
+    Blk blk;
+    const CompressArgs &a = g.a[group_locate(g, &blk)];
+    compress_streams_body<kLdsPos>(a, blk);
 }
 
 struct EncodeOneArgs {
@@ -741,13 +755,30 @@ extern "C" int cgic_compress_streams(const cgic_table *t, const int64_t *ind, co
     a.combine = (!a.tick && h * w <= kLdsPos) ? 1 : 0;
     const unsigned jobs = a.combine ? 3u + (hist ? 1u : 0u) : (unsigned)(a.parts[0] + a.parts[1] + a.parts[2]) + 2u + (hist ? 1u : 0u);
     if (a.combine && h * w <= kLdsPosSmall && (!hist || cgic_table_num_symbols(t) <= kLdsPosSmall)) {
-        hipLaunchKernelGGL(compress_streams_kernel<kLdsPosSmall>, dim3((unsigned)B, jobs), dim3(kEncThreads), 0, (hipStream_t)stream, a);
-        return launch_check("compress_streams_kernel");
+        const dim3 grid_s((unsigned)B, jobs);
+        hipStream_t s_ = (hipStream_t)stream;
+        return launch_or_record(KID_NONE, grid_s, dim3(kEncThreads), 0, a, [=] {
+            hipLaunchKernelGGL(compress_streams_kernel<kLdsPosSmall>, grid_s, dim3(kEncThreads), 0, s_, a);
+            return launch_check("compress_streams_kernel"); });
     }
-    hipLaunchKernelGGL(compress_streams_kernel<kLdsPos>, a.tick ? dim3(jobs, (unsigned)B) : dim3((unsigned)B, jobs), dim3(kEncThreads), dyn,
-                       (hipStream_t)stream, a);
-    return launch_check("compress_streams_kernel");
+    const dim3 grid = a.tick ? dim3(jobs, (unsigned)B) : dim3((unsigned)B, jobs);
+    hipStream_t s = (hipStream_t)stream;
+    return launch_or_record(KID_COMPRESS, grid, dim3(kEncThreads), dyn, a, [=] {
+        hipLaunchKernelGGL(compress_streams_kernel<kLdsPos>, grid, dim3(kEncThreads), dyn, s, a);
+        return launch_check("compress_streams_kernel"); });
 }
+
+static int compress_grouped_launch(const GroupRec *const *recs, int n, hipStream_t s)
+{
+    Grouped<CompressArgs> g;
+    size_t lds;
+    int rc = fill_grouped(recs, n, &g, &lds);
+    if (rc) return rc;
+    if (lds) { rc = ensure_dynamic_lds((const void *)compress_streams_grouped_kernel, lds); if (rc) return rc; }
+    hipLaunchKernelGGL(compress_streams_grouped_kernel, dim3(g.start[kMaxGroups]), dim3(kEncThreads), lds, s, g);
+    return launch_check("compress_streams_grouped_kernel");
+}
+static GroupedRegistrar reg_compress(KID_COMPRESS, compress_grouped_launch);
 
 extern "C" int cgic_encode_stream(const cgic_table *t, const void *syms, int elem_bytes, int64_t n, uint8_t *out,
                                   int64_t cap, int32_t *nbytes, void *workspace, cgic_stream_t stream)

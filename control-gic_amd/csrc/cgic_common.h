@@ -5,6 +5,9 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <functional>
+#include <vector>
+
 #include "../../include/cgic_hip.h"
 
 namespace cgic {
@@ -66,6 +69,73 @@ int acquire_tickets(hipStream_t stream, int n, unsigned int **ptr);
 // hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per (function, device) and size -- not on every launch
 int ensure_dynamic_lds(const void *fn, size_t bytes);
 
+// ---- launch groups (cgic_group_begin / _select / _launch, cgic_launch.hip) ------------------------------------------
+// Independent sub-batches of DIFFERENT shapes (the shape groups of one tiled image: inference_high_resolution.py:112-125 cuts
+// a 2040x1356 image into six tiles of four shapes, :246 runs them one by one) go through ONE launch per kernel: between
+// cgic_group_begin and cgic_group_launch the entry points of this thread record what they would have launched -- the host-side
+// shape logic of every call runs unchanged -- and cgic_group_launch issues, position by position, one launch whose grid is the
+// concatenation of the recorded grids.  A workgroup finds its group from blockIdx.x (<= kMaxGroups scalar compares), takes
+// that group's argument block from the kernarg segment (scalar loads with a uniform offset) and runs the unchanged kernel
+// body on its RELATIVE block index.  Kernels without a grouped form, or positions whose groups recorded different kernels,
+// are launched one by one: same results.
+constexpr int kMaxGroups = 4;           // shape groups of a tiled image: (full | ragged) x (full | ragged)
+struct Blk { unsigned int x, y, z, nx, ny; };      // block index inside the group's own grid (+ that grid's x / y extents)
+template <class A>
+struct Grouped {
+    unsigned int n;
+    unsigned int start[kMaxGroups + 1];           // first flat block of each group; start[n] = total
+    unsigned int gx[kMaxGroups], gy[kMaxGroups];  // the group's grid extents (x fastest, like the hardware's dispatch order)
+    A a[kMaxGroups];
+};
+enum KernelId { KID_NONE = 0, KID_ENTROPY_F32, KID_ENTROPY_U8, KID_VQF_ROUTER_AL, KID_VQF_ROUTER_UN, KID_COMPRESS, KID_DECODE_SPLIT,
+                KID_DECODE_IMAGE, KID_MERGE, KID_COUNT };
+
+// host side of a launch group
+struct GroupRec {                       // one recorded launch
+    int kid;
+    dim3 grid, block;
+    size_t lds;
+    std::vector<unsigned char> args;    // the kernel's argument block (the A of Grouped<A>)
+    std::function<int()> launch;        // the launch as it would have been made (fallback)
+};
+bool group_recording();                 // this thread is between cgic_group_begin and cgic_group_launch
+double group_cu_share();                // the current group's share of the chip (1.0 outside a group): persistent-workgroup kernels size their grid by it
+int group_record(int kid, dim3 grid, dim3 block, size_t lds, const void *args, size_t bytes, std::function<int()> launch);
+typedef int (*GroupedLauncher)(const GroupRec *const *recs, int n, hipStream_t s);
+struct GroupedRegistrar { GroupedRegistrar(int kid, GroupedLauncher fn); };
+
+// launch now, or record for cgic_group_launch
+template <class A, class F>
+inline int launch_or_record(int kid, dim3 grid, dim3 block, size_t lds, const A &a, F direct)
+{
+    if (group_recording()) return group_record(kid, grid, block, lds, &a, sizeof(A), std::function<int()>(direct));
+    return direct();
+}
+
+// the argument block of a grouped launch from the records of one position (same kernel id, same block size: checked by the caller)
+template <class A>
+inline int fill_grouped(const GroupRec *const *recs, int n, Grouped<A> *g, size_t *lds_max)
+{
+    static_assert(sizeof(Grouped<A>) <= 4096, "the grouped argument block must fit the kernarg segment");
+    CGIC_REQUIRE(n >= 1 && n <= kMaxGroups, CGIC_ERR_INVALID, "group launch: %d groups", n);
+    g->n = (unsigned int)n;
+    unsigned int at = 0;
+    *lds_max = 0;
+    for (int i = 0; i < kMaxGroups; ++i) {
+        const GroupRec *r = recs[i < n ? i : n - 1];          // unused entries repeat the last group (never selected)
+        CGIC_REQUIRE(r->args.size() == sizeof(A), CGIC_ERR_INVALID, "group launch: argument block of %zu bytes, expected %zu", r->args.size(), sizeof(A));
+        memcpy((void *)&g->a[i], r->args.data(), sizeof(A));
+        g->gx[i] = r->grid.x; g->gy[i] = r->grid.y;
+        g->start[i] = at;
+        if (i < n) {
+            at += r->grid.x * r->grid.y * r->grid.z;
+            if (r->lds > *lds_max) *lds_max = r->lds;
+        }
+    }
+    for (int i = n; i <= kMaxGroups; ++i) g->start[i] = at;
+    return CGIC_OK;
+}
+
 struct Table;  // host object behind cgic_table
 int table_device_view(const cgic_table *t, TableDev *out);  // uploads lazily
 
@@ -102,6 +172,22 @@ extern __device__ long long g_blk_t[2 * 4096];   // per-workgroup (start, end) o
 
 // ---- wave / block primitives ---------------------------------------------------
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & (kWave - 1)); }
+
+// which group this workgroup belongs to and its block index inside that group's grid (all scalar: blockIdx + kernarg loads)
+template <class A>
+__device__ __forceinline__ int group_locate(const Grouped<A> &g, Blk *blk)
+{
+    const unsigned int b = blockIdx.x;
+    int i = 0;
+#pragma unroll
+    for (int k = 1; k < kMaxGroups; ++k)
+        if (b >= g.start[k]) i = k;            // (start[k] = total for k >= n: never reached)
+    const unsigned int rel = b - g.start[i], nx = g.gx[i], ny = g.gy[i];
+    const unsigned int t = rel / nx;
+    blk->x = rel - t * nx; blk->z = t / ny; blk->y = t - blk->z * ny; blk->nx = nx; blk->ny = ny;
+    return i;
+}
+__device__ __forceinline__ Blk own_blk() { return Blk{blockIdx.x, blockIdx.y, blockIdx.z, gridDim.x, gridDim.y}; }
 
 // gfx950 v_permlane16_swap / v_permlane32_swap: exchange between the 16-lane rows / 32-lane halves of a wave on
 // the VALU, no LDS round trip.  Called with a == b == x they return

@@ -680,8 +680,9 @@ __device__ __forceinline__ void decode_roles(int n0, int n1, int n2, int wgs, in
     *q0 = p0; *q1 = p1; *q2 = p2;
 }
 
-__global__ __launch_bounds__(kDecThreads) CGIC_VGPR_CAP_DECODE void decode_split_kernel(DecodeArgs a)
+__device__ __forceinline__ void decode_split_body(const DecodeArgs &a_in, const Blk blk)
 {
+    DecodeArgs a = a_in;             // (the trie pointer is redirected to the LDS copy below)
     extern __shared__ __attribute__((aligned(16))) uint32_t sm[];
     __shared__ int s_count;
     __shared__ uint32_t s_fn[kWave];
@@ -690,7 +691,7 @@ __global__ __launch_bounds__(kDecThreads) CGIC_VGPR_CAP_DECODE void decode_split
     uint32_t *win = lut + kDecLutMax;
     SegShared *seg = reinterpret_cast<SegShared *>(win + kDecWaves * kSegWinWords);
     const int tid = threadIdx.x, wave = tid >> 6;
-    const int64_t b = blockIdx.y;
+    const int64_t b = blk.y;
     // who am I: every workgroup of the image derives the same split from the same three byte counts.  The counts and the
     // three header bytes are requested first, the LUT / trie staging (the same for every role) runs while they arrive.
     const uint8_t *in0 = a.in + (b * CGIC_NUM_STREAMS) * a.slot;
@@ -705,13 +706,13 @@ __global__ __launch_bounds__(kDecThreads) CGIC_VGPR_CAP_DECODE void decode_split
         a.tab.child = ltrie;
     }
     int p0, p1, p2;
-    decode_roles(n0, n1, n2, (int)gridDim.x, &p0, &p1, &p2);
-    int s, part = (int)blockIdx.x, nparts;
+    decode_roles(n0, n1, n2, (int)blk.nx, &p0, &p1, &p2);
+    int s, part = (int)blk.x, nparts;
     if (part < p1) { s = 1; nparts = p1; }
     else if ((part -= p1) < p2) { s = 2; nparts = p2; }
     else if ((part -= p2) < p0) { s = 0; nparts = p0; }
     else { s = -1; nparts = 0; }
-    if (blockIdx.x == 0 && tid == 0) {
+    if (blk.x == 0 && tid == 0) {
         if (a.status) a.status[b] = 0;
         if (n0 <= 0) a.dcount[b * 3] = n0 == 0 ? -1 : -2;          // empty file (None) / not sent
         if (n1 <= 0) a.dcount[b * 3 + 1] = n1 == 0 ? -1 : -2;
@@ -764,6 +765,18 @@ __global__ __launch_bounds__(kDecThreads) CGIC_VGPR_CAP_DECODE void decode_split
     if (tid == 0 && part == nparts - 1) *dc = s_count > cap ? -3 : s_count;      // the last part knows the total
 }
 
+__global__ __launch_bounds__(kDecThreads) CGIC_VGPR_CAP_DECODE void decode_split_kernel(DecodeArgs a)
+{
+    decode_split_body(a, own_blk());
+}
+
+// several shape groups in one launch (cgic_common.h: launch groups)
+__global__ __launch_bounds__(kDecThreads) CGIC_VGPR_CAP_DECODE void decode_split_grouped_kernel(Grouped<DecodeArgs> g)
+{
+    Blk blk;
+    decode_split_body(g.a[group_locate(g, &blk)], blk);
+}
+
 constexpr int kMergeThreads = 512;
 #ifndef CGIC_MERGE_ONE_BAND_THREADS
 #define CGIC_MERGE_ONE_BAND_THREADS 512      // 1024 until round 3: 512 measured ~0.5-1 us per step better in flight
@@ -796,15 +809,15 @@ struct MergeArgs {
 // of 512 threads execute 1.10 M VALU instructions per batch of 64 images where one band of 1024 executes less than half --
 // instructions that, with several batches in flight, come out of the same VALU budget as the VQ's.
 template <int NT>
-__global__ __launch_bounds__(NT) CGIC_VGPR_CAP_MERGE void merge_kernel(MergeArgs a)
+__device__ __forceinline__ void merge_body(const MergeArgs &a, const Blk blk)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t sm[];
     __shared__ uint32_t scan_smem[NT / kWave + 1];
     __shared__ int s_status;
     __shared__ int s_hdr[8];            // nbytes[3], nbytes[4], dcount[0..2]
     const int tid = threadIdx.x;
-    const int band = blockIdx.x;
-    const int64_t b = blockIdx.y;
+    const int band = blk.x;
+    const int64_t b = blk.y;
     const int64_t h = a.h, w = a.w, h2 = h >> 1, w2 = w >> 1, h4 = h >> 2, w4 = w >> 2;
     const int64_t n_c = h4 * w4, n_m = h2 * w2, n_f = h * w;
     const int64_t wc = (n_c + 31) >> 5, wm = (n_m + 31) >> 5;
@@ -820,7 +833,7 @@ __global__ __launch_bounds__(NT) CGIC_VGPR_CAP_MERGE void merge_kernel(MergeArgs
     uint32_t *pmb = pcb + wc;           // [wm]
     const int mode = a.mode;
     // this block's rows: bands of whole coarse rows (multiples of 4 fine rows)
-    const int64_t nbands = gridDim.x;
+    const int64_t nbands = blk.nx;
     const int64_t rows_per = ((h4 + nbands - 1) / nbands) * 4;
     const int64_t r0 = band * rows_per, r1 = r0 + rows_per < h ? r0 + rows_per : h;
     if (r0 >= h) return;
@@ -1121,6 +1134,19 @@ __global__ __launch_bounds__(NT) CGIC_VGPR_CAP_MERGE void merge_kernel(MergeArgs
     if (tid == 0 && a.status && (st || s_status)) atomicMin(&a.status[b], st ? st : s_status);
 }
 
+template <int NT>
+__global__ __launch_bounds__(NT) CGIC_VGPR_CAP_MERGE void merge_kernel(MergeArgs a)
+{
+    merge_body<NT>(a, own_blk());
+}
+
+// several shape groups in one launch (cgic_common.h: launch groups)
+__global__ __launch_bounds__(kMergeThreads) CGIC_VGPR_CAP_MERGE void merge_grouped_kernel(Grouped<MergeArgs> g)
+{
+    Blk blk;
+    merge_body<kMergeThreads>(g.a[group_locate(g, &blk)], blk);
+}
+
 __global__ void gather_kernel(const int64_t *__restrict__ ind, int64_t B, int64_t hw,
                               const float *__restrict__ cb, int K, float *__restrict__ out,
                               int32_t *__restrict__ status)
@@ -1240,8 +1266,10 @@ extern "C" int cgic_decompress_streams(const cgic_table *t, const uint8_t *in, i
             ss = true;
             { int rc_ = ensure_dynamic_lds((const void *)decode_image_kernel, lds_ss); if (rc_) return rc_; }
             const int T = large ? kDecThreads : CGIC_SS_THREADS_SMALL;
-            hipLaunchKernelGGL(decode_image_kernel, dim3((unsigned)B), dim3(T), lds_ss, s, d, (int)stage_cap, (int)chunk_cap);
-            rc = launch_check("decode_image_kernel");
+            const int sc_ = (int)stage_cap, cc_ = (int)chunk_cap;
+            rc = launch_or_record(KID_NONE, dim3((unsigned)B), dim3(T), lds_ss, d, [=] {
+                hipLaunchKernelGGL(decode_image_kernel, dim3((unsigned)B), dim3(T), lds_ss, s, d, sc_, cc_);
+                return launch_check("decode_image_kernel"); });
         }
     }
 #endif
@@ -1268,12 +1296,15 @@ extern "C" int cgic_decompress_streams(const cgic_table *t, const uint8_t *in, i
             c.bf = d.bf + (size_t)b0 * 3 * kDecPartsMax * kWave;
             rc = acquire_tickets(s, (int)(nb * 3), &c.tick);
             if (rc) return rc;
-            hipLaunchKernelGGL(decode_split_kernel, dim3(large ? CGIC_DEC_WGS_LARGE : CGIC_DEC_WGS_SMALL, (unsigned)nb), dim3(kDecThreads), lds_d, s, c);
-            rc = launch_check("decode_split_kernel");
+            const dim3 grid_c(large ? CGIC_DEC_WGS_LARGE : CGIC_DEC_WGS_SMALL, (unsigned)nb);
+            rc = launch_or_record(KID_DECODE_SPLIT, grid_c, dim3(kDecThreads), lds_d, c, [=] {
+                hipLaunchKernelGGL(decode_split_kernel, grid_c, dim3(kDecThreads), lds_d, s, c);
+                return launch_check("decode_split_kernel"); });
         }
     } else {
-        hipLaunchKernelGGL(decode_streams_kernel, dim3((unsigned)B, 3), dim3(kDecThreads), lds_d, s, d);
-        rc = launch_check("decode_streams_kernel");
+        rc = launch_or_record(KID_NONE, dim3((unsigned)B, 3), dim3(kDecThreads), lds_d, d, [=] {
+            hipLaunchKernelGGL(decode_streams_kernel, dim3((unsigned)B, 3), dim3(kDecThreads), lds_d, s, d);
+            return launch_check("decode_streams_kernel"); });
     }
     if (rc) return rc;
     MergeArgs m;
@@ -1314,14 +1345,40 @@ extern "C" int cgic_decompress_streams(const cgic_table *t, const uint8_t *in, i
         // several batches in flight: one band of 1024 threads per image (see merge_kernel)
         if (lds_m > 48 * 1024)
             { int rc_ = ensure_dynamic_lds((const void *)merge_kernel<kMergeOneBandThreads>, (size_t)lds_m); if (rc_) return rc_; }
-        hipLaunchKernelGGL(merge_kernel<kMergeOneBandThreads>, dim3(1u, (unsigned)B), dim3(kMergeOneBandThreads), lds_m, s, m);
-        return launch_check("merge_kernel");
+        return launch_or_record(KID_NONE, dim3(1u, (unsigned)B), dim3(kMergeOneBandThreads), lds_m, m, [=] {
+            hipLaunchKernelGGL(merge_kernel<kMergeOneBandThreads>, dim3(1u, (unsigned)B), dim3(kMergeOneBandThreads), lds_m, s, m);
+            return launch_check("merge_kernel"); });
     }
     if (lds_m > 48 * 1024)
         { int rc_ = ensure_dynamic_lds((const void *)merge_kernel<kMergeThreads>, (size_t)lds_m); if (rc_) return rc_; }
-    hipLaunchKernelGGL(merge_kernel<kMergeThreads>, dim3((unsigned)nbands, (unsigned)B), dim3(kMergeThreads), lds_m, s, m);
-    return launch_check("merge_kernel");
+    const dim3 grid_m((unsigned)nbands, (unsigned)B);
+    return launch_or_record(KID_MERGE, grid_m, dim3(kMergeThreads), lds_m, m, [=] {
+        hipLaunchKernelGGL(merge_kernel<kMergeThreads>, grid_m, dim3(kMergeThreads), lds_m, s, m);
+        return launch_check("merge_kernel"); });
 }
+
+static int decode_split_grouped_launch(const GroupRec *const *recs, int n, hipStream_t s)
+{
+    Grouped<DecodeArgs> g;
+    size_t lds;
+    int rc = fill_grouped(recs, n, &g, &lds);
+    if (rc) return rc;
+    if (lds > 48 * 1024) { rc = ensure_dynamic_lds((const void *)decode_split_grouped_kernel, lds); if (rc) return rc; }
+    hipLaunchKernelGGL(decode_split_grouped_kernel, dim3(g.start[kMaxGroups]), dim3(kDecThreads), lds, s, g);
+    return launch_check("decode_split_grouped_kernel");
+}
+static int merge_grouped_launch(const GroupRec *const *recs, int n, hipStream_t s)
+{
+    Grouped<MergeArgs> g;
+    size_t lds;
+    int rc = fill_grouped(recs, n, &g, &lds);
+    if (rc) return rc;
+    if (lds > 48 * 1024) { rc = ensure_dynamic_lds((const void *)merge_grouped_kernel, lds); if (rc) return rc; }
+    hipLaunchKernelGGL(merge_grouped_kernel, dim3(g.start[kMaxGroups]), dim3(kMergeThreads), lds, s, g);
+    return launch_check("merge_grouped_kernel");
+}
+static GroupedRegistrar reg_decode_split(KID_DECODE_SPLIT, decode_split_grouped_launch);
+static GroupedRegistrar reg_merge(KID_MERGE, merge_grouped_launch);
 
 extern "C" int cgic_embedding_gather_f32(const int64_t *ind, int64_t B, int64_t hw, const float *codebook, int K,
                                          int e_dim, float *out, int32_t *status, cgic_stream_t stream)

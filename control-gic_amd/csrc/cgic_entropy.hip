@@ -101,27 +101,28 @@ __device__ __forceinline__ unsigned int cvt_round_u32(float v)
 // them as the fp32 [B, 3, H, W] tensor the conv encoder takes (inference.py:50-59 + model.py:99-101): 3 B read + 12 B written
 // per pixel instead of 3 + 12 (ToTensor) and 12 again (Entropy)
 template <bool U8>
-__global__ __launch_bounds__(kEntThreads) void entropy_maps_kernel(
+__device__ __forceinline__ void entropy_maps_body(
     const void *__restrict__ xin, int64_t H, int64_t W, float exp2_scale, float *__restrict__ e8,
-    float *__restrict__ e16, BinsArg bins_arg, int patches_per_wave, float *__restrict__ x_out, float *__restrict__ flat8)
+    float *__restrict__ e16, const BinsArg &bins_arg, int patches_per_wave, float *__restrict__ x_out, float *__restrict__ flat8,
+    const Blk blk)
 {
     const float *__restrict__ x = reinterpret_cast<const float *>(xin);
     __shared__ __attribute__((aligned(16))) unsigned int hist_all[kEntWaves][kBins * kHistStride];
     __shared__ float bins[kBins + 4];
 
-    const int64_t b = blockIdx.z;
-    const int64_t row0 = (int64_t)blockIdx.y * 16;
+    const int64_t b = blk.z;
+    const int64_t row0 = (int64_t)blk.y * 16;
     const int tid = threadIdx.x;
     const int lane = lane_id();
     const int wave = tid >> 6;
     // the workgroup's band of 16-pixel-wide patches; wave w takes patches w, w + 4, ... of it
     const int64_t npx = W / 16;
-    const int64_t p_lo = (int64_t)blockIdx.x * (kEntWaves * patches_per_wave);
+    const int64_t p_lo = (int64_t)blk.x * (kEntWaves * patches_per_wave);
     const int64_t p_end = p_lo + kEntWaves * patches_per_wave < npx ? p_lo + kEntWaves * patches_per_wave : npx;
 
     CGIC_STAMP(16);
 #ifdef CGIC_PHASE_CLOCKS      // dev: per-workgroup (start, end) for tools/probes/probe_entropy.py
-    const unsigned int dbg_lin = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+    const unsigned int dbg_lin = (blk.z * blk.ny + blk.y) * blk.nx + blk.x;
     if (threadIdx.x == 0 && dbg_lin < 4096) g_blk_t[2 * dbg_lin] = wall_clock64();
     struct DbgEnd { unsigned int lin; __device__ ~DbgEnd() { if (threadIdx.x == 0 && lin < 4096) g_blk_t[2 * lin + 1] = wall_clock64(); } } dbg_end{dbg_lin};
 #endif
@@ -280,6 +281,30 @@ __global__ __launch_bounds__(kEntThreads) void entropy_maps_kernel(
     }
 }
 
+struct EntArgs {
+    const void *x;
+    int64_t H, W;
+    float exp2_scale;
+    int ppw;
+    float *e8, *e16, *x_out, *flat8;
+    BinsArg bins;
+};
+
+template <bool U8>
+__global__ __launch_bounds__(kEntThreads) void entropy_maps_kernel(EntArgs a)
+{
+    entropy_maps_body<U8>(a.x, a.H, a.W, a.exp2_scale, a.e8, a.e16, a.bins, a.ppw, a.x_out, a.flat8, own_blk());
+}
+
+// several shape groups in one launch (cgic_common.h: launch groups)
+template <bool U8>
+__global__ __launch_bounds__(kEntThreads) void entropy_maps_grouped_kernel(Grouped<EntArgs> g)
+{
+    Blk blk;
+    const EntArgs &a = g.a[group_locate(g, &blk)];
+    entropy_maps_body<U8>(a.x, a.H, a.W, a.exp2_scale, a.e8, a.e16, a.bins, a.ppw, a.x_out, a.flat8, blk);
+}
+
 // =====================================================================================================
 // Reference-arithmetic variant (opt-in, cgic_entropy_maps_ref_f32): the reference's own fp32 operation sequence and
 // summation ORDER, with exp / log correctly rounded (evaluated in fp64, rounded once).
@@ -413,21 +438,39 @@ static int entropy_maps_launch(const void *x, bool u8, int64_t B, int64_t H, int
     dim3 grid((unsigned)((W / 16 + per_wg - 1) / per_wg), (unsigned)(H / 16), (unsigned)B);
     // exp(-0.5 (r/sigma)^2) = exp2(c r^2), c = -0.5 log2(e) / sigma^2 (float64 on the host, rounded once)
     const float exp2_scale = (float)(-0.5 * 1.4426950408889634 / ((double)sigma * (double)sigma));
+    EntArgs a;
+    a.x = x; a.H = H; a.W = W; a.exp2_scale = exp2_scale; a.ppw = ppw; a.e8 = e8; a.e16 = e16; a.x_out = u8 ? x_out : nullptr; a.flat8 = flat8;
+    a.bins = ba;
 #ifdef CGIC_DEV_KNOBS
     // dev: pad the workgroup's LDS so that fewer of them fit a CU (co-residency experiments)
     static const int pad = getenv("CGIC_ENT_PAD") ? atoi(getenv("CGIC_ENT_PAD")) : 0;
-    if (pad > 0) {
+    if (pad > 0 && !u8 && !group_recording()) {
         CGIC_HIP_TRY(hipFuncSetAttribute((const void *)entropy_maps_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, pad));
-        hipLaunchKernelGGL(entropy_maps_kernel<false>, grid, dim3(kEntThreads), (size_t)pad, s, (const void *)x, H, W, exp2_scale, e8, e16, ba, ppw, (float *)nullptr, flat8);
+        hipLaunchKernelGGL(entropy_maps_kernel<false>, grid, dim3(kEntThreads), (size_t)pad, s, a);
         return launch_check("entropy_maps_kernel");
     }
 #endif
     if (u8)
-        hipLaunchKernelGGL(entropy_maps_kernel<true>, grid, dim3(kEntThreads), 0, s, x, H, W, exp2_scale, e8, e16, ba, ppw, x_out, flat8);
-    else
-        hipLaunchKernelGGL(entropy_maps_kernel<false>, grid, dim3(kEntThreads), 0, s, x, H, W, exp2_scale, e8, e16, ba, ppw, (float *)nullptr, flat8);
-    return launch_check("entropy_maps_kernel");
+        return launch_or_record(KID_ENTROPY_U8, grid, dim3(kEntThreads), 0, a, [=] {
+            hipLaunchKernelGGL(entropy_maps_kernel<true>, grid, dim3(kEntThreads), 0, s, a);
+            return launch_check("entropy_maps_kernel"); });
+    return launch_or_record(KID_ENTROPY_F32, grid, dim3(kEntThreads), 0, a, [=] {
+        hipLaunchKernelGGL(entropy_maps_kernel<false>, grid, dim3(kEntThreads), 0, s, a);
+        return launch_check("entropy_maps_kernel"); });
 }
+
+template <bool U8>
+static int entropy_grouped_launch(const GroupRec *const *recs, int n, hipStream_t s)
+{
+    Grouped<EntArgs> g;
+    size_t lds;
+    int rc = fill_grouped(recs, n, &g, &lds);
+    if (rc) return rc;
+    hipLaunchKernelGGL(entropy_maps_grouped_kernel<U8>, dim3(g.start[kMaxGroups]), dim3(kEntThreads), 0, s, g);
+    return launch_check("entropy_maps_grouped_kernel");
+}
+static GroupedRegistrar reg_ent_f32(KID_ENTROPY_F32, entropy_grouped_launch<false>);
+static GroupedRegistrar reg_ent_u8(KID_ENTROPY_U8, entropy_grouped_launch<true>);
 
 extern "C" int cgic_entropy_maps_f32(const float *x, int64_t B, int64_t H, int64_t W, const float *bins,
                                      int nbins, float sigma, float *e8, float *e16, float *flat8, cgic_stream_t stream)

@@ -13,3 +13,99 @@ extern "C" int cgic_launch_graphs(void *const *graph_execs, void *const *streams
     for (int i = 0; i < n; ++i) CGIC_HIP_TRY(hipGraphLaunch((hipGraphExec_t)graph_execs[i], (hipStream_t)streams[i]));
     return CGIC_OK;
 }
+
+// ---- launch groups ---------------------------------------------------------------------------------------------------
+// (cgic_common.h has the idea.)  State is per thread: the calls of a group come from the thread that opened it.
+#include <map>
+#include <memory>
+
+namespace cgic {
+
+struct GroupState {
+    int ngroups = 0, cur = 0;
+    double share[kMaxGroups] = {1.0, 1.0, 1.0, 1.0};
+    std::vector<GroupRec> rec[kMaxGroups];
+};
+static thread_local std::unique_ptr<GroupState> t_group;
+
+static GroupedLauncher *grouped_table()
+{
+    static GroupedLauncher table[KID_COUNT] = {};
+    return table;
+}
+GroupedRegistrar::GroupedRegistrar(int kid, GroupedLauncher fn) { grouped_table()[kid] = fn; }
+
+bool group_recording() { return (bool)t_group; }
+double group_cu_share() { return t_group ? t_group->share[t_group->cur] : 1.0; }
+
+int group_record(int kid, dim3 grid, dim3 block, size_t lds, const void *args, size_t bytes, std::function<int()> launch)
+{
+    GroupState *g = t_group.get();
+    CGIC_REQUIRE(g, CGIC_ERR_INVALID, "group_record outside a group");
+    GroupRec r;
+    r.kid = kid; r.grid = grid; r.block = block; r.lds = lds;
+    r.args.assign((const unsigned char *)args, (const unsigned char *)args + bytes);
+    r.launch = std::move(launch);
+    g->rec[g->cur].push_back(std::move(r));
+    return CGIC_OK;
+}
+
+}  // namespace cgic
+
+using namespace cgic;
+
+extern "C" int cgic_group_max(void) { return kMaxGroups; }
+
+extern "C" int cgic_group_begin(int ngroups, const double *shares)
+{
+    CGIC_REQUIRE(!t_group, CGIC_ERR_INVALID, "group_begin: a group is already open on this thread");
+    CGIC_REQUIRE(ngroups >= 1 && ngroups <= kMaxGroups, CGIC_ERR_INVALID, "group_begin: %d groups (1..%d)", ngroups, kMaxGroups);
+    std::unique_ptr<GroupState> g(new GroupState);
+    g->ngroups = ngroups;
+    for (int i = 0; i < ngroups; ++i) {
+        g->share[i] = shares ? shares[i] : 1.0 / ngroups;
+        CGIC_REQUIRE(g->share[i] > 0.0 && g->share[i] <= 1.0, CGIC_ERR_INVALID, "group_begin: share[%d] = %g", i, g->share[i]);
+    }
+    t_group = std::move(g);
+    return CGIC_OK;
+}
+
+extern "C" int cgic_group_select(int group)
+{
+    CGIC_REQUIRE(t_group, CGIC_ERR_INVALID, "group_select: no group is open on this thread");
+    CGIC_REQUIRE(group >= 0 && group < t_group->ngroups, CGIC_ERR_INVALID, "group_select: group %d of %d", group, t_group->ngroups);
+    t_group->cur = group;
+    return CGIC_OK;
+}
+
+extern "C" void cgic_group_abort(void) { t_group.reset(); }
+
+extern "C" int cgic_group_launch(cgic_stream_t stream)
+{
+    CGIC_REQUIRE(t_group, CGIC_ERR_INVALID, "group_launch: no group is open on this thread");
+    std::unique_ptr<GroupState> g = std::move(t_group);          // closed whatever happens below
+    size_t depth = 0;
+    for (int i = 0; i < g->ngroups; ++i) depth = g->rec[i].size() > depth ? g->rec[i].size() : depth;
+    int launches = 0;
+    for (size_t j = 0; j < depth; ++j) {
+        const GroupRec *recs[kMaxGroups];
+        int n = 0;
+        for (int i = 0; i < g->ngroups; ++i)
+            if (j < g->rec[i].size()) recs[n++] = &g->rec[i][j];
+        bool same = n >= 2 && recs[0]->kid != KID_NONE && grouped_table()[recs[0]->kid] != nullptr;
+        for (int i = 1; same && i < n; ++i)
+            same = recs[i]->kid == recs[0]->kid && recs[i]->block.x == recs[0]->block.x && recs[i]->block.y == 1 && recs[i]->block.z == 1;
+        if (same) {
+            int rc = grouped_table()[recs[0]->kid](recs, n, (hipStream_t)stream);
+            if (rc) return rc;
+            ++launches;
+            continue;
+        }
+        for (int i = 0; i < n; ++i) {
+            int rc = recs[i]->launch();
+            if (rc) return rc;
+            ++launches;
+        }
+    }
+    return launches;          // >= 0: launches issued
+}

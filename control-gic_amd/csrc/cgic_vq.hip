@@ -1099,6 +1099,27 @@ __global__ CGIC_VQF_BOUNDS void vq_filter_router_kernel(VqArgs a, RouterArgs r, 
     vq_filter_body<kVqfThreads, ALIGNED, CONV>(a, smem_f, blockIdx.x - vb);
 }
 
+// The same launch for several shape groups at once (cgic_common.h: launch groups): every group keeps its own VQ shares, router
+// workgroups and loss ticket; a workgroup's role is read off its block index inside its group.
+struct VqfrArgs {
+    VqArgs a;
+    RouterArgs r;
+    unsigned int nrouter, router_behind;
+};
+template <bool ALIGNED>
+__global__ CGIC_VQF_BOUNDS void vq_filter_router_grouped_kernel(Grouped<VqfrArgs> g)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_f[];
+    Blk blk;
+    const VqfrArgs &p = g.a[group_locate(g, &blk)];
+    const unsigned int rb = p.router_behind ? p.a.nblk : 0u, vb = p.router_behind ? 0u : p.nrouter;
+    if (blk.x - rb < p.nrouter) {
+        router_body<kVqfThreads>(p.r, (int64_t)(blk.x - rb), smem_f);
+        return;
+    }
+    vq_filter_body<kVqfThreads, ALIGNED, false>(p.a, smem_f, blk.x - vb);
+}
+
 // The codebook's LDS image, computed ONCE (cgic_vq_prepare_f32) instead of by every workgroup of every launch: inference
 // runs thousands of launches against one codebook, and deriving the image (two block-wide maxima, 11 fp16 splits per row, three
 // barriers) was ~3 us at the head of every ~23 us launch.  One workgroup; the image is followed by the two maxima.
@@ -1319,6 +1340,10 @@ static int launch_filter(const float *z, int64_t hw, int64_t N, const float *cb,
     // one resident workgroup per CU; its waves take groups from a counter.  Fewer groups than CUs x waves: spread them
     // over the CUs first (a small batch then costs one staging + one group per CU, whatever the waves per workgroup)
     if (dev_knob("CGIC_VQ_WGS_PER_CU") > 1) cus *= dev_knob("CGIC_VQ_WGS_PER_CU");      // dev: several resident workgroups per CU
+    if (group_recording()) {          // one shape group of a grouped launch: its share of the chip
+        cus = (int)((double)cus * group_cu_share() + 0.5);
+        cus = cus < 1 ? 1 : cus;
+    }
     int64_t nblk = ngroups < cus ? ngroups : cus;
     VqArgs a;
     a.z = z; a.hw = hw; a.N = N; a.cb = cb; a.K = K; a.idx_out = idx; a.zq_out = zq;
@@ -1367,10 +1392,28 @@ static int launch_filter(const float *z, int64_t hw, int64_t N, const float *cb,
     if (router_lds > lds) lds = router_lds;
     rc = ensure_dynamic_lds((const void *)vq_filter_router_kernel<ALIGNED, CONV>, lds);
     if (rc) return rc;
-    hipLaunchKernelGGL((vq_filter_router_kernel<ALIGNED, CONV>), dim3(a.nblk + (unsigned int)router_blocks), dim3(kVqfThreads), lds, s, a, *router,
-                       (unsigned int)router_blocks, router_first ? 0u : 1u);
-    return launch_check("vq_filter_router_kernel");
+    VqfrArgs p;
+    p.a = a; p.r = *router; p.nrouter = (unsigned int)router_blocks; p.router_behind = router_first ? 0u : 1u;
+    const dim3 grid(a.nblk + (unsigned int)router_blocks);
+    return launch_or_record(CONV ? KID_NONE : ALIGNED ? KID_VQF_ROUTER_AL : KID_VQF_ROUTER_UN, grid, dim3(kVqfThreads), lds, p, [=] {
+        hipLaunchKernelGGL((vq_filter_router_kernel<ALIGNED, CONV>), grid, dim3(kVqfThreads), lds, s, p.a, p.r, p.nrouter, p.router_behind);
+        return launch_check("vq_filter_router_kernel"); });
 }
+
+template <bool ALIGNED>
+static int vqfr_grouped_launch(const GroupRec *const *recs, int n, hipStream_t s)
+{
+    Grouped<VqfrArgs> g;
+    size_t lds;
+    int rc = fill_grouped(recs, n, &g, &lds);
+    if (rc) return rc;
+    rc = ensure_dynamic_lds((const void *)vq_filter_router_grouped_kernel<ALIGNED>, lds);
+    if (rc) return rc;
+    hipLaunchKernelGGL((vq_filter_router_grouped_kernel<ALIGNED>), dim3(g.start[kMaxGroups]), dim3(kVqfThreads), lds, s, g);
+    return launch_check("vq_filter_router_grouped_kernel");
+}
+static GroupedRegistrar reg_vqfr_al(KID_VQF_ROUTER_AL, vqfr_grouped_launch<true>);
+static GroupedRegistrar reg_vqfr_un(KID_VQF_ROUTER_UN, vqfr_grouped_launch<false>);
 
 static int vq_dispatch(const float *z, int64_t hw, int64_t N, const float *codebook, int K, int64_t *indices, float *z_q,
                        VqWs ws, float beta, int legacy, float *loss, hipStream_t s, const RouterArgs *router,

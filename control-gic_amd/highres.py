@@ -12,6 +12,7 @@ import math
 
 import torch
 
+from . import _lib
 from .codec import GrainCodec
 
 TILE = 768
@@ -147,7 +148,7 @@ class _Fork:
         self.used = []
 
 
-def _compress_groups(x, encode, codec, tile, concurrent):
+def _compress_groups(x, encode, codec, tile, concurrent, chain=False):
     """x [N,3,H,W] fp32 -- or uint8 frames [N,H,W,3], the tiles then reach `encode` as uint8 [T,th,tw,3] (entropy_maps_u8 makes the
     fp32 tiles and the maps in one pass) --: the shape groups of N images of one size, each group ONE batch of N * T tiles (image-major)
     -> (H, W), pad, tiles, [(tile indices, CompressedBatch, (ind, masks, mode))]"""
@@ -165,8 +166,13 @@ def _compress_groups(x, encode, codec, tile, concurrent):
     groups = []
     # the largest group first: it is the long pole, and lane 0 (no fork latency) is its stream
     order = sorted(by_shape.items(), key=lambda kv: -len(kv[1]) * kv[0][0] * kv[0][1])
-    fork = _Fork(x.device, concurrent)
+    chain = chain and 1 < len(order) <= _lib.lib().cgic_group_max()
+    fork = _Fork(x.device, concurrent and not chain)
     xv = x.permute(0, 3, 1, 2) if frames else x              # [N,3,H,W] view either way
+    # chain: ONE launch chain for all shape groups (cgic_group_begin / _launch): every group's calls are recorded, then issued as
+    # one launch per kernel whose grid is the concatenation of the groups' grids
+    grp = _lib.launch_group(len(order), [N * len(idxs) * th * tw for (th, tw), idxs in order], x.device) if chain else None
+    batches = []
     for lane, ((th, tw), idxs) in enumerate(order):
         with torch.cuda.stream(fork.lane(lane)):
             # pad + cut in ONE copy per tile (F.pad of the whole image and a stack of views would move every pixel twice): a tile
@@ -182,23 +188,38 @@ def _compress_groups(x, encode, codec, tile, concurrent):
                 for strip in (dst[:, :, :sy0 - y0], dst[:, :, sy1 - y0:], dst[:, :, :, :sx0 - x0], dst[:, :, :, sx1 - x0:]):
                     if strip.numel():
                         strip.zero_()
-            ind, masks, mode = encode(batch.view(-1, th, tw, 3) if frames else batch.view(-1, 3, th, tw))
+            batch = batch.view(-1, th, tw, 3) if frames else batch.view(-1, 3, th, tw)
+            if chain:
+                batches.append(batch)
+                continue
+            ind, masks, mode = encode(batch)
             groups.append((idxs, codec.compress(ind, masks, mode), (ind, masks, mode)))
+    if chain:
+        with grp as g:
+            for k, (((th, tw), idxs), batch) in enumerate(zip(order, batches)):
+                g.select(k)
+                ind, masks, mode = encode(batch)
+                groups.append((idxs, codec.compress(ind, masks, mode), (ind, masks, mode)))
     fork.join([(c, e) for _, c, e in groups])
     return (H, W), pad, tiles, groups
 
 
-def compress_tiled(x, encode, codec, tile=TILE, concurrent=False):
+def compress_tiled(x, encode, codec, tile=TILE, concurrent=False, chain=False):
     """x [1,3,H,W] on the device; encode(tiles [T,3,th,tw]) -> (ind [T*h*w] int64, masks [3 x int32], mode)
     with per-tile routing (the reference's per-tile B=1 call); codec: GrainCodec.  -> TiledImage.
-    concurrent: the shape groups run on parallel streams (same results; see _Fork)"""
+    concurrent: the shape groups run on parallel streams (same results; see _Fork).
+    chain: the shape groups (four for a 2040x1356 image) go through ONE launch chain -- entropy maps, VQ + router, compress: three
+    launches for all six tiles instead of three per group (cgic_group_begin / _launch; same bytes).  `encode` is then called
+    inside a launch group: it may allocate and call control_gic_amd's entropy_maps / entropy_maps_u8 / vq_forward_route (whose
+    launches are recorded and issued when all groups are in), but must not enqueue torch work that READS their outputs --
+    a conv encoder that consumes the router's gate cannot run under chain=True."""
     if x.dim() != 4 or x.shape[0] != 1:
         raise ValueError("compress_tiled takes one image [1,3,H,W] (or one uint8 frame [1,H,W,3]; the reference script uses batch 1); "
                          "compress_tiled_batch takes several of one size")
-    return TiledImage(*_compress_groups(x, encode, codec, tile, concurrent))
+    return TiledImage(*_compress_groups(x, encode, codec, tile, concurrent, chain))
 
 
-def compress_tiled_batch(x, encode, codec, tile=TILE, concurrent=False):
+def compress_tiled_batch(x, encode, codec, tile=TILE, concurrent=False, chain=False):
     """x [N,3,H,W] (or uint8 frames [N,H,W,3]: `encode` then gets uint8 tiles [T,th,tw,3] for entropy_maps_u8 -- a pad of zero
     bytes is the pad of zeros ToTensor would have produced): N images of ONE size (a folder of camera frames, a DIV2K bucket) -> list of N TiledImage, each what
     compress_tiled gives for that image alone (routing is per tile, so batching across images changes no byte).  The tiles
@@ -208,7 +229,7 @@ def compress_tiled_batch(x, encode, codec, tile=TILE, concurrent=False):
     if x.dim() != 4:
         raise ValueError("compress_tiled_batch takes [N,3,H,W] or uint8 [N,H,W,3]")
     N = x.shape[0]
-    hw, pad, tiles, groups = _compress_groups(x, encode, codec, tile, concurrent)
+    hw, pad, tiles, groups = _compress_groups(x, encode, codec, tile, concurrent, chain)
     out = []
     for n in range(N):
         mine = []
@@ -270,7 +291,7 @@ def decompress_tiled_batch(tiled_list, codec, concurrent=False, check=True):
     return per_image
 
 
-def decompress_tiled(tiled, codec, decode=None, concurrent=False, check=True):
+def decompress_tiled(tiled, codec, decode=None, concurrent=False, check=True, chain=False):
     """-> per-tile (ind, masks, z_q) in row-major order; with decode(z_q, masks) -> pixels also the blended,
     clamped, unpadded reconstruction (:248-255; tiles do not overlap, so the weights cancel).
     concurrent: shape groups on parallel streams; check=False skips the host synchronisation on the decoder status (for
@@ -278,15 +299,29 @@ def decompress_tiled(tiled, codec, decode=None, concurrent=False, check=True):
     per_tile = [None] * len(tiled.tiles)
     statuses = []
     dev = tiled.groups[0][1].data.device if tiled.groups else None
-    fork = _Fork(dev, concurrent and dev is not None)
+    chain = chain and dev is not None and 1 < len(tiled.groups) <= _lib.lib().cgic_group_max()
+    fork = _Fork(dev, concurrent and dev is not None and not chain)
     outs = []
+    # chain: the decoder and the merge of all shape groups as ONE launch each (see compress_tiled)
+    grp = _lib.launch_group(len(tiled.groups), [c.batch * c.h * c.w for _, c, _ in tiled.groups], dev) if chain else None
+    if chain:
+        grp.__enter__()
     for lane, (idxs, comp, _) in enumerate(tiled.groups):
-        with torch.cuda.stream(fork.lane(lane)):
-            ind, masks, zq, status = codec.decompress(comp)
+        try:
+            with torch.cuda.stream(fork.lane(lane)):
+                if chain:
+                    grp.select(lane)
+                ind, masks, zq, status = codec.decompress(comp)
+        except BaseException as e:
+            if chain:
+                grp.__exit__(type(e), e, None)
+            raise
         outs.append((ind, masks, zq, status))
         statuses.append(status)
         for k, i in enumerate(idxs):
             per_tile[i] = (ind[k:k + 1], [m[k:k + 1] for m in masks], zq[k:k + 1])
+    if chain:
+        grp.__exit__(None, None, None)
     fork.join(outs)
     if not check:
         return per_tile, (torch.cat(statuses) if statuses else None)

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define CGIC_ABI_VERSION 5
+#define CGIC_ABI_VERSION 6
 
 #define CGIC_OK 0
 #define CGIC_ERR_INVALID (-1)     /* bad argument (shape, ratio, NULL pointer ...) */
@@ -67,6 +67,27 @@ int cgic_ticket_slots_in_use(void);
  * calling thread.  For runtimes of several independent streams of batches (pipeline.LaneStream): from Python every launch is an
  * interpreter round trip and the last lane starts ~100 us after the first. */
 int cgic_launch_graphs(void *const *graph_execs, void *const *streams, int n);
+/* Launch groups (ABI 6): independent sub-batches of DIFFERENT shapes through ONE launch per kernel.  The reference cuts a high-
+ * resolution image into a 768-px grid with a ragged last row / column (inference_high_resolution.py:112-125) and runs
+ * model.compress on the tiles one after the other (:236-257); tiles of equal shape are one batch here, but a 2040x1356
+ * image is still four shapes = four launch chains.  Between cgic_group_begin(n, shares) and cgic_group_launch(stream) the calls
+ * of THIS thread to cgic_entropy_maps_f32 / _u8, cgic_vq_forward_route_f32, cgic_compress_streams and cgic_decompress_streams check
+ * their arguments and record their launches instead of making them (cgic_group_select(g) says which group the following calls belong
+ * to; within a group the calls are dependent in call order, across groups nothing is); cgic_group_launch then issues the j-th
+ * launches of all groups as ONE launch whose grid is the concatenation of theirs (each workgroup finds its group's argument block
+ * from its block index), j = 0, 1, ...  Other entry points, and positions where the groups recorded different kernels, are
+ * launched one by one: results never depend on the grouping.  Outputs of recorded calls are written when cgic_group_launch's
+ * launches run: nothing else may be enqueued on them in between, and every device buffer handed to a recorded call (inputs,
+ * outputs, workspaces) must stay allocated until cgic_group_launch has returned.
+ *   shares  host [n] or NULL: each group's share of the chip (sums to ~1; e.g. its share of the latent vectors): the
+ *           persistent-workgroup VQ launch of a group takes that share of the CUs.  NULL: 1/n each.
+ * cgic_group_launch returns the number of launches issued (>= 0) or CGIC_ERR_*; the group is closed either way.
+ * cgic_group_abort closes it without launching.  cgic_group_max: the largest n. */
+int cgic_group_max(void);
+int cgic_group_begin(int ngroups, const double *shares);
+int cgic_group_select(int group);
+int cgic_group_launch(cgic_stream_t stream);
+void cgic_group_abort(void);
 const char *cgic_last_error(void);
 int cgic_abi_version(void);
 /* number of visible HIP devices, or CGIC_ERR_HIP; never throws, never aborts */

@@ -21,7 +21,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(l, name), f"{name} declared in cgic_hip.h but not exported"
     assert declared == set(_lib.PROTOTYPES), "ctypes prototype table out of sync with the header"
-    assert _lib.lib().cgic_abi_version() == 5
+    assert _lib.lib().cgic_abi_version() == 6
 
 
 def test_device_count_does_not_abort_without_gpu():

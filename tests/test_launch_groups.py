@@ -1,0 +1,166 @@
+"""Launch groups (cgic_group_begin / _select / _launch): the shape groups of a tiled image through ONE launch per kernel.
+
+The reference runs model.compress tile by tile (inference_high_resolution.py:236-257); grouping is a property of how the launches
+are issued, never of the results: every test here compares the grouped chain with the ungrouped calls, byte for byte."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+
+def _setup(seed):
+    import control_gic_amd as cg
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(seed)
+    vq = cg.VectorQuantizer(1024, 4, beta=0.25).to(dev)
+    with torch.no_grad():
+        vq.embedding.weight.copy_(torch.from_numpy(rng.standard_normal((1024, 4)).astype(np.float32)))
+    vq.usage_counter.copy_(torch.from_numpy(rng.integers(1, 1000, 1024).astype(np.float32)))
+    codec = cg.GrainCodec(vq.embedding_counter, vq.embedding.weight.detach())
+    return cg, dev, rng, vq, codec
+
+
+def _same_decoded(a, b):
+    for (i0, m0, z0), (i1, m1, z1) in zip(a, b):
+        assert torch.equal(i0, i1) and torch.equal(z0, z1) and all(torch.equal(p, q) for p, q in zip(m0, m1))
+
+
+def test_group_api_misuse_is_refused():
+    """host logic only (no launch): begin twice, select out of range, launch / select without a group, too many groups"""
+    from control_gic_amd import _lib
+    l = _lib.lib()
+    assert l.cgic_group_max() >= 4
+    assert l.cgic_group_select(0) == _lib.ERR_INVALID
+    assert l.cgic_group_launch(None) == _lib.ERR_INVALID
+    assert l.cgic_group_begin(l.cgic_group_max() + 1, None) == _lib.ERR_INVALID
+    assert l.cgic_group_begin(0, None) == _lib.ERR_INVALID
+    bad = (ctypes.c_double * 2)(0.5, 0.0)
+    assert l.cgic_group_begin(2, bad) == _lib.ERR_INVALID
+    assert l.cgic_group_begin(2, None) == 0
+    try:
+        assert l.cgic_group_begin(2, None) == _lib.ERR_INVALID
+        assert l.cgic_group_select(2) == _lib.ERR_INVALID
+        assert l.cgic_group_select(1) == 0
+    finally:
+        l.cgic_group_abort()
+    assert l.cgic_group_select(0) == _lib.ERR_INVALID           # closed again
+    # an exception inside the block closes the group without launching
+    with pytest.raises(RuntimeError):
+        with _lib.launch_group(2):
+            raise RuntimeError("x")
+    assert l.cgic_group_begin(1, None) == 0
+    l.cgic_group_abort()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("H,W", [(1356, 2040), (1000, 1800), (700, 500), (768, 1000), (300, 900)])
+@pytest.mark.parametrize("content", ["noise", "smooth8"])
+def test_chain_of_ragged_tiles_equals_the_groups_one_by_one(H, W, content):
+    """compress_tiled / decompress_tiled with chain=True: the (up to four) shape groups of one image as ONE launch per kernel ==
+    the groups launched one after the other: every stream byte, bpp, decoded index, mask element and codebook row; three launches
+    for the encode side, two for the decode side, whatever the number of groups.  smooth8: 8-bit gradients, i.e. bands with
+    members -- the router's threshold-band refinement from the pixels runs inside the grouped launch too"""
+    from control_gic_amd import highres
+    from control_gic_amd.quantize import vq_forward_route
+    cg, dev, rng, vq, codec = _setup(H * 7 + W)
+    if content == "noise":
+        x = torch.from_numpy(rng.random((1, 3, H, W), dtype=np.float32)).to(dev)
+    else:
+        yy, xx = np.mgrid[0:H, 0:W]
+        g = ((yy * 0.11 + xx * 0.07) % 256).astype(np.uint8)
+        x = torch.from_numpy((np.stack([g, g, (g // 2) * 2]) / 255.0).astype(np.float32)[None]).to(dev)
+    from control_gic_amd.quantize import prepare_codebook
+    prepared = prepare_codebook(vq.embedding.weight.detach())
+
+    def encode(tiles):                      # a stand-in encoder that is a function of each tile's own pixels
+        z = torch.nn.functional.avg_pool2d(tiles, 4)
+        z = torch.cat([z, z[:, :1] * 2 - 1], dim=1) * 3 - 1.5
+        e8, e16 = cg.entropy_maps(tiles)
+        _, _, ind, mask, _, mode = vq_forward_route(z.contiguous(), vq.embedding.weight, 0.25, True, e16, e8, 0.1, 0.8, per_image=True,
+                                                    pixels=tiles, prepared=prepared)
+        return ind, mask, mode
+
+    ref = highres.compress_tiled(x, encode, codec)
+    got = highres.compress_tiled(x, encode, codec, chain=True)
+    torch.cuda.synchronize()
+    assert ref.tiles == got.tiles and ref.streams() == got.streams() and ref.bpp() == got.bpp()
+    for (_, _, (i0, m0, _)), (_, _, (i1, m1, _)) in zip(ref.groups, got.groups):
+        assert torch.equal(i0, i1) and all(torch.equal(p, q) for p, q in zip(m0, m1))
+    for mode in ("latency", "throughput"):
+        with cg.decoder_mode(mode):
+            dref, _ = highres.decompress_tiled(ref, codec)
+            dgot, _ = highres.decompress_tiled(got, codec, chain=True)
+        _same_decoded(dref, dgot)
+
+
+@pytest.mark.gpu
+def test_chain_launch_counts_and_uint8_frames():
+    """a 2040x1356 image (6 tiles, 4 shape groups): the encode chain is 3 launches, the decode chain 2; uint8 frames go through
+    the grouped ToTensor + entropy launch"""
+    from control_gic_amd import highres, _lib
+    from control_gic_amd.quantize import vq_forward_route
+    cg, dev, rng, vq, codec = _setup(5)
+    H, W = 1356, 2040
+    frames = torch.from_numpy(rng.integers(0, 256, (1, H, W, 3), dtype=np.uint8)).to(dev)
+    zs = {}
+
+    def encode_u8(tiles):
+        T, th, tw, _ = tiles.shape
+        if (T, th, tw) not in zs:
+            zs[(T, th, tw)] = torch.from_numpy(np.random.default_rng(th + tw).standard_normal((T, 4, th // 4, tw // 4), dtype=np.float32)).to(dev)
+        _, e8, e16 = cg.entropy_maps_u8(tiles, want_x=False)
+        _, _, ind, mask, _, mode = vq_forward_route(zs[(T, th, tw)], vq.embedding.weight, 0.25, True, e16, e8, 0.1, 0.8, per_image=True, pixels=tiles)
+        return ind, mask, mode
+
+    ref = highres.compress_tiled(frames, encode_u8, codec)
+    got = highres.compress_tiled(frames, encode_u8, codec, chain=True)
+    assert len(ref.groups) == 4 and ref.streams() == got.streams()
+    # launch counts, through the recorder itself
+    shapes = [(c.batch, c.h, c.w) for _, c, _ in got.groups]
+    grp = _lib.launch_group(len(got.groups), [b * h * w for b, h, w in shapes], dev)
+    with grp as g:
+        for k, (_, comp, (ind, masks, mode)) in enumerate(got.groups):
+            g.select(k)
+            codec.compress(ind, masks, mode)
+    assert grp.launches == 1
+    grp = _lib.launch_group(len(got.groups), None, dev)
+    with grp as g:
+        for k, (_, comp, _) in enumerate(got.groups):
+            g.select(k)
+            codec.decompress(comp)
+    assert grp.launches == 2
+    torch.cuda.synchronize()
+
+
+@pytest.mark.gpu
+def test_groups_of_mixed_kernels_fall_back_to_single_launches():
+    """a 256x256 batch (small-grid kernel variants) grouped with a 768x512 one: positions whose groups recorded different kernels are
+    launched one by one -- same results as ungrouped calls"""
+    from control_gic_amd import _lib
+    from control_gic_amd.quantize import vq_forward_route
+    cg, dev, rng, vq, codec = _setup(9)
+    xs = [torch.from_numpy(rng.random((5, 3, 256, 256), dtype=np.float32)).to(dev),
+          torch.from_numpy(rng.random((2, 3, 512, 768), dtype=np.float32)).to(dev),
+          torch.from_numpy(rng.random((1, 3, 64, 48), dtype=np.float32)).to(dev)]
+    zs = [torch.from_numpy(rng.standard_normal((x.shape[0], 4, x.shape[2] // 4, x.shape[3] // 4), dtype=np.float32)).to(dev) for x in xs]
+
+    def chain(x, z):
+        e8, e16 = cg.entropy_maps(x)
+        _, _, ind, mask, _, mode = vq_forward_route(z, vq.embedding.weight, 0.25, True, e16, e8, 0.1, 0.8, per_image=True, pixels=x)
+        comp = codec.compress(ind, mask, mode)
+        dec = codec.decompress(comp)
+        return e8, e16, ind, mask, comp, dec
+
+    ref = [chain(x, z) for x, z in zip(xs, zs)]
+    with _lib.launch_group(len(xs), [z.numel() for z in zs], dev) as g:
+        got = []
+        for k, (x, z) in enumerate(zip(xs, zs)):
+            g.select(k)
+            got.append(chain(x, z))
+    torch.cuda.synchronize()
+    for (e8a, e16a, ia, ma, ca, da), (e8b, e16b, ib, mb, cb, db) in zip(ref, got):
+        assert torch.equal(e8a, e8b) and torch.equal(e16a, e16b) and torch.equal(ia, ib)
+        assert all(torch.equal(p, q) for p, q in zip(ma, mb))
+        assert ca.to_host() == cb.to_host()
+        assert torch.equal(da[0], db[0]) and torch.equal(da[2], db[2]) and int(db[3].abs().max()) == 0
