@@ -666,10 +666,10 @@ def div2k_image(dev, cb, vq, codec, iters=8):
         N = 8
         xs = torch.from_numpy(np.random.default_rng(5).random((N, 3, H, W), dtype=np.float32)).to(dev)
 
-        def once_batch(concurrent):
+        def once_batch(concurrent, chain=False):
             def fn():
-                ts = highres.compress_tiled_batch(xs, encode, codec, concurrent=concurrent)
-                p, st = highres.decompress_tiled_batch(ts, codec, concurrent=concurrent, check=False)
+                ts = highres.compress_tiled_batch(xs, encode, codec, concurrent=concurrent, chain=chain)
+                p, st = highres.decompress_tiled_batch(ts, codec, concurrent=concurrent, check=False, chain=chain)
                 return ts, p, st
             return fn
         ts, p, st = once_batch(False)(); torch.cuda.synchronize()
@@ -689,8 +689,29 @@ def div2k_image(dev, cb, vq, codec, iters=8):
         t0 = time.perf_counter()
         gl.replay(2 * iters); gl.join(); torch.cuda.synchronize()
         dt4 = (time.perf_counter() - t0) / (2 * iters * 4 * N)
+        # the same as ONE launch chain per batch (launch groups): all four shape groups through one launch per kernel
+        chain_res = {}
+        try:
+            tsc, _, stc = once_batch(False, True)(); torch.cuda.synchronize()
+            same_c = int(stc.abs().max()) == 0 and all(a.streams() == b.streams() for a, b in zip(tsc, ts))
+            glc1 = GraphLanes(dev, [once_batch(False, True)], decoder="latency")
+            glc1.replay(2); glc1.join(); torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            glc1.replay(2 * iters); glc1.join(); torch.cuda.synchronize()
+            dtc1 = (time.perf_counter() - t0) / (2 * iters * N)
+            glc = GraphLanes(dev, [once_batch(False, True)] * 4)
+            glc.replay(2); glc.join(); torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            glc.replay(2 * iters); glc.join(); torch.cuda.synchronize()
+            dtc4 = (time.perf_counter() - t0) / (2 * iters * 4 * N)
+            chain_res = {"chain_ms_per_image": round(dtc1 * 1e3, 4), "chain_MPixels/s": round(H * W / dtc1 / 1e6, 1),
+                         "chain_four_in_flight_ms_per_image": round(dtc4 * 1e3, 4), "chain_four_in_flight_MPixels/s": round(H * W / dtc4 / 1e6, 1),
+                         "chain_streams_equal": bool(same_c)}
+        except Exception as e:
+            chain_res = {"chain_error": str(e)[:200]}
         res["batch_of_8"] = {"ms_per_image": round(dt1 * 1e3, 4), "MPixels/s": round(H * W / dt1 / 1e6, 1),
                              "four_in_flight_ms_per_image": round(dt4 * 1e3, 4), "four_in_flight_MPixels/s": round(H * W / dt4 / 1e6, 1),
+                             **chain_res,
                              "round_trip_ok": bool(okb), "bpp_mean": round(float(np.mean([t.bpp() for t in ts])), 6),
                              "note": "highres.compress_tiled_batch + decompress_tiled_batch on 8 images of one size: one batch of tiles per shape group; "
                                      "one hipGraph per batch (groups on parallel streams), then four batches on four HIP streams"}

@@ -171,7 +171,7 @@ class GrainCodec:
         nbytes = torch.empty((B, _lib.NUM_STREAMS), dtype=torch.int32, device=dev)
         wsb = l.cgic_compress_workspace_bytes(B, h, w)
         ws = torch.empty(wsb, dtype=torch.uint8, device=dev) if wsb else None
-        with torch.cuda.device(dev):
+        with _lib.on_device(dev):
             _lib.call("cgic_compress_streams", self.huffman.table.handle, _lib.ptr(ind), _lib.ptr(mc), _lib.ptr(mm),
                       _lib.ptr(mf), B, h, w, int(mode), _lib.ptr(data), slot, _lib.ptr(nbytes), _lib.ptr(hist),
                       _lib.ptr(ws), _lib.current_stream(dev))
@@ -182,7 +182,7 @@ class GrainCodec:
         cbk = self.codebook.detach().contiguous()
         out = torch.empty_like(cbk)
         qc, keep = _lib.conv_arg(post_quant_conv, bias_first)
-        with torch.cuda.device(cbk.device):
+        with _lib.on_device(cbk.device):
             _lib.call("cgic_conv1x1_rows_f32", _lib.ptr(cbk), cbk.shape[0], qc, _lib.ptr(out), _lib.current_stream(cbk.device))
         del keep
         return out
@@ -216,7 +216,7 @@ class GrainCodec:
             zq2 = torch.empty_like(zq)
         status = torch.empty(B, dtype=torch.int32, device=dev)
         ws = torch.empty(l.cgic_decompress_workspace_bytes(B, h, w), dtype=torch.uint8, device=dev)
-        with torch.cuda.device(dev):
+        with _lib.on_device(dev):
             _lib.call("cgic_decompress_streams", self.huffman.table.handle, _lib.ptr(cb.data), cb.data.shape[2],
                       _lib.ptr(cb.nbytes), B, h, w, cb.mode, _lib.ptr(ind),
                       _lib.ptr(masks[0]) if masks else None, _lib.ptr(masks[1]) if masks else None,

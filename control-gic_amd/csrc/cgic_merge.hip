@@ -137,6 +137,85 @@ __global__ __launch_bounds__(256) void decoder_blend_medium2_kernel(
     }
 }
 
+// ---- cgic_cut_tiles: pad + crop of the tiling driver as ONE pass -------------------------------------------------------
+// inference_high_resolution.py pads the image to a multiple of 16 (centred zeros, :145-173,:227-228) and crops it tile by
+// tile (:236-244).  Here every tile of every image is written straight from the UNPADDED image: a destination element is the
+// source pixel it covers, or zero where the tile reaches into the pad.  One thread = 4 consecutive destination pixels of one
+// row (tile widths are multiples of 16: 16-byte stores; the source is read element-wise because the centred pad may shift it
+// by an odd count).  fp32 [N,3,H,W] -> per tile [N, .., 3, th, tw];  uint8 [N,H,W,3] -> per tile [N, .., th, tw, 3].
+constexpr int kCutMaxTiles = 96;
+struct CutTile {
+    void *dst;               // element (image 0, this tile, channel 0 / row 0)
+    int64_t image_stride;    // elements between the same tile of consecutive images
+    int y0, x0;              // the tile's origin in UNPADDED source coordinates (negative inside the pad)
+    int th, tw;
+    unsigned int first;      // first work item (4-pixel unit) of this tile
+};
+struct CutArgs {
+    const void *src;
+    int H, W, ntiles;
+    unsigned int total;      // work items per image
+    CutTile t[kCutMaxTiles];
+};
+
+template <bool U8>
+__global__ __launch_bounds__(256) void cut_tiles_kernel(CutArgs a)
+{
+    const int64_t n = blockIdx.y;
+    const int H = a.H, W = a.W;
+    for (unsigned int item = blockIdx.x * 256u + threadIdx.x; item < a.total; item += gridDim.x * 256u) {
+        // which tile: every tile's work items are a multiple of 64 (checked on the host; tiles of the x16 grid are), so the 64
+        // consecutive items of a wave share their tile: the search and the tile's descriptor stay on the scalar unit
+        const unsigned int wbase = __builtin_amdgcn_readfirstlane(item);
+        int k = 0;
+        while (k + 1 < a.ntiles && wbase >= a.t[k + 1].first) ++k;
+        const CutTile &t = a.t[k];
+        const unsigned int rel = item - t.first, q = (unsigned int)t.tw >> 2;
+        if (U8) {
+            const unsigned int r = rel / q, c4 = (rel - r * q) * 4;                 // row, first of 4 columns
+            const int sy = t.y0 + (int)r;
+            const unsigned char *src = (const unsigned char *)a.src + ((n * H + sy) * (int64_t)W) * 3;
+            unsigned int w[3] = {0u, 0u, 0u};
+            if (sy >= 0 && sy < H) {
+                const int sx = t.x0 + (int)c4;
+                if (sx >= 0 && sx + 3 < W && ((((uintptr_t)src) + (unsigned int)sx * 3u) & 3u) == 0) {
+                    const unsigned int *p = (const unsigned int *)(src + (int64_t)sx * 3);
+                    w[0] = p[0]; w[1] = p[1]; w[2] = p[2];
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 12; ++j) {
+                        const int sxj = sx + j / 3;
+                        const unsigned int v = (sxj >= 0 && sxj < W) ? src[(int64_t)sxj * 3 + j % 3] : 0u;
+                        w[j >> 2] |= v << (8 * (j & 3));
+                    }
+                }
+            }
+            unsigned int *dst = (unsigned int *)((unsigned char *)t.dst + n * t.image_stride + ((int64_t)r * t.tw + c4) * 3);
+            dst[0] = w[0]; dst[1] = w[1]; dst[2] = w[2];
+        } else {
+            const unsigned int per_plane = (unsigned int)t.th * q;
+            const unsigned int ch = rel / per_plane, rr = rel - ch * per_plane, r = rr / q, c4 = (rr - r * q) * 4;
+            const int sy = t.y0 + (int)r;
+            const float *src = (const float *)a.src + ((n * 3 + ch) * (int64_t)H + sy) * W;
+            float4 v = {0.f, 0.f, 0.f, 0.f};
+            if (sy >= 0 && sy < H) {
+                const int sx = t.x0 + (int)c4;
+                if (sx >= 0 && sx + 3 < W) {
+                    if ((((uintptr_t)(src + sx)) & 15u) == 0) v = *reinterpret_cast<const float4 *>(src + sx);
+                    else { v.x = src[sx]; v.y = src[sx + 1]; v.z = src[sx + 2]; v.w = src[sx + 3]; }
+                } else {
+                    if (sx >= 0 && sx < W) v.x = src[sx];
+                    if (sx + 1 >= 0 && sx + 1 < W) v.y = src[sx + 1];
+                    if (sx + 2 >= 0 && sx + 2 < W) v.z = src[sx + 2];
+                    if (sx + 3 >= 0 && sx + 3 < W) v.w = src[sx + 3];
+                }
+            }
+            float *dst = (float *)t.dst + n * t.image_stride + ((int64_t)ch * t.th + r) * t.tw + c4;
+            *reinterpret_cast<float4 *>(dst) = v;
+        }
+    }
+}
+
 }  // namespace cgic
 
 using namespace cgic;
@@ -208,4 +287,41 @@ extern "C" int cgic_decoder_blend_fine_f32(const float *h, const float *h_fine, 
     hipLaunchKernelGGL(decoder_blend_kernel<true>, dim3(stream_grid(total)), dim3(256), 0, (hipStream_t)stream, h, h_fine, mask_c,
                        mask_m, mask_f, B, C, hh, ww, out);
     return launch_check("decoder_blend_kernel<fine>");
+}
+
+extern "C" int cgic_cut_tiles(const void *x, int is_u8, int64_t N, int64_t H, int64_t W, int ntiles, const cgic_tile *tiles,
+                              cgic_stream_t stream)
+{
+    CGIC_REQUIRE(x && tiles, CGIC_ERR_INVALID, "cut_tiles: NULL argument");
+    CGIC_REQUIRE(N >= 0 && H > 0 && W > 0 && H < (1 << 30) && W < (1 << 30), CGIC_ERR_INVALID, "cut_tiles: bad image shape");
+    CGIC_REQUIRE(ntiles >= 1 && ntiles <= kCutMaxTiles, CGIC_ERR_UNSUPPORTED, "cut_tiles: %d tiles (1..%d)", ntiles, kCutMaxTiles);
+    CutArgs a;
+    a.src = x; a.H = (int)H; a.W = (int)W; a.ntiles = ntiles;
+    uint64_t at = 0;
+    for (int k = 0; k < ntiles; ++k) {
+        const cgic_tile &t = tiles[k];
+        CGIC_REQUIRE(t.dst && t.th > 0 && t.tw > 0 && t.tw % 4 == 0, CGIC_ERR_INVALID, "cut_tiles: tile %d: %dx%d (width must be a positive multiple of 4)", k, t.th, t.tw);
+        CGIC_REQUIRE(((uintptr_t)t.dst & (is_u8 ? 3u : 15u)) == 0 && (is_u8 ? t.image_stride % 4 == 0 : t.image_stride % 4 == 0), CGIC_ERR_INVALID,
+                     "cut_tiles: tile %d: destination not aligned", k);
+        // a tile may reach into the pad, never lie wholly outside the image by more than itself
+        CGIC_REQUIRE(t.y0 > -(1 << 30) && t.x0 > -(1 << 30) && t.y0 < (1 << 30) && t.x0 < (1 << 30), CGIC_ERR_INVALID, "cut_tiles: tile %d origin", k);
+        a.t[k].dst = t.dst; a.t[k].image_stride = t.image_stride; a.t[k].y0 = t.y0; a.t[k].x0 = t.x0; a.t[k].th = t.th; a.t[k].tw = t.tw;
+        a.t[k].first = (unsigned int)at;
+        at += (uint64_t)(is_u8 ? 1 : 3) * (uint64_t)t.th * (uint64_t)(t.tw / 4);
+        CGIC_REQUIRE(at % 64 == 0, CGIC_ERR_UNSUPPORTED, "cut_tiles: tile %d: th * tw / 4 = %lld must be a multiple of 64 (tiles of the x16 grid are)",
+                     k, (long long)t.th * (t.tw / 4));
+        CGIC_REQUIRE(at < ((uint64_t)1 << 31), CGIC_ERR_UNSUPPORTED, "cut_tiles: image too large");
+    }
+    for (int k = ntiles; k < kCutMaxTiles; ++k) a.t[k] = a.t[ntiles - 1];
+    a.total = (unsigned int)at;
+    if (N == 0 || at == 0) return CGIC_OK;
+    CGIC_REQUIRE(N <= 65535, CGIC_ERR_UNSUPPORTED, "cut_tiles: more than 65535 images");
+    unsigned int nblk = (unsigned int)((at + 255) / 256);          // one item per thread up to 64 workgroups per CU, grid-stride beyond
+    if (nblk > 16384) nblk = 16384;
+    const dim3 grid(nblk, (unsigned)N);
+    if (is_u8)
+        hipLaunchKernelGGL(cut_tiles_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, a);
+    else
+        hipLaunchKernelGGL(cut_tiles_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, a);
+    return launch_check("cut_tiles_kernel");
 }

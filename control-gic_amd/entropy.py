@@ -34,7 +34,7 @@ def entropy_maps(x, want8=True, want16=True, sigma=0.01, reference_order=False, 
     B, _, H, W = x.shape
     e8 = torch.empty((B, H // 8, W // 8), dtype=torch.float32, device=x.device) if want8 else None
     e16 = torch.empty((B, H // 16, W // 16), dtype=torch.float32, device=x.device) if want16 else None
-    with torch.cuda.device(x.device):
+    with _lib.on_device(x.device):
         if reference_order:
             _lib.call("cgic_entropy_maps_ref_f32", _lib.ptr(x), B, H, W, _bins(), 32, float(sigma), _lib.ptr(e8), _lib.ptr(e16),
                       _lib.current_stream(x.device))
@@ -60,7 +60,7 @@ def entropy_maps_u8(frames, want_x=True, want8=True, want16=True, sigma=0.01, wa
     e8 = torch.empty((B, H // 8, W // 8), dtype=torch.float32, device=dev) if want8 else None
     e16 = torch.empty((B, H // 16, W // 16), dtype=torch.float32, device=dev) if want16 else None
     flat8 = torch.empty((B, H // 8, W // 8), dtype=torch.float32, device=dev) if want_flat else None
-    with torch.cuda.device(dev):
+    with _lib.on_device(dev):
         _lib.call("cgic_entropy_maps_u8", _lib.ptr(frames), B, H, W, _bins(), 32, float(sigma), _lib.ptr(x), _lib.ptr(e8), _lib.ptr(e16),
                   _lib.ptr(flat8), _lib.current_stream(dev))
     _tag((e8, e16), frames, flat8)

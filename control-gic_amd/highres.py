@@ -148,6 +148,26 @@ class _Fork:
         self.used = []
 
 
+def _cut_all(x, frames, N, H, W, top, left, tiles, order):
+    """the tile batches of all shape groups from the unpadded image(s) in one launch -> [batch per group], batch
+    [N, T, 3, th, tw] fp32 or [N, T, th, tw, 3] uint8 (inference_high_resolution.py:145-173 pad + :236-244 crop)"""
+    _lib.require_device(x)
+    n = sum(len(idxs) for _, idxs in order)
+    desc = (_lib.Tile * n)()
+    batches, j = [], 0
+    for (th, tw), idxs in order:
+        T = len(idxs)
+        batch = torch.empty((N, T, th, tw, 3) if frames else (N, T, 3, th, tw), dtype=x.dtype, device=x.device)
+        per = 3 * th * tw
+        for k, i in enumerate(idxs):
+            desc[j] = _lib.Tile(batch.data_ptr() + k * per * batch.element_size(), T * per, tiles[i][0] - top, tiles[i][1] - left, th, tw)
+            j += 1
+        batches.append(batch)
+    with torch.cuda.device(x.device):
+        _lib.call("cgic_cut_tiles", _lib.ptr(x), int(frames), N, H, W, n, desc, _lib.current_stream(x.device))
+    return batches
+
+
 def _compress_groups(x, encode, codec, tile, concurrent, chain=False):
     """x [N,3,H,W] fp32 -- or uint8 frames [N,H,W,3], the tiles then reach `encode` as uint8 [T,th,tw,3] (entropy_maps_u8 makes the
     fp32 tiles and the maps in one pass) --: the shape groups of N images of one size, each group ONE batch of N * T tiles (image-major)
@@ -173,13 +193,18 @@ def _compress_groups(x, encode, codec, tile, concurrent, chain=False):
     # one launch per kernel whose grid is the concatenation of the groups' grids
     grp = _lib.launch_group(len(order), [N * len(idxs) * th * tw for (th, tw), idxs in order], x.device) if chain else None
     batches = []
+    cut = None
+    if not fork.enabled and len(tiles) <= 96:
+        # pad + crop of ALL tiles as one launch (cgic_cut_tiles): every tile written straight from the unpadded image
+        cut = _cut_all(x.contiguous(), frames, N, H, W, top, left, tiles, order)
     for lane, ((th, tw), idxs) in enumerate(order):
         with torch.cuda.stream(fork.lane(lane)):
             # pad + cut in ONE copy per tile (F.pad of the whole image and a stack of views would move every pixel twice): a tile
             # is the part of the image it covers, zeros where it reaches into the centred pad
-            batch = torch.empty((N, len(idxs), th, tw, 3) if frames else (N, len(idxs), 3, th, tw), dtype=x.dtype, device=x.device)
+            batch = cut[lane] if cut is not None else \
+                torch.empty((N, len(idxs), th, tw, 3) if frames else (N, len(idxs), 3, th, tw), dtype=x.dtype, device=x.device)
             bv = batch.permute(0, 1, 4, 2, 3) if frames else batch
-            for k, i in enumerate(idxs):
+            for k, i in enumerate(idxs if cut is None else ()):
                 y0, x0 = tiles[i][0] - top, tiles[i][1] - left                  # in unpadded coordinates
                 sy0, sy1, sx0, sx1 = max(y0, 0), min(y0 + th, H), max(x0, 0), min(x0 + tw, W)
                 dst = bv[:, k]
@@ -245,7 +270,7 @@ def compress_tiled_batch(x, encode, codec, tile=TILE, concurrent=False, chain=Fa
     return out
 
 
-def decompress_tiled_batch(tiled_list, codec, concurrent=False, check=True):
+def decompress_tiled_batch(tiled_list, codec, concurrent=False, check=True, chain=False):
     """inverse of compress_tiled_batch for TiledImages of one geometry (from it, or from N compress_tiled calls on images
     of one size, or rebuilt from containers): ONE decompress per shape group over all the images
     -> list (per image) of per-tile (ind, masks, z_q); check=False: (that, [N * tiles] status tensor)"""
@@ -259,8 +284,10 @@ def decompress_tiled_batch(tiled_list, codec, concurrent=False, check=True):
     N = len(tiled_list)
     per_image = [[None] * len(first.tiles) for _ in range(N)]
     dev = first.groups[0][1].data.device
-    fork = _Fork(dev, concurrent)
+    chain = chain and 1 < len(first.groups) <= _lib.lib().cgic_group_max()
+    fork = _Fork(dev, concurrent and not chain)
     outs, statuses = [], []
+    pending = []
     whole = getattr(first, "_whole", None)
     if whole is not None and not (whole[2] == N and all(
             getattr(t, "_whole", (None,))[0] is whole[0] and t._whole[1] == n for n, t in enumerate(tiled_list))):
@@ -275,8 +302,17 @@ def decompress_tiled_batch(tiled_list, codec, concurrent=False, check=True):
                 data = torch.cat([c.data if c.data.shape[-1] == slot else
                                   torch.nn.functional.pad(c.data, (0, slot - c.data.shape[-1])) for c in comps])
                 comp = type(c0)(data, torch.cat([c.nbytes for c in comps]), c0.mode, c0.h, c0.w)
-            ind, masks, zq, status = codec.decompress(comp)
-        outs.append((ind, masks, zq, status))
+            if chain:
+                pending.append(comp)
+                continue
+            outs.append(codec.decompress(comp))
+    if chain:
+        # the decoder and the merge of all shape groups as ONE launch each (see compress_tiled)
+        with _lib.launch_group(len(pending), [c.batch * c.h * c.w for c in pending], dev) as g:
+            for k, comp in enumerate(pending):
+                g.select(k)
+                outs.append(codec.decompress(comp))
+    for (idxs, _, _), (ind, masks, zq, status) in zip(first.groups, outs):
         statuses.append(status)
         T = len(idxs)
         for n in range(N):
@@ -303,25 +339,19 @@ def decompress_tiled(tiled, codec, decode=None, concurrent=False, check=True, ch
     fork = _Fork(dev, concurrent and dev is not None and not chain)
     outs = []
     # chain: the decoder and the merge of all shape groups as ONE launch each (see compress_tiled)
-    grp = _lib.launch_group(len(tiled.groups), [c.batch * c.h * c.w for _, c, _ in tiled.groups], dev) if chain else None
     if chain:
-        grp.__enter__()
+        with _lib.launch_group(len(tiled.groups), [c.batch * c.h * c.w for _, c, _ in tiled.groups], dev) as g:
+            for lane, (_, comp, _) in enumerate(tiled.groups):
+                g.select(lane)
+                outs.append(codec.decompress(comp))
     for lane, (idxs, comp, _) in enumerate(tiled.groups):
-        try:
+        if not chain:
             with torch.cuda.stream(fork.lane(lane)):
-                if chain:
-                    grp.select(lane)
-                ind, masks, zq, status = codec.decompress(comp)
-        except BaseException as e:
-            if chain:
-                grp.__exit__(type(e), e, None)
-            raise
-        outs.append((ind, masks, zq, status))
+                outs.append(codec.decompress(comp))
+        ind, masks, zq, status = outs[lane]
         statuses.append(status)
         for k, i in enumerate(idxs):
             per_tile[i] = (ind[k:k + 1], [m[k:k + 1] for m in masks], zq[k:k + 1])
-    if chain:
-        grp.__exit__(None, None, None)
     fork.join(outs)
     if not check:
         return per_tile, (torch.cat(statuses) if statuses else None)

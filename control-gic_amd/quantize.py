@@ -84,7 +84,7 @@ def vq_backward(z, weight, idx, g_zq, g_loss, beta, legacy, want_gz=True, want_g
     gw = torch.empty_like(wt) if want_gw else None
     N = B * h * w
     ws = torch.empty(_lib.lib().cgic_vq_backward_workspace_bytes(N, wt.shape[0]), dtype=torch.uint8, device=dev) if want_gw else None
-    with torch.cuda.device(dev):
+    with _lib.on_device(dev):
         _lib.call("cgic_vq_backward_f32", _lib.ptr(z), B, h * w, _lib.ptr(wt), wt.shape[0], C, _lib.ptr(idx.contiguous()),
                   _lib.ptr(g_zq), _lib.ptr(g_loss), float(beta), int(bool(legacy)), _lib.ptr(gz), _lib.ptr(gw), _lib.ptr(ws),
                   _lib.current_stream(dev))
@@ -107,7 +107,7 @@ def prepare_codebook(weight, out=None):
     if out is not None and (out.numel() != nbytes or out.device != wt.device or out.dtype != torch.uint8):
         raise ValueError("prepare_codebook: `out` is not an image of a codebook of this size on this device")
     img = out if out is not None else torch.empty(nbytes, dtype=torch.uint8, device=wt.device)
-    with torch.cuda.device(wt.device):
+    with _lib.on_device(wt.device):
         _lib.call("cgic_vq_prepare_f32", _lib.ptr(wt), wt.shape[0], wt.shape[1], _lib.ptr(img), _lib.current_stream(wt.device))
     return img
 
@@ -134,7 +134,7 @@ def _vq_forward(z, weight, beta, legacy, hist, want_zq=True, want_loss=True, ker
     fn = "cgic_vq_forward_f32" if kernel == "mfma" else "cgic_vq_forward_valu_f32"
     qc, keep = _lib.conv_arg(quant_conv, conv_bias_first)
     extra = (_lib.ptr(prepared),) if kernel == "mfma" else ()
-    with torch.cuda.device(z.device):
+    with _lib.on_device(z.device):
         _lib.call(fn, _lib.ptr(z), B, h * w, _lib.ptr(weight), weight.shape[0], C, float(beta), int(bool(legacy)),
                   _lib.ptr(idx), _lib.ptr(z_q), _lib.ptr(loss), _lib.ptr(hist), _lib.ptr(ws), qc, *extra,
                   _lib.current_stream(z.device))
@@ -176,7 +176,7 @@ def vq_forward_route(z, weight, beta, legacy, e16, e8, coarse_ratio, medium_rati
     mode = ctypes.c_int(0)
     qc, keep = _lib.conv_arg(quant_conv, conv_bias_first)
     px, keep_px = _lib.pixels_arg(pixels, B, h16, w16, per_image, flat8=flat8)
-    with torch.cuda.device(dev):
+    with _lib.on_device(dev):
         _lib.call("cgic_vq_forward_route_f32", _lib.ptr(z), B, h * w, _lib.ptr(weight), weight.shape[0], C, float(beta),
                   int(bool(legacy)), _lib.ptr(idx), _lib.ptr(z_q), _lib.ptr(loss), _lib.ptr(ws), _lib.ptr(e16), _lib.ptr(e8),
                   h16, w16, float(coarse_ratio), float(medium_ratio), int(bool(per_image)), _lib.ptr(mc), _lib.ptr(mm),

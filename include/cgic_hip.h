@@ -423,6 +423,23 @@ int cgic_grain_merge_f32(const float *h_coarse, const float *h_medium, const flo
  *   divided by k*k (the order of ATen's CPU kernel: bit-identical to the CPU reference).
  * ------------------------------------------------------------------------- */
 int cgic_avgpool_f32(const float *x, int64_t planes, int64_t H, int64_t W, int k, float *out, cgic_stream_t stream);
+
+/* ---------------------------------------------------------------------------
+ * Tiling driver: pad + crop of inference_high_resolution.py as ONE pass (ABI 6).  The script pads the image to a multiple of 16
+ * with centred zeros (:145-173, :227-228) and crops the padded image tile by tile (:112-125, :236-244); here every tile of every
+ * image is written straight from the unpadded image (zeros where a tile reaches into the pad), one launch for all tiles.
+ *   x       device fp32 [N,3,H,W], or with is_u8 the uint8 frames [N,H,W,3]
+ *   tiles   host [ntiles] (<= 96): dst = device address of the tile of image 0 -- fp32 [3,th,tw] (16-byte aligned) or uint8
+ *           [th,tw,3] (4-byte aligned); image_stride = elements from there to the same tile of the next image; (y0, x0) = the
+ *           tile's origin in UNPADDED coordinates (negative inside the pad); th, tw with tw % 4 == 0
+ * ------------------------------------------------------------------------- */
+typedef struct cgic_tile {
+    void *dst;
+    int64_t image_stride;
+    int y0, x0, th, tw;
+} cgic_tile;
+int cgic_cut_tiles(const void *x, int is_u8, int64_t N, int64_t H, int64_t W, int ntiles, const cgic_tile *tiles,
+                   cgic_stream_t stream);
 int cgic_decoder_blend_medium_f32(const float *h, const float *h_medium, const int32_t *mask_c, const int32_t *mask_m,
                                   int64_t B, int C, int64_t hh, int64_t ww, float *out, cgic_stream_t stream);
 int cgic_decoder_blend_fine_f32(const float *h, const float *h_fine, const int32_t *mask_c, const int32_t *mask_m,

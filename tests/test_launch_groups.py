@@ -45,12 +45,18 @@ def test_group_api_misuse_is_refused():
     finally:
         l.cgic_group_abort()
     assert l.cgic_group_select(0) == _lib.ERR_INVALID           # closed again
-    # an exception inside the block closes the group without launching
+
+
+@pytest.mark.gpu
+def test_an_exception_inside_the_block_closes_the_group():
+    from control_gic_amd import _lib
+    l = _lib.lib()
     with pytest.raises(RuntimeError):
-        with _lib.launch_group(2):
+        with _lib.launch_group(2, None, torch.device("cuda", 0)):
             raise RuntimeError("x")
-    assert l.cgic_group_begin(1, None) == 0
+    assert l.cgic_group_begin(1, None) == 0          # not left open
     l.cgic_group_abort()
+    assert _lib.current_stream(torch.device("cuda", 0)) == torch.cuda.current_stream().cuda_stream
 
 
 @pytest.mark.gpu
@@ -164,3 +170,77 @@ def test_groups_of_mixed_kernels_fall_back_to_single_launches():
         assert all(torch.equal(p, q) for p, q in zip(ma, mb))
         assert ca.to_host() == cb.to_host()
         assert torch.equal(da[0], db[0]) and torch.equal(da[2], db[2]) and int(db[3].abs().max()) == 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("H,W", [(1356, 2040), (1001, 1803), (17, 33), (768, 768), (1537, 770)])
+@pytest.mark.parametrize("frames", [False, True])
+def test_cut_tiles_equals_pad_then_crop(H, W, frames):
+    """cgic_cut_tiles (all tiles of all images from the UNPADDED images in one launch) == the reference's F.pad to a multiple of 16
+    (centred, zeros; inference_high_resolution.py:145-173,:227-228) followed by the per-tile crops (:236-244), odd pads included"""
+    from control_gic_amd import highres
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(H + 3 * W)
+    N = 2
+    if frames:
+        x = torch.from_numpy(rng.integers(0, 256, (N, H, W, 3), dtype=np.uint8)).to(dev)
+        xc = x.permute(0, 3, 1, 2)
+    else:
+        x = torch.from_numpy(rng.random((N, 3, H, W), dtype=np.float32)).to(dev)
+        xc = x
+    (left, right, top, bottom), _ = highres.compute_padding(H, W)
+    padded = torch.nn.functional.pad(xc, (left, right, top, bottom), mode="constant", value=0)
+    tiles = highres.tile_grid(H + top + bottom, W + left + right)
+    by_shape = {}
+    for i, (_, _, th, tw) in enumerate(tiles):
+        by_shape.setdefault((th, tw), []).append(i)
+    order = sorted(by_shape.items(), key=lambda kv: -len(kv[1]) * kv[0][0] * kv[0][1])
+    batches = highres._cut_all(x, frames, N, H, W, top, left, tiles, order)
+    torch.cuda.synchronize()
+    for ((th, tw), idxs), batch in zip(order, batches):
+        for k, i in enumerate(idxs):
+            y, xx, _, _ = tiles[i]
+            want = padded[:, :, y:y + th, xx:xx + tw]
+            got = batch[:, k].permute(0, 3, 1, 2) if frames else batch[:, k]
+            assert torch.equal(got, want), (i, th, tw)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("H,W", [(1000, 1800), (1356, 2040)])
+def test_chain_of_a_batch_of_images(H, W):
+    """compress_tiled_batch / decompress_tiled_batch with chain=True (N images of one size: every shape group one batch of N x T tiles,
+    all groups one launch per kernel) == the ungrouped driver, fp32 images and uint8 frames"""
+    from control_gic_amd import highres
+    from control_gic_amd.quantize import vq_forward_route
+    cg, dev, rng, vq, codec = _setup(H + W)
+    N = 3
+    frames = torch.from_numpy(rng.integers(0, 256, (N, H, W, 3), dtype=np.uint8)).to(dev)
+    x = (frames.permute(0, 3, 1, 2).float() / 255).contiguous()
+
+    def latent(tiles_f32):
+        z = torch.nn.functional.avg_pool2d(tiles_f32, 4)
+        return (torch.cat([z, z[:, :1] * 2 - 1], dim=1) * 3 - 1.5).contiguous()
+
+    def encode(tiles):
+        e8, e16 = cg.entropy_maps(tiles)
+        _, _, ind, mask, _, mode = vq_forward_route(latent(tiles), vq.embedding.weight, 0.25, True, e16, e8, 0.1, 0.8, per_image=True, pixels=tiles)
+        return ind, mask, mode
+
+    def encode_u8(tiles):
+        z = latent(tiles.permute(0, 3, 1, 2).float() / 255)          # (torch work on the INPUT tiles only: allowed inside a chain)
+        _, e8, e16 = cg.entropy_maps_u8(tiles, want_x=False)
+        _, _, ind, mask, _, mode = vq_forward_route(z, vq.embedding.weight, 0.25, True, e16, e8, 0.1, 0.8, per_image=True, pixels=tiles)
+        return ind, mask, mode
+
+    for inp, enc in ((x, encode), (frames, encode_u8)):
+        ref = highres.compress_tiled_batch(inp, enc, codec)
+        got = highres.compress_tiled_batch(inp, enc, codec, chain=True)
+        for a, b in zip(ref, got):
+            assert a.streams() == b.streams() and a.bpp() == b.bpp()
+        dref = highres.decompress_tiled_batch(ref, codec)
+        dgot = highres.decompress_tiled_batch(got, codec, chain=True)
+        dcat = highres.decompress_tiled_batch([got[1], got[0]], codec, chain=True)         # not the shared buffers: concatenated first
+        for n in range(N):
+            _same_decoded(dref[n], dgot[n])
+        _same_decoded(dref[1], dcat[0])
+        _same_decoded(dref[0], dcat[1])
