@@ -747,8 +747,8 @@ def div2k_image(dev, cb, vq, codec, iters=8):
                                           "status_ok": int(st8.abs().max()) == 0, "bpp_mean": round(float(np.mean([t.bpp() for t in ts8])), 6),
                                           "note": "input = uint8 [8,H,W,3] frames = round(255 x) of batch_of_8's images (so its bpp differs slightly: other pixels, "
                                                   "not a parity gap -- equality with frames / 255 as fp32 input is what tests/test_highres_container.py checks); "
-                                                  "measured NO faster than the fp32 input in flight (0.044 vs 0.0435 ms per image): the byte-wise pad / cut copies "
-                                                  "cost what the fp32 ones do"}
+                                                  "round 3 measured it NO faster than the fp32 input (byte-wise torch copies per tile); "
+                                                  "with cgic_cut_tiles (all tiles in one launch, 12-byte units) the frames are ahead"}
     except Exception as e:
         res["batch_of_8_uint8_frames"] = {"error": str(e)[:200]}
     return res
@@ -937,16 +937,17 @@ class MixedStream:
                 e8, e16 = cg.entropy_maps(tiles)
                 _, _, ind, mask, _, mode = vq_forward_route(zs[key], vq.embedding.weight, 0.25, True, e16, e8, ratio[0], ratio[1], per_image=True,
                                                             pixels=tiles)
-                lib.call("cgic_index_histogram", ind.data_ptr(), ind.numel(), 1024, hist.data_ptr(), lib.current_stream(dev))
+                lib.call("cgic_index_histogram", lib.ptr(ind), ind.numel(), 1024, lib.ptr(hist), lib.current_stream(dev))
                 return ind, mask, mode
 
+            # (chain: the four shape groups of the tiled images through one launch per kernel -- launch groups)
             def d_enc():
-                box2["tiled"] = highres.compress_tiled_batch(xd, encode, codec)
+                box2["tiled"] = highres.compress_tiled_batch(xd, encode, codec, chain=True)
                 return box2["tiled"]
 
             def d_dec():
                 with cg.decoder_mode("throughput"):
-                    box2["dec"] = highres.decompress_tiled_batch(box2["tiled"], codec, check=False)
+                    box2["dec"] = highres.decompress_tiled_batch(box2["tiled"], codec, check=False, chain=True)
                 return box2["dec"]
             self.chains.append((st[1], d_enc, d_dec, box2))
         self.graphs = []

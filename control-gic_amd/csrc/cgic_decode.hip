@@ -1267,7 +1267,9 @@ extern "C" int cgic_decompress_streams(const cgic_table *t, const uint8_t *in, i
             { int rc_ = ensure_dynamic_lds((const void *)decode_image_kernel, lds_ss); if (rc_) return rc_; }
             const int T = large ? kDecThreads : CGIC_SS_THREADS_SMALL;
             const int sc_ = (int)stage_cap, cc_ = (int)chunk_cap;
-            rc = launch_or_record(KID_NONE, dim3((unsigned)B), dim3(T), lds_ss, d, [=] {
+            DecodeImageArgs dia;
+            dia.a = d; dia.stage_cap = sc_; dia.chunk_cap = cc_;
+            rc = launch_or_record(KID_DECODE_IMAGE, dim3((unsigned)B), dim3(T), lds_ss, dia, [=] {
                 hipLaunchKernelGGL(decode_image_kernel, dim3((unsigned)B), dim3(T), lds_ss, s, d, sc_, cc_);
                 return launch_check("decode_image_kernel"); });
         }

@@ -248,7 +248,7 @@ __device__ __forceinline__ MeFn me_walk_all(const TableDev &t, const uint32_t *l
     return f;
 }
 
-__global__ __launch_bounds__(kDecThreads) void decode_image_kernel(DecodeArgs a, int stage_cap, int chunk_cap)
+__device__ __forceinline__ void decode_image_body(const DecodeArgs &a, const int stage_cap, const int chunk_cap, const Blk blk)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t sm[];
     __shared__ int s_scan[kDecWaves + 1];
@@ -258,7 +258,7 @@ __global__ __launch_bounds__(kDecThreads) void decode_image_kernel(DecodeArgs a,
     uint8_t *stage = reinterpret_cast<uint8_t *>(lut + (1 << a.tab.lut_bits));
     uint8_t *ent = stage + stage_cap, *ext = ent + chunk_cap, *cnt = ext + chunk_cap;
     const int tid = threadIdx.x, T = blockDim.x, lane = lane_id(), wave = tid >> 6, nw = T >> 6;
-    const int64_t b = blockIdx.x;
+    const int64_t b = blk.x;
     CGIC_STAMP3(0);
     const uint8_t *in0 = a.in + (b * CGIC_NUM_STREAMS) * a.slot;
     int nb[3];
@@ -420,7 +420,7 @@ __global__ __launch_bounds__(kDecThreads) void decode_image_kernel(DecodeArgs a,
         atomicMax(&a.stats[2], (unsigned int)dbg_sweeps);
     }
 #ifdef CGIC_PHASE_CLOCKS
-    if (blockIdx.x == 0 && tid == 0) g_phase_clk[9] = dbg_sweeps;
+    if (blk.x == 0 && tid == 0) g_phase_clk[9] = dbg_sweeps;
 #endif
     // output positions: exclusive prefix of the counts over the chunks, restarted at every stream
     int mine = 0;
@@ -470,4 +470,32 @@ __global__ __launch_bounds__(kDecThreads) void decode_image_kernel(DecodeArgs a,
     }
 }
 
+__global__ __launch_bounds__(kDecThreads) void decode_image_kernel(DecodeArgs a, int stage_cap, int chunk_cap)
+{
+    decode_image_body(a, stage_cap, chunk_cap, own_blk());
+}
+
+// several shape groups in one launch (cgic_common.h: launch groups); the groups share the workgroup size (checked by
+// cgic_group_launch) and take the largest LDS footprint
+__global__ __launch_bounds__(kDecThreads) void decode_image_grouped_kernel(Grouped<DecodeImageArgs> g)
+{
+    Blk blk;
+    const DecodeImageArgs &p = g.a[group_locate(g, &blk)];
+    decode_image_body(p.a, p.stage_cap, p.chunk_cap, blk);
+}
+
 }  // namespace cgic
+
+using namespace cgic;
+static int decode_image_grouped_launch(const GroupRec *const *recs, int n, hipStream_t s)
+{
+    Grouped<DecodeImageArgs> g;
+    size_t lds;
+    int rc = fill_grouped(recs, n, &g, &lds);
+    if (rc) return rc;
+    rc = ensure_dynamic_lds((const void *)decode_image_grouped_kernel, lds);
+    if (rc) return rc;
+    hipLaunchKernelGGL(decode_image_grouped_kernel, dim3(g.start[kMaxGroups]), recs[0]->block, lds, s, g);
+    return launch_check("decode_image_grouped_kernel");
+}
+static GroupedRegistrar reg_decode_image(KID_DECODE_IMAGE, decode_image_grouped_launch);

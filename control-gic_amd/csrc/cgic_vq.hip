@@ -1232,9 +1232,11 @@ static int launch_hist(const int64_t *idx, int64_t n, int K, int64_t *hist, hipS
     int nblk = (int)((n + 4095) / 4096);
     if (nblk > 64) nblk = 64;
     if (nblk < 1) nblk = 1;
-    hipLaunchKernelGGL(index_hist_kernel, dim3(nblk), dim3(1024), sizeof(unsigned int) * (size_t)K, s, idx, n, K,
-                       (unsigned long long *)hist);
-    return launch_check("index_hist_kernel");
+    // (inside a launch group: recorded at its position and launched on its own -- histograms of several groups add into one table)
+    const size_t lds = sizeof(unsigned int) * (size_t)K;
+    return launch_or_record(KID_NONE, dim3(nblk), dim3(1024), lds, n, [=] {
+        hipLaunchKernelGGL(index_hist_kernel, dim3(nblk), dim3(1024), lds, s, idx, n, K, (unsigned long long *)hist);
+        return launch_check("index_hist_kernel"); });
 }
 
 static int vq_check(const float *z, int64_t B, int64_t hw, const float *cb, int K, int e_dim,

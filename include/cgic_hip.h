@@ -71,7 +71,8 @@ int cgic_launch_graphs(void *const *graph_execs, void *const *streams, int n);
  * resolution image into a 768-px grid with a ragged last row / column (inference_high_resolution.py:112-125) and runs
  * model.compress on the tiles one after the other (:236-257); tiles of equal shape are one batch here, but a 2040x1356
  * image is still four shapes = four launch chains.  Between cgic_group_begin(n, shares) and cgic_group_launch(stream) the calls
- * of THIS thread to cgic_entropy_maps_f32 / _u8, cgic_vq_forward_route_f32, cgic_compress_streams and cgic_decompress_streams check
+ * of THIS thread to cgic_entropy_maps_f32 / _u8, cgic_vq_forward_route_f32, cgic_index_histogram, cgic_compress_streams and
+ * cgic_decompress_streams check
  * their arguments and record their launches instead of making them (cgic_group_select(g) says which group the following calls belong
  * to; within a group the calls are dependent in call order, across groups nothing is); cgic_group_launch then issues the j-th
  * launches of all groups as ONE launch whose grid is the concatenation of theirs (each workgroup finds its group's argument block

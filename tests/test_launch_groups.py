@@ -136,6 +136,15 @@ def test_chain_launch_counts_and_uint8_frames():
             g.select(k)
             codec.decompress(comp)
     assert grp.launches == 2
+    with cg.decoder_mode("throughput"):                     # the self-synchronising decoder has a grouped form too
+        grp = _lib.launch_group(len(got.groups), None, dev)
+        with grp as g:
+            for k, (_, comp, _) in enumerate(got.groups):
+                g.select(k)
+                codec.decompress(comp)
+    # (the 768x768 group's worst case does not fit the one-workgroup decoder's LDS: it records the split-stream decoder, the other
+    # groups the self-synchronising one -- a position with different kernels is launched group by group; the merge is one launch)
+    assert 2 <= grp.launches <= len(got.groups) + 1
     torch.cuda.synchronize()
 
 
