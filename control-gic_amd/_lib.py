@@ -104,6 +104,8 @@ PROTOTYPES = {
     "cgic_grain_merge_f32": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _int, _i64, _i64, _vp, _vp]),
     "cgic_avgpool_f32": (_int, [_vp, _i64, _i64, _i64, _int, _vp, _vp]),
     "cgic_cut_tiles": (_int, [_vp, _int, _i64, _i64, _i64, _int, C.POINTER(Tile), _vp]),
+    "cgic_entropy_maps_tiles": (_int, [_vp, _int, _i64, _i64, _i64, _int, C.POINTER(_int), _i64, _i64, C.POINTER(_f32), _int, _f32, _vp, _vp, _vp,
+                                       _vp, _vp]),
     "cgic_decoder_blend_medium_f32": (_int, [_vp, _vp, _vp, _vp, _i64, _int, _i64, _i64, _vp, _vp]),
     "cgic_decoder_blend_fine_f32": (_int, [_vp, _vp, _vp, _vp, _vp, _i64, _int, _i64, _i64, _vp, _vp]),
     "cgic_embedding_gather_f32": (_int, [_vp, _i64, _i64, _vp, _int, _int, _vp, _vp, _vp]),

@@ -87,7 +87,7 @@ struct Grouped {
     unsigned int gx[kMaxGroups], gy[kMaxGroups];  // the group's grid extents (x fastest, like the hardware's dispatch order)
     A a[kMaxGroups];
 };
-enum KernelId { KID_NONE = 0, KID_ENTROPY_F32, KID_ENTROPY_U8, KID_VQF_ROUTER_AL, KID_VQF_ROUTER_UN, KID_COMPRESS, KID_DECODE_SPLIT,
+enum KernelId { KID_NONE = 0, KID_ENTROPY_F32, KID_ENTROPY_U8, KID_ENTROPY_WIN_F32, KID_ENTROPY_WIN_U8, KID_VQF_ROUTER_AL, KID_VQF_ROUTER_UN, KID_COMPRESS, KID_DECODE_SPLIT,
                 KID_DECODE_IMAGE, KID_MERGE, KID_COUNT };
 
 // host side of a launch group

@@ -100,11 +100,23 @@ __device__ __forceinline__ unsigned int cvt_round_u32(float v)
 // 12 bytes of its 4 pixels, converts them to the fp32 values T.ToTensor() produces (bit for bit) and, if x_out is given, writes
 // them as the fp32 [B, 3, H, W] tensor the conv encoder takes (inference.py:50-59 + model.py:99-101): 3 B read + 12 B written
 // per pixel instead of 3 + 12 (ToTensor) and 12 again (Entropy)
-template <bool U8>
+// WIN (cgic_entropy_maps_tiles): the batch is the tiles of ONE shape cut out of unpadded images -- pad + crop of the tiling driver
+// (inference_high_resolution.py:145-173, :236-244) and the maps in one pass: image b = (source image b / T, tile b % T); a lane
+// reads its 4 pixels from the SOURCE window (zeros where the tile reaches into the centred pad), the tile itself is written to
+// x_out as a by-product (the conv encoder's input and the router's refinement pixels).  33 MB read + 33 MB written for a
+// 2040x1356 image instead of (33 + 33) for the cut and 33 again for the maps.
+constexpr int kEntMaxTiles = 48;
+struct EntWindow {
+    const void *src;          // fp32 [N,3,srcH,srcW] or uint8 [N,srcH,srcW,3]
+    int srcH, srcW, T;
+    int org[kEntMaxTiles][2]; // (y0, x0) of tile k in unpadded source coordinates (negative inside the pad)
+};
+
+template <bool U8, bool WIN = false>
 __device__ __forceinline__ void entropy_maps_body(
     const void *__restrict__ xin, int64_t H, int64_t W, float exp2_scale, float *__restrict__ e8,
     float *__restrict__ e16, const BinsArg &bins_arg, int patches_per_wave, float *__restrict__ x_out, float *__restrict__ flat8,
-    const Blk blk)
+    const Blk blk, const EntWindow *win = nullptr)
 {
     const float *__restrict__ x = reinterpret_cast<const float *>(xin);
     __shared__ __attribute__((aligned(16))) unsigned int hist_all[kEntWaves][kBins * kHistStride];
@@ -133,7 +145,61 @@ __device__ __forceinline__ void entropy_maps_body(
     const int64_t plane = H * W;
     float4 pR = {0.f, 0.f, 0.f, 0.f}, pG = pR, pB = pR;
     unsigned int raw0 = 0, raw1 = 0, raw2 = 0;      // U8: the 12 bytes R0 G0 B0 R1 | G1 B1 R2 G2 | B2 R3 G3 B3 of the lane's 4 pixels
+    // WIN: this tile's window of its source image (all scalar)
+    int wn = 0, wy0 = 0, wx0 = 0, sH = 0, sW = 0;
+    bool wvec = false;
+    if constexpr (WIN) {
+        wn = (int)(b / win->T);
+        const int wk = (int)b - wn * win->T;
+        wy0 = win->org[wk][0]; wx0 = win->org[wk][1]; sH = win->srcH; sW = win->srcW;
+        // whole 4-pixel units can be fetched as vectors when the window is shifted by a multiple of 4 pixels in rows of a multiple of 4
+        wvec = ((wx0 | sW) & 3) == 0 && (reinterpret_cast<uintptr_t>(win->src) & 15) == 0;
+    }
     auto request = [&](int64_t patch) {
+        if constexpr (WIN) {
+            if (patch < p_end) {
+                const int sy = wy0 + (int)(row0 + prow), sx = wx0 + (int)(patch * 16 + pc4);
+                const bool row_ok = sy >= 0 && sy < sH, all_in = sx >= 0 && sx + 3 < sW;
+                if (U8) {
+                    raw0 = raw1 = raw2 = 0u;
+                    if (row_ok) {
+                        const unsigned char *q = reinterpret_cast<const unsigned char *>(win->src) + (((int64_t)wn * sH + sy) * (int64_t)sW + sx) * 3;
+                        if (all_in && wvec) {
+                            const unsigned int *qw = reinterpret_cast<const unsigned int *>(q);
+                            raw0 = qw[0]; raw1 = qw[1]; raw2 = qw[2];
+                        } else {
+#pragma unroll
+                            for (int j = 0; j < 12; ++j) {
+                                const int sxj = sx + j / 3;
+                                const unsigned int v = (sxj >= 0 && sxj < sW) ? q[j] : 0u;
+                                if (j < 4) raw0 |= v << (8 * j); else if (j < 8) raw1 |= v << (8 * (j - 4)); else raw2 |= v << (8 * (j - 8));
+                            }
+                        }
+                    }
+                } else {
+                    const float4 zero = {0.f, 0.f, 0.f, 0.f};
+                    pR = zero; pG = zero; pB = zero;
+                    if (row_ok) {
+                        const int64_t splane = (int64_t)sH * sW;
+                        const float *p = reinterpret_cast<const float *>(win->src) + ((int64_t)wn * 3) * splane + (int64_t)sy * sW + sx;
+                        if (all_in && wvec) {
+                            pR = *reinterpret_cast<const float4 *>(p);
+                            pG = *reinterpret_cast<const float4 *>(p + splane);
+                            pB = *reinterpret_cast<const float4 *>(p + 2 * splane);
+                        } else {
+                            float r[4], g4[4], bl[4];
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) {
+                                const bool ok = sx + j >= 0 && sx + j < sW;
+                                r[j] = ok ? p[j] : 0.f; g4[j] = ok ? p[splane + j] : 0.f; bl[j] = ok ? p[2 * splane + j] : 0.f;
+                            }
+                            pR = {r[0], r[1], r[2], r[3]}; pG = {g4[0], g4[1], g4[2], g4[3]}; pB = {bl[0], bl[1], bl[2], bl[3]};
+                        }
+                    }
+                }
+            }
+            return;
+        }
         if (patch < p_end) {
             if (U8) {
                 const unsigned int *q = reinterpret_cast<const unsigned int *>(
@@ -174,12 +240,12 @@ __device__ __forceinline__ void entropy_maps_body(
             pR = {unit_of_byte(byte_f(raw0, 0)), unit_of_byte(byte_f(raw0, 3)), unit_of_byte(byte_f(raw1, 2)), unit_of_byte(byte_f(raw2, 1))};
             pG = {unit_of_byte(byte_f(raw0, 1)), unit_of_byte(byte_f(raw1, 0)), unit_of_byte(byte_f(raw1, 3)), unit_of_byte(byte_f(raw2, 2))};
             pB = {unit_of_byte(byte_f(raw0, 2)), unit_of_byte(byte_f(raw1, 1)), unit_of_byte(byte_f(raw2, 0)), unit_of_byte(byte_f(raw2, 3))};
-            if (x_out) {
-                float *o = x_out + (b * 3) * plane + (row0 + prow) * W + patch * 16 + pc4;
-                *reinterpret_cast<float4 *>(o) = pR;
-                *reinterpret_cast<float4 *>(o + plane) = pG;
-                *reinterpret_cast<float4 *>(o + 2 * plane) = pB;
-            }
+        }
+        if constexpr (U8 || WIN) if (x_out) {
+            float *o = x_out + (b * 3) * plane + (row0 + prow) * W + patch * 16 + pc4;
+            *reinterpret_cast<float4 *>(o) = pR;
+            *reinterpret_cast<float4 *>(o + plane) = pG;
+            *reinterpret_cast<float4 *>(o + 2 * plane) = pB;
         }
         // gray = 0.2989 R + 0.5870 G + 0.1140 B  (:471)
         float g[4];
@@ -303,6 +369,23 @@ __global__ __launch_bounds__(kEntThreads) void entropy_maps_grouped_kernel(Group
     Blk blk;
     const EntArgs &a = g.a[group_locate(g, &blk)];
     entropy_maps_body<U8>(a.x, a.H, a.W, a.exp2_scale, a.e8, a.e16, a.bins, a.ppw, a.x_out, a.flat8, blk);
+}
+
+struct EntWinArgs {
+    EntArgs e;
+    EntWindow w;
+};
+template <bool U8>
+__global__ __launch_bounds__(kEntThreads) void entropy_tiles_kernel(EntWinArgs a)
+{
+    entropy_maps_body<U8, true>(nullptr, a.e.H, a.e.W, a.e.exp2_scale, a.e.e8, a.e.e16, a.e.bins, a.e.ppw, a.e.x_out, a.e.flat8, own_blk(), &a.w);
+}
+template <bool U8>
+__global__ __launch_bounds__(kEntThreads) void entropy_tiles_grouped_kernel(Grouped<EntWinArgs> g)
+{
+    Blk blk;
+    const EntWinArgs &a = g.a[group_locate(g, &blk)];
+    entropy_maps_body<U8, true>(nullptr, a.e.H, a.e.W, a.e.exp2_scale, a.e.e8, a.e.e16, a.e.bins, a.e.ppw, a.e.x_out, a.e.flat8, blk, &a.w);
 }
 
 // =====================================================================================================
@@ -471,6 +554,60 @@ static int entropy_grouped_launch(const GroupRec *const *recs, int n, hipStream_
 }
 static GroupedRegistrar reg_ent_f32(KID_ENTROPY_F32, entropy_grouped_launch<false>);
 static GroupedRegistrar reg_ent_u8(KID_ENTROPY_U8, entropy_grouped_launch<true>);
+
+template <bool U8>
+static int entropy_tiles_grouped_launch(const GroupRec *const *recs, int n, hipStream_t s)
+{
+    Grouped<EntWinArgs> g;
+    size_t lds;
+    int rc = fill_grouped(recs, n, &g, &lds);
+    if (rc) return rc;
+    hipLaunchKernelGGL(entropy_tiles_grouped_kernel<U8>, dim3(g.start[kMaxGroups]), dim3(kEntThreads), 0, s, g);
+    return launch_check("entropy_tiles_grouped_kernel");
+}
+static GroupedRegistrar reg_ent_win_f32(KID_ENTROPY_WIN_F32, entropy_tiles_grouped_launch<false>);
+static GroupedRegistrar reg_ent_win_u8(KID_ENTROPY_WIN_U8, entropy_tiles_grouped_launch<true>);
+
+extern "C" int cgic_entropy_maps_tiles(const void *src, int is_u8, int64_t N, int64_t H, int64_t W, int T, const int *origins,
+                                       int64_t th, int64_t tw, const float *bins, int nbins, float sigma, float *x_out,
+                                       float *e8, float *e16, float *flat8, cgic_stream_t stream)
+{
+    CGIC_REQUIRE(src && bins && origins && x_out, CGIC_ERR_INVALID, "entropy_maps_tiles: src, bins, origins and x_out must not be NULL");
+    CGIC_REQUIRE(nbins == kBins, CGIC_ERR_UNSUPPORTED, "entropy: nbins=%d; the reference uses 32 (model.py:480)", nbins);
+    CGIC_REQUIRE(N >= 0 && H > 0 && W > 0 && H < (1 << 30) && W < (1 << 30), CGIC_ERR_INVALID, "entropy_maps_tiles: bad source shape");
+    CGIC_REQUIRE(T >= 1 && T <= kEntMaxTiles, CGIC_ERR_UNSUPPORTED, "entropy_maps_tiles: %d tiles per image in this group (1..%d): cut them with cgic_cut_tiles",
+                 T, kEntMaxTiles);
+    CGIC_REQUIRE(th > 0 && tw > 0 && th % 16 == 0 && tw % 16 == 0, CGIC_ERR_INVALID,
+                 "entropy_maps_tiles: tile %lldx%lld must be positive multiples of 16", (long long)th, (long long)tw);
+    CGIC_REQUIRE(N * T <= 65535 && th / 16 <= 65535, CGIC_ERR_UNSUPPORTED, "entropy: batch/height exceed the grid limits");
+    CGIC_REQUIRE(sigma > 0.f && sigma <= 0.0105f, CGIC_ERR_UNSUPPORTED,
+                 "entropy: sigma=%g; the 2-bin window assumes the reference's sigma=0.01 (model.py:481)", sigma);
+    for (int i = 1; i < kBins; ++i)
+        CGIC_REQUIRE(fabsf((bins[i] - bins[i - 1]) - 2.0f / 31.0f) < 1e-5f, CGIC_ERR_UNSUPPORTED, "entropy: bins are not linspace(-1, 1, 32)");
+    CGIC_REQUIRE((reinterpret_cast<uintptr_t>(x_out) & 15) == 0 && (!is_u8 || (reinterpret_cast<uintptr_t>(src) & 3) == 0), CGIC_ERR_INVALID,
+                 "entropy_maps_tiles: x_out must be 16-byte aligned (uint8 frames 4-byte aligned)");
+    if (N == 0) return CGIC_OK;
+    EntWinArgs a;
+    memcpy(a.e.bins.v, bins, sizeof(a.e.bins.v));
+    a.e.x = nullptr; a.e.H = th; a.e.W = tw; a.e.ppw = 4; a.e.e8 = e8; a.e.e16 = e16; a.e.x_out = x_out; a.e.flat8 = flat8;
+    a.e.exp2_scale = (float)(-0.5 * 1.4426950408889634 / ((double)sigma * (double)sigma));
+    a.w.src = src; a.w.srcH = (int)H; a.w.srcW = (int)W; a.w.T = T;
+    for (int k = 0; k < kEntMaxTiles; ++k) {
+        const int kk = k < T ? k : T - 1;
+        a.w.org[k][0] = origins[2 * kk]; a.w.org[k][1] = origins[2 * kk + 1];
+        CGIC_REQUIRE(abs(a.w.org[k][0]) < (1 << 29) && abs(a.w.org[k][1]) < (1 << 29), CGIC_ERR_INVALID, "entropy_maps_tiles: tile origin out of range");
+    }
+    const int64_t per_wg = (int64_t)kEntWaves * a.e.ppw;
+    const dim3 grid((unsigned)((tw / 16 + per_wg - 1) / per_wg), (unsigned)(th / 16), (unsigned)(N * T));
+    hipStream_t s = (hipStream_t)stream;
+    if (is_u8)
+        return launch_or_record(KID_ENTROPY_WIN_U8, grid, dim3(kEntThreads), 0, a, [=] {
+            hipLaunchKernelGGL(entropy_tiles_kernel<true>, grid, dim3(kEntThreads), 0, s, a);
+            return launch_check("entropy_tiles_kernel"); });
+    return launch_or_record(KID_ENTROPY_WIN_F32, grid, dim3(kEntThreads), 0, a, [=] {
+        hipLaunchKernelGGL(entropy_tiles_kernel<false>, grid, dim3(kEntThreads), 0, s, a);
+        return launch_check("entropy_tiles_kernel"); });
+}
 
 extern "C" int cgic_entropy_maps_f32(const float *x, int64_t B, int64_t H, int64_t W, const float *bins,
                                      int nbins, float sigma, float *e8, float *e16, float *flat8, cgic_stream_t stream)

@@ -30,6 +30,10 @@ def entropy_maps(x, want8=True, want16=True, sigma=0.01, reference_order=False, 
     _lib.require_device(x)
     if x.dim() != 4 or x.shape[1] != 3:
         raise ValueError(f"expected [B,3,H,W], got {tuple(x.shape)}")
+    made = getattr(x, "_cgic_maps", None)
+    if made is not None and not reference_order and float(sigma) == 0.01:
+        # a tile batch that entropy_maps_tiles wrote: its maps were made in the same pass
+        return (made[0] if want8 else None), (made[1] if want16 else None)
     x = x.contiguous().float()
     B, _, H, W = x.shape
     e8 = torch.empty((B, H // 8, W // 8), dtype=torch.float32, device=x.device) if want8 else None
@@ -44,6 +48,34 @@ def entropy_maps(x, want8=True, want16=True, sigma=0.01, reference_order=False, 
                       _lib.current_stream(x.device))
             _tag((e8, e16), x, flat8)
     return e8, e16
+
+
+def entropy_maps_tiles(src, origins, th, tw, sigma=0.01):
+    """pad + crop of the tiling driver (inference_high_resolution.py:145-173, :236-244) and both entropy maps in ONE pass
+    (cgic_entropy_maps_tiles).  src: fp32 [N,3,H,W] unpadded images (or uint8 frames [N,H,W,3]); origins: [(y0, x0)] of the T tiles of ONE
+    shape th x tw in unpadded coordinates -> (tiles [N*T,3,th,tw] fp32 image-major, e8, e16).  The tile batch comes back tagged with its
+    maps: entropy_maps(tiles) returns them without another pass, and the router finds pixels + flat8 on the maps as usual."""
+    import ctypes
+    _lib.require_device(src)
+    u8 = src.dtype == torch.uint8
+    if src.dim() != 4 or (src.shape[3] if u8 else src.shape[1]) != 3 or (not u8 and src.dtype != torch.float32):
+        raise ValueError(f"expected fp32 [N,3,H,W] or uint8 [N,H,W,3], got {src.dtype} {tuple(src.shape)}")
+    src = src.contiguous()
+    N = src.shape[0]
+    H, W = (src.shape[1], src.shape[2]) if u8 else (src.shape[2], src.shape[3])
+    T = len(origins)
+    dev = src.device
+    tiles = torch.empty((N * T, 3, th, tw), dtype=torch.float32, device=dev)
+    e8 = torch.empty((N * T, th // 8, tw // 8), dtype=torch.float32, device=dev)
+    e16 = torch.empty((N * T, th // 16, tw // 16), dtype=torch.float32, device=dev)
+    flat8 = torch.empty((N * T, th // 8, tw // 8), dtype=torch.float32, device=dev)
+    org = (ctypes.c_int * (2 * T))(*[int(v) for yx in origins for v in yx])
+    with _lib.on_device(dev):
+        _lib.call("cgic_entropy_maps_tiles", _lib.ptr(src), int(u8), N, H, W, T, org, th, tw, _bins(), 32, float(sigma), _lib.ptr(tiles),
+                  _lib.ptr(e8), _lib.ptr(e16), _lib.ptr(flat8), _lib.current_stream(dev))
+    _tag((e8, e16), tiles, flat8)
+    tiles._cgic_maps = (e8, e16, flat8)
+    return tiles, e8, e16
 
 
 def entropy_maps_u8(frames, want_x=True, want8=True, want16=True, sigma=0.01, want_flat=True):

@@ -168,7 +168,7 @@ def _cut_all(x, frames, N, H, W, top, left, tiles, order):
     return batches
 
 
-def _compress_groups(x, encode, codec, tile, concurrent, chain=False):
+def _compress_groups(x, encode, codec, tile, concurrent, chain=False, fuse_maps=True):
     """x [N,3,H,W] fp32 -- or uint8 frames [N,H,W,3], the tiles then reach `encode` as uint8 [T,th,tw,3] (entropy_maps_u8 makes the
     fp32 tiles and the maps in one pass) --: the shape groups of N images of one size, each group ONE batch of N * T tiles (image-major)
     -> (H, W), pad, tiles, [(tile indices, CompressedBatch, (ind, masks, mode))]"""
@@ -193,8 +193,20 @@ def _compress_groups(x, encode, codec, tile, concurrent, chain=False):
     # one launch per kernel whose grid is the concatenation of the groups' grids
     grp = _lib.launch_group(len(order), [N * len(idxs) * th * tw for (th, tw), idxs in order], x.device) if chain else None
     batches = []
-    cut = None
-    if not fork.enabled and len(tiles) <= 96:
+    cut, made = None, []
+    if chain and not frames and fuse_maps and max(len(idxs) for _, idxs in order) <= 48:
+        # pad + crop + BOTH entropy maps of all shape groups in ONE launch (cgic_entropy_maps_tiles, grouped): the tile batches come
+        # back tagged with their maps -- encode's entropy_maps(tiles) returns them without another pass over the pixels
+        from .entropy import entropy_maps_tiles
+        xc = x.contiguous()
+        cut, made = [], []
+        with _lib.launch_group(len(order), [N * len(idxs) * th * tw for (th, tw), idxs in order], x.device) as g:
+            for k, ((th, tw), idxs) in enumerate(order):
+                g.select(k)
+                t, _, _ = entropy_maps_tiles(xc, [(tiles[i][0] - top, tiles[i][1] - left) for i in idxs], th, tw)
+                made.append(t._cgic_maps)
+                cut.append(t.view(N, len(idxs), 3, th, tw))
+    elif not fork.enabled and len(tiles) <= 96:
         # pad + crop of ALL tiles as one launch (cgic_cut_tiles): every tile written straight from the unpadded image
         cut = _cut_all(x.contiguous(), frames, N, H, W, top, left, tiles, order)
     for lane, ((th, tw), idxs) in enumerate(order):
@@ -214,6 +226,10 @@ def _compress_groups(x, encode, codec, tile, concurrent, chain=False):
                     if strip.numel():
                         strip.zero_()
             batch = batch.view(-1, th, tw, 3) if frames else batch.view(-1, 3, th, tw)
+            if made:                                     # (tags do not survive a view: this is the object `encode` sees)
+                e8, e16, flat8 = made[lane]
+                batch._cgic_maps = made[lane]
+                e8._cgic_pixels = e16._cgic_pixels = batch
             if chain:
                 batches.append(batch)
                 continue
@@ -229,7 +245,7 @@ def _compress_groups(x, encode, codec, tile, concurrent, chain=False):
     return (H, W), pad, tiles, groups
 
 
-def compress_tiled(x, encode, codec, tile=TILE, concurrent=False, chain=False):
+def compress_tiled(x, encode, codec, tile=TILE, concurrent=False, chain=False, fuse_maps=True):
     """x [1,3,H,W] on the device; encode(tiles [T,3,th,tw]) -> (ind [T*h*w] int64, masks [3 x int32], mode)
     with per-tile routing (the reference's per-tile B=1 call); codec: GrainCodec.  -> TiledImage.
     concurrent: the shape groups run on parallel streams (same results; see _Fork).
@@ -237,14 +253,16 @@ def compress_tiled(x, encode, codec, tile=TILE, concurrent=False, chain=False):
     launches for all six tiles instead of three per group (cgic_group_begin / _launch; same bytes).  `encode` is then called
     inside a launch group: it may allocate and call control_gic_amd's entropy_maps / entropy_maps_u8 / vq_forward_route (whose
     launches are recorded and issued when all groups are in), but must not enqueue torch work that READS their outputs --
-    a conv encoder that consumes the router's gate cannot run under chain=True."""
+    a conv encoder that consumes the router's gate cannot run under chain=True.
+    fuse_maps (with chain, fp32 input): the tiles are cut AND their entropy maps made in one pass over the image
+    (cgic_entropy_maps_tiles); the tile batches `encode` receives carry their maps, entropy_maps(tiles) returns them as they are."""
     if x.dim() != 4 or x.shape[0] != 1:
         raise ValueError("compress_tiled takes one image [1,3,H,W] (or one uint8 frame [1,H,W,3]; the reference script uses batch 1); "
                          "compress_tiled_batch takes several of one size")
-    return TiledImage(*_compress_groups(x, encode, codec, tile, concurrent, chain))
+    return TiledImage(*_compress_groups(x, encode, codec, tile, concurrent, chain, fuse_maps))
 
 
-def compress_tiled_batch(x, encode, codec, tile=TILE, concurrent=False, chain=False):
+def compress_tiled_batch(x, encode, codec, tile=TILE, concurrent=False, chain=False, fuse_maps=True):
     """x [N,3,H,W] (or uint8 frames [N,H,W,3]: `encode` then gets uint8 tiles [T,th,tw,3] for entropy_maps_u8 -- a pad of zero
     bytes is the pad of zeros ToTensor would have produced): N images of ONE size (a folder of camera frames, a DIV2K bucket) -> list of N TiledImage, each what
     compress_tiled gives for that image alone (routing is per tile, so batching across images changes no byte).  The tiles
@@ -254,7 +272,7 @@ def compress_tiled_batch(x, encode, codec, tile=TILE, concurrent=False, chain=Fa
     if x.dim() != 4:
         raise ValueError("compress_tiled_batch takes [N,3,H,W] or uint8 [N,H,W,3]")
     N = x.shape[0]
-    hw, pad, tiles, groups = _compress_groups(x, encode, codec, tile, concurrent, chain)
+    hw, pad, tiles, groups = _compress_groups(x, encode, codec, tile, concurrent, chain, fuse_maps)
     out = []
     for n in range(N):
         mine = []

@@ -441,6 +441,18 @@ typedef struct cgic_tile {
 } cgic_tile;
 int cgic_cut_tiles(const void *x, int is_u8, int64_t N, int64_t H, int64_t W, int ntiles, const cgic_tile *tiles,
                    cgic_stream_t stream);
+/* cgic_cut_tiles for the tiles of ONE shape + cgic_entropy_maps_f32 / _u8 on them, in one pass: a lane of the map kernel reads its pixels
+ * from the source window (zeros inside the pad) and the tile batch is written as a by-product -- 12 B read + 12 B written per pixel
+ * instead of 12 + 12 for the cut and 12 again for the maps.  Recorded like the other entropy calls inside a launch group.
+ *   src      device fp32 [N,3,H,W] (unpadded), or with is_u8 the uint8 frames [N,H,W,3]
+ *   origins  host [T][2] int: (y0, x0) of the T (<= 48) tiles of this shape in unpadded coordinates; the batch is image-major:
+ *            tile b of the outputs = (image b / T, tile b % T)
+ *   x_out    device fp32 [N*T, 3, th, tw]: the tiles (from frames: byte / 255 as T.ToTensor() rounds it) -- required: it is what the
+ *            conv encoder and the router's refinement (cgic_pixels.x, is_u8 = 0) read
+ *   e8, e16, flat8 as cgic_entropy_maps_f32 for a batch of N*T images of th x tw; bit-identical to the two separate calls. */
+int cgic_entropy_maps_tiles(const void *src, int is_u8, int64_t N, int64_t H, int64_t W, int T, const int *origins,
+                            int64_t th, int64_t tw, const float *bins, int nbins, float sigma, float *x_out,
+                            float *e8, float *e16, float *flat8, cgic_stream_t stream);
 int cgic_decoder_blend_medium_f32(const float *h, const float *h_medium, const int32_t *mask_c, const int32_t *mask_m,
                                   int64_t B, int C, int64_t hh, int64_t ww, float *out, cgic_stream_t stream);
 int cgic_decoder_blend_fine_f32(const float *h, const float *h_fine, const int32_t *mask_c, const int32_t *mask_m,

@@ -253,3 +253,56 @@ def test_chain_of_a_batch_of_images(H, W):
             _same_decoded(dref[n], dgot[n])
         _same_decoded(dref[1], dcat[0])
         _same_decoded(dref[0], dcat[1])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("H,W", [(1356, 2040), (1001, 1803), (40, 50), (1537, 770)])
+@pytest.mark.parametrize("frames", [False, True])
+def test_maps_of_tiles_in_one_pass_equal_cut_then_maps(H, W, frames):
+    """cgic_entropy_maps_tiles (pad + crop + both entropy maps + flat8 in one pass over the unpadded images; vector loads when the
+    window is shifted by a multiple of 4 pixels, element-wise otherwise, zeros inside the pad) == cgic_cut_tiles followed by
+    cgic_entropy_maps_f32 / _u8: tiles, maps and flat8 bit for bit; alone and inside a launch group"""
+    import control_gic_amd as cg
+    from control_gic_amd import highres, _lib
+    from control_gic_amd.entropy import entropy_maps_tiles
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(H * 5 + W)
+    N = 2
+    if frames:
+        x = torch.from_numpy(rng.integers(0, 256, (N, H, W, 3), dtype=np.uint8)).to(dev)
+        x[:, : H // 3, : W // 2] = 77                                        # constant patches: flat8 has numbers, not only NaN
+    else:
+        x = torch.from_numpy(rng.random((N, 3, H, W), dtype=np.float32)).to(dev)
+        x[:, :, : H // 3, : W // 2] = 0.25
+    (left, right, top, bottom), _ = highres.compute_padding(H, W)
+    tiles = highres.tile_grid(H + top + bottom, W + left + right)
+    by_shape = {}
+    for i, (_, _, th, tw) in enumerate(tiles):
+        by_shape.setdefault((th, tw), []).append(i)
+    order = sorted(by_shape.items(), key=lambda kv: -len(kv[1]) * kv[0][0] * kv[0][1])
+    cut = highres._cut_all(x, frames, N, H, W, top, left, tiles, order)
+    ref = []
+    for ((th, tw), idxs), batch in zip(order, cut):
+        if frames:
+            xt, e8, e16 = cg.entropy_maps_u8(batch.view(-1, th, tw, 3))
+        else:
+            xt = batch.view(-1, 3, th, tw)
+            e8, e16 = cg.entropy_maps(xt)
+        ref.append((xt, e8, e16, e8._cgic_flat8))
+
+    def fused():
+        return [entropy_maps_tiles(x, [(tiles[i][0] - top, tiles[i][1] - left) for i in idxs], th, tw) for (th, tw), idxs in order]
+
+    got_alone = fused()
+    with _lib.launch_group(len(order), None, dev) as g:
+        got_grouped = []
+        for k, ((th, tw), idxs) in enumerate(order):
+            g.select(k)
+            got_grouped.append(entropy_maps_tiles(x, [(tiles[i][0] - top, tiles[i][1] - left) for i in idxs], th, tw))
+    assert g.launches == 1 or len(order) == 1
+    torch.cuda.synchronize()
+    for got in (got_alone, got_grouped):
+        for (xt, e8, e16, f8), (t, g8, g16) in zip(ref, got):
+            assert torch.equal(xt, t) and torch.equal(e8, g8) and torch.equal(e16, g16)
+            assert torch.equal(torch.nan_to_num(f8, nan=-7.0), torch.nan_to_num(g8._cgic_flat8, nan=-7.0))
+            assert cg.entropy_maps(t)[0] is g8                               # the tile batch carries its maps
