@@ -657,6 +657,19 @@ def div2k_image(dev, cb, vq, codec, iters=8):
         same4 = all(int(o[2].abs().max()) == 0 and o[0].streams() == tiled.streams() for o in gl.results)
         res["four_in_flight"] = {"ms_per_image": round(dt4 * 1e3, 4), "MPixels/s": round(H * W / dt4 / 1e6, 1), "streams_equal_eager": bool(same4),
                                  "note": "four images on four independent HIP streams (pipeline.GraphLanes), one hipGraph per image, throughput decoder"}
+
+        def once_lane_chain():
+            t = highres.compress_tiled(x, encode, codec, chain=True)
+            p, st = highres.decompress_tiled(t, codec, check=False, chain=True)
+            return t, p, st
+        glc = GraphLanes(dev, [once_lane_chain] * 4)
+        glc.replay(2); glc.join(); torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        glc.replay(2 * iters); glc.join(); torch.cuda.synchronize()
+        dt4c = (time.perf_counter() - t0) / (2 * iters * 4)
+        same4c = all(int(o[2].abs().max()) == 0 and o[0].streams() == tiled.streams() for o in glc.results)
+        res["four_in_flight"].update({"chain_ms_per_image": round(dt4c * 1e3, 4), "chain_MPixels/s": round(H * W / dt4c / 1e6, 1),
+                                      "chain_streams_equal_eager": bool(same4c)})
     except Exception as e:
         res["four_in_flight"] = {"error": str(e)[:200]}
     # eight images of that size at once (highres.compress_tiled_batch: the equal-shape tiles of all the images are one batch per
