@@ -783,6 +783,7 @@ static GroupedRegistrar reg_compress(KID_COMPRESS, compress_grouped_launch);
 extern "C" int cgic_encode_stream(const cgic_table *t, const void *syms, int elem_bytes, int64_t n, uint8_t *out,
                                   int64_t cap, int32_t *nbytes, void *workspace, cgic_stream_t stream)
 {
+    CGIC_NOT_IN_GROUP("cgic_encode_stream");
     CGIC_REQUIRE(t && out && nbytes && (syms || n == 0), CGIC_ERR_INVALID, "encode_stream: NULL argument");
     CGIC_REQUIRE(elem_bytes == 8 || elem_bytes == 4, CGIC_ERR_INVALID, "encode_stream: elem_bytes must be 4 or 8");
     CGIC_REQUIRE(n >= 0 && n < ((int64_t)1 << 26), CGIC_ERR_UNSUPPORTED, "encode_stream: n out of range");

@@ -88,7 +88,7 @@ struct Grouped {
     A a[kMaxGroups];
 };
 enum KernelId { KID_NONE = 0, KID_ENTROPY_F32, KID_ENTROPY_U8, KID_ENTROPY_WIN_F32, KID_ENTROPY_WIN_U8, KID_VQF_ROUTER_AL, KID_VQF_ROUTER_UN, KID_COMPRESS, KID_DECODE_SPLIT,
-                KID_DECODE_IMAGE, KID_MERGE, KID_COUNT };
+                KID_DECODE_IMAGE, KID_MERGE, KID_DECODE_MERGE, KID_COUNT };
 
 // host side of a launch group
 struct GroupRec {                       // one recorded launch
@@ -103,6 +103,9 @@ double group_cu_share();                // the current group's share of the chip
 int group_record(int kid, dim3 grid, dim3 block, size_t lds, const void *args, size_t bytes, std::function<int()> launch);
 typedef int (*GroupedLauncher)(const GroupRec *const *recs, int n, hipStream_t s);
 struct GroupedRegistrar { GroupedRegistrar(int kid, GroupedLauncher fn); };
+
+// entry points without a recorded form refuse to run inside a group (their launch would overtake the recorded ones)
+#define CGIC_NOT_IN_GROUP(name) CGIC_REQUIRE(!::cgic::group_recording(), CGIC_ERR_INVALID, name ": not available between cgic_group_begin and cgic_group_launch (it has no recorded form: call it before or after the group)")
 
 // launch now, or record for cgic_group_launch
 template <class A, class F>

@@ -808,8 +808,27 @@ struct MergeArgs {
 // band per image (throughput mode, grids up to 64x64): every band repeats the staging, the bitsets and the prefixes, so four bands
 // of 512 threads execute 1.10 M VALU instructions per batch of 64 images where one band of 1024 executes less than half --
 // instructions that, with several batches in flight, come out of the same VALU budget as the VQ's.
-template <int NT>
-__device__ __forceinline__ void merge_body(const MergeArgs &a, const Blk blk)
+// the wait of a merge workgroup that rides in the decoder's launch (decode_merge_kernel): `done` counts the image's decoder
+// workgroups (each adds 1 after its last store + an agent-scope release); every band that has seen them all adds 1 itself and
+// the last one to do so puts the word back to zero (nobody can still be polling then): the ticket is self-resetting.
+// Called by all threads of the workgroup (contains a barrier); what follows may read what the decoder wrote.
+__device__ __forceinline__ void wait_decoded(unsigned int *done, unsigned int need, unsigned int total)
+{
+    if (threadIdx.x == 0) {
+        while (__hip_atomic_load(done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) __builtin_amdgcn_s_sleep(8);
+        const unsigned int old = __hip_atomic_fetch_add(done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (old + 1u == total) __hip_atomic_store(done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");     // ONE cache invalidate per workgroup: the loads below do not hit lines cached before the decoder's release
+    }
+    __syncthreads();
+}
+
+// WAIT: the workgroup shares its launch with the image's decoder workgroups: everything that does not depend on the decoded
+// symbols (mask streams -> bitsets, popcount prefixes, the fine symbols consumed above the band, the codebook) runs while
+// the decoder works; the symbol counts and the symbols themselves are fetched after wait_decoded()
+template <int NT, bool WAIT = false>
+__device__ __forceinline__ void merge_body(const MergeArgs &a, const Blk blk, unsigned int *done = nullptr, unsigned int need = 0,
+                                           unsigned int total = 0)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t sm[];
     __shared__ uint32_t scan_smem[NT / kWave + 1];
@@ -847,11 +866,11 @@ __device__ __forceinline__ void merge_body(const MergeArgs &a, const Blk blk)
     // aligned and at least wc*4+8 / wm*4+8 bytes long), all decoded symbols, the codebook
     if (tid == 0) s_status = 0;
     if (tid < 2) s_hdr[tid] = a.nbytes[b * CGIC_NUM_STREAMS + 3 + tid];
-    else if (tid < 5) s_hdr[tid] = a.dcount[b * 3 + (tid - 2)];
+    else if (!WAIT && tid < 5) s_hdr[tid] = a.dcount[b * 3 + (tid - 2)];
     if (send_mc) for (int64_t i = tid; i < wc + 2; i += NT) rawc[i] = reinterpret_cast<const uint32_t *>(in_mc)[i];
     if (send_mm) for (int64_t i = tid; i < wm + 2; i += NT) rawm[i] = reinterpret_cast<const uint32_t *>(in_mm)[i];
     const uint16_t *gsym = a.dsym + b * nsym;
-    if (a.stage_sym) {
+    if (!WAIT && a.stage_sym) {
         // nsym = 21 * n_c is even; the per-image base is 4-byte aligned when nsym is even
         const uint32_t *g32 = reinterpret_cast<const uint32_t *>(gsym);
         uint32_t *l32 = reinterpret_cast<uint32_t *>(lsym);
@@ -869,6 +888,7 @@ __device__ __forceinline__ void merge_body(const MergeArgs &a, const Blk blk)
     }
     __syncthreads();
     if (s_status) {
+        if (WAIT) wait_decoded(done, need, total);        // (the decoder's first workgroup initialises status[b])
         if (tid == 0 && a.status) atomicMin(&a.status[b], s_status);
         return;
     }
@@ -1007,6 +1027,16 @@ __device__ __forceinline__ void merge_body(const MergeArgs &a, const Blk blk)
         (void)block_exclusive_scan(mine, scan_smem, &fbase);
     }
     CGIC_STAMP(13);
+    if (WAIT) {
+        wait_decoded(done, need, total);
+        if (tid >= 2 && tid < 5) s_hdr[tid] = a.dcount[b * 3 + (tid - 2)];
+        if (a.stage_sym) {
+            const uint32_t *g32 = reinterpret_cast<const uint32_t *>(gsym);
+            uint32_t *l32 = reinterpret_cast<uint32_t *>(lsym);
+            for (int64_t i = tid; i < (nsym + 1) / 2; i += NT) l32[i] = g32[i];
+        }
+        __syncthreads();
+    }
 
     const uint16_t *ds_c = a.stage_sym ? lsym : gsym, *ds_m = ds_c + n_c, *ds_f = ds_m + n_m;
     const int64_t dc_c = s_hdr[2], dc_m = s_hdr[3], dc_f = s_hdr[4];
@@ -1147,6 +1177,44 @@ __global__ __launch_bounds__(kMergeThreads) CGIC_VGPR_CAP_MERGE void merge_group
     merge_body<kMergeThreads>(g.a[group_locate(g, &blk)], blk);
 }
 
+// Decoder AND merge of a small launch as ONE launch (latency path: B = 1 .. a few dozen images, every workgroup on a CU of its
+// own): blocks [0, ndec * B) are the split-stream decoder's (image-major, `ndec` per image), the others the merge bands, which
+// do their symbol-independent half while the decoder runs and pick the symbols up through a per-image ticket.  Decoder
+// workgroups come first in dispatch order and never wait for a merge workgroup: no deadlock whatever is resident.
+struct DecodeMergeArgs {
+    DecodeArgs c;
+    MergeArgs m;
+    unsigned int *done;        // [B] ticket words, kTicketStride apart
+    unsigned int ndec, nbands, active_bands, B;
+};
+__device__ __forceinline__ void decode_merge_body(const DecodeMergeArgs &p, const unsigned int id)
+{
+    const unsigned int ndec_all = p.ndec * p.B;
+    if (id < ndec_all) {
+        const unsigned int b = id / p.ndec;
+        decode_split_body(p.c, Blk{id - b * p.ndec, b, 0u, p.ndec, p.B});
+        __syncthreads();                       // every wave's stores are out (workgroup-scope release)
+        if (threadIdx.x == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            __hip_atomic_fetch_add(p.done + (size_t)b * kTicketStride, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        return;
+    }
+    const unsigned int r = id - ndec_all, b = r / p.nbands;
+    merge_body<kDecThreads, true>(p.m, Blk{r - b * p.nbands, b, 0u, p.nbands, p.B}, p.done + (size_t)b * kTicketStride, p.ndec,
+                                  p.ndec + p.active_bands);
+}
+__global__ __launch_bounds__(kDecThreads) CGIC_VGPR_CAP_DECODE void decode_merge_kernel(DecodeMergeArgs p)
+{
+    decode_merge_body(p, blockIdx.x);
+}
+__global__ __launch_bounds__(kDecThreads) CGIC_VGPR_CAP_DECODE void decode_merge_grouped_kernel(Grouped<DecodeMergeArgs> g)
+{
+    Blk blk;
+    const DecodeMergeArgs &p = g.a[group_locate(g, &blk)];
+    decode_merge_body(p, blk.x);
+}
+
 __global__ void gather_kernel(const int64_t *__restrict__ ind, int64_t B, int64_t hw,
                               const float *__restrict__ cb, int K, float *__restrict__ out,
                               int32_t *__restrict__ status)
@@ -1169,6 +1237,7 @@ using namespace cgic;
 extern "C" int cgic_decode_stream(const cgic_table *t, const uint8_t *in, int64_t nbytes, int64_t *syms,
                                   int64_t cap, int64_t *count, cgic_stream_t stream)
 {
+    CGIC_NOT_IN_GROUP("cgic_decode_stream");
     CGIC_REQUIRE(t && count && (in || nbytes == 0) && (syms || cap == 0), CGIC_ERR_INVALID, "decode_stream: NULL argument");
     CGIC_REQUIRE(nbytes >= 0 && cap >= 0 && nbytes < ((int64_t)1 << 28), CGIC_ERR_INVALID, "decode_stream: size out of range");
     DecodeOneArgs a;
@@ -1184,6 +1253,31 @@ extern "C" int cgic_decode_stream(const cgic_table *t, const uint8_t *in, int64_
 
 static const size_t kLdsBudget = 150 * 1024;
 
+#ifndef CGIC_DEC_WGS_SMALL
+#define CGIC_DEC_WGS_SMALL 4
+#endif
+#ifndef CGIC_DEC_WGS_LARGE
+#define CGIC_DEC_WGS_LARGE 24
+#endif
+#ifdef CGIC_DEV_KNOBS
+static int dev_knob_dec(const char *name) { const char *v = getenv(name); return v ? atoi(v) : 0; }
+#else
+static int dev_knob_dec(const char *) { return 0; }      // the environment knobs exist in `make dbg` builds only
+#endif
+static int device_cu_count_dec(int *out)
+{
+    static std::atomic<int> cached{0};
+    int n = cached.load();
+    if (n == 0) {
+        int dev = 0;
+        CGIC_HIP_TRY(hipGetDevice(&dev));
+        CGIC_HIP_TRY(hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev));
+        if (n <= 0) n = 256;
+        cached.store(n);
+    }
+    *out = n;
+    return CGIC_OK;
+}
 static std::atomic<int> g_decode_mode{CGIC_DECODE_AUTO};
 static std::atomic<unsigned int *> g_decode_stats{nullptr};
 extern "C" int cgic_decode_stats(unsigned int *device_counters)
@@ -1256,6 +1350,72 @@ extern "C" int cgic_decompress_streams(const cgic_table *t, const uint8_t *in, i
     d.stats = g_decode_stats.load(std::memory_order_relaxed);
     // The self-synchronising one-workgroup-per-image decoder when the worst case of the grid fits its LDS: bits <= symbols
     // the three grids can hold x the longest code.  (Longer inputs are an overflow on any path.)
+    MergeArgs m;
+    m.in = in; m.slot = slot; m.nbytes = nbytes; m.h = h; m.w = w; m.mode = mode;
+    m.dsym = d.dsym; m.dcount = d.dcount; m.ind_out = ind_out;
+    m.mc_out = mask_c_out; m.mm_out = mask_m_out; m.mf_out = mask_f_out;
+    m.codebook = codebook; m.K = K; m.zq = z_q; m.codebook2 = codebook2; m.zq2 = z_q2; m.status = status;
+    const size_t wc = (size_t)(((h / 4) * (w / 4) + 31) / 32), wm = (size_t)(((h / 2) * (w / 2) + 31) / 32);
+    size_t lds_m = (3 * (wc + wm) + 4) * sizeof(uint32_t);
+    CGIC_REQUIRE(lds_m <= kLdsBudget, CGIC_ERR_UNSUPPORTED, "decompress_streams: grid too large for the mask bitsets");
+    m.stage_cb = (z_q && lds_m + (size_t)K * 16 <= 64 * 1024) ? 1 : 0;
+    if (m.stage_cb) lds_m += (size_t)K * 16;
+    m.stage_sym = (per % 2 == 0 && lds_m + per * 2 + 4 <= 64 * 1024) ? 1 : 0;
+    if (m.stage_sym) lds_m += ((per + 1) / 2) * 4;
+    // mask-stream slots must cover the word-wise staging reads
+    CGIC_REQUIRE((size_t)slot >= (wm + 2) * 4, CGIC_ERR_CAPACITY, "decompress_streams: slot smaller than a mask stream");
+    // 4 bands per image fill the GPU at B = 64; a few large tiles get more (every band re-derives the mask prefixes,
+    // so not more than needed): ~256 workgroups in all, at least 2 coarse rows per band
+    // Decoder and merge go out as ONE launch when every workgroup of both gets a CU of its own (B = 1 .. a few dozen images, or
+    // a few tiles; inside a launch group: within the group's share of the chip)
+    const unsigned int ndec = large ? CGIC_DEC_WGS_LARGE : CGIC_DEC_WGS_SMALL;
+    int cus = 0;
+    rc = device_cu_count_dec(&cus);
+    if (rc) return rc;
+    const int64_t cu_budget = (int64_t)((double)cus * group_cu_share() + 0.5);
+    const bool fuse_base = dec_mode != CGIC_DECODE_THROUGHPUT && d.tab.max_len <= 64 && B * 3 <= (int64_t)(16384 / 4) && !dev_knob_dec("CGIC_NO_DECODE_MERGE");
+    int64_t nbands = kMergeBands;
+    {
+        const int64_t h4 = h >> 2;
+#ifndef CGIC_MERGE_MINROWS
+#define CGIC_MERGE_MINROWS 1
+#endif
+#ifndef CGIC_MERGE_WGS
+#define CGIC_MERGE_WGS 256
+#endif
+        while (nbands * B < CGIC_MERGE_WGS && nbands * 2 <= h4 / CGIC_MERGE_MINROWS) {
+            // (keep a small launch fusable with its decoder: see below)
+            if (fuse_base && B * (int64_t)(ndec + 2 * nbands) > cu_budget && B * (int64_t)(ndec + nbands) <= cu_budget) break;
+            nbands *= 2;
+        }
+    }
+    // the image's symbols do not fit LDS: every band stages its own three rank ranges (at most 21/16 symbols per position)
+    m.band_syms = 0;
+    if (!m.stage_sym) {
+        const int64_t rows_per = (((h >> 2) + nbands - 1) / nbands) * 4;
+        const int64_t need = rows_per * w * 21 / 16 + 8;
+        if (lds_m + (size_t)need * 2 <= 64 * 1024) { m.band_syms = need; lds_m += (size_t)need * 2; }
+    }
+    // ---- decoder and merge as ONE launch ----
+    {
+        const int64_t rows_per = (((h >> 2) + nbands - 1) / nbands) * 4;
+        const unsigned int active = (unsigned int)((h + rows_per - 1) / rows_per);
+        const size_t lds_f = lds_d > lds_m ? lds_d : lds_m;
+        if (fuse_base && B * (int64_t)(ndec + nbands) <= cu_budget) {
+            DecodeMergeArgs p;
+            p.c = d; p.m = m; p.ndec = ndec; p.nbands = (unsigned int)nbands; p.active_bands = active; p.B = (unsigned int)B;
+            rc = acquire_tickets(s, (int)(B * 3), &p.c.tick);
+            if (rc) return rc;
+            rc = acquire_tickets(s, (int)B, &p.done);
+            if (rc) return rc;
+            rc = ensure_dynamic_lds((const void *)decode_merge_kernel, lds_f);
+            if (rc) return rc;
+            const dim3 grid_f((unsigned int)(B * (ndec + nbands)));
+            return launch_or_record(KID_DECODE_MERGE, grid_f, dim3(kDecThreads), lds_f, p, [=] {
+                hipLaunchKernelGGL(decode_merge_kernel, grid_f, dim3(kDecThreads), lds_f, s, p);
+                return launch_check("decode_merge_kernel"); });
+        }
+    }
     bool ss = false;
 #ifndef CGIC_DEC_NO_SS
     if (d.tab.max_len <= 64 && dec_mode == CGIC_DECODE_THROUGHPUT) {
@@ -1279,12 +1439,6 @@ extern "C" int cgic_decompress_streams(const cgic_table *t, const uint8_t *in, i
     } else if (d.tab.max_len <= 64) {
         if (lds_d > 48 * 1024)
             { int rc_ = ensure_dynamic_lds((const void *)decode_split_kernel, (size_t)lds_d); if (rc_) return rc_; }
-#ifndef CGIC_DEC_WGS_SMALL
-#define CGIC_DEC_WGS_SMALL 4
-#endif
-#ifndef CGIC_DEC_WGS_LARGE
-#define CGIC_DEC_WGS_LARGE 24
-#endif
         // one ticket request covers 3 slots per image: larger batches are cut into several launches of the same kernel
         const int64_t per_launch = (int64_t)(16384 / 4) / 3;
         for (int64_t b0 = 0; b0 < B && rc == CGIC_OK; b0 += per_launch) {
@@ -1309,40 +1463,6 @@ extern "C" int cgic_decompress_streams(const cgic_table *t, const uint8_t *in, i
             return launch_check("decode_streams_kernel"); });
     }
     if (rc) return rc;
-    MergeArgs m;
-    m.in = in; m.slot = slot; m.nbytes = nbytes; m.h = h; m.w = w; m.mode = mode;
-    m.dsym = d.dsym; m.dcount = d.dcount; m.ind_out = ind_out;
-    m.mc_out = mask_c_out; m.mm_out = mask_m_out; m.mf_out = mask_f_out;
-    m.codebook = codebook; m.K = K; m.zq = z_q; m.codebook2 = codebook2; m.zq2 = z_q2; m.status = status;
-    const size_t wc = (size_t)(((h / 4) * (w / 4) + 31) / 32), wm = (size_t)(((h / 2) * (w / 2) + 31) / 32);
-    size_t lds_m = (3 * (wc + wm) + 4) * sizeof(uint32_t);
-    CGIC_REQUIRE(lds_m <= kLdsBudget, CGIC_ERR_UNSUPPORTED, "decompress_streams: grid too large for the mask bitsets");
-    m.stage_cb = (z_q && lds_m + (size_t)K * 16 <= 64 * 1024) ? 1 : 0;
-    if (m.stage_cb) lds_m += (size_t)K * 16;
-    m.stage_sym = (per % 2 == 0 && lds_m + per * 2 + 4 <= 64 * 1024) ? 1 : 0;
-    if (m.stage_sym) lds_m += ((per + 1) / 2) * 4;
-    // mask-stream slots must cover the word-wise staging reads
-    CGIC_REQUIRE((size_t)slot >= (wm + 2) * 4, CGIC_ERR_CAPACITY, "decompress_streams: slot smaller than a mask stream");
-    // 4 bands per image fill the GPU at B = 64; a few large tiles get more (every band re-derives the mask prefixes,
-    // so not more than needed): ~256 workgroups in all, at least 2 coarse rows per band
-    int64_t nbands = kMergeBands;
-    {
-        const int64_t h4 = h >> 2;
-#ifndef CGIC_MERGE_MINROWS
-#define CGIC_MERGE_MINROWS 1
-#endif
-#ifndef CGIC_MERGE_WGS
-#define CGIC_MERGE_WGS 256
-#endif
-        while (nbands * B < CGIC_MERGE_WGS && nbands * 2 <= h4 / CGIC_MERGE_MINROWS) nbands *= 2;
-    }
-    // the image's symbols do not fit LDS: every band stages its own three rank ranges (at most 21/16 symbols per position)
-    m.band_syms = 0;
-    if (!m.stage_sym) {
-        const int64_t rows_per = (((h >> 2) + nbands - 1) / nbands) * 4;
-        const int64_t need = rows_per * w * 21 / 16 + 8;
-        if (lds_m + (size_t)need * 2 <= 64 * 1024) { m.band_syms = need; lds_m += (size_t)need * 2; }
-    }
     if (dec_mode == CGIC_DECODE_THROUGHPUT && !large && m.stage_sym) {
         // several batches in flight: one band of 1024 threads per image (see merge_kernel)
         if (lds_m > 48 * 1024)
@@ -1379,12 +1499,25 @@ static int merge_grouped_launch(const GroupRec *const *recs, int n, hipStream_t 
     hipLaunchKernelGGL(merge_grouped_kernel, dim3(g.start[kMaxGroups]), dim3(kMergeThreads), lds, s, g);
     return launch_check("merge_grouped_kernel");
 }
+static int decode_merge_grouped_launch(const GroupRec *const *recs, int n, hipStream_t s)
+{
+    Grouped<DecodeMergeArgs> g;
+    size_t lds;
+    int rc = fill_grouped(recs, n, &g, &lds);
+    if (rc) return rc;
+    rc = ensure_dynamic_lds((const void *)decode_merge_grouped_kernel, lds);
+    if (rc) return rc;
+    hipLaunchKernelGGL(decode_merge_grouped_kernel, dim3(g.start[kMaxGroups]), dim3(kDecThreads), lds, s, g);
+    return launch_check("decode_merge_grouped_kernel");
+}
+static GroupedRegistrar reg_decode_merge(KID_DECODE_MERGE, decode_merge_grouped_launch);
 static GroupedRegistrar reg_decode_split(KID_DECODE_SPLIT, decode_split_grouped_launch);
 static GroupedRegistrar reg_merge(KID_MERGE, merge_grouped_launch);
 
 extern "C" int cgic_embedding_gather_f32(const int64_t *ind, int64_t B, int64_t hw, const float *codebook, int K,
                                          int e_dim, float *out, int32_t *status, cgic_stream_t stream)
 {
+    CGIC_NOT_IN_GROUP("cgic_embedding_gather_f32");
     CGIC_REQUIRE(ind && codebook && out, CGIC_ERR_INVALID, "embedding_gather: NULL argument");
     CGIC_REQUIRE(e_dim == 4 && K > 0, CGIC_ERR_UNSUPPORTED, "embedding_gather: needs a [K,4] codebook");
     const int64_t n = B * hw;

@@ -625,6 +625,7 @@ extern "C" int cgic_entropy_maps_u8(const unsigned char *x_hwc, int64_t B, int64
 extern "C" int cgic_entropy_maps_ref_f32(const float *x, int64_t B, int64_t H, int64_t W, const float *bins,
                                          int nbins, float sigma, float *e8, float *e16, cgic_stream_t stream)
 {
+    CGIC_NOT_IN_GROUP("cgic_entropy_maps_ref_f32");
     CGIC_REQUIRE(x && bins, CGIC_ERR_INVALID, "entropy: x and bins must not be NULL");
     CGIC_REQUIRE(nbins == kBins, CGIC_ERR_UNSUPPORTED, "entropy: nbins=%d; the reference uses 32 (model.py:480)", nbins);
     CGIC_REQUIRE(B >= 0 && H > 0 && W > 0 && H % 16 == 0 && W % 16 == 0, CGIC_ERR_INVALID,

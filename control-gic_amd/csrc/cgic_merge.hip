@@ -224,6 +224,7 @@ extern "C" int cgic_grain_merge_f32(const float *h_coarse, const float *h_medium
                                     const int32_t *mask_c, const int32_t *mask_m, const int32_t *mask_f, int64_t B,
                                     int C, int64_t h, int64_t w, float *out, cgic_stream_t stream)
 {
+    CGIC_NOT_IN_GROUP("cgic_grain_merge_f32");
     CGIC_REQUIRE(h_coarse && h_medium && h_fine && mask_c && mask_m && mask_f && out, CGIC_ERR_INVALID, "grain_merge: NULL tensor");
     CGIC_REQUIRE(B >= 0 && C > 0 && h > 0 && w > 0 && h % 4 == 0 && w % 4 == 0, CGIC_ERR_INVALID,
                  "grain_merge: fine grid %lldx%lld must be positive multiples of 4", (long long)h, (long long)w);
@@ -245,6 +246,7 @@ static int stream_grid(int64_t total)
 
 extern "C" int cgic_avgpool_f32(const float *x, int64_t planes, int64_t H, int64_t W, int k, float *out, cgic_stream_t stream)
 {
+    CGIC_NOT_IN_GROUP("cgic_avgpool_f32");
     CGIC_REQUIRE(x && out, CGIC_ERR_INVALID, "avgpool: NULL tensor");
     CGIC_REQUIRE(k == 2 || k == 4, CGIC_ERR_UNSUPPORTED, "avgpool: window %d; the decoder uses 4 and 2 (decoder.py:304-305)", k);
     CGIC_REQUIRE(planes >= 0 && H > 0 && W > 0 && H % k == 0 && W % k == 0, CGIC_ERR_INVALID,
@@ -258,6 +260,7 @@ extern "C" int cgic_avgpool_f32(const float *x, int64_t planes, int64_t H, int64
 extern "C" int cgic_decoder_blend_medium_f32(const float *h, const float *h_medium, const int32_t *mask_c, const int32_t *mask_m,
                                              int64_t B, int C, int64_t hh, int64_t ww, float *out, cgic_stream_t stream)
 {
+    CGIC_NOT_IN_GROUP("cgic_decoder_blend_medium_f32");
     CGIC_REQUIRE(h && h_medium && mask_c && mask_m && out, CGIC_ERR_INVALID, "decoder_blend_medium: NULL tensor");
     CGIC_REQUIRE(B >= 0 && C > 0 && hh > 0 && ww > 0 && hh % 2 == 0 && ww % 2 == 0, CGIC_ERR_INVALID,
                  "decoder_blend_medium: medium grid %lldx%lld (need even height and width)", (long long)hh, (long long)ww);
@@ -279,6 +282,7 @@ extern "C" int cgic_decoder_blend_fine_f32(const float *h, const float *h_fine, 
                                            const int32_t *mask_f, int64_t B, int C, int64_t hh, int64_t ww, float *out,
                                            cgic_stream_t stream)
 {
+    CGIC_NOT_IN_GROUP("cgic_decoder_blend_fine_f32");
     CGIC_REQUIRE(h && h_fine && mask_c && mask_m && mask_f && out, CGIC_ERR_INVALID, "decoder_blend_fine: NULL tensor");
     CGIC_REQUIRE(B >= 0 && C > 0 && hh > 0 && ww > 0 && hh % 4 == 0 && ww % 4 == 0, CGIC_ERR_INVALID,
                  "decoder_blend_fine: fine grid %lldx%lld must be positive multiples of 4", (long long)hh, (long long)ww);
@@ -292,6 +296,7 @@ extern "C" int cgic_decoder_blend_fine_f32(const float *h, const float *h_fine, 
 extern "C" int cgic_cut_tiles(const void *x, int is_u8, int64_t N, int64_t H, int64_t W, int ntiles, const cgic_tile *tiles,
                               cgic_stream_t stream)
 {
+    CGIC_NOT_IN_GROUP("cgic_cut_tiles");
     CGIC_REQUIRE(x && tiles, CGIC_ERR_INVALID, "cut_tiles: NULL argument");
     CGIC_REQUIRE(N >= 0 && H > 0 && W > 0 && H < (1 << 30) && W < (1 << 30), CGIC_ERR_INVALID, "cut_tiles: bad image shape");
     CGIC_REQUIRE(ntiles >= 1 && ntiles <= kCutMaxTiles, CGIC_ERR_UNSUPPORTED, "cut_tiles: %d tiles (1..%d)", ntiles, kCutMaxTiles);

@@ -122,6 +122,7 @@ extern "C" int cgic_router_f32(const float *e16, const float *e8, int64_t B, int
                                int32_t *mask_m, int32_t *mask_f, float *gate, int *mode_out,
                                const cgic_pixels *refine, cgic_stream_t stream)
 {
+    CGIC_NOT_IN_GROUP("cgic_router_f32");
     if (mode_out) *mode_out = cgic_router_mode(c_ratio, m_ratio);
     CGIC_REQUIRE(B >= 0, CGIC_ERR_INVALID, "router: bad shape");
     if (B == 0) return CGIC_OK;

@@ -1303,8 +1303,12 @@ static int launch_mfma(const float *z, int64_t hw, int64_t N, const float *cb, i
     if (router_lds > lds) lds = router_lds;
     int rc = ensure_dynamic_lds((const void *)vq_router_kernel<ZT>, lds);
     if (rc) return rc;
-    hipLaunchKernelGGL(vq_router_kernel<ZT>, dim3(a.nblk + (unsigned int)router_blocks), dim3(kVqThreads), lds, s, a, *router);
-    return launch_check("vq_router_kernel");
+    // (no grouped form: inside a launch group this position is launched group by group)
+    const RouterArgs r = *router;
+    const dim3 grid(a.nblk + (unsigned int)router_blocks);
+    return launch_or_record(KID_NONE, grid, dim3(kVqThreads), lds, a, [=] {
+        hipLaunchKernelGGL(vq_router_kernel<ZT>, grid, dim3(kVqThreads), lds, s, a, r);
+        return launch_check("vq_router_kernel"); });
 }
 
 static int device_cu_count(int *out)
@@ -1456,6 +1460,7 @@ extern "C" size_t cgic_vq_workspace_bytes(int64_t n_vectors)
 extern "C" int cgic_vq_filter_probe_f32(const float *z, int64_t B, int64_t hw, const float *codebook, int K, int64_t *indices,
                                         float *scores, float *aux, cgic_stream_t stream)
 {
+    CGIC_NOT_IN_GROUP("cgic_vq_filter_probe_f32");
     int rc = vq_check(z, B, hw, codebook, K, 4, nullptr, nullptr, false);
     if (rc) return rc;
     CGIC_REQUIRE(K % 64 == 0 && K <= kVqfMaxK, CGIC_ERR_UNSUPPORTED, "vq_filter_probe: K=%d has no filter path", K);
@@ -1502,6 +1507,7 @@ extern "C" size_t cgic_vq_prepared_bytes(int K)
 
 extern "C" int cgic_vq_prepare_f32(const float *codebook, int K, int e_dim, void *prepared, cgic_stream_t stream)
 {
+    CGIC_NOT_IN_GROUP("cgic_vq_prepare_f32");
     CGIC_REQUIRE(codebook && prepared, CGIC_ERR_INVALID, "vq_prepare: NULL argument");
     CGIC_REQUIRE(e_dim == 4, CGIC_ERR_UNSUPPORTED, "vq_prepare: e_dim=%d; this build implements embed_dim == 4", e_dim);
     CGIC_REQUIRE(cgic_vq_prepared_bytes(K) != 0, CGIC_ERR_UNSUPPORTED, "vq_prepare: K=%d has no filter path (need K %% 64 == 0, K <= %d)", K, kVqfMaxK);
@@ -1518,6 +1524,7 @@ extern "C" int cgic_vq_forward_f32(const float *z, int64_t B, int64_t hw, const 
                                    float *loss, int64_t *hist, void *workspace, const cgic_conv1x1 *quant_conv,
                                    const void *prepared, cgic_stream_t stream)
 {
+    CGIC_NOT_IN_GROUP("cgic_vq_forward_f32");
     int rc = vq_check(z, B, hw, codebook, K, e_dim, loss, workspace, hist && !indices);
     if (rc) return rc;
     rc = conv_check(quant_conv);
@@ -1571,6 +1578,7 @@ extern "C" int cgic_vq_forward_valu_f32(const float *z, int64_t B, int64_t hw, c
                                         float *loss, int64_t *hist, void *workspace, const cgic_conv1x1 *quant_conv,
                                         cgic_stream_t stream)
 {
+    CGIC_NOT_IN_GROUP("cgic_vq_forward_valu_f32");
     int rc = vq_check(z, B, hw, codebook, K, e_dim, loss, workspace, hist && !indices);
     if (rc) return rc;
     rc = conv_check(quant_conv);
@@ -1611,6 +1619,7 @@ __global__ __launch_bounds__(256) void conv_rows_kernel(const float4 *__restrict
 
 extern "C" int cgic_conv1x1_rows_f32(const float *rows, int64_t n, const cgic_conv1x1 *conv, float *out, cgic_stream_t stream)
 {
+    CGIC_NOT_IN_GROUP("cgic_conv1x1_rows_f32");
     CGIC_REQUIRE(rows && out && conv && conv->weight && n >= 0, CGIC_ERR_INVALID, "conv1x1_rows: NULL argument");
     if (n == 0) return CGIC_OK;
     int64_t nblk = (n + 255) / 256;

@@ -132,6 +132,7 @@ extern "C" int cgic_vq_backward_f32(const float *z, int64_t B, int64_t hw, const
                                     const int64_t *indices, const float *g_zq, const float *g_loss, float beta, int legacy,
                                     float *g_z, float *g_codebook, void *workspace, cgic_stream_t stream)
 {
+    CGIC_NOT_IN_GROUP("cgic_vq_backward_f32");
     CGIC_REQUIRE(z && codebook && indices, CGIC_ERR_INVALID, "vq_backward: z, codebook and indices must not be NULL");
     CGIC_REQUIRE(e_dim == 4 && K > 0 && K <= 2048, CGIC_ERR_UNSUPPORTED, "vq_backward: needs a [K<=2048, 4] codebook (K=%d, e_dim=%d)", K, e_dim);
     CGIC_REQUIRE(B >= 0 && hw >= 0, CGIC_ERR_INVALID, "vq_backward: negative shape");

@@ -42,6 +42,10 @@ def test_group_api_misuse_is_refused():
         assert l.cgic_group_begin(2, None) == _lib.ERR_INVALID
         assert l.cgic_group_select(2) == _lib.ERR_INVALID
         assert l.cgic_group_select(1) == 0
+        # entry points without a recorded form refuse to run inside a group (their launch would overtake the recorded ones)
+        assert l.cgic_cut_tiles(None, 0, 1, 16, 16, 1, None, None) == _lib.ERR_INVALID
+        assert b"no recorded form" in l.cgic_last_error()
+        assert l.cgic_avgpool_f32(None, 1, 4, 4, 2, None, None) == _lib.ERR_INVALID and b"no recorded form" in l.cgic_last_error()
     finally:
         l.cgic_group_abort()
     assert l.cgic_group_select(0) == _lib.ERR_INVALID           # closed again
@@ -102,7 +106,7 @@ def test_chain_of_ragged_tiles_equals_the_groups_one_by_one(H, W, content):
 
 @pytest.mark.gpu
 def test_chain_launch_counts_and_uint8_frames():
-    """a 2040x1356 image (6 tiles, 4 shape groups): the encode chain is 3 launches, the decode chain 2; uint8 frames go through
+    """a 2040x1356 image (6 tiles, 4 shape groups): the encode chain is 3 launches (2 + the tile cut inside the map launch), the decode chain 1; uint8 frames go through
     the grouped ToTensor + entropy launch"""
     from control_gic_amd import highres, _lib
     from control_gic_amd.quantize import vq_forward_route
@@ -135,7 +139,7 @@ def test_chain_launch_counts_and_uint8_frames():
         for k, (_, comp, _) in enumerate(got.groups):
             g.select(k)
             codec.decompress(comp)
-    assert grp.launches == 2
+    assert grp.launches == 1                                # decoder + merge of every group in one launch (decode_merge_kernel)
     with cg.decoder_mode("throughput"):                     # the self-synchronising decoder has a grouped form too
         grp = _lib.launch_group(len(got.groups), None, dev)
         with grp as g:
@@ -306,3 +310,34 @@ def test_maps_of_tiles_in_one_pass_equal_cut_then_maps(H, W, frames):
             assert torch.equal(xt, t) and torch.equal(e8, g8) and torch.equal(e16, g16)
             assert torch.equal(torch.nan_to_num(f8, nan=-7.0), torch.nan_to_num(g8._cgic_flat8, nan=-7.0))
             assert cg.entropy_maps(t)[0] is g8                               # the tile batch carries its maps
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,H,W", [(1, 256, 256), (5, 256, 256), (13, 256, 256), (32, 256, 256), (33, 256, 256), (3, 768, 768), (2, 64, 48), (1, 16, 16)])
+def test_decoder_and_merge_in_one_launch_equal_the_throughput_path(B, H, W):
+    """small launches in latency mode go out as ONE launch (decode_merge_kernel: the merge bands do their symbol-independent half while
+    the split-stream decoder runs and pick the symbols up through a per-image ticket); the throughput decoder keeps two launches.
+    Same indices, masks, rows and statuses -- over repeated calls (the ticket resets itself) and all seven routing modes"""
+    from control_gic_amd.quantize import vq_forward_route
+    cg, dev, rng, vq, codec = _setup(B * 3 + H)
+    x = torch.from_numpy(rng.random((B, 3, H, W), dtype=np.float32)).to(dev)
+    z = torch.from_numpy(rng.standard_normal((B, 4, H // 4, W // 4), dtype=np.float32)).to(dev)
+    e8, e16 = cg.entropy_maps(x)
+    for cr, mr in ((0.1, 0.8), (0.0, 0.5), (0.5, 0.0), (0.3, 0.7), (1.0, 0.0), (0.0, 1.0), (0.0, 0.0)):
+        _, _, ind, mask, _, mode = vq_forward_route(z, vq.embedding.weight, 0.25, True, e16, e8, cr, mr, per_image=True)
+        comp = codec.compress(ind, mask, mode)
+        ref = codec.decompress(comp, decoder="throughput")
+        for _ in range(3):
+            got = codec.decompress(comp, decoder="latency")
+            assert torch.equal(ref[0], got[0]) and torch.equal(ref[2], got[2]) and torch.equal(ref[3], got[3])
+            assert all(torch.equal(p, q) for p, q in zip(ref[1], got[1]))
+        assert int(got[3].abs().max()) == 0
+    # a corrupt mask stream is reported by the merge half after the decoder has initialised the status word
+    bad = cg.CompressedBatch(comp.data.clone(), comp.nbytes.clone(), comp.mode, comp.h, comp.w)
+    _, _, ind, mask, _, mode = vq_forward_route(z, vq.embedding.weight, 0.25, True, e16, e8, 0.1, 0.8, per_image=True)
+    comp = codec.compress(ind, mask, mode)
+    bad = cg.CompressedBatch(comp.data.clone(), comp.nbytes.clone(), comp.mode, comp.h, comp.w)
+    bad.nbytes[0, 4] += 1
+    st_l = codec.decompress(bad, decoder="latency")[3]
+    st_t = codec.decompress(bad, decoder="throughput")[3]
+    assert int(st_l[0]) != 0 and torch.equal(st_l, st_t)

@@ -1,5 +1,5 @@
 """dev: the 2040x1356 tiling driver as one launch chain -- cProfile of the eager call (host side) or a loop for rocprofv3 --kernel-trace.
-usage: profile_chain.py host | loop [n]"""
+usage: profile_chain.py host | loop [n] [nochain]"""
 import cProfile, os, pstats, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
@@ -26,9 +26,12 @@ def encode(tiles):
     return ind, mask, mode
 
 
+CHAIN = "nochain" not in sys.argv
+
+
 def once(check=False):
-    t = highres.compress_tiled(x, encode, codec, chain=True)
-    return t, highres.decompress_tiled(t, codec, check=check, chain=True)
+    t = highres.compress_tiled(x, encode, codec, chain=CHAIN)
+    return t, highres.decompress_tiled(t, codec, check=check, chain=CHAIN)
 
 
 once(); torch.cuda.synchronize()
