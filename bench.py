@@ -623,7 +623,7 @@ def div2k_image(dev, cb, vq, codec, iters=8):
         dtc = (time.perf_counter() - t0) / iters
         same_c = tc.streams() == tiled.streams() and all(torch.equal(a[0], b[0]) and torch.equal(a[2], b[2]) for a, b in zip(pc, per_tile))
         res["chain"] = {"eager_ms_per_image": round(dtc * 1e3, 4), "eager_MPixels/s": round(H * W / dtc / 1e6, 1), "streams_equal_eager": bool(same_c),
-                        "note": "all shape groups through ONE launch per kernel (cgic_group_*): 5 launches, the tiles cut inside the entropy-map launch (cgic_entropy_maps_tiles)"}
+                        "note": "all shape groups through ONE launch per kernel (cgic_group_*): 4 launches -- the tiles are cut inside the entropy-map launch (cgic_entropy_maps_tiles), decoder + merge are one launch"}
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         gc_, (tgc, pgc, stgc) = cg.capture_graph(lambda: once_chain(False), side)

@@ -377,7 +377,11 @@ size_t cgic_decompress_workspace_bytes(int64_t B, int64_t h, int64_t w);
 /* Which prefix decoder cgic_decompress_streams launches (same results either way; process-wide, read at launch / capture):
  *   CGIC_DECODE_LATENCY     the split-stream decoders: every 64-bit chunk's exit offset for all 64 entry offsets, composed
  *                           across workgroups -- 1-24 workgroups of 1024 threads and 132 KB of LDS per image; shortest time for
- *                           ONE batch on an otherwise idle GPU (B=64 of 256x256: 15 us)
+ *                           ONE batch on an otherwise idle GPU (B=64 of 256x256: 15 us).  Small launches (every workgroup of the
+ *                           decoder and of the merge on a CU of its own: B <= 32 images of 256x256, a few 768x768 tiles) go out
+ *                           as ONE launch: the merge workgroups ride behind the decoder's, build their bitsets and prefixes while
+ *                           it runs and pick the symbols up through a per-image ticket (B=1: 23.9 -> 20.8 us per call, one
+ *                           768x768 tile 36.7 -> 28.6 us)
  *   CGIC_DECODE_THROUGHPUT  the self-synchronising decoder: one workgroup per image guesses entry offsets and re-walks until
  *                           they agree -- 256 threads and 41 KB of LDS per 256x256 image, 25 us alone, but it leaves the GPU
  *                           to the kernels of other batches in flight (pipeline.LaneStream: 86 -> 101 GPixel/s); the merge
