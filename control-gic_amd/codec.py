@@ -187,12 +187,13 @@ class GrainCodec:
         del keep
         return out
 
-    def decompress(self, cb, want_masks=True, want_zq=True, post_quant_conv=None, conv_bias_first=False, decoder=None):
+    def decompress(self, cb, want_masks=True, want_zq=True, post_quant_conv=None, conv_bias_first=False, decoder=None, status=None):
         """CompressedBatch -> (ind [B,h,w] int64, [mask_c, mask_m, mask_f] int32 [B,1,.,.] or None,
         z_q [B,4,h,w] fp32 or None, status [B] int32 on the device (0 = ok)).
         With post_quant_conv (a Conv2d(4, 4, 1) or (weight, bias)) the third element is the pair
         (z_q, post_quant_conv(z_q)) -- what CGIC.decode feeds the decoder (model.py:114-116) -- from the same pass.
-        decoder: "latency" / "throughput" / "auto" for THIS call (None: the enclosing decoder_mode block, else the process default)."""
+        decoder: "latency" / "throughput" / "auto" for THIS call (None: the enclosing decoder_mode block, else the process default).
+        status: where to write the [B] status words (e.g. a slice of one buffer shared by several calls) instead of a new tensor."""
         B, h, w, dev = cb.batch, cb.h, cb.w, cb.data.device
         l = _lib.lib()
         ind = torch.empty((B, h, w), dtype=torch.int64, device=dev)
@@ -214,7 +215,10 @@ class GrainCodec:
                 raise ValueError("post_quant_conv needs want_zq")
             cbk2 = self.post_conv_table(post_quant_conv, conv_bias_first)
             zq2 = torch.empty_like(zq)
-        status = torch.empty(B, dtype=torch.int32, device=dev)
+        if status is None:
+            status = torch.empty(B, dtype=torch.int32, device=dev)
+        elif status.dtype != torch.int32 or status.numel() != B or not status.is_contiguous() or status.device != dev:
+            raise ValueError("status must be a contiguous int32 tensor with one element per image on the streams' device")
         ws = torch.empty(l.cgic_decompress_workspace_bytes(B, h, w), dtype=torch.uint8, device=dev)
         with _lib.on_device(dev):
             _lib.call("cgic_decompress_streams", self.huffman.table.handle, _lib.ptr(cb.data), cb.data.shape[2],

@@ -328,12 +328,16 @@ def decompress_tiled_batch(tiled_list, codec, concurrent=False, check=True, chai
                 pending.append(comp)
                 continue
             outs.append(codec.decompress(comp))
+    status_all = None
     if chain:
-        # the decoder and the merge of all shape groups as ONE launch each (see compress_tiled)
+        # the decoder and the merge of all shape groups as ONE launch each (see compress_tiled); one status buffer for all of them
+        status_all = torch.empty(sum(c.batch for c in pending), dtype=torch.int32, device=dev)
+        at = 0
         with _lib.launch_group(len(pending), [c.batch * c.h * c.w for c in pending], dev) as g:
             for k, comp in enumerate(pending):
                 g.select(k)
-                outs.append(codec.decompress(comp))
+                outs.append(codec.decompress(comp, status=status_all[at:at + comp.batch]))
+                at += comp.batch
     for (idxs, _, _), (ind, masks, zq, status) in zip(first.groups, outs):
         statuses.append(status)
         T = len(idxs)
@@ -342,9 +346,10 @@ def decompress_tiled_batch(tiled_list, codec, concurrent=False, check=True, chai
                 j = n * T + k
                 per_image[n][i] = (ind[j:j + 1], [m[j:j + 1] for m in masks], zq[j:j + 1])
     fork.join(outs)
+    all_status = status_all if status_all is not None else torch.cat(statuses)
     if not check:
-        return per_image, torch.cat(statuses)
-    if int(torch.cat(statuses).abs().max()) != 0:
+        return per_image, all_status
+    if int(all_status.abs().max()) != 0:
         raise RuntimeError("corrupt tile stream")
     return per_image
 
@@ -361,11 +366,16 @@ def decompress_tiled(tiled, codec, decode=None, concurrent=False, check=True, ch
     fork = _Fork(dev, concurrent and dev is not None and not chain)
     outs = []
     # chain: the decoder and the merge of all shape groups as ONE launch each (see compress_tiled)
+    status_all = None
     if chain:
+        # (one status buffer for all groups: no concatenation kernel afterwards)
+        status_all = torch.empty(sum(c.batch for _, c, _ in tiled.groups), dtype=torch.int32, device=dev)
+        at = 0
         with _lib.launch_group(len(tiled.groups), [c.batch * c.h * c.w for _, c, _ in tiled.groups], dev) as g:
             for lane, (_, comp, _) in enumerate(tiled.groups):
                 g.select(lane)
-                outs.append(codec.decompress(comp))
+                outs.append(codec.decompress(comp, status=status_all[at:at + comp.batch]))
+                at += comp.batch
     for lane, (idxs, comp, _) in enumerate(tiled.groups):
         if not chain:
             with fork.on(lane):
@@ -375,10 +385,11 @@ def decompress_tiled(tiled, codec, decode=None, concurrent=False, check=True, ch
         for k, i in enumerate(idxs):
             per_tile[i] = (ind[k:k + 1], [m[k:k + 1] for m in masks], zq[k:k + 1])
     fork.join(outs)
+    all_status = status_all if status_all is not None else (torch.cat(statuses) if statuses else None)
     if not check:
-        return per_tile, (torch.cat(statuses) if statuses else None)
+        return per_tile, all_status
     # ONE host synchronisation for the whole image (not one per shape group)
-    if statuses and int(torch.cat(statuses).abs().max()) != 0:
+    if all_status is not None and int(all_status.abs().max()) != 0:
         raise RuntimeError("corrupt tile stream")
     if decode is None:
         return per_tile, None

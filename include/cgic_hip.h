@@ -82,7 +82,8 @@ int cgic_launch_graphs(void *const *graph_execs, void *const *streams, int n);
  * outputs, workspaces) must stay allocated until cgic_group_launch has returned.
  *   shares  host [n] or NULL: each group's share of the chip (sums to ~1; e.g. its share of the latent vectors): the
  *           persistent-workgroup VQ launch of a group takes that share of the CUs.  NULL: 1/n each.
- * cgic_group_launch returns the number of launches issued (>= 0) or CGIC_ERR_*; the group is closed either way.
+ * cgic_group_launch returns the number of launches issued (>= 0) or CGIC_ERR_*; the group is closed either way.  `stream` must be
+ * the stream the recorded calls were given (positions without a grouped form are launched on the stream they recorded).
  * cgic_group_abort closes it without launching.  cgic_group_max: the largest n. */
 int cgic_group_max(void);
 int cgic_group_begin(int ngroups, const double *shares);
