@@ -54,7 +54,8 @@ def entropy_maps_tiles(src, origins, th, tw, sigma=0.01):
     """pad + crop of the tiling driver (inference_high_resolution.py:145-173, :236-244) and both entropy maps in ONE pass
     (cgic_entropy_maps_tiles).  src: fp32 [N,3,H,W] unpadded images (or uint8 frames [N,H,W,3]); origins: [(y0, x0)] of the T tiles of ONE
     shape th x tw in unpadded coordinates -> (tiles [N*T,3,th,tw] fp32 image-major, e8, e16).  The tile batch comes back tagged with its
-    maps: entropy_maps(tiles) returns them without another pass, and the router finds pixels + flat8 on the maps as usual."""
+    maps: entropy_maps(tiles) returns them without another pass, and the router finds pixels + flat8 on the maps as usual
+    (the tag describes the tiles as they were written: it is void once the batch is modified in place)."""
     import ctypes
     _lib.require_device(src)
     u8 = src.dtype == torch.uint8

@@ -382,7 +382,10 @@ size_t cgic_decompress_workspace_bytes(int64_t B, int64_t h, int64_t w);
  *                           decoder and of the merge on a CU of its own: B <= 32 images of 256x256, a few 768x768 tiles) go out
  *                           as ONE launch: the merge workgroups ride behind the decoder's, build their bitsets and prefixes while
  *                           it runs and pick the symbols up through a per-image ticket (B=1: 23.9 -> 20.8 us per call, one
- *                           768x768 tile 36.7 -> 28.6 us)
+ *                           768x768 tile 36.7 -> 28.6 us).  Workgroups of this mode wait for workgroups of their own launch
+ *                           (the decoder's parts for each other, the merge bands for the decoder): meant for ONE stream of
+ *                           launches at a time -- several streams decoding concurrently take CGIC_DECODE_THROUGHPUT, whose
+ *                           workgroups never wait for another one
  *   CGIC_DECODE_THROUGHPUT  the self-synchronising decoder: one workgroup per image guesses entry offsets and re-walks until
  *                           they agree -- 256 threads and 41 KB of LDS per 256x256 image, 25 us alone, but it leaves the GPU
  *                           to the kernels of other batches in flight (pipeline.LaneStream: 86 -> 101 GPixel/s); the merge
