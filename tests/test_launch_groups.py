@@ -341,3 +341,26 @@ def test_decoder_and_merge_in_one_launch_equal_the_throughput_path(B, H, W):
     st_l = codec.decompress(bad, decoder="latency")[3]
     st_t = codec.decompress(bad, decoder="throughput")[3]
     assert int(st_l[0]) != 0 and torch.equal(st_l, st_t)
+
+
+def test_tile_entry_points_check_their_arguments():
+    """argument checks of cgic_cut_tiles / cgic_entropy_maps_tiles come before any launch (host logic only)"""
+    import ctypes
+    from control_gic_amd import _lib
+    l = _lib.lib()
+    dummy = ctypes.c_void_p(16)                  # never dereferenced: every call below fails its checks first
+    bins = _lib.linspace_bins()
+    t = (_lib.Tile * 1)(_lib.Tile(16, 0, 0, 0, 16, 18))                       # width not a multiple of 4
+    assert l.cgic_cut_tiles(dummy, 0, 1, 16, 16, 1, t, None) == _lib.ERR_INVALID
+    t = (_lib.Tile * 1)(_lib.Tile(20, 0, 0, 0, 16, 16))                       # fp32 destination not 16-byte aligned
+    assert l.cgic_cut_tiles(dummy, 0, 1, 16, 16, 1, t, None) == _lib.ERR_INVALID
+    assert l.cgic_cut_tiles(dummy, 0, 1, 16, 16, 97, t, None) == _lib.ERR_UNSUPPORTED          # more tiles than one launch takes
+    assert l.cgic_cut_tiles(dummy, 0, 1, 16, 16, 0, t, None) == _lib.ERR_UNSUPPORTED
+    org = (ctypes.c_int * 2)(0, 0)
+    args = lambda T, th, tw, x_out=dummy: (dummy, 0, 1, 64, 64, T, org, th, tw, bins, 32, 0.01, x_out, None, None, None, None)
+    assert l.cgic_entropy_maps_tiles(*args(49, 16, 16)) == _lib.ERR_UNSUPPORTED                # tiles per image of one shape
+    assert l.cgic_entropy_maps_tiles(*args(1, 16, 24)) == _lib.ERR_INVALID                     # tile not a multiple of 16
+    assert l.cgic_entropy_maps_tiles(*args(1, 16, 16, None)) == _lib.ERR_INVALID               # the tile batch is required
+    assert l.cgic_entropy_maps_tiles(dummy, 0, 1, 64, 64, 1, org, 16, 16, bins, 31, 0.01, dummy, None, None, None, None) == _lib.ERR_UNSUPPORTED
+    assert l.cgic_entropy_maps_tiles(dummy, 0, 1, 64, 64, 1, org, 16, 16, bins, 32, 0.5, dummy, None, None, None, None) == _lib.ERR_UNSUPPORTED
+    assert l.cgic_entropy_maps_tiles(dummy, 0, 0, 64, 64, 1, org, 16, 16, bins, 32, 0.01, dummy, None, None, None, None) == 0   # empty batch
