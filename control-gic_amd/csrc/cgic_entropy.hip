@@ -589,7 +589,10 @@ extern "C" int cgic_entropy_maps_tiles(const void *src, int is_u8, int64_t N, in
     if (N == 0) return CGIC_OK;
     EntWinArgs a;
     memcpy(a.e.bins.v, bins, sizeof(a.e.bins.v));
-    a.e.x = nullptr; a.e.H = th; a.e.W = tw; a.e.ppw = 4; a.e.e8 = e8; a.e.e16 = e16; a.e.x_out = x_out; a.e.flat8 = flat8;
+#ifndef CGIC_ENT_TILES_PPW
+#define CGIC_ENT_TILES_PPW 4
+#endif
+    a.e.x = nullptr; a.e.H = th; a.e.W = tw; a.e.ppw = CGIC_ENT_TILES_PPW; a.e.e8 = e8; a.e.e16 = e16; a.e.x_out = x_out; a.e.flat8 = flat8;
     a.e.exp2_scale = (float)(-0.5 * 1.4426950408889634 / ((double)sigma * (double)sigma));
     a.w.src = src; a.w.srcH = (int)H; a.w.srcW = (int)W; a.w.T = T;
     for (int k = 0; k < kEntMaxTiles; ++k) {
