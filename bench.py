@@ -756,7 +756,25 @@ def div2k_image(dev, cb, vq, codec, iters=8):
         t0 = time.perf_counter()
         gl.replay(2 * iters); gl.join(); torch.cuda.synchronize()
         dt4 = (time.perf_counter() - t0) / (2 * iters * 4 * 8)
-        res["batch_of_8_uint8_frames"] = {"four_in_flight_ms_per_image": round(dt4 * 1e3, 4), "four_in_flight_MPixels/s": round(H * W / dt4 / 1e6, 1),
+        # the same frames through the launch chain with ToTensor + pad + crop + maps as ONE pass (frames_fp32: `encode` gets fp32 tiles)
+        extra_u8 = {}
+        try:
+            def once_u8c():
+                ts = highres.compress_tiled_batch(frames, encode, codec, chain=True, frames_fp32=True)
+                p, st = highres.decompress_tiled_batch(ts, codec, check=False, chain=True)
+                return ts, p, st
+            tsc8, _, stc8 = once_u8c(); torch.cuda.synchronize()
+            same8 = int(stc8.abs().max()) == 0 and all(a.streams() == b.streams() for a, b in zip(tsc8, ts8))
+            glc8 = GraphLanes(dev, [once_u8c] * 4)
+            glc8.replay(2); glc8.join(); torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            glc8.replay(2 * iters); glc8.join(); torch.cuda.synchronize()
+            dtc8 = (time.perf_counter() - t0) / (2 * iters * 4 * 8)
+            extra_u8 = {"chain_four_in_flight_ms_per_image": round(dtc8 * 1e3, 4), "chain_four_in_flight_MPixels/s": round(H * W / dtc8 / 1e6, 1),
+                        "chain_streams_equal": bool(same8)}
+        except Exception as e:
+            extra_u8 = {"chain_error": str(e)[:200]}
+        res["batch_of_8_uint8_frames"] = {**extra_u8, "four_in_flight_ms_per_image": round(dt4 * 1e3, 4), "four_in_flight_MPixels/s": round(H * W / dt4 / 1e6, 1),
                                           "status_ok": int(st8.abs().max()) == 0, "bpp_mean": round(float(np.mean([t.bpp() for t in ts8])), 6),
                                           "note": "input = uint8 [8,H,W,3] frames = round(255 x) of batch_of_8's images (so its bpp differs slightly: other pixels, "
                                                   "not a parity gap -- equality with frames / 255 as fp32 input is what tests/test_highres_container.py checks); "

@@ -172,7 +172,7 @@ def _cut_all(x, frames, N, H, W, top, left, tiles, order):
     return batches
 
 
-def _compress_groups(x, encode, codec, tile, concurrent, chain=False, fuse_maps=True):
+def _compress_groups(x, encode, codec, tile, concurrent, chain=False, fuse_maps=True, frames_fp32=False):
     """x [N,3,H,W] fp32 -- or uint8 frames [N,H,W,3], the tiles then reach `encode` as uint8 [T,th,tw,3] (entropy_maps_u8 makes the
     fp32 tiles and the maps in one pass) --: the shape groups of N images of one size, each group ONE batch of N * T tiles (image-major)
     -> (H, W), pad, tiles, [(tile indices, CompressedBatch, (ind, masks, mode))]"""
@@ -198,7 +198,7 @@ def _compress_groups(x, encode, codec, tile, concurrent, chain=False, fuse_maps=
     grp = _lib.launch_group(len(order), [N * len(idxs) * th * tw for (th, tw), idxs in order], x.device) if chain else None
     batches = []
     cut, made = None, []
-    if chain and not frames and fuse_maps and max(len(idxs) for _, idxs in order) <= 48:
+    if chain and (not frames or frames_fp32) and fuse_maps and max(len(idxs) for _, idxs in order) <= 48:
         # pad + crop + BOTH entropy maps of all shape groups in ONE launch (cgic_entropy_maps_tiles, grouped): the tile batches come
         # back tagged with their maps -- encode's entropy_maps(tiles) returns them without another pass over the pixels
         from .entropy import entropy_maps_tiles
@@ -219,7 +219,7 @@ def _compress_groups(x, encode, codec, tile, concurrent, chain=False, fuse_maps=
             # is the part of the image it covers, zeros where it reaches into the centred pad
             batch = cut[lane] if cut is not None else \
                 torch.empty((N, len(idxs), th, tw, 3) if frames else (N, len(idxs), 3, th, tw), dtype=x.dtype, device=x.device)
-            bv = batch.permute(0, 1, 4, 2, 3) if frames else batch
+            bv = batch.permute(0, 1, 4, 2, 3) if frames and not made else batch
             for k, i in enumerate(idxs if cut is None else ()):
                 y0, x0 = tiles[i][0] - top, tiles[i][1] - left                  # in unpadded coordinates
                 sy0, sy1, sx0, sx1 = max(y0, 0), min(y0 + th, H), max(x0, 0), min(x0 + tw, W)
@@ -229,7 +229,7 @@ def _compress_groups(x, encode, codec, tile, concurrent, chain=False, fuse_maps=
                 for strip in (dst[:, :, :sy0 - y0], dst[:, :, sy1 - y0:], dst[:, :, :, :sx0 - x0], dst[:, :, :, sx1 - x0:]):
                     if strip.numel():
                         strip.zero_()
-            batch = batch.view(-1, th, tw, 3) if frames else batch.view(-1, 3, th, tw)
+            batch = batch.view(-1, th, tw, 3) if frames and not made else batch.view(-1, 3, th, tw)
             if made:                                     # (tags do not survive a view: this is the object `encode` sees)
                 e8, e16, flat8 = made[lane]
                 batch._cgic_maps = made[lane]
@@ -249,7 +249,7 @@ def _compress_groups(x, encode, codec, tile, concurrent, chain=False, fuse_maps=
     return (H, W), pad, tiles, groups
 
 
-def compress_tiled(x, encode, codec, tile=TILE, concurrent=False, chain=False, fuse_maps=True):
+def compress_tiled(x, encode, codec, tile=TILE, concurrent=False, chain=False, fuse_maps=True, frames_fp32=False):
     """x [1,3,H,W] on the device; encode(tiles [T,3,th,tw]) -> (ind [T*h*w] int64, masks [3 x int32], mode)
     with per-tile routing (the reference's per-tile B=1 call); codec: GrainCodec.  -> TiledImage.
     concurrent: the shape groups run on parallel streams (same results; see _Fork).
@@ -259,14 +259,16 @@ def compress_tiled(x, encode, codec, tile=TILE, concurrent=False, chain=False, f
     launches are recorded and issued when all groups are in), but must not enqueue torch work that READS their outputs --
     a conv encoder that consumes the router's gate cannot run under chain=True.
     fuse_maps (with chain, fp32 input): the tiles are cut AND their entropy maps made in one pass over the image
-    (cgic_entropy_maps_tiles); the tile batches `encode` receives carry their maps, entropy_maps(tiles) returns them as they are."""
+    (cgic_entropy_maps_tiles); the tile batches `encode` receives carry their maps, entropy_maps(tiles) returns them as they are.
+    frames_fp32 (uint8 frames with chain + fuse_maps): `encode` receives the fp32 tiles T.ToTensor() would have produced (tagged with their
+    maps) instead of uint8 tiles -- ToTensor, pad, crop and both maps are then one pass over the frames (3 B read + 12 B written per pixel)."""
     if x.dim() != 4 or x.shape[0] != 1:
         raise ValueError("compress_tiled takes one image [1,3,H,W] (or one uint8 frame [1,H,W,3]; the reference script uses batch 1); "
                          "compress_tiled_batch takes several of one size")
-    return TiledImage(*_compress_groups(x, encode, codec, tile, concurrent, chain, fuse_maps))
+    return TiledImage(*_compress_groups(x, encode, codec, tile, concurrent, chain, fuse_maps, frames_fp32))
 
 
-def compress_tiled_batch(x, encode, codec, tile=TILE, concurrent=False, chain=False, fuse_maps=True):
+def compress_tiled_batch(x, encode, codec, tile=TILE, concurrent=False, chain=False, fuse_maps=True, frames_fp32=False):
     """x [N,3,H,W] (or uint8 frames [N,H,W,3]: `encode` then gets uint8 tiles [T,th,tw,3] for entropy_maps_u8 -- a pad of zero
     bytes is the pad of zeros ToTensor would have produced): N images of ONE size (a folder of camera frames, a DIV2K bucket) -> list of N TiledImage, each what
     compress_tiled gives for that image alone (routing is per tile, so batching across images changes no byte).  The tiles
@@ -276,7 +278,7 @@ def compress_tiled_batch(x, encode, codec, tile=TILE, concurrent=False, chain=Fa
     if x.dim() != 4:
         raise ValueError("compress_tiled_batch takes [N,3,H,W] or uint8 [N,H,W,3]")
     N = x.shape[0]
-    hw, pad, tiles, groups = _compress_groups(x, encode, codec, tile, concurrent, chain, fuse_maps)
+    hw, pad, tiles, groups = _compress_groups(x, encode, codec, tile, concurrent, chain, fuse_maps, frames_fp32)
     out = []
     for n in range(N):
         mine = []

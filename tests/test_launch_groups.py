@@ -245,6 +245,11 @@ def test_chain_of_a_batch_of_images(H, W):
         _, _, ind, mask, _, mode = vq_forward_route(z, vq.embedding.weight, 0.25, True, e16, e8, 0.1, 0.8, per_image=True, pixels=tiles)
         return ind, mask, mode
 
+    # frames_fp32: ToTensor + pad + crop + maps of the uint8 frames in one pass; `encode` then gets the fp32 tiles (tagged with their maps)
+    ref_u8 = highres.compress_tiled_batch(frames, encode_u8, codec)
+    got_f = highres.compress_tiled_batch(frames, encode, codec, chain=True, frames_fp32=True)
+    for a, b in zip(ref_u8, got_f):
+        assert a.streams() == b.streams() and a.bpp() == b.bpp()
     for inp, enc in ((x, encode), (frames, encode_u8)):
         ref = highres.compress_tiled_batch(inp, enc, codec)
         got = highres.compress_tiled_batch(inp, enc, codec, chain=True)

@@ -9,7 +9,7 @@ dev = torch.device("cuda", 0)
 cb = np.random.default_rng(12345).standard_normal((1024, 4), dtype=np.float32)
 vq = bench.make_quantizer(dev, cb)
 codec = cg.GrainCodec(vq.embedding_counter, vq.embedding.weight)
-for B, H, W in ((1, 256, 256), (4, 256, 256), (8, 256, 256), (1, 512, 768)):
+for B, H, W in ((1, 768, 768), (2, 768, 768), (4, 768, 768), (1, 512, 768)):
     rng = np.random.default_rng(B + H)
     x = torch.from_numpy(rng.random((B, 3, H, W), dtype=np.float32)).to(dev)
     z = torch.from_numpy(rng.standard_normal((B, 4, H // 4, W // 4), dtype=np.float32)).to(dev)
