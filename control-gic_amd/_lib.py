@@ -163,6 +163,7 @@ class launch_group:
         try:
             call("cgic_group_begin", self.n, arr)
             _group_tls.stream = torch.cuda.current_stream(self.device).cuda_stream
+            _group_tls.device_index = torch.cuda.current_device()
         except BaseException:
             self._dev_ctx.__exit__(None, None, None)
             raise
@@ -331,6 +332,9 @@ def on_device(device):
     """`with on_device(dev):` == `with torch.cuda.device(dev):`, except inside a launch_group block, which holds its device for
     the whole block (the ~10 us of the torch context manager per recorded call were a third of the host time of a tiled image)"""
     if getattr(_group_tls, "stream", None) is not None:
+        want, have = getattr(device, "index", None), getattr(_group_tls, "device_index", None)
+        if want is not None and have is not None and want != have:
+            raise RuntimeError(f"a launch group is open on cuda:{have}; tensors on cuda:{want} cannot be recorded into it")
         return _null_ctx
     import torch
     return torch.cuda.device(device)
