@@ -1368,7 +1368,11 @@ extern "C" int cgic_decompress_streams(const cgic_table *t, const uint8_t *in, i
     // so not more than needed): ~256 workgroups in all, at least 2 coarse rows per band
     // Decoder and merge go out as ONE launch when every workgroup of both gets a CU of its own (B = 1 .. a few dozen images, or
     // a few tiles; inside a launch group: within the group's share of the chip)
-    const unsigned int ndec = large ? CGIC_DEC_WGS_LARGE : CGIC_DEC_WGS_SMALL;
+#ifndef CGIC_DEC_WGS_FUSED_LARGE
+#define CGIC_DEC_WGS_FUSED_LARGE 16      // decoder workgroups per large grid when the merge rides in the launch: as fast as 24 per call, and the
+                                         // CUs it leaves go to merge bands (2040x1356 chain 0.105 -> 0.104 ms; 12 falls off the fast path)
+#endif
+    const unsigned int ndec = large ? CGIC_DEC_WGS_FUSED_LARGE : CGIC_DEC_WGS_SMALL;
     int cus = 0;
     rc = device_cu_count_dec(&cus);
     if (rc) return rc;
