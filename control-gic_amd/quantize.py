@@ -364,8 +364,10 @@ class VectorQuantize2(nn.Module):
         with torch.no_grad():
             total = self.usage_counter.to(torch.float64).round().to(torch.int64)
             base = getattr(self, "_usage_synced", None)
-            if base is None or base.shape != total.shape or base.device != total.device:
+            if base is None or base.shape != total.shape:
                 base = torch.zeros_like(total)
+            elif base.device != total.device:
+                base = base.to(total.device)        # load_state_dict on CPU, then .cuda(): the buffer moved, the base follows
             delta = total - base
             cdist.all_reduce_histogram(delta)
             total = base + delta

@@ -192,7 +192,19 @@ def _counter_worker(rank, world, port, out_dir):
     late.usage_hist += torch.from_numpy(total)
     late.fold_usage_hist()
     late.sync_usage_counter_now()
-    torch.save({"synced": vq.usage_counter.clone(), "local": local.usage_counter.clone(), "mine": torch.from_numpy(total), "late": late.usage_counter.clone(),
+    # a checkpoint of the whole job's counts, loaded on every rank, module moved afterwards, synced twice: nothing to add
+    ckpt = cg.VectorQuantizer(1024, 4, beta=0.25)
+    ckpt.usage_counter.copy_(torch.arange(1024, dtype=torch.float32) * 3)
+    loaded = cg.VectorQuantizer(1024, 4, beta=0.25).train()
+    loaded.load_state_dict(ckpt.state_dict())
+    loaded = loaded.to(torch.device("cpu"))
+    loaded.sync_usage_counter_now()
+    loaded.sync_usage_counter_now()
+    assert torch.equal(loaded.usage_counter, ckpt.usage_counter), "checkpointed counts were multiplied by the world size"
+    loaded.usage_hist += torch.from_numpy(total)                   # then each rank counts its shard: only that delta is summed
+    loaded.fold_usage_hist()
+    loaded.sync_usage_counter_now()
+    torch.save({"loaded": loaded.usage_counter.clone(), "ckpt": ckpt.usage_counter.clone(), "synced": vq.usage_counter.clone(), "local": local.usage_counter.clone(), "mine": torch.from_numpy(total), "late": late.usage_counter.clone(),
                 "hist_left": int(vq.usage_hist.abs().sum()), "key3": float(vq.embedding_counter["3"].item())},
                os.path.join(out_dir, f"c{rank}.pt"))
     dist.barrier()
@@ -211,4 +223,5 @@ def test_training_usage_counter_is_reduced_over_ranks(tmp_path):
         assert torch.equal(r["synced"], want) and r["hist_left"] == 0 and r["key3"] == float(want[3])
         assert torch.equal(r["local"], r["mine"].float())
         assert torch.equal(r["late"], want)                      # sync_usage_counter_now(): the same table from one collective
+        assert torch.equal(r["loaded"], r["ckpt"] + want)        # checkpoint base once + the ranks' deltas
     assert not torch.equal(res[0]["local"], res[1]["local"])

@@ -69,6 +69,25 @@ def test_vq_module_forward_and_counter(golden, orc):
     assert vq.embedding_counter["3"].item() == float(g["counter_cnt"][3])
 
 
+def test_usage_counter_sync_base_follows_the_module_to_the_gpu(monkeypatch):
+    """load_state_dict on the CPU, then .cuda(): the buffer moves and the synced base has to follow it; otherwise the next
+    sync_usage_counter_now() reduces the whole checkpointed table again (= multiplies it by the world size)"""
+    from control_gic_amd import dist as cdist
+    ckpt = cg.VectorQuantizer(1024, 4, beta=0.25)
+    ckpt.usage_counter.copy_(torch.arange(1024, dtype=torch.float32) * 5)
+    vq = cg.VectorQuantizer(1024, 4, beta=0.25)
+    vq.load_state_dict(ckpt.state_dict())
+    vq = vq.to(DEV).train()
+    monkeypatch.setattr(cdist, "all_reduce_histogram", lambda t: t.mul_(2))        # two ranks that counted the same delta
+    vq.sync_usage_counter_now()
+    vq.sync_usage_counter_now()
+    assert torch.equal(vq.usage_counter.cpu(), ckpt.usage_counter)
+    vq.usage_hist += 1
+    vq.fold_usage_hist()
+    vq.sync_usage_counter_now()
+    assert torch.equal(vq.usage_counter.cpu(), ckpt.usage_counter + 2)
+
+
 @pytest.mark.parametrize("shape,scale", [((64, 4, 64, 64), 1.0), ((3, 4, 192, 192), 1.0), ((5, 4, 20, 36), 0.002),
                                          ((1, 4, 512, 512), 1.0), ((5, 4, 63, 65), 1.0), ((1, 4, 1, 1), 1.0), ((1, 4, 4, 4096), 1.0)])
 def test_vq_vs_oracle_and_cross_kernel(orc, shape, scale):

@@ -21,7 +21,14 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(l, name), f"{name} declared in cgic_hip.h but not exported"
     assert declared == set(_lib.PROTOTYPES), "ctypes prototype table out of sync with the header"
-    assert _lib.lib().cgic_abi_version() == 6
+    import __graft_entry__ as entry
+    assert _lib.lib().cgic_abi_version() == entry.header_abi_version()
+
+
+def test_graft_entry_build_passes():
+    """the driver's build check: make (a no-op when the tree is built) + the ABI of the loaded library against the header"""
+    import __graft_entry__ as entry
+    assert entry.build() == cg.LIB_PATH
 
 
 def test_device_count_does_not_abort_without_gpu():
