@@ -36,7 +36,8 @@ _cv = C.POINTER(Conv1x1)
 
 class Pixels(C.Structure):
     """struct cgic_pixels (include/cgic_hip.h): the image batch behind a pair of entropy maps, for the router's refinement"""
-    _fields_ = [("x", _vp), ("is_u8", _int), ("bins", C.POINTER(_f32)), ("nbins", _int), ("sigma", _f32), ("flat8", _vp)]
+    _fields_ = [("x", _vp), ("is_u8", _int), ("bins", C.POINTER(_f32)), ("nbins", _int), ("sigma", _f32), ("flat8", _vp),
+                ("scratch", _vp), ("scratch_bytes", _sz)]
 
 
 _px = C.POINTER(Pixels)
@@ -82,6 +83,7 @@ PROTOTYPES = {
     "cgic_entropy_maps_u8": (_int, [_vp, _i64, _i64, _i64, C.POINTER(_f32), _int, _f32, _vp, _vp, _vp, _vp, _vp]),
     "cgic_router_mode": (_int, [_f64, _f64]),
     "cgic_router_refine_supported": (_int, [_i64, _i64, _i64, _int]),
+    "cgic_router_refine_scratch_bytes": (_sz, [_i64, _i64, _i64, _int]),
     "cgic_router_f32": (_int, [_vp, _vp, _i64, _i64, _i64, _f64, _f64, _int, _vp, _vp, _vp, _vp, C.POINTER(_int), _px, _vp]),
     "cgic_table_create": (_int, [C.POINTER(_i64), C.POINTER(_i32), _int, C.POINTER(_vp)]),
     "cgic_table_binary": (_int, [C.POINTER(_vp)]),
@@ -232,12 +234,17 @@ def linspace_bins():
     return _BINS
 
 
-def pixels_arg(pixels, B, h16, w16, per_image, sigma=0.01, flat8=None):
+#: False: bands are evaluated inside the image's own router workgroup only (no refinement queues: the pre-ABI-7 behaviour; tests, A/B)
+REFINE_QUEUES = True
+
+
+def pixels_arg(pixels, B, h16, w16, per_image, sigma=0.01, flat8=None, queues=False):
     """(ctypes pointer or None, keep-alive) for the router's `refine` argument.  pixels: None, the fp32 [B,3,16 h16,16 w16] image
     batch the maps were made from, or the uint8 [B,16 h16,16 w16,3] frames; flat8: the constant-patch map the same entropy call
     made (entropy_maps(...) attaches it to its maps as `_cgic_flat8`), optional.  None is also returned (no refinement, the maps
     decide as given) when the routing segment does not fit the workgroup's LDS (cgic_router_refine_supported: flattened
-    batches / images beyond ~768x768 routed as one segment)."""
+    batches / images beyond ~768x768 routed as one segment).  queues: also hand over the scratch of the launch's refinement
+    queues (cgic_pixels.scratch: the stand-alone router launch evaluates long bands with every idle wave of the launch)."""
     if pixels is None:
         return None, ()
     import torch
@@ -255,8 +262,12 @@ def pixels_arg(pixels, B, h16, w16, per_image, sigma=0.01, flat8=None):
         if tuple(flat8.shape) != (B, 2 * h16, 2 * w16) or flat8.dtype != torch.float32:
             raise ValueError(f"flat8 {flat8.dtype} {tuple(flat8.shape)} does not belong to these maps")
         flat8 = flat8.contiguous()
-    st = Pixels(ptr(px), int(u8), linspace_bins(), 32, float(sigma), ptr(flat8))
-    return C.byref(st), (st, px, flat8)
+    # scratch of the launch's refinement queues (long bands are evaluated by every idle workgroup of the launch): an ordinary
+    # temporary of the call -- the caching allocator keeps it alive for the stream, a captured graph keeps its own
+    nbytes = lib().cgic_router_refine_scratch_bytes(B, h16, w16, int(bool(per_image))) if (queues and REFINE_QUEUES) else 0
+    scratch = torch.empty(nbytes, dtype=torch.uint8, device=px.device) if nbytes else None
+    st = Pixels(ptr(px), int(u8), linspace_bins(), 32, float(sigma), ptr(flat8), ptr(scratch), nbytes)
+    return C.byref(st), (st, px, flat8, scratch)
 
 
 class ticket_scope:

@@ -64,7 +64,10 @@ struct TableDev {
 // `n` consecutive self-resetting ticket words (zero on entry; the kernel that uses one must leave it zero),
 // 64 bytes apart: ptr[0], ptr[16], ptr[32] ... (kTicketStride words).  See cgic_table.hip.
 constexpr int kTicketStride = 16;
-int acquire_tickets(hipStream_t stream, int n, unsigned int **ptr);
+// kind 1: slots of a second pool with the router's refinement-queue contract instead (cgic_router_dev.h: zero when first handed out,
+// afterwards whatever a finished launch left -- a queue word that says "nothing to claim", counters that only ever grow or return
+// to zero): never mixed with the zero-on-entry slots of kind 0.
+int acquire_tickets(hipStream_t stream, int n, unsigned int **ptr, int kind = 0);
 
 // hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per (function, device) and size -- not on every launch
 int ensure_dynamic_lds(const void *fn, size_t bytes);

@@ -19,12 +19,12 @@ namespace cgic {
 __global__ __launch_bounds__(kRouterThreads) void router_kernel(RouterArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char dyn[];
-    router_body<kRouterThreads>(a, blockIdx.x, dyn);
+    router_body<kRouterThreads, true>(a, blockIdx.x, dyn);
 }
 
 int router_prepare(const float *e16, const float *e8, int64_t B, int64_t h16, int64_t w16, double c_ratio,
                    double m_ratio, int per_image, int32_t *mask_c, int32_t *mask_m, int32_t *mask_f, float *gate,
-                   RouterArgs *out, int64_t *nseg_out, size_t *lds_out, size_t lds_budget, const cgic_pixels *refine)
+                   RouterArgs *out, int64_t *nseg_out, size_t *lds_out, size_t lds_budget, const cgic_pixels *refine, hipStream_t stream, bool queues)
 {
     CGIC_REQUIRE(e16 && e8 && mask_c && mask_m && mask_f, CGIC_ERR_INVALID, "router: NULL tensor");
     CGIC_REQUIRE(B > 0 && h16 > 0 && w16 > 0, CGIC_ERR_INVALID, "router: bad shape");
@@ -56,6 +56,7 @@ int router_prepare(const float *e16, const float *e8, int64_t B, int64_t h16, in
         a.mg_n4 = magic(4 * N8, n4); a.mg_w4 = magic(n4, w4);
     }
     a.rf.x = nullptr;
+    a.rq.hdr = nullptr; a.rq.board = nullptr; a.rq.scratch = nullptr; a.rq.nq = 0; a.rq.pad = 0;
     if (refine && refine->x && (mode <= 3)) {          // (modes 4-6 compare nothing)
         CGIC_REQUIRE(refine->bins && refine->nbins == kBins, CGIC_ERR_UNSUPPORTED, "router: refinement needs the 32 bin centres (model.py:480)");
         CGIC_REQUIRE(refine->sigma > 0.f && refine->sigma <= 0.0105f, CGIC_ERR_UNSUPPORTED,
@@ -90,6 +91,19 @@ int router_prepare(const float *e16, const float *e8, int64_t B, int64_t h16, in
         a.bands = nb >= 2 ? (int)nb : 1;
     }
     CGIC_REQUIRE(lds <= 150 * 1024, CGIC_ERR_UNSUPPORTED, "router: segment of %lld coarse patches exceeds LDS", (long long)N16);
+    // the launch's refinement queues: one header per (segment, select) + the board, in library-owned slots (a pool of their own); payload in the caller's scratch
+    if (queues && a.rf.x && refine->scratch && 2 * nseg <= 4096) {
+        const size_t need = (size_t)nseg * refine_scratch_bytes_per_segment(N16, N8);
+        CGIC_REQUIRE(refine->scratch_bytes >= need, CGIC_ERR_INVALID, "router: refinement scratch of %zu bytes, %zu needed (cgic_router_refine_scratch_bytes)",
+                     refine->scratch_bytes, need);
+        CGIC_REQUIRE(((uintptr_t)refine->scratch & 15u) == 0, CGIC_ERR_INVALID, "router: the refinement scratch must be 16-byte aligned");
+        int rc = acquire_tickets(stream, (int)(2 * nseg), &a.rq.hdr, 1);
+        if (rc) return rc;
+        rc = acquire_tickets(stream, 1, &a.rq.board, 0);
+        if (rc) return rc;
+        a.rq.scratch = reinterpret_cast<unsigned char *>(refine->scratch);
+        a.rq.nq = (unsigned int)(2 * nseg);
+    }
     *out = a; *nseg_out = nseg * a.bands; *lds_out = lds;       // workgroups of the launch
     return CGIC_OK;
 }
@@ -117,6 +131,14 @@ extern "C" int cgic_router_refine_supported(int64_t B, int64_t h16, int64_t w16,
     return st == 1 ? 1 : 0;
 }
 
+extern "C" size_t cgic_router_refine_scratch_bytes(int64_t B, int64_t h16, int64_t w16, int per_image)
+{
+    if (!cgic_router_refine_supported(B, h16, w16, per_image)) return 0;
+    const int64_t nseg = per_image ? B : 1, N16 = (per_image ? 1 : B) * h16 * w16;
+    if (2 * nseg > 4096) return 0;
+    return (size_t)nseg * refine_scratch_bytes_per_segment(N16, 4 * N16);
+}
+
 extern "C" int cgic_router_f32(const float *e16, const float *e8, int64_t B, int64_t h16, int64_t w16,
                                double c_ratio, double m_ratio, int per_image, int32_t *mask_c,
                                int32_t *mask_m, int32_t *mask_f, float *gate, int *mode_out,
@@ -130,7 +152,7 @@ extern "C" int cgic_router_f32(const float *e16, const float *e8, int64_t B, int
     int64_t nseg;
     size_t lds;
     int rc = router_prepare(e16, e8, B, h16, w16, c_ratio, m_ratio, per_image, mask_c, mask_m, mask_f, gate, &a, &nseg, &lds,
-                            96 * 1024, refine);
+                            96 * 1024, refine, (hipStream_t)stream, true);
     if (rc) return rc;
     if (lds > 64 * 1024)
         { int rc_ = ensure_dynamic_lds((const void *)router_kernel, (size_t)lds); if (rc_) return rc_; }

@@ -129,6 +129,15 @@ __device__ float radix_select(F val, int64_t n, unsigned int rank0, RouterShared
     return key2f(prefix);
 }
 
+// the view of the launch's refinement queues (see "evaluating a band's patches with the whole chip" below)
+struct RefineQ {
+    unsigned int *hdr;          // library-owned slots (kTicketStride words each, acquire_tickets kind 1): slot 2 segment + bank = a select's queue
+    unsigned int *board;        // one zero-on-entry ticket slot (kind 0): the launch's board
+    unsigned char *scratch;     // caller-owned: per segment {items, values, final index, final value} x {N16, N8} 32-bit words
+    unsigned int nq;            // 2 x segments; 0 = no queues (every band is evaluated inside its own workgroup)
+    unsigned int pad;
+};
+
 struct RouterArgs {
     const float *e16;
     const float *e8;
@@ -143,6 +152,7 @@ struct RouterArgs {
     int bands;             // workgroups per segment (per-image segments only): every one finds the thresholds, each writes
                            // only its band of rows of the masks (one CU per 768x768 tile spent 10 us writing 200 KB of masks)
     RefineSrc rf;          // rf.x != nullptr (stage 1 only): threshold-band refinement from the pixels, see refine_select
+    RefineQ rq;            // rq.nq != 0: large bands are evaluated by every idle wave of the launch (refine_help_wave)
     unsigned int mg_n8, mg_w8, mg_n4, mg_w4;      // ceil(2^32 / d) for d = n8, w8, n4, w4, or 0: divide (router_prepare)
 };
 
@@ -157,22 +167,87 @@ struct RouterArgs {
 // (cgic_entropy_dev.h), write the values into the LDS copy of the map and select again.  Typical images: band of one, nothing
 // to do.  8-bit smooth content: a handful of patches per image.
 constexpr float kRefineBand = 4e-6f;       // >= 2 x the default entropy kernel's error (measured <= 1.1e-6, held to 2e-6 by the tests)
-constexpr int kRefWavesMax = 8;            // waves of a router workgroup that evaluate patches (LDS scratch is sized for them)
+// The error bound by VALUE (round 5).  The coarse threshold is the 10 % quantile of the 16x16 entropies: on smooth content it falls
+// into the cluster of nearly constant patches, values of 1e-7 .. 1e-4 a few 1e-7 apart, and +-4e-6 around it held up to 41 patches of
+// a 256x256 image (334 of a 768x768 tile) -- 60 us of re-evaluation in the image's one router workgroup.  Down there the default
+// kernel is much closer to the reference's arithmetic than at large values (what is left is one rounding of the dominant bin's
+// p = 1 - eps): measured over every content family, tile and smooth variant of tools/probes/probe_entropy_err.py
+//     value   < 1e-5   < 1e-4   < 1e-3   < 1e-2   < 0.1    >= 0.1
+//     error   2.8e-7   3.4e-7   4.4e-7   5.8e-7   8.8e-7   1.06e-6
+// delta(v) = 7e-7 up to 1e-4, then rising with slope 0.01 to the 2e-6 that holds everywhere (2 x the measured error throughout;
+// tests/test_gpu_parity.py holds the kernel to it).  The order-statistic argument goes through with any nondecreasing bound of
+// slope < 1: the k elements at or below the approximate threshold t_a are exactly at most t_a + delta(t_a), and an element above
+// t_a is exactly at least a - delta(a) >= t_a - delta(t_a), so |t* - t_a| <= delta(t_a); whatever differs from t_a by more than
+// delta(t_a) + its own delta keeps its side.  One width for a select: 2 delta(t_a + 4e-6) covers every element within the old band.
+__host__ __device__ inline float refine_delta(float v)
+{
+    const float d = 7e-7f + 0.01f * (v > 1e-4f ? v - 1e-4f : 0.f);
+    return d < 2e-6f ? d : 2e-6f;          // (NaN: 2e-6)
+}
+constexpr int kRefWavesMax = 8;            // waves of a workgroup that evaluate patches (LDS scratch is sized for them): two teams of four
 constexpr int kRefListCap = 1024;          // band elements listed per sweep (a longer band is swept range by range)
 constexpr int kRefFlatSlots = 128;         // distinct grays of constant patches per select (more: the rest go patch by patch)
 constexpr unsigned int kRefEmpty = 0xFFFFFFFFu;      // (a NaN pattern: never the gray of a constant patch)
-struct RefineShared {
-    unsigned int cnt[16];                                  // two banks of 8 (coarse / medium select; zeroed once, when the router starts): band size | of
-                                                           // which not exactly known | list length | below the band
-    unsigned int list[kRefListCap];
+
+// ---- evaluating a band's patches with the whole chip -------------------------------------------------------------------------
+// A band of a few patches is evaluated where it was found (four waves per 16x16 patch, side by side).  A long one -- smooth or flat
+// 8-bit content puts tens to hundreds of patches within 4e-6 of a threshold -- used to run 64 pixels per wave and step inside the
+// image's ONE router workgroup while the rest of the chip idled (fused launch 24 -> 88 us on smooth 256x256 batches, a smooth
+// 768x768 tile 0.56 ms; a unit is ~1.5 us of SIMD time: a CU does 164 units in ~60 us, the chip in one).  Now the owner PUBLISHES
+// the patch list, keeps evaluating at its own pace, and waves of the launch that have nothing left to do take patches from it:
+// the other row bands of the same tile and the waves of router workgroups that are done.  (The stand-alone router launch only,
+// refine_select's RQ: see there for why the fused VQ + router launch keeps the in-workgroup evaluation.)
+//
+//   queue word (64 bit): (items published << 32) | claims made.  A claim is ONE fetch-and-add of the word (the count of items taken,
+//     1 or 4): whoever finds claims < published in the value it gets back owns those items, whatever happened before or after --
+//     the word is self-describing, so a late or futile add can only take what is really there or push the claims further past the
+//     published count.  (Compare-and-swap on the word as read: with 512 evaluator teams after 10 queues every generation of
+//     attempts had one winner -- 5 400 failed claims per launch, 41 patches took 60+ us.)  The owner publishes with a store.
+//   payload, in caller-owned scratch: items = (tag << 32 | patch index), results = (tag << 32 | value bits) by patch index -- ONE
+//     8-byte write-through store each (sc1: relaxed agent-scope atomics), no counter behind them and nothing to drain: the owner
+//     clears its items' result slots before it publishes and polls them afterwards (the tag, a per-queue publication count, tells a
+//     result of THIS list from whatever the memory held).  A helper's item costs it four dependent global round trips (queue scan,
+//     claim, item, pixels) + the arithmetic; with a done counter behind drained stores it was seven (~17 us per item under load).
+//     The per-XCD L2s are not coherent with each other; an agent-scope fence per hand-off would cost ~1.7 us and stall the CU.
+//   nobody ever waits for a workgroup that may not have started: the owner waits only for items that were CLAIMED (their
+//     claimers are running), a row band that is not the owner (the first to arrive is) waits for that owner, which is running.
+//   Header slots come from a pool of their own (acquire_tickets kind 1): zero when first handed out; a finished launch leaves the
+//     queue word saying "nothing to claim" (claims >= published), the publication count wherever it got to, and everything else
+//     zero again (the last user restores the row-band words).  The board (one zero-on-entry ticket) counts the router workgroups
+//     that hold a band open: helpers look for work only while it is non-zero.
+enum { QH_CLAIM = 0 /* + 1: the 64-bit queue word */, QH_SEQ = 2, QH_ARRIVE = 3, QH_FIN = 4, QH_LEFT = 5, QH_THR = 6, QH_NFINAL = 7 };
+enum { QB_BUSY = 0 };
+__host__ __device__ inline size_t refine_scratch_bytes_per_segment(int64_t N16, int64_t N8) { return 24 * (size_t)(N16 + N8); }
+
+__device__ __forceinline__ unsigned int ld_sc1(const unsigned int *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ float ld_sc1(const float *p) { return __uint_as_float(__hip_atomic_load(reinterpret_cast<const unsigned int *>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)); }
+__device__ __forceinline__ unsigned long long ld_sc1(const unsigned long long *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_sc1(unsigned int *p, unsigned int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_sc1(float *p, float v) { __hip_atomic_store(reinterpret_cast<unsigned int *>(p), __float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_sc1(unsigned long long *p, unsigned long long v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void drain_stores() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+__device__ __forceinline__ unsigned int add_sc1(unsigned int *p, unsigned int v) { return __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// per-workgroup LDS of the patch evaluators (router workgroups: inside RefineShared; VQ workgroups: over their codebook image)
+struct RefineTeamLds {
     float T[kRefWavesMax][kRefUnitRows * kRefRow];         // chunk sums: the four units of a 16x16 patch are four consecutive waves'
     float rec[kRefWavesMax][kRefRecFloats];
     float P[kRefWavesMax][2 * kBins];
     float bins[kBins];
+    unsigned int job_first, job_count;                     // the owner's current round: first item, items
+};
+struct RefineShared {
+    unsigned int cnt[16];                                  // two banks of 8 (coarse / medium select; zeroed once, when the router starts): band size | of
+                                                           // which not exactly known | list length | below the band | items published
+    unsigned int list[kRefListCap];
+    RefineTeamLds tl;
     unsigned int flat_key[kRefFlatSlots];                  // open-addressing set of the constant patches' grays (bit patterns)
     float flat_val[kRefFlatSlots];
     unsigned int small[64];                                // all band elements, when there are at most 64 (the final pick)
     float thr;
+    unsigned int busy_held;                                // this workgroup has raised the board's busy count
+    unsigned int tag;                                      // the current list's publication count
+    unsigned int flag;
 };
 
 __device__ __forceinline__ unsigned int flat_hash(unsigned int key) { return (key * 2654435761u) >> 25; }      // 7 bits
@@ -187,14 +262,208 @@ __device__ __forceinline__ int flat_find(const unsigned int *keys, unsigned int 
     }
     return -1;
 }
-__device__ __forceinline__ void flat_insert(unsigned int *keys, unsigned int key)
+// the slot `key` sits in afterwards, or -1 (full: the element is evaluated patch by patch)
+__device__ __forceinline__ int flat_insert(unsigned int *keys, unsigned int key)
 {
     unsigned int s = flat_hash(key);
     for (int t = 0; t < kRefFlatSlots; ++t, s = (s + 1) & (kRefFlatSlots - 1)) {
         const unsigned int old = atomicCAS(&keys[s], kRefEmpty, key);
-        if (old == kRefEmpty || old == key) return;
-    }       // (full: the element is evaluated patch by patch)
+        if (old == kRefEmpty || old == key) return (int)s;
+    }
+    return -1;
 }
+
+// one unit: lane = pixel `lane` of quarter q of patch e of the segment whose first image is img0 (an 8x8 patch is its own single
+// quarter) -> chunk sums in T.  wP, nP: patches per image row / per image.
+template <int P>
+__device__ __forceinline__ void refine_unit(const RefineSrc &rf, const float *bins, int64_t img0, int wP, int nP, int e, int q, float *rec, float *T)
+{
+    const int lane = lane_id();
+    const int bi = e / nP, r = e - bi * nP;
+    const int py = r / wP, px = r - py * wP;
+    int64_t y, x;
+    if (P == 16) { y = 16 * (int64_t)py + 4 * q + (lane >> 4); x = 16 * (int64_t)px + (lane & 15); }
+    else         { y = 8 * (int64_t)py + (lane >> 3);          x = 8 * (int64_t)px + (lane & 7); }
+    const float gray = ref_gray_at(rf, img0 + bi, y, x);
+    int j0;
+    float v[kRefWin];
+    ref_pixel(bins, rf.sigma, gray, j0, v);
+    ref_unit_chunks(rec, j0, v, T);
+}
+
+// what a helper needs to know about the launch
+struct RoundCtx {
+    RefineQ rq;
+    RefineSrc rf;
+    int64_t per;
+    int h16, w16;
+};
+__device__ __forceinline__ RoundCtx round_ctx(const RouterArgs &a)
+{
+    RoundCtx c;
+    c.rq = a.rq; c.rf = a.rf; c.per = a.per; c.h16 = (int)a.h16; c.w16 = (int)a.w16;
+    return c;
+}
+// where a select's queue lives
+struct RefineQView {
+    unsigned int *hdr;
+    unsigned long long *items;   // [published] (tag << 32 | patch index of the segment)
+    unsigned long long *vals;    // [n] result by patch index: (tag << 32 | value bits)
+    unsigned int *fidx;          // [<= n] the final (index, value) list a tile's row bands share
+    float *fval;
+};
+__device__ __forceinline__ RefineQView refine_qview(const RefineQ &rq, int64_t N16, int q)
+{
+    const int64_t N8 = 4 * N16;
+    const int seg = q >> 1, bank = q & 1;
+    const size_t n = (size_t)(bank ? N8 : N16);
+    unsigned char *base = rq.scratch + (size_t)seg * refine_scratch_bytes_per_segment(N16, N8) + (bank ? 24 * (size_t)N16 : 0);
+    RefineQView v;
+    v.hdr = rq.hdr + (size_t)q * kTicketStride;
+    v.items = reinterpret_cast<unsigned long long *>(base);
+    v.vals = reinterpret_cast<unsigned long long *>(base + 8 * n);
+    v.fidx = reinterpret_cast<unsigned int *>(base + 16 * n);
+    v.fval = reinterpret_cast<float *>(base + 20 * n);
+    return v;
+}
+__device__ __forceinline__ unsigned long long *refine_qword(const RefineQ &rq, int q)
+{
+    return reinterpret_cast<unsigned long long *>(rq.hdr + (size_t)q * kTicketStride + QH_CLAIM);
+}
+__device__ __forceinline__ unsigned long long granule(unsigned int tag, float v) { return ((unsigned long long)tag << 32) | __float_as_uint(v); }
+
+#ifdef CGIC_PHASE_CLOCKS      // dev: g_phase_clk[20..]: sum of helper item times [10 ns] | helper claims that found nothing | - | items helpers took | VQ waves that helped | publications
+#define CGIC_RQ_COUNT(k, n) atomicAdd((unsigned long long *)&g_phase_clk[20 + (k)], (unsigned long long)(n))
+// dev: per (segment, select) of the first 64 segments: [0] published [1] own rounds exhausted [2] all done [3] items published [4] of which this workgroup's own
+#define CGIC_RQ_STAMP(qid, k, v) do { if (threadIdx.x == 0 && (qid) < 128) g_blk_t[4096 + 8 * (qid) + (k)] = (v); } while (0)
+#else
+#define CGIC_RQ_COUNT(k, n) do {} while (0)
+#define CGIC_RQ_STAMP(qid, k, v) do {} while (0)
+#endif
+
+// One wave with nothing left to do looks for a queue with unclaimed items -- own_q first (-1: none), then the launch's queues,
+// lane = queue, one drawn with probability proportional to what it has left (so that the helpers spread like the work does) --
+// takes one 16x16 patch or up to four 8x8 ones, evaluates them (64 pixels per step) and stores the results.  Returns whether it
+// found anything.  T, rec, P: this wave's LDS scratch; bins: the bin centres in LDS.  No barrier inside.
+static __device__ __forceinline__ bool refine_help_wave(const RoundCtx &c, float *T, float *rec, float *P, const float *bins, int own_q,
+                                                        unsigned int salt)
+{
+    const int lane = lane_id();
+    const int nq = (int)c.rq.nq;
+#ifdef CGIC_PHASE_CLOCKS
+    const long long dbg_t0 = wall_clock64();
+#endif
+#pragma unroll 1
+    for (int attempt = 0; attempt < 4; ++attempt) {
+        int cand = -1;
+        if (own_q >= 0) {
+            const unsigned long long w = ld_sc1(refine_qword(c.rq, own_q));
+            if ((unsigned int)w < (unsigned int)(w >> 32)) cand = own_q;
+        }
+        if (cand < 0) {
+            const unsigned int rnd = ((unsigned int)clock64() ^ (salt * 2654435761u)) + (unsigned int)(attempt * 97);
+            const int nchunk = (nq + 63) >> 6;
+            const int c0 = (int)(salt % (unsigned int)nchunk);
+#pragma unroll 1
+            for (int ci = 0; ci < nchunk && cand < 0; ci += 2) {       // (two chunks per round trip)
+                int ch0 = c0 + ci, ch1 = c0 + ci + 1;
+                if (ch0 >= nchunk) ch0 -= nchunk;
+                if (ch1 >= nchunk) ch1 -= nchunk;
+                const int q0 = 64 * ch0 + lane, q1 = 64 * ch1 + lane;
+                unsigned long long w0 = 0, w1 = 0;
+                if (q0 < nq) w0 = ld_sc1(refine_qword(c.rq, q0));
+                if (ci + 1 < nchunk && q1 < nq) w1 = ld_sc1(refine_qword(c.rq, q1));
+#pragma unroll
+                for (int h = 0; h < 2 && cand < 0; ++h) {
+                    const unsigned long long w = h ? w1 : w0;
+                    const unsigned int wl = (unsigned int)w, wh = (unsigned int)(w >> 32);
+                    const unsigned int left = wl < wh ? wh - wl : 0u;
+                    const unsigned int incl = wave_inclusive_scan_u32(left);
+                    const unsigned int total = (unsigned int)__builtin_amdgcn_readlane((int)incl, 63);
+                    if (total) {
+                        const unsigned int r = rnd % total;
+                        const unsigned long long hit = __ballot(left != 0 && incl - left <= r && r < incl);
+                        const int src = hit ? __builtin_ctzll(hit) : 0;
+                        cand = __builtin_amdgcn_readlane(h ? q1 : q0, src);
+                    }
+                }
+            }
+        }
+        if (cand < 0) return false;
+        const unsigned int take = (cand & 1) ? 4u : 1u;      // (the word as it comes back says how many of them are really there)
+        unsigned int lo = 0, hi = 0;
+        if (lane == 0) {
+            const unsigned long long old = __hip_atomic_fetch_add(refine_qword(c.rq, cand), (unsigned long long)take, __ATOMIC_RELAXED,
+                                                                  __HIP_MEMORY_SCOPE_AGENT);
+            lo = (unsigned int)old; hi = (unsigned int)(old >> 32);
+        }
+        lo = (unsigned int)__builtin_amdgcn_readfirstlane((int)lo);
+        hi = (unsigned int)__builtin_amdgcn_readfirstlane((int)hi);
+        if (lo >= hi) { if (lane == 0) CGIC_RQ_COUNT(1, 1); continue; }
+        const unsigned int got = hi - lo < take ? hi - lo : take;
+        const int n16 = c.h16 * c.w16;
+        const RefineQView v = refine_qview(c.rq, c.per * n16, cand);
+        const int64_t img0 = (int64_t)(cand >> 1) * c.per;
+        unsigned long long it[4];
+#pragma unroll
+        for (unsigned int k = 0; k < 4; ++k) it[k] = k < got ? ld_sc1(v.items + lo + k) : 0ull;      // (all loads in front of the first use)
+#pragma unroll 1
+        for (unsigned int k = 0; k < got; ++k) {
+            const unsigned long long item = k == 0 ? it[0] : k == 1 ? it[1] : k == 2 ? it[2] : it[3];
+            const int e = (int)(unsigned int)item;
+            const unsigned int tag = (unsigned int)(item >> 32);
+            float ent;
+            if (cand & 1) {
+                refine_unit<8>(c.rf, bins, img0, 2 * c.w16, 4 * n16, e, 0, rec, T);
+                ent = ref_finalize(ref_add_rows(0.f, T), 64, P);
+            } else {
+                float acc = 0.f;
+                for (int q = 0; q < 4; ++q) {
+                    refine_unit<16>(c.rf, bins, img0, c.w16, n16, e, q, rec, T);
+                    acc = ref_add_rows(acc, T);
+                }
+                ent = ref_finalize(acc, 256, P);
+            }
+            if (lane == 0) st_sc1(v.vals + e, granule(tag, ent));
+        }
+#ifdef CGIC_PHASE_CLOCKS
+        if (lane == 0) { CGIC_RQ_COUNT(0, wall_clock64() - dbg_t0); CGIC_RQ_COUNT(3, got); }
+#endif
+        return true;
+    }
+    return false;
+}
+
+// The waves of a router workgroup that is done evaluate other images' band patches while a router holds a band open (stand-alone
+// launch).  `tl`: the workgroup's evaluator LDS (bins are set).  Waves beyond the LDS scratch leave at once.
+__device__ __forceinline__ void refine_help_while_busy(const RouterArgs &a, RefineTeamLds *tl)
+{
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    if (wave >= kRefWavesMax) return;
+    const RoundCtx c = round_ctx(a);
+#pragma unroll 1
+    for (;;) {
+        if (refine_help_wave(c, tl->T[wave], tl->rec[wave], tl->P[wave], tl->bins, -1, blockIdx.x * 16u + (unsigned int)wave)) continue;
+        if (ld_sc1(a.rq.board + QB_BUSY) == 0) break;
+        __builtin_amdgcn_s_sleep(32);
+    }
+}
+
+// is_exact of refine_select: element i of the masked medium map is a gated zero -- exactly known, never re-evaluated -- when its
+// coarse parent's gate bit is set
+struct ExactGate {
+    const unsigned long long *gc_bits;      // nullptr: nothing is exact
+    int n8i, w8i, n16i, w16i;
+    unsigned int mg_n8, mg_w8;
+    __device__ __forceinline__ bool operator()(int i) const
+    {
+        if (!gc_bits) return false;
+        const int b = mg_n8 ? (int)__umulhi((unsigned int)i, mg_n8) : i / n8i, r = i - b * n8i;
+        const int y = mg_w8 ? (int)__umulhi((unsigned int)r, mg_w8) : r / w8i, x = r - y * w8i;
+        const int c = b * n16i + (y >> 1) * w16i + (x >> 1);
+        return (gc_bits[c >> 6] >> (c & 63)) & 1ull;
+    }
+};
 
 // One select's refinement.  arr: the LDS copy of the map (n values; element i = patch i of the segment's images in order),
 // t_a: its rank-th smallest value as found, is_exact(i): the value is exact already (a gated zero of the masked medium map).
@@ -202,19 +471,31 @@ __device__ __forceinline__ void flat_insert(unsigned int *keys, unsigned int key
 //   1. count the band (and note its members while they are few); the threshold element alone -> done.
 //   FEW (<= 64 members, the usual case): evaluate the members, then pick the (rank - below)-th smallest among them with one wave.
 //   MANY (flat / smooth content): constant patches first (flat8 says so without touching a pixel): one evaluation per DISTINCT
-//        gray, handed out lane-parallel; the others range by range; then a full select over the patched copy.
-// A patch is 64 pixels per wave and step: an 8x8 patch is one step, a 16x16 one four (quarters of four rows), by four waves side by
-// side when there are at most two patches, else by one wave each (no workgroup barrier inside the sweep).
-template <int NT, int P, typename EX>
-__device__ float refine_select(float *arr, int n, unsigned int rank, float t_a, EX is_exact, const RefineSrc &rf, int64_t img0,
-                               int wP, int nP, RefineShared *rs_, RouterShared *sh, const SelInfo &si, int bank)
+//        gray (its first member stands for all); the others range by range; then a full select over the patched copy.
+// A patch is 64 pixels per wave and step: an 8x8 patch is one step, a 16x16 one four (quarters of four rows).  A list that this
+// workgroup's waves finish in two steps is evaluated here (four waves per 16x16 patch, side by side); a longer one is published
+// to the launch's queue (see above) when there is one, else swept by one wave per patch.
+// Row bands (nb > 1 workgroups per segment, each repeating the selects): with a queue, the first band to arrive at a refinement
+// that goes to the queue owns it; the others evaluate what it publishes and take over its final (index, value) list and threshold.
+// RQ: with the launch's refinement queues (the stand-alone router launch).  The fused VQ + router launch instantiates RQ = false: the
+// queue code inlined into its router workgroups cost the router's ORDINARY path -- that launch's critical path -- 3 to 12 us
+// through register allocation (B = 64 x 256x256: 23.5 -> 29.4 us with the owner's side inlined, 35.8 with the row bands' side as
+// well, no refinement even running), a real function call is not an option (the callee's register count becomes the kernel's:
+// 248, one wave per SIMD), and the VQ workgroups' last waves as helpers bought nothing in a stream of batches (the long launch
+// overlaps the other lanes' work either way, and helpers hold CUs those lanes want: 68 vs 82 GPixel/s on smooth 8-bit batches).
+template <int NT, int P, bool RQ>
+__device__ __forceinline__ float refine_select(const RouterArgs &a, int qid, int nb, float *arr, int n, unsigned int rank, float t_a,
+                                                       ExactGate is_exact, int64_t img0, int wP, int nP, RefineShared *rs_, RouterShared *sh,
+                                                       const SelInfo &si)
 {
     RefineShared *rs = rs_;
+    const RefineSrc &rf = a.rf;
+    const int bank = qid & 1;
     unsigned int *cnt = rs->cnt + 8 * bank;
     constexpr int NW = NT / 64, NWR = NW < kRefWavesMax ? NW : kRefWavesMax;
     constexpr int UPP = P == 16 ? 4 : 1;              // units (64 pixels, one wave and step) per patch
     const int tid = threadIdx.x, lane = lane_id(), wave = tid >> 6;
-    const float w = kRefineBand;
+    const float w = 2.f * refine_delta(t_a + kRefineBand);
     // 0. The usual image leaves here WITHOUT a pass over the map and without a barrier: the select's last pass counted the low
     // key byte of everything that shares the threshold's upper 24 key bits, and a band of +-4e-6 around a value in [0.13, 4) is
     // at most +-250 such steps -- when both band edges share those 24 bits with the threshold (most of the time for values
@@ -269,32 +550,122 @@ __device__ float refine_select(float *arr, int n, unsigned int rank, float t_a, 
     // 25.4 -> 27.4 us when no image refines (the VQ workgroups pay), refining images 35.5 -> 30.3 us; raised only here: both.
     __builtin_amdgcn_s_setprio(3);
 
-    // one unit: lane = pixel `lane` of quarter q of patch e (an 8x8 patch is its own single quarter) -> chunk sums in T
-    auto unit = [&](int e, int q, float *T) {
-        const int bi = e / nP, r = e - bi * nP;
-        const int py = r / wP, px = r - py * wP;
-        int64_t y, x;
-        if (P == 16) { y = 16 * (int64_t)py + 4 * q + (lane >> 4); x = 16 * (int64_t)px + (lane & 15); }
-        else         { y = 8 * (int64_t)py + (lane >> 3);          x = 8 * (int64_t)px + (lane & 7); }
-        const float gray = ref_gray_at(rf, img0 + bi, y, x);
-        int j0;
-        float v[kRefWin];
-        ref_pixel(rs->bins, rf.sigma, gray, j0, v);
-        ref_unit_chunks(rs->rec[wave], j0, v, T);
-    };
-    // evaluate the patches lst[0..L) that `todo` accepts and write their entropies into arr
-    auto sweep = [&](const unsigned int *lst, int L, auto todo) {
-        if (P == 16 && L * UPP <= NWR) {
+    const bool have_q = RQ && a.rq.nq != 0;
+    RefineQView qv;
+    if (have_q) qv = refine_qview(a.rq, a.per * a.h16 * a.w16, qid);
+    const RoundCtx rc = round_ctx(a);
+    bool share = false;           // this workgroup owns a refinement whose outcome the segment's other row bands take over
+
+    auto unit = [&](int e, int q, float *T) { refine_unit<P>(rf, rs->tl.bins, img0, wP, nP, e, q, rs->tl.rec[wave], T); };
+    // Evaluate the patches lst[0..L) that `todo(k, e)` accepts (Lw of them) and hand each result to out(k, e, value).
+    auto sweep = [&](const unsigned int *lst, int L, int Lw, auto todo, auto out) {
+        if (RQ && have_q && Lw * UPP > 4 * NWR) {
+            // ---- through the launch's queue.  The list in queue order, in LDS for this workgroup and in the scratch for everybody else
+            unsigned int *qitems = (Lw == L && lst == rs->list) ? rs->list : rs->list + kRefListCap / 2;
+            if (tid == 0) rs->tag = ld_sc1(qv.hdr + QH_SEQ) + 1u;         // (only a queue's owner touches its publication count)
+            __syncthreads();
+            const unsigned int tag = rs->tag;
+            if (qitems == lst) {
+                for (int k = tid; k < L; k += NT) {
+                    const unsigned int e = lst[k];
+                    st_sc1(qv.vals + e, 0ull);                             // (tags start at 1: whatever the slot held, it is not of this list)
+                    st_sc1(qv.items + k, ((unsigned long long)tag << 32) | e);
+                }
+            } else {
+                for (int k = tid; k < L; k += NT) {
+                    const unsigned int e = lst[k];
+                    if (todo(k, (int)e)) {
+                        const unsigned int pos = atomicAdd(&cnt[4], 1u);
+                        qitems[pos] = e;
+                        st_sc1(qv.vals + e, 0ull);
+                        st_sc1(qv.items + pos, ((unsigned long long)tag << 32) | e);
+                    }
+                }
+            }
+            drain_stores();
+            __syncthreads();
+            const unsigned int Lq = (unsigned int)Lw;
+            // The owner takes its own items a round at a time -- NWR units: two 16x16 patches (four waves each, side by side) or
+            // eight 8x8 ones -- at the pace of the in-workgroup sweep: the items are in LDS, and the ONE fetch-and-add per round
+            // that keeps the launch's idle waves off them is issued a round ahead.  It never sits on more than two rounds:
+            // whatever it has not claimed those waves take as soon as they are free (refine_help_wave).
+            constexpr unsigned int PER = (unsigned int)(NWR / UPP);       // patches per round
+            auto claim = [&]() -> unsigned long long {
+                return __hip_atomic_fetch_add(refine_qword(a.rq, qid), (unsigned long long)PER, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            };
+            auto post = [&](unsigned long long old) {        // thread 0: what the claim got -> the round's slot
+                const unsigned int lo = (unsigned int)old, hi = (unsigned int)(old >> 32);
+                rs->tl.job_first = lo;
+                rs->tl.job_count = lo < hi ? (hi - lo < PER ? hi - lo : PER) : 0u;
+            };
+            if (tid == 0) {
+                if (!rs->busy_held) { rs->busy_held = 1; add_sc1(a.rq.board + QB_BUSY, 1u); }
+                st_sc1(qv.hdr + QH_SEQ, tag);
+                st_sc1(refine_qword(a.rq, qid), (unsigned long long)Lq << 32);
+                CGIC_RQ_COUNT(5, 1);
+                CGIC_RQ_STAMP(qid, 0, wall_clock64());
+                CGIC_RQ_STAMP(qid, 3, Lq);
+                post(claim());
+            }
+            __syncthreads();
+            unsigned int mine = 0;
+#pragma unroll 1
+            for (;;) {
+                const unsigned int got = rs->tl.job_count, first = rs->tl.job_first;
+                __syncthreads();
+                if (!got) break;
+                unsigned long long nextc = 0;
+                if (tid == 0) nextc = claim();                  // (the next round: its round trip runs under this one's evaluation)
+                const int slot = wave / UPP;                    // which of the round's patches this wave works on
+                const bool go = wave < NWR && (unsigned int)slot < got;
+                const int e = go ? (int)qitems[first + slot] : 0;
+                if (go) unit(e, wave % UPP, rs->tl.T[wave]);
+                if (UPP > 1) __syncthreads();
+                if (go && wave % UPP == 0) {
+                    float acc = 0.f;
+                    for (int q = 0; q < UPP; ++q) acc = ref_add_rows(acc, rs->tl.T[wave + q]);
+                    const float ent = ref_finalize(acc, P * P, rs->tl.P[wave]);
+                    if (lane == 0) st_sc1(qv.vals + e, granule(tag, ent));
+                }
+                mine += got;
+                if (tid == 0) post(nextc);
+                __syncthreads();
+            }
+            // the rest is with other waves of the launch (or done): poll the result slots
+            CGIC_RQ_STAMP(qid, 1, wall_clock64());
+            CGIC_RQ_STAMP(qid, 4, mine); (void)mine;
+            drain_stores();               // (this workgroup's own results)
+#pragma unroll 1
+            for (;;) {
+                if (tid == 0) rs->flag = 0;
+                __syncthreads();
+                unsigned int missing = 0;
+                for (unsigned int k = tid; k < Lq; k += NT)
+                    missing += (unsigned int)(ld_sc1(qv.vals + qitems[k]) >> 32) != tag ? 1u : 0u;
+                if (missing) rs->flag = 1;
+                __syncthreads();
+                const unsigned int again = rs->flag;
+                __syncthreads();
+                if (!again) break;
+                __builtin_amdgcn_s_sleep(4);
+            }
+            CGIC_RQ_STAMP(qid, 2, wall_clock64());
+            if (tid == 0) cnt[4] = 0;
+            for (int k = tid; k < L; k += NT) {
+                const int e = (int)lst[k];
+                if (todo(k, e)) out(k, e, __uint_as_float((unsigned int)ld_sc1(qv.vals + e)));
+            }
+        } else if (P == 16 && L * UPP <= NWR) {
             // a couple of 16x16 patches: four waves each, side by side
             const int e = wave < L * UPP ? (int)lst[wave / UPP] : -1;
             const bool go = e >= 0 && todo(wave / UPP, e);
-            if (go) unit(e, wave % UPP, rs->T[wave]);
+            if (go) unit(e, wave % UPP, rs->tl.T[wave]);
             __syncthreads();
             if (go && wave % UPP == 0) {
                 float acc = 0.f;
-                for (int q = 0; q < UPP; ++q) acc = ref_add_rows(acc, rs->T[wave + q]);
-                const float ent = ref_finalize(acc, P * P, rs->P[wave]);
-                if (lane == 0) arr[e] = ent;
+                for (int q = 0; q < UPP; ++q) acc = ref_add_rows(acc, rs->tl.T[wave + q]);
+                const float ent = ref_finalize(acc, P * P, rs->tl.P[wave]);
+                if (lane == 0) out(wave / UPP, e, ent);
             }
         } else if (wave < NWR) {
             for (int k = wave; k < L; k += NWR) {
@@ -302,11 +673,11 @@ __device__ float refine_select(float *arr, int n, unsigned int rank, float t_a, 
                 if (!todo(k, e)) continue;                            // (wave-uniform)
                 float acc = 0.f;
                 for (int q = 0; q < UPP; ++q) {
-                    unit(e, q, rs->T[wave]);
-                    acc = ref_add_rows(acc, rs->T[wave]);
+                    unit(e, q, rs->tl.T[wave]);
+                    acc = ref_add_rows(acc, rs->tl.T[wave]);
                 }
-                const float ent = ref_finalize(acc, P * P, rs->P[wave]);
-                if (lane == 0) arr[e] = ent;
+                const float ent = ref_finalize(acc, P * P, rs->tl.P[wave]);
+                if (lane == 0) out(k, e, ent);
             }
         }
         __syncthreads();
@@ -321,24 +692,76 @@ __device__ float refine_select(float *arr, int n, unsigned int rank, float t_a, 
         return (f == q[1] && f == q[2 * wP] && f == q[2 * wP + 1]) ? __float_as_uint(f) : kRefEmpty;           // (NaN: never equal)
     };
 
-    if (m_all <= 64 && rank >= c_below && rank - c_below < m_all) {
-        // constant patches of one gray are one evaluation: member k is evaluated only if it is the first of its gray.  Every wave
-        // works that out for itself (lane = member): no LDS, no barrier
-        unsigned int key = kRefEmpty;
-        const int my = lane < (int)m_all ? (int)rs->small[lane] : 0;
-        const bool exact_l = lane < (int)m_all ? is_exact(my) : true;
+    const bool few = m_all <= 64 && rank >= c_below && rank - c_below < m_all;
+    // FEW: constant patches of one gray are one evaluation: member k is evaluated only if it is the first of its gray.  Every wave
+    // works that out for itself (lane = member): no LDS, no barrier
+    unsigned int key = kRefEmpty;
+    int my = 0, lead = lane;
+    bool exact_l = true;
+    unsigned long long work = 0;
+    if (few) {
+        my = lane < (int)m_all ? (int)rs->small[lane] : 0;
+        exact_l = lane < (int)m_all ? is_exact(my) : true;
         if (flat && lane < (int)m_all && !exact_l) key = flat_key_of(my);
-        int lead = lane;
         for (int j = (int)m_all - 1; j >= 0; --j) {
             const unsigned int kj = (unsigned int)__builtin_amdgcn_readlane((int)key, j);
             if (kj == key && key != kRefEmpty) lead = j;                  // ends at the smallest j of this gray
         }
-        const unsigned long long work = __ballot(lane < (int)m_all && !exact_l && lead == lane);      // bit k: member k is evaluated
-        sweep(rs->small, (int)m_all, [&](int k, int) { return (work >> k) & 1ull; });
+        work = __ballot(lane < (int)m_all && !exact_l && lead == lane);      // bit k: member k is evaluated
+    }
+    // Row bands: does this refinement go to the queue?  (The same answer in every band: the counts do not depend on the order in
+    // which a band's threads listed the members.)  Then the first band to arrive does it for all.
+    if (RQ && nb > 1 && have_q && (!few || __builtin_popcountll(work) * UPP > 4 * NWR)) {
+        if (tid == 0) rs->flag = add_sc1(qv.hdr + QH_ARRIVE, 1u);
+        __syncthreads();
+        share = rs->flag == 0;
+        if (!share) {
+            // not the owner: its waves evaluate what the owner publishes (or anything else) until the outcome is there, then take it over
+            if (wave < NWR) {
+#pragma unroll 1
+                for (;;) {
+                    if (refine_help_wave(rc, rs->tl.T[wave], rs->tl.rec[wave], rs->tl.P[wave], rs->tl.bins, qid, blockIdx.x * 16u + (unsigned int)wave)) continue;
+                    if (ld_sc1(qv.hdr + QH_FIN)) break;
+                    __builtin_amdgcn_s_sleep(4);
+                }
+            }
+            __syncthreads();
+            const unsigned int nf = ld_sc1(qv.hdr + QH_NFINAL);
+            const float thr = __uint_as_float(ld_sc1(qv.hdr + QH_THR));
+            for (unsigned int k = tid; k < nf; k += NT) arr[ld_sc1(qv.fidx + k)] = ld_sc1(qv.fval + k);
+            __syncthreads();
+            if (tid == 0 && add_sc1(qv.hdr + QH_LEFT, 1u) == (unsigned int)nb - 1u) {       // the last band out restores the header
+                st_sc1(qv.hdr + QH_ARRIVE, 0u); st_sc1(qv.hdr + QH_FIN, 0u); st_sc1(qv.hdr + QH_LEFT, 0u);
+                st_sc1(qv.hdr + QH_THR, 0u); st_sc1(qv.hdr + QH_NFINAL, 0u);
+            }
+            __builtin_amdgcn_s_setprio(0);
+            return thr;
+        }
+    }
+    // the owner's hand-over to the other row bands: the final list is complete in qv.fidx / qv.fval (nf entries)
+    auto hand_over = [&](unsigned int nf, float thr) {
+        drain_stores();
+        __syncthreads();
+        if (tid == 0) {
+            st_sc1(qv.hdr + QH_NFINAL, nf);
+            st_sc1(qv.hdr + QH_THR, __float_as_uint(thr));
+            drain_stores();
+            st_sc1(qv.hdr + QH_FIN, 1u);
+            if (add_sc1(qv.hdr + QH_LEFT, 1u) == (unsigned int)nb - 1u) {
+                st_sc1(qv.hdr + QH_ARRIVE, 0u); st_sc1(qv.hdr + QH_FIN, 0u); st_sc1(qv.hdr + QH_LEFT, 0u);
+                st_sc1(qv.hdr + QH_THR, 0u); st_sc1(qv.hdr + QH_NFINAL, 0u);
+            }
+        }
+    };
+
+    if (few) {
+        sweep(rs->small, (int)m_all, __builtin_popcountll(work), [&](int k, int) { return (work >> k) & 1ull; },
+              [&](int, int e, float ent) { arr[e] = ent; });
         // everything below the band is below the true threshold, everything above it above: it is the band's (rank - below)-th
         if (wave == 0) {
             float v = lane < (int)m_all ? arr[rs->small[lead]] : __builtin_inff();        // (a follower takes its leader's value)
             if (lane < (int)m_all && lead != lane) arr[my] = v;
+            if (share && lane < (int)m_all) { st_sc1(qv.fidx + lane, (unsigned int)my); st_sc1(qv.fval + lane, v); }
             unsigned int less = 0, leq = 0;
             for (unsigned int j = 0; j < m_all; ++j) {
                 const float vj = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), (int)j));
@@ -349,34 +772,55 @@ __device__ float refine_select(float *arr, int n, unsigned int rank, float t_a, 
             if (lane < (int)m_all && less <= r && r < leq) rs->thr = v;       // (lanes holding equal values write the same bits)
         }
         __syncthreads();
+        const float thr = rs->thr;
+        if (share) hand_over(m_all, thr);
         __builtin_amdgcn_s_setprio(0);
-        return rs->thr;
+        return thr;
     }
 
     // ---- MANY.  Membership of the band is decided on the values as they were when the select ran: every element is tested
     // before it is written, and written once.
     auto in_band = [&](int i) { return fabsf(arr[i] - t_a) <= w && !is_exact(i); };
+    auto put = [&](int i, float v) {
+        arr[i] = v;
+        if (share) { const unsigned int pos = atomicAdd(&cnt[5], 1u); st_sc1(qv.fidx + pos, (unsigned int)i); st_sc1(qv.fval + pos, v); }
+    };
     if (flat) {
-        for (int i = tid; i < kRefFlatSlots; i += NT) rs->flat_key[i] = kRefEmpty;
+        // the distinct grays of the band's constant patches; the member with the smallest index stands for its gray
+        unsigned int *flat_rep = rs->list;               // [kRefFlatSlots] (the list is free until the ranges below)
+        for (int i = tid; i < kRefFlatSlots; i += NT) { rs->flat_key[i] = kRefEmpty; flat_rep[i] = kRefEmpty; }
         __syncthreads();
         for (int i = tid; i < n; i += NT)
-            if (in_band(i)) { const unsigned int k = flat_key_of(i); if (k != kRefEmpty) flat_insert(rs->flat_key, k); }
-        __syncthreads();
-        if (wave < NWR) {
-            for (int s = wave; s < kRefFlatSlots; s += NWR) {
-                const unsigned int k = rs->flat_key[s];              // (wave-uniform)
-                if (k == kRefEmpty) continue;
-                int j0;
-                float v[kRefWin];
-                ref_pixel(rs->bins, rf.sigma, __uint_as_float(k), j0, v);        // every pixel of the patch is this one
-                ref_unit_chunks(rs->rec[wave], j0, v, rs->T[wave]);
-                float acc = 0.f;
-                for (int q = 0; q < UPP; ++q) acc = ref_add_rows(acc, rs->T[wave]);
-                const float ent = ref_finalize(acc, P * P, rs->P[wave]);
-                if (lane == 0) rs->flat_val[s] = ent;
+            if (in_band(i)) {
+                const unsigned int k = flat_key_of(i);
+                if (k != kRefEmpty) { const int slot = flat_insert(rs->flat_key, k); if (slot >= 0) atomicMin(&flat_rep[slot], (unsigned int)i); }
             }
-        }
         __syncthreads();
+        unsigned int used = 0;
+        for (int i = lane; i < kRefFlatSlots; i += 64) used += rs->flat_key[i] != kRefEmpty ? 1u : 0u;
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) used += __shfl_xor(used, d, kWave);
+        if (RQ && have_q && (int)used * UPP > 4 * NWR) {
+            // (evaluated from the pixels like any other patch -- 64 or 256 equal ones: the same bits as one evaluation of the gray)
+            sweep(flat_rep, kRefFlatSlots, (int)used, [&](int, int e) { return (unsigned int)e != kRefEmpty; },
+                  [&](int k, int, float ent) { rs->flat_val[k] = ent; });
+        } else {
+            if (wave < NWR) {
+                for (int s = wave; s < kRefFlatSlots; s += NWR) {
+                    const unsigned int k = rs->flat_key[s];              // (wave-uniform)
+                    if (k == kRefEmpty) continue;
+                    int j0;
+                    float v[kRefWin];
+                    ref_pixel(rs->tl.bins, rf.sigma, __uint_as_float(k), j0, v);        // every pixel of the patch is this one
+                    ref_unit_chunks(rs->tl.rec[wave], j0, v, rs->tl.T[wave]);
+                    float acc = 0.f;
+                    for (int q = 0; q < UPP; ++q) acc = ref_add_rows(acc, rs->tl.T[wave]);
+                    const float ent = ref_finalize(acc, P * P, rs->tl.P[wave]);
+                    if (lane == 0) rs->flat_val[s] = ent;
+                }
+            }
+            __syncthreads();
+        }
     }
     for (int base = 0; base < n; base += kRefListCap) {
         if (tid == 0) cnt[2] = 0;
@@ -386,14 +830,16 @@ __device__ float refine_select(float *arr, int n, unsigned int rank, float t_a, 
             if (!in_band(i)) continue;
             int slot = -1;
             if (flat) { const unsigned int k = flat_key_of(i); if (k != kRefEmpty) slot = flat_find(rs->flat_key, k); }
-            if (slot >= 0) arr[i] = rs->flat_val[slot];
+            if (slot >= 0) put(i, rs->flat_val[slot]);
             else rs->list[atomicAdd(&cnt[2], 1u)] = (unsigned int)i;
         }
         __syncthreads();
-        sweep(rs->list, (int)cnt[2], [](int, int) { return true; });
+        const int L = (int)cnt[2];
+        sweep(rs->list, L, L, [](int, int) { return true; }, [&](int, int e, float ent) { put(e, ent); });
     }
     const lds_cf32 arr_l = as_lds(arr);                  // (refinement only runs on staged maps)
     const float thr = radix_select<NT>([&](int64_t i) { return arr_l[i]; }, n, rank, sh);
+    if (share) { __syncthreads(); hand_over(cnt[5], thr); }
     __builtin_amdgcn_s_setprio(0);
     return thr;
 }
@@ -401,17 +847,19 @@ __device__ float refine_select(float *arr, int n, unsigned int rank, float t_a, 
 // The whole router for segment `seg`, executed by a block of NT threads; `dyn` = dynamic LDS of at least router_lds_bytes() bytes.
 // ST: both maps are staged in LDS (a.stage == 1: every segment that fits -- per-image routing up to 768x768 tiles): the copy the
 // launches of the timed paths run, all element reads ds_read; the other copy serves the unstaged / half-staged segments.
-template <int NT, bool ST>
+// HELP: the stand-alone launch -- with the refinement queues (refine_select's RQ), and a router workgroup that is done evaluates
+// other images' band patches while any is open.  The fused launch's routers refine inside their own workgroup only.
+template <int NT, bool ST, bool HELP>
 __device__ __forceinline__ void router_team(const RouterArgs &a, int64_t blk, unsigned char *dyn);
 
-template <int NT>
+template <int NT, bool HELP = false>
 __device__ __forceinline__ void router_body(const RouterArgs &a, int64_t blk, unsigned char *dyn)
 {
-    if (a.stage == 1) router_team<NT, true>(a, blk, dyn);
-    else router_team<NT, false>(a, blk, dyn);
+    if (a.stage == 1) router_team<NT, true, HELP>(a, blk, dyn);
+    else router_team<NT, false, false>(a, blk, dyn);
 }
 
-template <int NT, bool ST>
+template <int NT, bool ST, bool HELP>
 __device__ __forceinline__ void router_team(const RouterArgs &a, int64_t blk, unsigned char *dyn)
 {
     const int nb = a.bands > 1 ? a.bands : 1;
@@ -450,7 +898,8 @@ __device__ __forceinline__ void router_team(const RouterArgs &a, int64_t blk, un
         if (a.rf.x) {
             rs = reinterpret_cast<RefineShared *>((reinterpret_cast<uintptr_t>(l8 + N8) + 15) & ~(uintptr_t)15);
             if (tid < 16) rs->cnt[tid] = 0;
-            if (tid < kBins) rs->bins[tid] = linspace_bin(tid);
+            if (tid == 0) rs->busy_held = 0;
+            if (tid < kBins) rs->tl.bins[tid] = linspace_bin(tid);
         }
         __syncthreads();
     }
@@ -470,9 +919,9 @@ __device__ __forceinline__ void router_team(const RouterArgs &a, int64_t blk, un
     if (has_thr_c) {
         SelInfo si;
         thr_c = radix_select<NT>(rd16, N16, a.rank_c, sh, &si);
-        if (refine)
-            thr_c = refine_select<NT, 16>(const_cast<float *>(e16), (int)N16, a.rank_c, thr_c, [](int) { return false; }, a.rf,
-                                          seg * a.per, (int)w16, (int)n16, rs, sh, si, 0);
+        if constexpr (ST) if (refine)
+            thr_c = refine_select<NT, 16, HELP>(a, (int)(2 * seg), nb, const_cast<float *>(e16), (int)N16, a.rank_c, thr_c, ExactGate{nullptr, 0, 0, 0, 0, 0, 0},
+                                          seg * a.per, (int)w16, (int)n16, rs, sh, si);
     }
     CGIC_STAMP(2);
     CGIC_RT_STAMP(1);
@@ -531,9 +980,9 @@ __device__ __forceinline__ void router_team(const RouterArgs &a, int64_t blk, un
             __syncthreads();
             SelInfo si;
             thr_m = radix_select<NT>(rd8, N8, a.rank_m, sh, &si);        // (stage 2: the masked copy through the generic pointer)
-            if (refine)       // (a gated element's 0 is exact: never re-evaluated, never overwritten)
-                thr_m = refine_select<NT, 8>(l8m, (int)N8, a.rank_m, thr_m, [&](int i) { return gc_of8(i); }, a.rf, seg * a.per, w8i,
-                                             n8i, rs, sh, si, 1);
+            if constexpr (ST) if (refine)       // (a gated element's 0 is exact: never re-evaluated, never overwritten)
+                thr_m = refine_select<NT, 8, HELP>(a, (int)(2 * seg + 1), nb, l8m, (int)N8, a.rank_m, thr_m,
+                                             ExactGate{gc_bits, n8i, w8i, n16i, w16i, mg_n8, mg_w8}, seg * a.per, w8i, n8i, rs, sh, si);
         } else {
             thr_m = radix_select<NT>([&](int64_t i) { return e8[i] * (1.0f - (gc_of8(i) ? 1.0f : 0.0f)); }, N8, a.rank_m, sh);
         }
@@ -541,9 +990,9 @@ __device__ __forceinline__ void router_team(const RouterArgs &a, int64_t blk, un
     if (mode == 1) {      // :40-43
         SelInfo si;
         thr_m = radix_select<NT>(rd8, N8, a.rank_m, sh, &si);
-        if (refine)
-            thr_m = refine_select<NT, 8>(const_cast<float *>(e8), (int)N8, a.rank_m, thr_m, [](int) { return false; }, a.rf, seg * a.per,
-                                         w8i, n8i, rs, sh, si, 1);
+        if constexpr (ST) if (refine)
+            thr_m = refine_select<NT, 8, HELP>(a, (int)(2 * seg + 1), nb, const_cast<float *>(e8), (int)N8, a.rank_m, thr_m, ExactGate{nullptr, 0, 0, 0, 0, 0, 0},
+                                         seg * a.per, w8i, n8i, rs, sh, si);
     }
     auto gm_rule = [&](float v, bool gc) -> bool {
         switch (mode) {
@@ -555,6 +1004,12 @@ __device__ __forceinline__ void router_team(const RouterArgs &a, int64_t blk, un
         }
     };
     auto gm_of8 = [&](int64_t i) -> bool { return gm_rule(rd8(i), (mode == 0 || mode == 3) ? gc_of8(i) : false); };
+    // past the last select: this workgroup no longer holds a band open (helpers of the launch may leave)
+    unsigned int board_busy = 0;
+    if (refine && a.rq.nq && tid == 0) {
+        if (rs->busy_held) { rs->busy_held = 0; __hip_atomic_fetch_sub(a.rq.board + QB_BUSY, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+        if (HELP) board_busy = ld_sc1(a.rq.board + QB_BUSY);          // (consumed behind the mask writes)
+    }
     CGIC_STAMP(4);
     CGIC_RT_STAMP(2);
     if (rows2d) {
@@ -607,6 +1062,11 @@ __device__ __forceinline__ void router_team(const RouterArgs &a, int64_t blk, un
     }
     CGIC_STAMP(6);
     CGIC_RT_STAMP(3);
+    if (HELP && refine && a.rq.nq) {
+        if (tid == 0) rs->flag = board_busy;
+        __syncthreads();
+        if (rs->flag) refine_help_while_busy(a, &rs->tl);
+    }
 }
 
 
@@ -630,7 +1090,8 @@ __host__ __device__ inline size_t router_lds_bytes(int64_t N16, int64_t N8, int 
 // host-side argument preparation shared by the stand-alone and the VQ-fused launch
 int router_prepare(const float *e16, const float *e8, int64_t B, int64_t h16, int64_t w16, double c_ratio,
                    double m_ratio, int per_image, int32_t *mask_c, int32_t *mask_m, int32_t *mask_f, float *gate,
-                   RouterArgs *out, int64_t *nseg, size_t *lds, size_t lds_budget = 96 * 1024, const cgic_pixels *refine = nullptr);
+                   RouterArgs *out, int64_t *nseg, size_t *lds, size_t lds_budget = 96 * 1024, const cgic_pixels *refine = nullptr,
+                   hipStream_t stream = nullptr, bool queues = false);
 
 // LDS budget of a router workgroup in the fused VQ + router launch (two allocations per 160 KB CU); refinement is offered
 // for segments that fit THIS budget, in the stand-alone launch too, so that one answer holds for both

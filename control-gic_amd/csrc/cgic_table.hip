@@ -85,7 +85,7 @@ static void free_range(TicketPool &p, TicketRange r)
     }
 }
 
-int acquire_tickets(hipStream_t s, int n, unsigned int **ptr)
+int acquire_tickets(hipStream_t s, int n, unsigned int **ptr, int kind)
 {
     CGIC_REQUIRE(n > 0 && (size_t)n <= kRingSlots / 4, CGIC_ERR_INVALID, "acquire_tickets: bad count %d", n);
     int dev = 0;
@@ -93,7 +93,7 @@ int acquire_tickets(hipStream_t s, int n, unsigned int **ptr)
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
     CGIC_HIP_TRY(hipStreamIsCapturing(s, &cap));
     std::lock_guard<std::mutex> lock(g_ticket_mu);
-    TicketPool &p = g_ticket_pools[dev];
+    TicketPool &p = g_ticket_pools[2 * dev + (kind ? 1 : 0)];      // (kind 1: the router's refinement headers -- their own memory, their own contract)
     if (cap == hipStreamCaptureStatusNone) {
         if (!p.chunk) {
             CGIC_HIP_TRY(hipMalloc((void **)&p.chunk, sizeof(unsigned int) * kTicketStride * kChunkSlots));
@@ -354,7 +354,7 @@ extern "C" int cgic_ticket_slots_in_use(void)
     int dev = 0;
     CGIC_HIP_TRY(hipGetDevice(&dev));
     std::lock_guard<std::mutex> lock(g_ticket_mu);
-    const TicketPool &p = g_ticket_pools[dev];
+    const TicketPool &p = g_ticket_pools[2 * dev];
     size_t used = p.chunk_next;
     for (const TicketRange &r : p.free_ranges) used -= r.count;
     return (int)used;

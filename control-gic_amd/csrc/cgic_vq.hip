@@ -1564,7 +1564,7 @@ extern "C" int cgic_vq_forward_route_f32(const float *z, int64_t B, int64_t hw, 
     size_t rlds;
     // (78 KB: a router workgroup of the fused launch shares its CU with a VQ workgroup -- two allocations per 160 KB)
     rc = router_prepare(e16, e8, B, h16, w16, coarse_ratio, medium_ratio, per_image, mask_c, mask_m, mask_f, gate, &r, &nseg, &rlds,
-                        kRouterFusedLds, refine);
+                        kRouterFusedLds, refine, (hipStream_t)stream);
     if (rc) return rc;
     hipStream_t s = (hipStream_t)stream;
     VqWs ws;

@@ -60,7 +60,7 @@ class TripleGrainFixedEntropyRouter(nn.Module):
         mf = torch.empty((B, 1, 4 * h16, 4 * w16), dtype=torch.int32, device=dev)
         gate = torch.empty((B, 1, 4 * h16, 12 * w16), dtype=torch.float32, device=dev) if want_gate else None
         mode = ctypes.c_int(0)
-        px, keep = _lib.pixels_arg(pixels if self.refine else None, B, h16, w16, self.per_image, flat8=flat8)
+        px, keep = _lib.pixels_arg(pixels if self.refine else None, B, h16, w16, self.per_image, flat8=flat8, queues=True)
         with torch.cuda.device(dev):
             _lib.call("cgic_router_f32", _lib.ptr(e16), _lib.ptr(e8), B, h16, w16,
                       float(self.coarse_grain_ratio), float(self.medium_grain_ratio), int(bool(self.per_image)),

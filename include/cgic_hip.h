@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define CGIC_ABI_VERSION 6
+#define CGIC_ABI_VERSION 7
 
 #define CGIC_OK 0
 #define CGIC_ERR_INVALID (-1)     /* bad argument (shape, ratio, NULL pointer ...) */
@@ -138,7 +138,15 @@ typedef struct cgic_pixels {
     const float *flat8; /* device [B, 2 h16, 2 w16] fp32 or NULL: the flat8 output of the entropy call that made the maps.
                          * Without it constant patches are re-evaluated one by one like any other (same result, slower on
                          * flat content) */
+    void *scratch;      /* device, cgic_router_refine_scratch_bytes(...) bytes, or NULL (ABI 7).  With it a long band -- smooth or
+                         * flat 8-bit content puts tens to hundreds of patches within the band of a threshold -- is evaluated
+                         * by every idle workgroup of the launch (the other row bands of a tile, finished router workgroups,
+                         * the VQ workgroups of the fused launch once their own work is done) instead of by the image's one
+                         * router workgroup.  Same masks either way.  Uninitialised memory; one per launch in flight */
+    size_t scratch_bytes;
 } cgic_pixels;
+/* scratch for cgic_pixels.scratch of a router / fused call with these arguments (0: the call takes none) */
+size_t cgic_router_refine_scratch_bytes(int64_t B, int64_t h16, int64_t w16, int per_image);
 
 typedef struct cgic_conv1x1 {
     const float *weight;   /* device [4, 4] fp32 = Conv2d.weight[:, :, 0, 0], row = output channel */

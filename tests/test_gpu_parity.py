@@ -225,6 +225,43 @@ def test_entropy_tie_families_vs_reference_fixture(golden, name):
     e8, e16 = cg.entropy_maps(x.to(DEV))
     assert np.abs(e8.cpu().numpy() - g[name + "_e8"]).max() < 2e-6
     assert np.abs(e16.cpu().numpy() - g[name + "_e16"]).max() < 2e-6
+    # ... and by value: the bound the router's band width is made of (cgic_router_dev.h: refine_delta), against the REAL class
+    for e, ref in ((e8, g[name + "_e8"]), (e16, g[name + "_e16"])):
+        assert (np.abs(e.cpu().numpy().astype(np.float64) - ref) <= _refine_delta(ref)).all()
+
+
+def _refine_delta(v):
+    """cgic_router_dev.h: refine_delta -- the default entropy kernel's error bound by value"""
+    v = np.asarray(v, np.float64)
+    return np.minimum(2e-6, 7e-7 + 0.01 * np.maximum(0.0, v - 1e-4))
+
+
+def test_entropy_error_by_value_holds_the_band_width():
+    """The router's threshold band is 2 x refine_delta(threshold): the default kernel against the reference-arithmetic kernel on
+    every content family, 768x768 tiles, smooth gradients of other amplitudes / frequencies (8-bit and fp32) -- the error has to
+    stay under the bound everywhere, with room (<= 0.7 of it)"""
+    from oracle.content_families import families
+    rng = np.random.default_rng(1)
+    sets = dict(families(n=16))
+    sets.update({"tile_" + k: v for k, v in families(n=1, H=768, W=768, seed=11).items()})
+    sets["rand"] = rng.random((16, 3, 256, 256)).astype(np.float32)
+    yy, xx = np.mgrid[0:256, 0:256].astype(np.float32)
+    gsm = np.empty((32, 3, 256, 256), np.float32)
+    for i in range(32):
+        a = rng.uniform(0, 2 * np.pi); f = rng.uniform(0.05, 3.0)
+        base = rng.uniform(0.1, 0.9) + rng.uniform(0.01, 0.4) * np.sin((np.cos(a) * xx + np.sin(a) * yy) * f * 2 * np.pi / 256)
+        for c in range(3):
+            gsm[i, c] = base * rng.uniform(0.5, 1.0) + rng.integers(-2, 3, (256, 256)) / 255.0 * rng.integers(0, 2)
+    sets["smooth_var8"] = np.round(np.clip(gsm, 0, 1) * 255.0).astype(np.float32) / 255.0
+    sets["smooth_f32"] = np.clip(gsm, 0, 1).astype(np.float32)
+    for name, x in sets.items():
+        xd = _t(x)
+        e8, e16 = cg.entropy_maps(xd)
+        r8, r16 = cg.entropy_maps(xd, reference_order=True)
+        for e, r in ((e8, r8), (e16, r16)):
+            r = r.cpu().numpy().astype(np.float64)
+            worst = (np.abs(e.cpu().numpy() - r) / _refine_delta(r)).max()
+            assert worst <= 0.7, (name, worst)
 
 
 def test_reference_arithmetic_entropy_kernel(orc, golden):
@@ -340,8 +377,8 @@ def test_refined_router_equals_router_on_reference_arithmetic_maps(ratio):
     """The refinement's claim, checked on the GPU alone: router(default maps, pixels) == router(reference-arithmetic maps) --
     every patch within the band of a threshold is re-evaluated with the arithmetic of cgic_entropy_maps_ref_f32, everything
     outside the band keeps its side.  All four modes that compare (0, 1, 2, 3), stand-alone and VQ-fused launch, fp32 pixels and
-    uint8 frames, images and 768x768 tiles (several workgroups per image), plus maps perturbed by +-1.5e-6 (within the band's
-    error budget): the masks must not move."""
+    uint8 frames, images and 768x768 tiles (several workgroups per image), plus maps perturbed by +-0.95 of the kernel's error
+    bound by value (refine_delta: what the band is made of): the masks must not move."""
     from control_gic_amd.quantize import vq_forward_route
     c, m = ratio
     router = cg.TripleGrainFixedEntropyRouter(c, m, per_image=True)
@@ -358,9 +395,10 @@ def test_refined_router_equals_router_on_reference_arithmetic_maps(ratio):
         z = _t(rng.standard_normal((B, 4, H // 4, W // 4), dtype=np.float32))
         fused = vq_forward_route(z, w, 0.25, True, e16, e8, c, m, per_image=True, pixels=xd)[3]
         assert all(torch.equal(a, b) for a, b in zip(fused, want)), (name, ratio, "fused")
-        # the maps may sit anywhere within the kernel's error of the reference arithmetic
-        n8 = (torch.rand(e8.shape, device=DEV) - 0.5) * 3e-6
-        n16 = (torch.rand(e16.shape, device=DEV) - 0.5) * 3e-6
+        # the maps may sit anywhere within the kernel's error bound (by value: refine_delta) of the reference arithmetic
+        dl = lambda r: torch.clamp(7e-7 + 0.01 * torch.clamp(r - 1e-4, min=0.0), max=2e-6)
+        n8 = (torch.rand(e8.shape, device=DEV) - 0.5) * 1.9 * dl(r8)
+        n16 = (torch.rand(e16.shape, device=DEV) - 0.5) * 1.9 * dl(r16)
         got = router(r16 + n16, r8 + n8, want_gate=False, pixels=xd)[0]
         assert all(torch.equal(a, b) for a, b in zip(got, want)), (name, ratio, "perturbed")
         if name in ("smooth8", "tiles_768"):
@@ -369,6 +407,55 @@ def test_refined_router_equals_router_on_reference_arithmetic_maps(ratio):
             assert torch.equal(x2, xd) and torch.equal(f8, e8) and torch.equal(f16, e16)
             got = router(f16, f8, want_gate=False, pixels=frames)[0]
             assert all(torch.equal(a, b) for a, b in zip(got, want)), (name, ratio, "uint8 frames")
+
+
+def test_refinement_queues_change_nothing_and_survive_concurrent_launches():
+    """The stand-alone router launch evaluates long bands with every idle wave of the launch (refinement queues: the band's
+    owner publishes its patch list; the other row bands of a tile and router workgroups that are done take patches; results as
+    tagged 8-byte granules): masks identical with and without the queues and to the routing on the reference-arithmetic maps --
+    batches of images, 768x768 tiles (eight row bands per tile share one select), uint8 frames, repeated launches over the same
+    header slots, and four streams at once (launches of different streams share nothing but the library's slot pools)."""
+    from control_gic_amd import _lib
+    router = cg.TripleGrainFixedEntropyRouter(0.1, 0.8, per_image=True)
+    sets = _tie_sets(n=32, flat=8)
+    assert "tiles_768" in sets
+    want = {}
+    for name, x in sets.items():
+        xd = torch.from_numpy(x).to(DEV)
+        e8, e16 = cg.entropy_maps(xd)
+        r8, r16 = cg.entropy_maps(xd, reference_order=True)
+        want[name] = (xd, e8, e16, [m.clone() for m in router(r16, r8, want_gate=False, pixels=None)[0]])
+    try:
+        for name, (xd, e8, e16, ref) in want.items():
+            _lib.REFINE_QUEUES = False
+            plain = router(e16, e8, want_gate=False, pixels=xd)[0]
+            assert all(torch.equal(a, b) for a, b in zip(plain, ref)), (name, "in-workgroup")
+            _lib.REFINE_QUEUES = True
+            for rep in range(4):                      # (the same header slots again and again: whatever a launch leaves must read as "nothing to claim")
+                got = router(e16, e8, want_gate=False, pixels=xd)[0]
+                assert all(torch.equal(a, b) for a, b in zip(got, ref)), (name, "queues", rep, [int((a != b).sum()) for a, b in zip(got, ref)])
+        # four streams, eight rounds: every stream routes every set
+        streams = [torch.cuda.Stream() for _ in range(4)]
+        torch.cuda.synchronize()
+        outs = []
+        names = list(want)
+        for rnd in range(8):
+            for k, st in enumerate(streams):
+                name = names[(rnd + k) % len(names)]
+                xd, e8, e16, ref = want[name]
+                with torch.cuda.stream(st):
+                    outs.append((name, router(e16, e8, want_gate=False, pixels=xd)[0]))
+        torch.cuda.synchronize()
+        for name, got in outs:
+            assert all(torch.equal(a, b) for a, b in zip(got, want[name][3])), (name, "concurrent streams")
+        # uint8 frames through the queues
+        xd = want["smooth8"][0]
+        frames = (xd * 255.0).round().to(torch.uint8).permute(0, 2, 3, 1).contiguous()
+        _, f8, f16 = cg.entropy_maps_u8(frames)
+        got = router(f16, f8, want_gate=False, pixels=frames)[0]
+        assert all(torch.equal(a, b) for a, b in zip(got, want["smooth8"][3]))
+    finally:
+        _lib.REFINE_QUEUES = True
 
 
 def test_flat_map_and_constant_patch_shortcut():
