@@ -438,6 +438,36 @@ def lanes_rate(vq, codec, ratio, xz, lanes, steps, copies=1):
     return (time.perf_counter() - t0) / steps, ls
 
 
+def content_8bit(dev, z, cb, vq, codec, ratio, value, steps=64):
+    """The timed step on the content the reference feeds the path: 8-bit images through ToTensor (inference.py:62-67), thresholds =
+    k-th smallest entropies under a strict '<' (RouterTriple.py:21-34).  Three synthetic 8-bit families (oracle/content_families.py:
+    quantised noise, smooth gradients + faint texture, flat regions with edges), each as a LaneStream of 8 slots (4 distinct batches
+    of 64 images x 2, four in flight, same graphs as `value`), MPixel/s by wall time, and the parity of what the stream left behind
+    checked from the pixels against the oracle (reference-arithmetic maps -> router -> coder) on a sample of images of two slots."""
+    from oracle.content_families import families
+    out = {}
+    zd = torch.from_numpy(z).to(dev)
+    worst = None
+    for name in ("noise8", "smooth8", "flat_edges"):
+        xs = [families(n=64, seed=7 + 13 * k)[name] for k in range(4)]
+        xz = [(torch.from_numpy(x).to(dev), zd) for x in xs]
+        dt, ls = lanes_rate(vq, codec, ratio, xz, 4, steps, copies=2)
+        torch.cuda.synchronize()
+        ok = True
+        for k in (0, 7):
+            okk, _ = check_against_oracle(slot_out(ls, k), xs[k // 2], z, cb, ratio, images=range(k, 64, 8))
+            ok = ok and okk
+        mp = 64 * 65536 / dt / 1e6
+        out[name] = {"MPixels/s": round(mp, 1), "frac_of_value": round(mp / value, 3), "bpp_match": bool(ok)}
+        worst = mp if worst is None else min(worst, mp)
+        del ls
+    out["min_MPixels/s"] = round(worst, 1)
+    out["min_frac_of_value"] = round(worst / value, 3)
+    out["note"] = ("fp32 images with 8-bit values (what ToTensor hands over), 4 distinct batches x 2 slots per family, four batches in flight, "
+                   f"{steps} steps; parity from the pixels on 16 images per family")
+    return out
+
+
 def ratio_sweep(dev, x, z, cb, vq, codec, steps=30):
     out = []
     B, H, W = x.shape[0], x.shape[2], x.shape[3]
@@ -1247,7 +1277,16 @@ def run_rank(a, rank, world, local):
         if dist_note:
             res["config"]["distributed"] = dist_note
         if not stub and not a.no_report:
-            res.update(report(a, dev, world, stream, slots_np, vq, codec, ratio))
+            line, extras = report(a, dev, world, stream, slots_np, vq, codec, ratio, res["value"])
+            res.update(line)
+            try:
+                path = a.extras_file or os.path.join(ROOT, "gpurun_out", "bench_extras.json")
+                os.makedirs(os.path.dirname(path), exist_ok=True)
+                with open(path, "w") as f:
+                    json.dump(extras, f, indent=1)
+                res["extras_file"] = os.path.relpath(path, ROOT)
+            except OSError as e:
+                res["extras_file"] = f"not written: {e}"
         print(json.dumps(res), flush=True)
     if dist is not None:
         dist.barrier()
@@ -1260,11 +1299,14 @@ def slot_out(stream, k):
     return (e["e8"], e["e16"], e["mask"], e["mode"], e["z_q"], e["ind"], e["comp"], *s.dec)
 
 
-def report(a, dev, world, stream, slots_np, vq, codec, ratio):
-    """everything next to the headline value (outside the timed region)"""
+def report(a, dev, world, stream, slots_np, vq, codec, ratio, value):
+    """everything next to the headline value (outside the timed region) -> (what goes on the JSON line, the bulky rest).  The
+    driver's record keeps the first ~2 KB of the line: roofline, cpu_baseline, the parity summary and the 8-bit-content figure
+    sit there; every other extra goes to the side file (bench.py --extras-file, default gpurun_out/bench_extras.json)."""
     B, H, W = a.batch, a.size, a.size
     x, z, cb = slots_np[0]
     res = {}
+    line = {}
     # parity of the timed work itself: ALL images of slot 0 and of the last slot, as left behind by the timed steps
     torch.cuda.synchronize()
     ok0, bpp = check_against_oracle(slot_out(stream, 0), x, z, cb, ratio)
@@ -1300,14 +1342,14 @@ def report(a, dev, world, stream, slots_np, vq, codec, ratio):
     flops = 2.0 * N * 1024 * 4                        # 2*N*K*D per launch (0.512 kFLOP/pixel)
     t_live = stages["vq+router_fused_launch"] * 1e-6  # HIP events around 20 launches in a hipGraph, on the stream they run on
     prof = None
-    pj = os.path.join(ROOT, "profiles", "r04_roofline.json")
+    pj = next((q for q in (os.path.join(ROOT, "profiles", f"r0{r}_roofline.json") for r in (5, 4)) if os.path.exists(q)), "")
     if os.path.exists(pj) and (B, H) == (64, 256):
         try:
             prof = json.load(open(pj))
         except Exception:                             # noqa: BLE001
             prof = None
     # `frac` is priced with the PROFILER's average duration of the kernel for the same command (tools/run_roofline_cmd.py = this
-    # measurement under rocprofv3 --kernel-trace --stats; profiles/r04_roofline.json, made by tools/gpu_profile_r04.sh): the number a
+    # measurement under rocprofv3 --kernel-trace --stats; profiles/rNN_roofline.json of the latest round, made by tools/gpu_profile.sh): the number a
     # reader can recompute from profiles/.  The live HIP-event figure of this run stays next to it.
     t_dom = prof["rocprof_avg_us_alone_graph"] * 1e-6 if prof else t_live
     achieved = flops / t_dom / 1e12
@@ -1317,7 +1359,7 @@ def report(a, dev, world, stream, slots_np, vq, codec, ratio):
         "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4),
         "traffic": prof.get("hbm_bytes_per_launch") if prof else None,
         "duration_us": round(t_dom * 1e6, 3),
-        "duration_source": ("profiles/r04_roofline.json: rocprofv3 --kernel-trace average over the 100 timed launches of tools/run_roofline_cmd.py "
+        "duration_source": (os.path.relpath(pj, ROOT) + ": rocprofv3 --kernel-trace average over the 100 timed launches of tools/run_roofline_cmd.py "
                             "(the same 20-launches-per-hipGraph command as the live measurement)") if prof else "live HIP events (no profile JSON found)",
         "frac_hip_events": round(flops / t_live / 1e12 / PEAK_F32_MFMA_TFLOPS, 4), "hip_events_us": round(t_live * 1e6, 3),
         "frac_one_lane_loop": prof.get("frac_lanes1_loop") if prof else None,
@@ -1330,7 +1372,7 @@ def report(a, dev, world, stream, slots_np, vq, codec, ratio):
                 "fp32 MFMA peak (results are bit-identical to the fp32 sequence); the kernel issues fp16 MFMAs with 16 K-slots per 4-dim contraction "
                 f"({2.0 * N * 1024 * 16 / 1e9:.1f} GFLOP per launch = {2.0 * N * 1024 * 16 / t_dom / 2.5e15:.2f} of the 2.5 PFLOP/s fp16 peak) "
                 "and is bound by VALU + MFMA issue (one v_min3 per two scores), not by the matrix cores alone: mfma_busy_frac = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x "
-                "the launch's cycles), from the counter passes of the same command (profiles/r04_pmc_sq_vq.md).  frac: the launch by itself, "
+                "the launch's cycles), from the counter passes of the same command (profiles/rNN_pmc_sq_vq.md).  frac: the launch by itself, "
                 "back to back; frac_one_lane_loop: the same kernel inside the one-batch-in-flight step (behind the entropy kernel's 50 MB: cold "
                 "L2); in_step_us: its duration while the kernels of three other batches share the GPU (not a kernel property; under the "
                 "profiler, which serialises part of the overlap); vq_alone_frac: the VQ kernel without the router workgroups, live"}
@@ -1343,6 +1385,10 @@ def report(a, dev, world, stream, slots_np, vq, codec, ratio):
         except Exception as e:                                   # an extra data point: never fail the bench line
             res["roofline"]["four_streams"] = {"error": str(e)[:200]}
     if world == 1 and (B, H) == (64, 256) and not a.no_extra:
+        try:
+            res["8bit_content"] = content_8bit(dev, z, cb, vq, codec, ratio, value)
+        except Exception as e:                                   # an extra data point: never fail the bench line
+            res["8bit_content"] = {"error": str(e)[:300]}
         hp.step()
         res["mask_mismatch"] = mask_mismatch(hp, x, z, cb, ratio)
         try:
@@ -1367,7 +1413,35 @@ def report(a, dev, world, stream, slots_np, vq, codec, ratio):
             res["end_to_end_estimate"] = {"error": str(e)[:200]}
     if not a.no_cpu_baseline and world == 1:             # the CPU port is timed at N=1 only (rank 0's host cores)
         res["cpu_baseline"] = cpu_baseline(x, z, cb, ratio)
-    return res
+    # ---- the line: compact
+    line["bpp"], line["bpp_match"] = res.pop("bpp"), res.pop("bpp_match")
+    rf = res["roofline"]
+    line["roofline"] = {k: rf[k] for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "duration_us", "frac_hip_events", "in_step_us",
+                                           "mfma_busy_frac") if k in rf}
+    line["roofline"]["kernel"] = "vq_filter_router_kernel"
+    if "cpu_baseline" in res:
+        cbl = res.pop("cpu_baseline")
+        line["cpu_baseline"] = {k: cbl[k] for k in ("value", "unit", "cores", "kind", "sample") if k in cbl}
+        res["cpu_baseline_detail"] = cbl
+    par = {"timed_batches_bpp_match": line["bpp_match"]}
+    mm = res.get("mask_mismatch")
+    if mm:
+        par["timed_batch_from_pixels"] = {k: mm[k] for k in ("images", "differing_mask_elements", "differing_bin_files") if k in mm}
+        th = mm.get("tie_heavy_content") or {}
+        par["tie_heavy_content"] = {k: [v.get("differing_mask_elements"), v.get("differing_bin_files")] for k, v in th.items()
+                                    if isinstance(v, dict) and "differing_mask_elements" in v}
+        par["tie_heavy_launch_us"] = {k: [v.get("vq+router_us"), v.get("vq+router_no_refinement_us")] for k, v in th.items()
+                                      if isinstance(v, dict) and "vq+router_us" in v}
+    line["parity"] = par
+    if "8bit_content" in res:
+        c8 = res["8bit_content"]
+        line["8bit_content"] = {k: (v["MPixels/s"] if isinstance(v, dict) else v) for k, v in c8.items() if k != "note"}
+        line["8bit_content"]["bpp_match"] = all(v["bpp_match"] for v in c8.values() if isinstance(v, dict))
+    if "one_batch_in_flight" in res:
+        line["one_batch_in_flight_us"] = round(res["one_batch_in_flight"]["ms_per_step"] * 1e3, 2)
+    if isinstance(res.get("b1_latency"), dict):
+        line["b1_latency_us"] = {k: v for k, v in res["b1_latency"].items() if isinstance(v, (int, float))}
+    return line, res
 
 
 # ------------------------------------------------------------------------------------------------ launcher
@@ -1408,6 +1482,7 @@ def parse_args(argv=None):
     ap.add_argument("--no-dist", action="store_true", help="N=1 only: do not create the one-rank communicator")
     ap.add_argument("--no-report", action="store_true", help="only the timed loop and the headline fields (for kernel traces: the last K chains of the trace are the timed steps)")
     ap.add_argument("--no-extra", action="store_true", help="skip the extra data points (mask mismatch, ratio sweep, DIV2K, B=1)")
+    ap.add_argument("--extras-file", default="", help="where the extras that do not go on the JSON line are written (default gpurun_out/bench_extras.json)")
     ap.add_argument("--stub", action="store_true", help=argparse.SUPPRESS)      # CPU test of the launcher only (gloo, no kernels)
     return ap.parse_args(argv)
 
