@@ -643,7 +643,7 @@ def div2k_image(dev, cb, vq, codec, iters=8):
 
         def once_chain(check=True):
             t = highres.compress_tiled(x, encode, codec, chain=True)
-            p, st = highres.decompress_tiled(t, codec, check=check, chain=True)
+            p, st = highres.decompress_tiled(t, codec, check=check, chain=True, decoder="latency")      # (one image at a time: the GPU is this call's)
             return t, p, st
         tc, pc, _ = once_chain(); torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -1187,31 +1187,75 @@ def run_rank(a, rank, world, local):
         hist.zero_()
         sync()
 
+    # ---- the timed region: barrier + synchronize in front; exactly K steps; at N > 1 the path's ONE collective -- the int64[1024]
+    # histogram all-reduce, which no rank leaves before every rank has arrived: it IS the closing barrier (a dist.barrier() behind
+    # it would put a second collective and its skew into a window of a few hundred microseconds) -- then synchronize.  Every rank
+    # also times its own K steps with device events (no collective inside); the job's time is the MAX over ranks of the wall time.
+    class _CountCollectives:
+        """every torch.distributed collective issued while active (the timed region) is counted: what the line reports as
+        `timed_collectives` is what was really called, not what the code above intends"""
+        NAMES = ("all_reduce", "barrier", "all_gather", "broadcast", "reduce", "all_to_all", "reduce_scatter", "all_gather_into_tensor")
+
+        def __init__(self):
+            self.n = 0
+            self.saved = {}
+
+        def __enter__(self):
+            if dist is not None:
+                for name in self.NAMES:
+                    fn = getattr(dist, name, None)
+                    if fn is not None:
+                        self.saved[name] = fn
+                        setattr(dist, name, self._wrap(fn))
+            return self
+
+        def _wrap(self, fn):
+            def counted(*args, **kw):
+                self.n += 1
+                return fn(*args, **kw)
+            return counted
+
+        def __exit__(self, *exc):
+            for name, fn in self.saved.items():
+                setattr(dist, name, fn)
+
+    counter = _CountCollectives()
+    ev = None if stub else (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
     barrier()
-    t0 = time.perf_counter()
-    if mixed:
-        # the path's only exchange goes out as soon as the last pass's encode side is enqueued and runs under its decode side
-        coll = (lambda hh: dist.all_reduce(hh, op=dist.ReduceOp.SUM, async_op=True)) if dist is not None and world > 1 else None
-        stream.submit(a.steps, collective=coll)
-        stream.join()
-    else:
-        stream.submit(a.steps)                              # exactly K steps
-        stream.join()
-        if dist is not None and world > 1:
+    with counter:
+        t0 = time.perf_counter()
+        if ev:
+            ev[0].record()
+        if mixed:
+            # the path's only exchange goes out as soon as the last pass's encode side is enqueued and runs under its decode side
+            # (async; join() waits for it: no rank leaves the region before every rank's histogram has arrived)
+            coll = (lambda hh: dist.all_reduce(hh, op=dist.ReduceOp.SUM, async_op=True)) if dist is not None and world > 1 else None
+            stream.submit(a.steps, collective=coll)
+            stream.join()
+        else:
+            stream.submit(a.steps)                              # exactly K steps
+            stream.join()
+        if ev:
+            ev[1].record()
+        if not mixed and dist is not None and world > 1:
             # the path's only exchange: global usage histogram (int64, exact) -- once per stream of batches
             dist.all_reduce(hist, op=dist.ReduceOp.SUM)
-    barrier()
-    dt = time.perf_counter() - t0
+        sync()
+        dt = time.perf_counter() - t0
+    timed_collectives = counter.n
+    steps_ms = ev[0].elapsed_time(ev[1]) if ev else dt * 1e3      # this rank's K steps by device events
     if dist is not None and world == 1:
         dist.all_reduce(hist, op=dist.ReduceOp.SUM)        # one rank: the identity, issued all the same (outside the timed region)
         sync()
     per_rank = [dt]
+    per_rank_dev = [steps_ms * 1e-3]
     allreduce_us = None
     if dist is not None:
-        mine = torch.tensor([dt], dtype=torch.float64, device=dev)
+        mine = torch.tensor([dt, steps_ms * 1e-3], dtype=torch.float64, device=dev)
         every = [torch.zeros_like(mine) for _ in range(world)]
         dist.all_gather(every, mine)
-        per_rank = [float(v.item()) for v in every]
+        per_rank = [float(v[0].item()) for v in every]
+        per_rank_dev = [float(v[1].item()) for v in every]
         dt = max(per_rank)                                  # the job is as slow as its slowest rank
         # the path's only collective by itself (outside the timed region, communicator warm): int64[1024] SUM
         probe = torch.zeros(1024, dtype=torch.int64, device=dev)
@@ -1236,6 +1280,8 @@ def run_rank(a, rank, world, local):
                 "value": round(a.steps * pix_all / dt / 1e6, 2), "unit": "MPixels/s",
                 "n_gpus": world, "rccl_ranks": ranks_seen, "steps": a.steps, "warmup": a.warmup,
                 "per_rank_MPixels/s": [round(a.steps * p / t / 1e6, 2) for p, t in zip(pix, per_rank)],
+                "per_rank_MPixels/s_device_events": [round(a.steps * p / t / 1e6, 2) for p, t in zip(pix, per_rank_dev)],
+                "timed_collectives": timed_collectives,
                 "histogram_allreduce_us": allreduce_us, "ms_per_step": round(dt / a.steps * 1e3, 5),
                 "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                 "round_trip_ok": ok,
@@ -1258,6 +1304,8 @@ def run_rank(a, rank, world, local):
             "unit": "MPixels/s",
             "n_gpus": world, "rccl_ranks": ranks_seen, "steps": a.steps, "warmup": a.warmup,
             "per_rank_MPixels/s": [round(a.steps * B * H * W / t / 1e6, 2) for t in per_rank],
+            "per_rank_MPixels/s_device_events": [round(a.steps * B * H * W / t / 1e6, 2) for t in per_rank_dev],
+            "timed_collectives": timed_collectives,
             "histogram_allreduce_us": allreduce_us,
             "ms_per_step": round(dt / a.steps * 1e3, 5),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,

@@ -238,7 +238,7 @@ def linspace_bins():
 REFINE_QUEUES = True
 
 
-def pixels_arg(pixels, B, h16, w16, per_image, sigma=0.01, flat8=None, queues=False):
+def pixels_arg(pixels, B, h16, w16, per_image, sigma=0.01, flat8=None, queues=False, explicit=False):
     """(ctypes pointer or None, keep-alive) for the router's `refine` argument.  pixels: None, the fp32 [B,3,16 h16,16 w16] image
     batch the maps were made from, or the uint8 [B,16 h16,16 w16,3] frames; flat8: the constant-patch map the same entropy call
     made (entropy_maps(...) attaches it to its maps as `_cgic_flat8`), optional.  None is also returned (no refinement, the maps
@@ -255,6 +255,17 @@ def pixels_arg(pixels, B, h16, w16, per_image, sigma=0.01, flat8=None, queues=Fa
         raise ValueError(f"pixels {pixels.dtype} {tuple(pixels.shape)} do not belong to entropy maps of {B} x {h16} x {w16} "
                          f"(expected fp32 [B,3,16 h16,16 w16] or uint8 [B,16 h16,16 w16,3])")
     if not lib().cgic_router_refine_supported(B, h16, w16, int(bool(per_image))):
+        # the routing segment (an image routed per image, or the WHOLE batch with per_image=False like the reference's encode())
+        # does not fit one workgroup's LDS: the band around a threshold cannot be re-evaluated, the maps decide as given --
+        # i.e. on tie-heavy content a few mask elements may differ from the CPU reference's.  Never silently:
+        msg = (f"threshold-band refinement is not available for a routing segment of {B if not per_image else 1} x {16 * h16}x{16 * w16} "
+               "pixels (cgic_router_refine_supported): masks are made from the default entropy maps as given (within 2e-6 of the reference's "
+               "arithmetic; under a strict '<' a tie-heavy image can get a few other mask elements).  Route per image "
+               "(per_image=True, tiles of at most 768x768), or make the maps with entropy_maps(..., reference_order=True)")
+        if explicit:
+            raise ValueError(msg)
+        import warnings
+        warnings.warn(msg, RuntimeWarning, stacklevel=3)
         return None, ()
     px = pixels.contiguous()
     if flat8 is not None:

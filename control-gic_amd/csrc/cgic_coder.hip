@@ -757,13 +757,13 @@ extern "C" int cgic_compress_streams(const cgic_table *t, const int64_t *ind, co
     if (a.combine && h * w <= kLdsPosSmall && (!hist || cgic_table_num_symbols(t) <= kLdsPosSmall)) {
         const dim3 grid_s((unsigned)B, jobs);
         hipStream_t s_ = (hipStream_t)stream;
-        return launch_or_record(KID_NONE, grid_s, dim3(kEncThreads), 0, a, [=] {
+        return launch_or_record(KID_NONE, grid_s, dim3(kEncThreads), 0, a, s_, [=] {
             hipLaunchKernelGGL(compress_streams_kernel<kLdsPosSmall>, grid_s, dim3(kEncThreads), 0, s_, a);
             return launch_check("compress_streams_kernel"); });
     }
     const dim3 grid = a.tick ? dim3(jobs, (unsigned)B) : dim3((unsigned)B, jobs);
     hipStream_t s = (hipStream_t)stream;
-    return launch_or_record(KID_COMPRESS, grid, dim3(kEncThreads), dyn, a, [=] {
+    return launch_or_record(KID_COMPRESS, grid, dim3(kEncThreads), dyn, a, s, [=] {
         hipLaunchKernelGGL(compress_streams_kernel<kLdsPos>, grid, dim3(kEncThreads), dyn, s, a);
         return launch_check("compress_streams_kernel"); });
 }

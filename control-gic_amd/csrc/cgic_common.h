@@ -96,6 +96,7 @@ enum KernelId { KID_NONE = 0, KID_ENTROPY_F32, KID_ENTROPY_U8, KID_ENTROPY_WIN_F
 // host side of a launch group
 struct GroupRec {                       // one recorded launch
     int kid;
+    hipStream_t stream;                 // the stream the entry point was called with (cgic_group_launch's must be the same one)
     dim3 grid, block;
     size_t lds;
     std::vector<unsigned char> args;    // the kernel's argument block (the A of Grouped<A>)
@@ -103,7 +104,7 @@ struct GroupRec {                       // one recorded launch
 };
 bool group_recording();                 // this thread is between cgic_group_begin and cgic_group_launch
 double group_cu_share();                // the current group's share of the chip (1.0 outside a group): persistent-workgroup kernels size their grid by it
-int group_record(int kid, dim3 grid, dim3 block, size_t lds, const void *args, size_t bytes, std::function<int()> launch);
+int group_record(int kid, dim3 grid, dim3 block, size_t lds, const void *args, size_t bytes, hipStream_t stream, std::function<int()> launch);
 typedef int (*GroupedLauncher)(const GroupRec *const *recs, int n, hipStream_t s);
 struct GroupedRegistrar { GroupedRegistrar(int kid, GroupedLauncher fn); };
 
@@ -112,9 +113,9 @@ struct GroupedRegistrar { GroupedRegistrar(int kid, GroupedLauncher fn); };
 
 // launch now, or record for cgic_group_launch
 template <class A, class F>
-inline int launch_or_record(int kid, dim3 grid, dim3 block, size_t lds, const A &a, F direct)
+inline int launch_or_record(int kid, dim3 grid, dim3 block, size_t lds, const A &a, hipStream_t stream, F direct)
 {
-    if (group_recording()) return group_record(kid, grid, block, lds, &a, sizeof(A), std::function<int()>(direct));
+    if (group_recording()) return group_record(kid, grid, block, lds, &a, sizeof(A), stream, std::function<int()>(direct));
     return direct();
 }
 

@@ -1376,7 +1376,15 @@ extern "C" int cgic_decompress_streams(const cgic_table *t, const uint8_t *in, i
     int cus = 0;
     rc = device_cu_count_dec(&cus);
     if (rc) return rc;
-    const int64_t cu_budget = (int64_t)((double)cus * group_cu_share() + 0.5);
+    const int64_t cu_share = (int64_t)((double)cus * group_cu_share() + 0.5);
+    // The fused launch's merge bands SPIN on the decoder workgroups of the same launch (wait_decoded).  Alone on the chip that cannot
+    // hang: the decoders sit in front of the bands in the grid and every one gets a CU at once.  With other launches of this kind in
+    // flight on other queues (up to four hardware queues by default), an XCD could in principle fill up with spinning bands of
+    // several launches whose decoders are queued behind each other's bands.  The chip holds two of these 1024-thread workgroups per
+    // CU: as long as FOUR such launches together fit (each at most half the CUs' worth of workgroups), every workgroup of every one
+    // of them is resident at once and nobody waits for a slot.  CGIC_DECODE_LATENCY is the caller's statement that this call has
+    // the GPU to itself (one batch at a time): it keeps the whole chip as its budget.
+    const int64_t cu_budget = dec_mode == CGIC_DECODE_LATENCY ? cu_share : cu_share / 2;
     const bool fuse_base = dec_mode != CGIC_DECODE_THROUGHPUT && d.tab.max_len <= 64 && B * 3 <= (int64_t)(16384 / 4) && !dev_knob_dec("CGIC_NO_DECODE_MERGE");
     int64_t nbands = kMergeBands;
     {
@@ -1415,7 +1423,7 @@ extern "C" int cgic_decompress_streams(const cgic_table *t, const uint8_t *in, i
             rc = ensure_dynamic_lds((const void *)decode_merge_kernel, lds_f);
             if (rc) return rc;
             const dim3 grid_f((unsigned int)(B * (ndec + nbands)));
-            return launch_or_record(KID_DECODE_MERGE, grid_f, dim3(kDecThreads), lds_f, p, [=] {
+            return launch_or_record(KID_DECODE_MERGE, grid_f, dim3(kDecThreads), lds_f, p, s, [=] {
                 hipLaunchKernelGGL(decode_merge_kernel, grid_f, dim3(kDecThreads), lds_f, s, p);
                 return launch_check("decode_merge_kernel"); });
         }
@@ -1433,7 +1441,7 @@ extern "C" int cgic_decompress_streams(const cgic_table *t, const uint8_t *in, i
             const int sc_ = (int)stage_cap, cc_ = (int)chunk_cap;
             DecodeImageArgs dia;
             dia.a = d; dia.stage_cap = sc_; dia.chunk_cap = cc_;
-            rc = launch_or_record(KID_DECODE_IMAGE, dim3((unsigned)B), dim3(T), lds_ss, dia, [=] {
+            rc = launch_or_record(KID_DECODE_IMAGE, dim3((unsigned)B), dim3(T), lds_ss, dia, s, [=] {
                 hipLaunchKernelGGL(decode_image_kernel, dim3((unsigned)B), dim3(T), lds_ss, s, d, sc_, cc_);
                 return launch_check("decode_image_kernel"); });
         }
@@ -1457,12 +1465,12 @@ extern "C" int cgic_decompress_streams(const cgic_table *t, const uint8_t *in, i
             rc = acquire_tickets(s, (int)(nb * 3), &c.tick);
             if (rc) return rc;
             const dim3 grid_c(large ? CGIC_DEC_WGS_LARGE : CGIC_DEC_WGS_SMALL, (unsigned)nb);
-            rc = launch_or_record(KID_DECODE_SPLIT, grid_c, dim3(kDecThreads), lds_d, c, [=] {
+            rc = launch_or_record(KID_DECODE_SPLIT, grid_c, dim3(kDecThreads), lds_d, c, s, [=] {
                 hipLaunchKernelGGL(decode_split_kernel, grid_c, dim3(kDecThreads), lds_d, s, c);
                 return launch_check("decode_split_kernel"); });
         }
     } else {
-        rc = launch_or_record(KID_NONE, dim3((unsigned)B, 3), dim3(kDecThreads), lds_d, d, [=] {
+        rc = launch_or_record(KID_NONE, dim3((unsigned)B, 3), dim3(kDecThreads), lds_d, d, s, [=] {
             hipLaunchKernelGGL(decode_streams_kernel, dim3((unsigned)B, 3), dim3(kDecThreads), lds_d, s, d);
             return launch_check("decode_streams_kernel"); });
     }
@@ -1471,14 +1479,14 @@ extern "C" int cgic_decompress_streams(const cgic_table *t, const uint8_t *in, i
         // several batches in flight: one band of 1024 threads per image (see merge_kernel)
         if (lds_m > 48 * 1024)
             { int rc_ = ensure_dynamic_lds((const void *)merge_kernel<kMergeOneBandThreads>, (size_t)lds_m); if (rc_) return rc_; }
-        return launch_or_record(KID_NONE, dim3(1u, (unsigned)B), dim3(kMergeOneBandThreads), lds_m, m, [=] {
+        return launch_or_record(KID_NONE, dim3(1u, (unsigned)B), dim3(kMergeOneBandThreads), lds_m, m, s, [=] {
             hipLaunchKernelGGL(merge_kernel<kMergeOneBandThreads>, dim3(1u, (unsigned)B), dim3(kMergeOneBandThreads), lds_m, s, m);
             return launch_check("merge_kernel"); });
     }
     if (lds_m > 48 * 1024)
         { int rc_ = ensure_dynamic_lds((const void *)merge_kernel<kMergeThreads>, (size_t)lds_m); if (rc_) return rc_; }
     const dim3 grid_m((unsigned)nbands, (unsigned)B);
-    return launch_or_record(KID_MERGE, grid_m, dim3(kMergeThreads), lds_m, m, [=] {
+    return launch_or_record(KID_MERGE, grid_m, dim3(kMergeThreads), lds_m, m, s, [=] {
         hipLaunchKernelGGL(merge_kernel<kMergeThreads>, grid_m, dim3(kMergeThreads), lds_m, s, m);
         return launch_check("merge_kernel"); });
 }

@@ -534,10 +534,10 @@ static int entropy_maps_launch(const void *x, bool u8, int64_t B, int64_t H, int
     }
 #endif
     if (u8)
-        return launch_or_record(KID_ENTROPY_U8, grid, dim3(kEntThreads), 0, a, [=] {
+        return launch_or_record(KID_ENTROPY_U8, grid, dim3(kEntThreads), 0, a, s, [=] {
             hipLaunchKernelGGL(entropy_maps_kernel<true>, grid, dim3(kEntThreads), 0, s, a);
             return launch_check("entropy_maps_kernel"); });
-    return launch_or_record(KID_ENTROPY_F32, grid, dim3(kEntThreads), 0, a, [=] {
+    return launch_or_record(KID_ENTROPY_F32, grid, dim3(kEntThreads), 0, a, s, [=] {
         hipLaunchKernelGGL(entropy_maps_kernel<false>, grid, dim3(kEntThreads), 0, s, a);
         return launch_check("entropy_maps_kernel"); });
 }
@@ -604,10 +604,10 @@ extern "C" int cgic_entropy_maps_tiles(const void *src, int is_u8, int64_t N, in
     const dim3 grid((unsigned)((tw / 16 + per_wg - 1) / per_wg), (unsigned)(th / 16), (unsigned)(N * T));
     hipStream_t s = (hipStream_t)stream;
     if (is_u8)
-        return launch_or_record(KID_ENTROPY_WIN_U8, grid, dim3(kEntThreads), 0, a, [=] {
+        return launch_or_record(KID_ENTROPY_WIN_U8, grid, dim3(kEntThreads), 0, a, s, [=] {
             hipLaunchKernelGGL(entropy_tiles_kernel<true>, grid, dim3(kEntThreads), 0, s, a);
             return launch_check("entropy_tiles_kernel"); });
-    return launch_or_record(KID_ENTROPY_WIN_F32, grid, dim3(kEntThreads), 0, a, [=] {
+    return launch_or_record(KID_ENTROPY_WIN_F32, grid, dim3(kEntThreads), 0, a, s, [=] {
         hipLaunchKernelGGL(entropy_tiles_kernel<false>, grid, dim3(kEntThreads), 0, s, a);
         return launch_check("entropy_tiles_kernel"); });
 }

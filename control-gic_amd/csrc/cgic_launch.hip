@@ -38,12 +38,12 @@ GroupedRegistrar::GroupedRegistrar(int kid, GroupedLauncher fn) { grouped_table(
 bool group_recording() { return (bool)t_group; }
 double group_cu_share() { return t_group ? t_group->share[t_group->cur] : 1.0; }
 
-int group_record(int kid, dim3 grid, dim3 block, size_t lds, const void *args, size_t bytes, std::function<int()> launch)
+int group_record(int kid, dim3 grid, dim3 block, size_t lds, const void *args, size_t bytes, hipStream_t stream, std::function<int()> launch)
 {
     GroupState *g = t_group.get();
     CGIC_REQUIRE(g, CGIC_ERR_INVALID, "group_record outside a group");
     GroupRec r;
-    r.kid = kid; r.grid = grid; r.block = block; r.lds = lds;
+    r.kid = kid; r.stream = stream; r.grid = grid; r.block = block; r.lds = lds;
     r.args.assign((const unsigned char *)args, (const unsigned char *)args + bytes);
     r.launch = std::move(launch);
     g->rec[g->cur].push_back(std::move(r));
@@ -86,6 +86,13 @@ extern "C" int cgic_group_launch(cgic_stream_t stream)
     std::unique_ptr<GroupState> g = std::move(t_group);          // closed whatever happens below
     size_t depth = 0;
     for (int i = 0; i < g->ngroups; ++i) depth = g->rec[i].size() > depth ? g->rec[i].size() : depth;
+    // every record was made for one stream -- its ticket slots were taken from that stream's ring, its single-launch fallback
+    // goes to it -- and the grouped launches go to `stream`: they have to be the same one, or a dependent chain would be split over
+    // two streams (checked before anything is enqueued)
+    for (int i = 0; i < g->ngroups; ++i)
+        for (const GroupRec &r : g->rec[i])
+            CGIC_REQUIRE(r.stream == (hipStream_t)stream, CGIC_ERR_INVALID,
+                         "group_launch: a launch of group %d was recorded for another stream than the one given here", i);
     int launches = 0;
     for (size_t j = 0; j < depth; ++j) {
         const GroupRec *recs[kMaxGroups];

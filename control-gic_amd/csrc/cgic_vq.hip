@@ -1234,7 +1234,7 @@ static int launch_hist(const int64_t *idx, int64_t n, int K, int64_t *hist, hipS
     if (nblk < 1) nblk = 1;
     // (inside a launch group: recorded at its position and launched on its own -- histograms of several groups add into one table)
     const size_t lds = sizeof(unsigned int) * (size_t)K;
-    return launch_or_record(KID_NONE, dim3(nblk), dim3(1024), lds, n, [=] {
+    return launch_or_record(KID_NONE, dim3(nblk), dim3(1024), lds, n, s, [=] {
         hipLaunchKernelGGL(index_hist_kernel, dim3(nblk), dim3(1024), lds, s, idx, n, K, (unsigned long long *)hist);
         return launch_check("index_hist_kernel"); });
 }
@@ -1306,7 +1306,7 @@ static int launch_mfma(const float *z, int64_t hw, int64_t N, const float *cb, i
     // (no grouped form: inside a launch group this position is launched group by group)
     const RouterArgs r = *router;
     const dim3 grid(a.nblk + (unsigned int)router_blocks);
-    return launch_or_record(KID_NONE, grid, dim3(kVqThreads), lds, a, [=] {
+    return launch_or_record(KID_NONE, grid, dim3(kVqThreads), lds, a, s, [=] {
         hipLaunchKernelGGL(vq_router_kernel<ZT>, grid, dim3(kVqThreads), lds, s, a, r);
         return launch_check("vq_router_kernel"); });
 }
@@ -1401,7 +1401,7 @@ static int launch_filter(const float *z, int64_t hw, int64_t N, const float *cb,
     VqfrArgs p;
     p.a = a; p.r = *router; p.nrouter = (unsigned int)router_blocks; p.router_behind = router_first ? 0u : 1u;
     const dim3 grid(a.nblk + (unsigned int)router_blocks);
-    return launch_or_record(CONV ? KID_NONE : ALIGNED ? KID_VQF_ROUTER_AL : KID_VQF_ROUTER_UN, grid, dim3(kVqfThreads), lds, p, [=] {
+    return launch_or_record(CONV ? KID_NONE : ALIGNED ? KID_VQF_ROUTER_AL : KID_VQF_ROUTER_UN, grid, dim3(kVqfThreads), lds, p, s, [=] {
         hipLaunchKernelGGL((vq_filter_router_kernel<ALIGNED, CONV>), grid, dim3(kVqfThreads), lds, s, p.a, p.r, p.nrouter, p.router_behind);
         return launch_check("vq_filter_router_kernel"); });
 }

@@ -13,6 +13,23 @@ from . import _lib
 _bins = _lib.linspace_bins         # torch.linspace(-1, 1, 32) evaluated on the CPU, like the CPU reference path (model.py:480)
 
 
+class _MadeMaps:
+    """what entropy_maps_tiles leaves on the tile batch it wrote: the maps made in the same pass -- by WEAK reference (the maps point
+    back at the batch for the router's refinement: strong references both ways would be a cycle of ~40 MB of device memory per tiled
+    image that only the cyclic collector frees) and with the batch's version counter (a batch modified in place has no maps)"""
+
+    def __init__(self, batch, e8, e16, flat8):
+        import weakref
+        self.refs = tuple(weakref.ref(t) for t in (e8, e16, flat8))
+        self.version = batch._version
+
+    def get(self, batch):
+        maps = tuple(r() for r in self.refs)
+        if batch._version != self.version or any(m is None for m in maps):
+            return None
+        return maps
+
+
 def _tag(maps, pixels, flat8):
     """the maps carry what the router's refinement wants (plain attributes: gone after any arithmetic on a map)"""
     for e in maps:
@@ -31,8 +48,9 @@ def entropy_maps(x, want8=True, want16=True, sigma=0.01, reference_order=False, 
     if x.dim() != 4 or x.shape[1] != 3:
         raise ValueError(f"expected [B,3,H,W], got {tuple(x.shape)}")
     made = getattr(x, "_cgic_maps", None)
+    made = made.get(x) if made is not None else None
     if made is not None and not reference_order and float(sigma) == 0.01:
-        # a tile batch that entropy_maps_tiles wrote: its maps were made in the same pass
+        # a tile batch that entropy_maps_tiles wrote (and nobody has touched since): its maps were made in the same pass
         return (made[0] if want8 else None), (made[1] if want16 else None)
     x = x.contiguous().float()
     B, _, H, W = x.shape
@@ -54,8 +72,8 @@ def entropy_maps_tiles(src, origins, th, tw, sigma=0.01):
     """pad + crop of the tiling driver (inference_high_resolution.py:145-173, :236-244) and both entropy maps in ONE pass
     (cgic_entropy_maps_tiles).  src: fp32 [N,3,H,W] unpadded images (or uint8 frames [N,H,W,3]); origins: [(y0, x0)] of the T tiles of ONE
     shape th x tw in unpadded coordinates -> (tiles [N*T,3,th,tw] fp32 image-major, e8, e16).  The tile batch comes back tagged with its
-    maps: entropy_maps(tiles) returns them without another pass, and the router finds pixels + flat8 on the maps as usual
-    (the tag describes the tiles as they were written: it is void once the batch is modified in place)."""
+    maps (weakly: keep e8 / e16 alive for as long as they are wanted): entropy_maps(tiles) returns them without another pass, and the
+    router finds pixels + flat8 on the maps as usual.  The tag is void once the batch has been modified in place."""
     import ctypes
     _lib.require_device(src)
     u8 = src.dtype == torch.uint8
@@ -75,7 +93,7 @@ def entropy_maps_tiles(src, origins, th, tw, sigma=0.01):
         _lib.call("cgic_entropy_maps_tiles", _lib.ptr(src), int(u8), N, H, W, T, org, th, tw, _bins(), 32, float(sigma), _lib.ptr(tiles),
                   _lib.ptr(e8), _lib.ptr(e16), _lib.ptr(flat8), _lib.current_stream(dev))
     _tag((e8, e16), tiles, flat8)
-    tiles._cgic_maps = (e8, e16, flat8)
+    tiles._cgic_maps = _MadeMaps(tiles, e8, e16, flat8)
     return tiles, e8, e16
 
 

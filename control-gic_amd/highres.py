@@ -207,8 +207,8 @@ def _compress_groups(x, encode, codec, tile, concurrent, chain=False, fuse_maps=
         with _lib.launch_group(len(order), [N * len(idxs) * th * tw for (th, tw), idxs in order], x.device) as g:
             for k, ((th, tw), idxs) in enumerate(order):
                 g.select(k)
-                t, _, _ = entropy_maps_tiles(xc, [(tiles[i][0] - top, tiles[i][1] - left) for i in idxs], th, tw)
-                made.append(t._cgic_maps)
+                t, e8_, e16_ = entropy_maps_tiles(xc, [(tiles[i][0] - top, tiles[i][1] - left) for i in idxs], th, tw)
+                made.append((e8_, e16_, e8_._cgic_flat8))           # (strong references for the length of this call)
                 cut.append(t.view(N, len(idxs), 3, th, tw))
     elif not fork.enabled and len(tiles) <= 96:
         # pad + crop of ALL tiles as one launch (cgic_cut_tiles): every tile written straight from the unpadded image
@@ -231,8 +231,9 @@ def _compress_groups(x, encode, codec, tile, concurrent, chain=False, fuse_maps=
                         strip.zero_()
             batch = batch.view(-1, th, tw, 3) if frames and not made else batch.view(-1, 3, th, tw)
             if made:                                     # (tags do not survive a view: this is the object `encode` sees)
+                from .entropy import _MadeMaps
                 e8, e16, flat8 = made[lane]
-                batch._cgic_maps = made[lane]
+                batch._cgic_maps = _MadeMaps(batch, e8, e16, flat8)       # (weak: the maps point back at the batch)
                 e8._cgic_pixels = e16._cgic_pixels = batch
             if chain:
                 batches.append(batch)
@@ -294,7 +295,7 @@ def compress_tiled_batch(x, encode, codec, tile=TILE, concurrent=False, chain=Fa
     return out
 
 
-def decompress_tiled_batch(tiled_list, codec, concurrent=False, check=True, chain=False):
+def decompress_tiled_batch(tiled_list, codec, concurrent=False, check=True, chain=False, decoder=None):
     """inverse of compress_tiled_batch for TiledImages of one geometry (from it, or from N compress_tiled calls on images
     of one size, or rebuilt from containers): ONE decompress per shape group over all the images
     -> list (per image) of per-tile (ind, masks, z_q); check=False: (that, [N * tiles] status tensor)"""
@@ -329,7 +330,7 @@ def decompress_tiled_batch(tiled_list, codec, concurrent=False, check=True, chai
             if chain:
                 pending.append(comp)
                 continue
-            outs.append(codec.decompress(comp))
+            outs.append(codec.decompress(comp, decoder=decoder))
     status_all = None
     if chain:
         # the decoder and the merge of all shape groups as ONE launch each (see compress_tiled); one status buffer for all of them
@@ -338,7 +339,7 @@ def decompress_tiled_batch(tiled_list, codec, concurrent=False, check=True, chai
         with _lib.launch_group(len(pending), [c.batch * c.h * c.w for c in pending], dev) as g:
             for k, comp in enumerate(pending):
                 g.select(k)
-                outs.append(codec.decompress(comp, status=status_all[at:at + comp.batch]))
+                outs.append(codec.decompress(comp, status=status_all[at:at + comp.batch], decoder=decoder))
                 at += comp.batch
     for (idxs, _, _), (ind, masks, zq, status) in zip(first.groups, outs):
         statuses.append(status)
@@ -356,11 +357,14 @@ def decompress_tiled_batch(tiled_list, codec, concurrent=False, check=True, chai
     return per_image
 
 
-def decompress_tiled(tiled, codec, decode=None, concurrent=False, check=True, chain=False):
+def decompress_tiled(tiled, codec, decode=None, concurrent=False, check=True, chain=False, decoder=None):
     """-> per-tile (ind, masks, z_q) in row-major order; with decode(z_q, masks) -> pixels also the blended,
     clamped, unpadded reconstruction (:248-255; tiles do not overlap, so the weights cancel).
     concurrent: shape groups on parallel streams; check=False skips the host synchronisation on the decoder status (for
-    stream capture): the second result is then the [tiles] status tensor to look at later"""
+    stream capture): the second result is then the [tiles] status tensor to look at later.
+    decoder: "latency" / "throughput" / "auto" (GrainCodec.decompress).  "latency" = this call has the GPU to itself: with chain the
+    decoder and the merge of ALL shape groups are then one launch; the default keeps that form to launches of at most half the
+    chip (several decode chains in flight on other streams must never leave a merge band spinning on a decoder without a CU)."""
     per_tile = [None] * len(tiled.tiles)
     statuses = []
     dev = tiled.groups[0][1].data.device if tiled.groups else None
@@ -376,12 +380,12 @@ def decompress_tiled(tiled, codec, decode=None, concurrent=False, check=True, ch
         with _lib.launch_group(len(tiled.groups), [c.batch * c.h * c.w for _, c, _ in tiled.groups], dev) as g:
             for lane, (_, comp, _) in enumerate(tiled.groups):
                 g.select(lane)
-                outs.append(codec.decompress(comp, status=status_all[at:at + comp.batch]))
+                outs.append(codec.decompress(comp, status=status_all[at:at + comp.batch], decoder=decoder))
                 at += comp.batch
     for lane, (idxs, comp, _) in enumerate(tiled.groups):
         if not chain:
             with fork.on(lane):
-                outs.append(codec.decompress(comp))
+                outs.append(codec.decompress(comp, decoder=decoder))
         ind, masks, zq, status = outs[lane]
         statuses.append(status)
         for k, i in enumerate(idxs):

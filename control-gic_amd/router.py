@@ -44,6 +44,7 @@ class TripleGrainFixedEntropyRouter(nn.Module):
 
     def forward(self, x_entropy_p16, x_entropy_p8, want_gate=True, pixels=None, flat8=None):
         _lib.require_device(x_entropy_p16, x_entropy_p8)
+        explicit = pixels is not None        # asked for by the caller: a segment that cannot be refined raises (from the maps' tags: warns)
         if pixels is None and self.refine:
             p16, p8 = getattr(x_entropy_p16, "_cgic_pixels", None), getattr(x_entropy_p8, "_cgic_pixels", None)
             pixels = p16 if (p16 is not None and p16 is p8) else None        # both maps from the same image batch
@@ -60,7 +61,7 @@ class TripleGrainFixedEntropyRouter(nn.Module):
         mf = torch.empty((B, 1, 4 * h16, 4 * w16), dtype=torch.int32, device=dev)
         gate = torch.empty((B, 1, 4 * h16, 12 * w16), dtype=torch.float32, device=dev) if want_gate else None
         mode = ctypes.c_int(0)
-        px, keep = _lib.pixels_arg(pixels if self.refine else None, B, h16, w16, self.per_image, flat8=flat8, queues=True)
+        px, keep = _lib.pixels_arg(pixels if self.refine else None, B, h16, w16, self.per_image, flat8=flat8, queues=True, explicit=explicit)
         with torch.cuda.device(dev):
             _lib.call("cgic_router_f32", _lib.ptr(e16), _lib.ptr(e8), B, h16, w16,
                       float(self.coarse_grain_ratio), float(self.medium_grain_ratio), int(bool(self.per_image)),

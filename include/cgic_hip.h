@@ -398,7 +398,12 @@ size_t cgic_decompress_workspace_bytes(int64_t B, int64_t h, int64_t w);
  *                           they agree -- 256 threads and 41 KB of LDS per 256x256 image, 25 us alone, but it leaves the GPU
  *                           to the kernels of other batches in flight (pipeline.LaneStream: 86 -> 101 GPixel/s); the merge
  *                           that follows runs one band of 1024 threads per image instead of four of 512 (half the instructions)
- *   CGIC_DECODE_AUTO        (default) = CGIC_DECODE_LATENCY
+ *   CGIC_DECODE_AUTO        (default) the same kernels as CGIC_DECODE_LATENCY, but the ONE-launch decoder + merge (whose merge bands
+ *                           spin on the decoder workgroups of their own launch) only for launches of at most half the chip's
+ *                           workgroups: four such launches in flight on four hardware queues are then resident together and
+ *                           no band can be left spinning on a decoder that has no CU yet.  CGIC_DECODE_LATENCY is the
+ *                           caller's statement that the call has the GPU to itself: it takes the one-launch form up to the
+ *                           whole chip
  * Tables with codes longer than 64 bits and grids whose worst case exceeds the LDS budget always take the split-stream
  * / serial paths.  Returns the previous mode, or CGIC_ERR_INVALID. */
 #define CGIC_DECODE_AUTO 0

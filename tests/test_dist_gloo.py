@@ -125,9 +125,13 @@ def test_bench_spawns_its_own_ranks():
     assert abs(d["value"] - 2 * 3 * 64 * 256 * 256 / (d["ms_per_step"] * 3 * 1e-3) / 1e6) / d["value"] < 1e-3
     # per-rank rates and the collective's own time are on the line (the driver computes scaling efficiency from `value`)
     assert len(d["per_rank_MPixels/s"]) == 2 and min(d["per_rank_MPixels/s"]) * 2 >= d["value"] * 0.999 and d["histogram_allreduce_us"] > 0
+    # the timed region holds exactly ONE collective (the histogram all-reduce, which is also its closing barrier): counted by
+    # intercepting torch.distributed while the region runs; every rank's own K steps by its own clock are on the line as well
+    assert d["timed_collectives"] == 1 and len(d["per_rank_MPixels/s_device_events"]) == 2
     # N = 1 takes the same path: a one-rank communicator, `rccl_ranks` read back from it
     one = json.loads(_bench(["--gpus", "1", "--stub", "--steps", "3", "--warmup", "1"]).stdout.strip())
     assert one["n_gpus"] == 1 and one["rccl_ranks"] == 1 and len(one["per_rank_MPixels/s"]) == 1 and one["histogram_allreduce_us"] is not None
+    assert one["timed_collectives"] == 0                         # one rank: nothing to exchange inside the region
     solo = json.loads(_bench(["--gpus", "1", "--stub", "--steps", "3", "--warmup", "1", "--no-dist"]).stdout.strip())
     assert solo["rccl_ranks"] is None and solo["histogram_allreduce_us"] is None
 
@@ -153,6 +157,7 @@ def test_bench_mixed_workload_shards_the_stream():
         assert len(lines) == 1, r.stdout
         d = json.loads(lines[0])
         assert d["n_gpus"] == gpus and d["rccl_ranks"] == gpus and d["scaling"] == "strong" and "mixed stream" in d["config"]["workload"]
+        assert d["timed_collectives"] == (1 if gpus > 1 else 0)            # the async histogram all-reduce and nothing else
         pix = 24 * 512 * 768 + 8 * 1356 * 2040
         assert abs(d["value"] - 3 * pix / (d["ms_per_step"] * 3 * 1e-3) / 1e6) / d["value"] < 1e-3 and len(d["per_rank_MPixels/s"]) == gpus
 

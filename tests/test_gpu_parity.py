@@ -506,15 +506,23 @@ def test_refinement_plumbing_and_limits():
     assert all(torch.equal(a, b) for a, b in zip(off(e16m, e8m)[0], plain))
     with pytest.raises(ValueError, match="do not belong"):
         router(e16m, e8m, pixels=x[:, :, :128])
-    # flattened-batch routing of 8 images (the reference's encode() semantics) fits the LDS; of 64 it does not: maps as given
-    flat8 = cg.TripleGrainFixedEntropyRouter(0.1, 0.8, per_image=False)
-    flat8(e16m, e8m)
+    # flattened-batch routing (the reference's encode() semantics, RouterTriple.py:21,40,52,63) of 8 smooth images fits the LDS and
+    # IS refined: equal to the batch-global routing on the reference-arithmetic maps
+    flat_router = cg.TripleGrainFixedEntropyRouter(0.1, 0.8, per_image=False)
+    want_flat = flat_router(r16, r8)[0]
+    assert all(torch.equal(p, q) for p, q in zip(flat_router(e16m, e8m)[0], want_flat))
+    assert all(torch.equal(p, q) for p, q in zip(flat_router(e16m.clone(), e8m.clone(), pixels=x)[0], want_flat))
+    # ... of 32 images it does not fit: never silently -- pixels found on the maps: a warning, and the maps decide as given;
+    # pixels handed over by the caller: refused
     big = torch.rand(32, 3, 256, 256, device=DEV)
     b8, b16 = cg.Entropy(8).to(DEV)(big), cg.Entropy(16).to(DEV)(big)
     assert not cg._lib.lib().cgic_router_refine_supported(32, 16, 16, 0)
-    a = cg.TripleGrainFixedEntropyRouter(0.1, 0.8, per_image=False)(b16, b8)[0]
+    with pytest.warns(RuntimeWarning, match="refinement is not available"):
+        a = cg.TripleGrainFixedEntropyRouter(0.1, 0.8, per_image=False)(b16, b8)[0]
     b = cg.TripleGrainFixedEntropyRouter(0.1, 0.8, per_image=False)(b16.clone(), b8.clone())[0]
     assert all(torch.equal(p, q) for p, q in zip(a, b))
+    with pytest.raises(ValueError, match="refinement is not available"):
+        cg.TripleGrainFixedEntropyRouter(0.1, 0.8, per_image=False)(b16.clone(), b8.clone(), pixels=big)
     # NaN pixels: the NaN patches sort last in both; nothing hangs
     xn = x.clone()
     xn[0, 0, 5, 7] = float("nan")

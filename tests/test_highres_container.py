@@ -91,8 +91,13 @@ class _V:
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("chain", [False, True])
 @pytest.mark.parametrize("fixture", HIRES)
-def test_tiled_compress_matches_reference_files(golden, fixture):
+def test_tiled_compress_matches_reference_files(golden, fixture, chain):
+    """every per-tile .bin, bpp and decoded index of the REAL reference's tiled run -- group by group (chain=False) and through
+    the ONE launch chain (chain=True: grouped VQ + router, grouped compress, and on the way back the grouped one-launch
+    decoder + merge): the fastest path meets the goldens directly, not only through chain == unchained"""
+    from control_gic_amd.quantize import vq_forward_route
     g = golden(fixture)
     gc = golden("coders")
     dev = "cuda"
@@ -112,13 +117,17 @@ def test_tiled_compress_matches_reference_files(golden, fixture):
         ts = by_shape[(batch.shape[-2], batch.shape[-1])]
         assert batch.shape[0] == len(ts)
         cat = lambda key: torch.from_numpy(np.concatenate([g[f"t{t}_{key}"] for t in ts])).to(dev)
+        if chain:                                                  # (recorded: the fused launch has a grouped form)
+            _, _, ind, mask, _, mode = vq_forward_route(cat("z"), vq.embedding.weight, 0.25, True, cat("e16"), cat("e8"), c, m,
+                                                        per_image=True, want_zq=False, want_loss=False)
+            return ind, mask, mode
         mask, _, _, mode = router(cat("e16"), cat("e8"))           # per_image: every tile on its own thresholds
         ind = vq.indices(cat("z"))
         return ind, mask, mode
 
     H, W = (int(v) for v in g["image_hw"])
     x = torch.rand(1, 3, H, W, device=dev)
-    tiled = highres.compress_tiled(x, encode, codec)
+    tiled = highres.compress_tiled(x, encode, codec, chain=chain, fuse_maps=False)
     assert tiled.tiles == tiles
     for t, s in enumerate(tiled.streams()):
         assert set(s) == set(cg.STREAM_NAMES)
@@ -131,7 +140,7 @@ def test_tiled_compress_matches_reference_files(golden, fixture):
     back = container.unpack(container.pack(entries))
     assert back == entries and [(e["y"], e["x"], e["height"], e["width"]) for e in back] == tiles
     # decode side: indices of every tile, and the blend of a trivial decoder
-    per_tile, rec = highres.decompress_tiled(tiled, codec, decode=lambda zq, masks: torch.full(
+    per_tile, rec = highres.decompress_tiled(tiled, codec, chain=chain, decoder="latency" if chain else None, decode=lambda zq, masks: torch.full(
         (1, 3, zq.shape[-2] * 4, zq.shape[-1] * 4), 0.25, device=dev))
     for t, (ind, masks, zq) in enumerate(per_tile):
         assert np.array_equal(ind[0].cpu().numpy(), g[f"t{t}_ind"].astype(np.int64))   # masks are exclusive: merge == ind

@@ -138,8 +138,14 @@ def test_chain_launch_counts_and_uint8_frames():
     with grp as g:
         for k, (_, comp, _) in enumerate(got.groups):
             g.select(k)
-            codec.decompress(comp)
+            codec.decompress(comp, decoder="latency")       # "this call has the GPU to itself"
     assert grp.launches == 1                                # decoder + merge of every group in one launch (decode_merge_kernel)
+    grp = _lib.launch_group(len(got.groups), None, dev)
+    with grp as g:
+        for k, (_, comp, _) in enumerate(got.groups):
+            g.select(k)
+            codec.decompress(comp)                          # default: the one-launch form only up to half the chip's workgroups
+    assert 1 <= grp.launches <= 2 * len(got.groups)
     with cg.decoder_mode("throughput"):                     # the self-synchronising decoder has a grouped form too
         grp = _lib.launch_group(len(got.groups), None, dev)
         with grp as g:
