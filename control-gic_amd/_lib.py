@@ -43,6 +43,20 @@ class Pixels(C.Structure):
 _px = C.POINTER(Pixels)
 
 
+class ImageIO(C.Structure):
+    """struct cgic_image_io (include/cgic_hip.h): the buffers of one cgic_compress_image call"""
+    _fields_ = [("x", _vp), ("x_is_u8", _int), ("z", _vp), ("x_out", _vp), ("e8", _vp), ("e16", _vp), ("flat8", _vp),
+                ("ind", _vp), ("z_q", _vp), ("loss", _vp), ("mask_c", _vp), ("mask_m", _vp), ("mask_f", _vp),
+                ("streams", _vp), ("slot", _i64), ("nbytes", _vp), ("hist", _vp),
+                ("dind", _vp), ("dmask_c", _vp), ("dmask_m", _vp), ("dmask_f", _vp), ("dz_q", _vp), ("status", _vp),
+                ("ws_vq", _vp), ("ws_compress", _vp), ("ws_decompress", _vp)]
+
+
+class TileGroup(C.Structure):
+    """struct cgic_tile_group (include/cgic_hip.h): one shape group of cgic_compress_tiled"""
+    _fields_ = [("ntiles", _int), ("th", _int), ("tw", _int), ("origins", C.POINTER(_int)), ("share", _f64), ("io", ImageIO)]
+
+
 class Tile(C.Structure):
     """struct cgic_tile (include/cgic_hip.h): one destination tile of cgic_cut_tiles"""
     _fields_ = [("dst", _vp), ("image_stride", _i64), ("y0", _int), ("x0", _int), ("th", _int), ("tw", _int)]
@@ -82,6 +96,10 @@ PROTOTYPES = {
     "cgic_entropy_maps_ref_f32": (_int, [_vp, _i64, _i64, _i64, C.POINTER(_f32), _int, _f32, _vp, _vp, _vp]),
     "cgic_entropy_maps_u8": (_int, [_vp, _i64, _i64, _i64, C.POINTER(_f32), _int, _f32, _vp, _vp, _vp, _vp, _vp]),
     "cgic_router_mode": (_int, [_f64, _f64]),
+    "cgic_compress_image": (_int, [_vp, _vp, _int, _int, _vp, _i64, _i64, _i64, _f64, _f64, _f32, _int, C.POINTER(_f32), _int, _f32, _int,
+                                  C.POINTER(ImageIO), C.POINTER(_int), _vp]),
+    "cgic_compress_tiled": (_int, [_vp, _vp, _int, _int, _vp, _vp, _int, _i64, _i64, _i64, _int, C.POINTER(TileGroup), _f64, _f64, _f32, _int,
+                                  C.POINTER(_f32), _int, _f32, _int, C.POINTER(_int), _vp]),
     "cgic_router_refine_supported": (_int, [_i64, _i64, _i64, _int]),
     "cgic_router_refine_scratch_bytes": (_sz, [_i64, _i64, _i64, _int]),
     "cgic_router_f32": (_int, [_vp, _vp, _i64, _i64, _i64, _f64, _f64, _int, _vp, _vp, _vp, _vp, C.POINTER(_int), _px, _vp]),

@@ -116,3 +116,82 @@ extern "C" int cgic_group_launch(cgic_stream_t stream)
     }
     return launches;          // >= 0: launches issued
 }
+
+// One call per call the reference makes (include/cgic_hip.h, section H'): the four entry points of the hot path, in order, on one stream.
+extern "C" int cgic_compress_image(const cgic_table *t, const float *codebook, int K, int e_dim, const void *prepared, int64_t B, int64_t H,
+                                   int64_t W, double coarse_ratio, double medium_ratio, float beta, int legacy, const float *bins, int nbins,
+                                   float sigma, int decoder, const cgic_image_io *io, int *mode_out, cgic_stream_t stream)
+{
+    CGIC_REQUIRE(io && io->x && io->z && io->e8 && io->e16 && io->ind && io->mask_c && io->mask_m && io->mask_f && io->streams && io->nbytes,
+                 CGIC_ERR_INVALID, "compress_image: NULL input / output");
+    CGIC_REQUIRE(B > 0 && H > 0 && W > 0 && H % 16 == 0 && W % 16 == 0, CGIC_ERR_INVALID, "compress_image: H and W must be positive multiples of 16");
+    const int64_t h = H / 4, w = W / 4;
+    int rc;
+    if (io->x_is_u8)
+        rc = cgic_entropy_maps_u8(reinterpret_cast<const unsigned char *>(io->x), B, H, W, bins, nbins, sigma, io->x_out, io->e8, io->e16, io->flat8, stream);
+    else
+        rc = cgic_entropy_maps_f32(reinterpret_cast<const float *>(io->x), B, H, W, bins, nbins, sigma, io->e8, io->e16, io->flat8, stream);
+    if (rc) return rc;
+    // (the refinement reads the frames themselves -- ToTensor's arithmetic is part of the patch evaluation -- or the fp32 pixels)
+    cgic_pixels px;
+    memset(&px, 0, sizeof(px));
+    px.x = io->x; px.is_u8 = io->x_is_u8 ? 1 : 0; px.bins = bins; px.nbins = nbins; px.sigma = sigma; px.flat8 = io->flat8;
+    const cgic_pixels *refine = cgic_router_refine_supported(B, H / 16, W / 16, 1) ? &px : nullptr;
+    int mode = 0;
+    rc = cgic_vq_forward_route_f32(io->z, B, h * w, codebook, K, e_dim, beta, legacy, io->ind, io->z_q, io->loss, io->ws_vq, io->e16, io->e8,
+                                   H / 16, W / 16, coarse_ratio, medium_ratio, 1, io->mask_c, io->mask_m, io->mask_f, nullptr, &mode, nullptr,
+                                   prepared, refine, stream);
+    if (rc) return rc;
+    if (mode_out) *mode_out = mode;
+    rc = cgic_compress_streams(t, io->ind, io->mask_c, io->mask_m, io->mask_f, B, h, w, mode, io->streams, io->slot, io->nbytes, io->hist,
+                               io->ws_compress, stream);
+    if (rc || !io->dind) return rc;
+    return cgic_decompress_streams(t, io->streams, io->slot, io->nbytes, B, h, w, mode, io->dind, io->dmask_c, io->dmask_m, io->dmask_f,
+                                   io->dz_q ? codebook : nullptr, K, e_dim, io->dz_q, nullptr, nullptr, io->status, io->ws_decompress, decoder,
+                                   stream);
+}
+
+extern "C" int cgic_compress_tiled(const cgic_table *t, const float *codebook, int K, int e_dim, const void *prepared, const void *src,
+                                   int src_is_u8, int64_t N, int64_t H, int64_t W, int ngroups, const cgic_tile_group *groups,
+                                   double coarse_ratio, double medium_ratio, float beta, int legacy, const float *bins, int nbins, float sigma,
+                                   int decoder, int *mode_out, cgic_stream_t stream)
+{
+    CGIC_REQUIRE(src && groups && ngroups >= 1 && ngroups <= kMaxGroups && N > 0, CGIC_ERR_INVALID, "compress_tiled: bad arguments (1..%d shape groups)", kMaxGroups);
+    double shares[kMaxGroups];
+    for (int g = 0; g < ngroups; ++g) {
+        const cgic_tile_group &G = groups[g];
+        const cgic_image_io &io = G.io;
+        CGIC_REQUIRE(G.ntiles >= 1 && G.origins && G.th > 0 && G.tw > 0 && G.th % 16 == 0 && G.tw % 16 == 0, CGIC_ERR_INVALID, "compress_tiled: group %d: bad tile shape", g);
+        CGIC_REQUIRE(io.z && io.x_out && io.e8 && io.e16 && io.flat8 && io.ind && io.mask_c && io.mask_m && io.mask_f && io.streams && io.nbytes,
+                     CGIC_ERR_INVALID, "compress_tiled: group %d: NULL buffer", g);
+        shares[g] = G.share;
+    }
+    int rc = cgic_group_begin(ngroups, shares);
+    if (rc) return rc;
+    int mode = cgic_router_mode(coarse_ratio, medium_ratio);
+    for (int g = 0; g < ngroups && !rc; ++g) {
+        const cgic_tile_group &G = groups[g];
+        const cgic_image_io &io = G.io;
+        const int64_t B = N * G.ntiles, h = G.th / 4, w = G.tw / 4;
+        rc = cgic_group_select(g);
+        if (!rc) rc = cgic_entropy_maps_tiles(src, src_is_u8, N, H, W, G.ntiles, G.origins, G.th, G.tw, bins, nbins, sigma, io.x_out, io.e8, io.e16,
+                                              io.flat8, stream);
+        cgic_pixels px;
+        memset(&px, 0, sizeof(px));
+        px.x = io.x_out; px.is_u8 = 0; px.bins = bins; px.nbins = nbins; px.sigma = sigma; px.flat8 = io.flat8;
+        const cgic_pixels *refine = cgic_router_refine_supported(B, G.th / 16, G.tw / 16, 1) ? &px : nullptr;
+        if (!rc) rc = cgic_vq_forward_route_f32(io.z, B, h * w, codebook, K, e_dim, beta, legacy, io.ind, io.z_q, io.loss, io.ws_vq, io.e16, io.e8,
+                                                G.th / 16, G.tw / 16, coarse_ratio, medium_ratio, 1, io.mask_c, io.mask_m, io.mask_f, nullptr, nullptr,
+                                                nullptr, prepared, refine, stream);
+        if (!rc) rc = cgic_compress_streams(t, io.ind, io.mask_c, io.mask_m, io.mask_f, B, h, w, mode, io.streams, io.slot, io.nbytes, io.hist,
+                                            io.ws_compress, stream);
+        if (!rc && io.dind)
+            rc = cgic_decompress_streams(t, io.streams, io.slot, io.nbytes, B, h, w, mode, io.dind, io.dmask_c, io.dmask_m, io.dmask_f,
+                                         io.dz_q ? codebook : nullptr, K, e_dim, io.dz_q, nullptr, nullptr, io.status, io.ws_decompress, decoder,
+                                         stream);
+    }
+    if (rc) { cgic_group_abort(); return rc; }
+    if (mode_out) *mode_out = mode;
+    rc = cgic_group_launch(stream);
+    return rc < 0 ? rc : CGIC_OK;
+}

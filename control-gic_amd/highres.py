@@ -295,6 +295,116 @@ def compress_tiled_batch(x, encode, codec, tile=TILE, concurrent=False, chain=Fa
     return out
 
 
+class TiledCall:
+    """The tiled driver (inference_high_resolution.py:236-257: one compress() per tile) for images of ONE size as ONE foreign call
+    per image batch (cgic_compress_tiled): pad + crop + both entropy maps, VQ + per-tile router, stream coder and -- decode=True --
+    decoder + merge, every link one launch for all shape groups, over buffers allocated once.  Hot path only: the latent of every
+    shape group is the caller's (`zs`).  The results live in this object's buffers: valid until the next call.
+    -> __call__(x, zs): x [N,3,H,W] fp32 or uint8 frames [N,H,W,3]; zs: per shape group (self.groups order: (th, tw), tile indices) the
+    latent [N*T,4,th/4,tw/4]; returns a TiledImage (N == 1) or a list of N, .decoded = per group (ind, masks, z_q, status)."""
+
+    def __init__(self, quantizer, coarse_ratio, medium_ratio, N, H, W, frequency=None, decode=True, frames=False, decoder=None, tile=TILE,
+                 prepare=True):
+        import ctypes
+        from .codec import GrainCodec, _decoder_flag
+        from .quantize import prepare_codebook
+        w = quantizer.embedding.weight
+        dev = w.device
+        _lib.require_device(w)
+        self.vq, self.dev, self.N, self.H, self.W, self.frames = quantizer, dev, N, H, W, bool(frames)
+        self.ratios = (float(coarse_ratio), float(medium_ratio))
+        self.codec = GrainCodec(frequency if frequency is not None else quantizer.embedding_counter, w)
+        self.prepared = prepare_codebook(w) if prepare else None
+        self.decoder = _decoder_flag(decoder)
+        self.pad, _ = compute_padding(H, W)
+        left, right, top, bottom = self.pad
+        self.tiles = tile_grid(H + top + bottom, W + left + right, tile)
+        by_shape = {}
+        for i, (_, _, th, tw) in enumerate(self.tiles):
+            by_shape.setdefault((th, tw), []).append(i)
+        self.groups = sorted(by_shape.items(), key=lambda kv: -len(kv[1]) * kv[0][0] * kv[0][1])
+        l = _lib.lib()
+        if len(self.groups) > l.cgic_group_max():
+            raise ValueError(f"{len(self.groups)} tile shapes; cgic_compress_tiled takes at most {l.cgic_group_max()}")
+        f32, i32, i64, u8t = torch.float32, torch.int32, torch.int64, torch.uint8
+        E = lambda shape, dt: torch.empty(shape, dtype=dt, device=dev)
+        total = sum(len(ix) * th * tw for (th, tw), ix in self.groups)
+        self._arr = (_lib.TileGroup * len(self.groups))()
+        self._buf, self._keep = [], []
+        p = _lib.ptr
+        for k, ((th, tw), idxs) in enumerate(self.groups):
+            T, B, h, ww = len(idxs), N * len(idxs), th // 4, tw // 4
+            slot = self.codec.slot_bytes(h, ww)
+            t = {"x": E((B, 3, th, tw), f32), "e8": E((B, th // 8, tw // 8), f32), "e16": E((B, th // 16, tw // 16), f32),
+                 "flat8": E((B, th // 8, tw // 8), f32), "ind": E((B * h * ww,), i64),
+                 "mask": [E((B, 1, h // 4, ww // 4), i32), E((B, 1, h // 2, ww // 2), i32), E((B, 1, h, ww), i32)],
+                 "data": E((B, _lib.NUM_STREAMS, slot), u8t), "nbytes": E((B, _lib.NUM_STREAMS), i32), "slot": slot, "h": h, "w": ww}
+            if decode:
+                t.update({"dind": E((B, h, ww), i64), "dz_q": E((B, 4, h, ww), f32), "status": E((B,), i32),
+                          "dmask": [E((B, 1, h // 4, ww // 4), i32), E((B, 1, h // 2, ww // 2), i32), E((B, 1, h, ww), i32)]})
+            ws_c = E((max(1, l.cgic_compress_workspace_bytes(B, h, ww)),), u8t)
+            ws_d = E((l.cgic_decompress_workspace_bytes(B, h, ww),), u8t) if decode else None
+            org = (ctypes.c_int * (2 * T))(*[v for i in idxs for v in (self.tiles[i][0] - top, self.tiles[i][1] - left)])
+            g = self._arr[k]
+            g.ntiles, g.th, g.tw, g.origins, g.share = T, th, tw, org, len(idxs) * th * tw / total
+            io = g.io
+            io.x_out, io.e8, io.e16, io.flat8, io.ind = p(t["x"]), p(t["e8"]), p(t["e16"]), p(t["flat8"]), p(t["ind"])
+            io.mask_c, io.mask_m, io.mask_f = (p(m) for m in t["mask"])
+            io.streams, io.slot, io.nbytes = p(t["data"]), slot, p(t["nbytes"])
+            if decode:
+                io.dind, io.dz_q, io.status = p(t["dind"]), p(t["dz_q"]), p(t["status"])
+                io.dmask_c, io.dmask_m, io.dmask_f = (p(m) for m in t["dmask"])
+            io.ws_compress, io.ws_decompress = p(ws_c), p(ws_d)
+            self._buf.append(t)
+            self._keep += [org, ws_c, ws_d]
+        self._mode = ctypes.c_int(0)
+        self._fn = l.cgic_compress_tiled
+        self._bins = _lib.linspace_bins()
+        self._decode = bool(decode)
+        self.decoded = None
+
+    def __call__(self, x, zs):
+        import ctypes
+        from .codec import CompressedBatch
+        N, H, W = self.N, self.H, self.W
+        if tuple(x.shape) != ((N, H, W, 3) if self.frames else (N, 3, H, W)) or x.dtype != (torch.uint8 if self.frames else torch.float32) \
+                or not x.is_contiguous() or x.device != self.dev or len(zs) != len(self.groups):
+            raise ValueError("TiledCall: x / zs do not have the shape, dtype, device or layout this object was built for")
+        for k, (((th, tw), idxs), z) in enumerate(zip(self.groups, zs)):
+            if tuple(z.shape) != (N * len(idxs), 4, th // 4, tw // 4) or z.dtype != torch.float32 or not z.is_contiguous() or z.device != self.dev:
+                raise ValueError(f"TiledCall: latent of shape group {k} must be fp32 [{N * len(idxs)},4,{th // 4},{tw // 4}]")
+            self._arr[k].io.z = z.data_ptr()
+        w = self.vq.embedding.weight
+
+        def go():
+            _lib.check(self._fn(self.codec.huffman.table.handle, w.data_ptr(), w.shape[0], w.shape[1], _lib.ptr(self.prepared), x.data_ptr(),
+                                int(self.frames), N, H, W, len(self.groups), self._arr, self.ratios[0], self.ratios[1], float(self.vq.beta),
+                                int(bool(self.vq.legacy)), self._bins, 32, 0.01, self.decoder, ctypes.byref(self._mode),
+                                torch.cuda.current_stream(self.dev).cuda_stream))
+        if torch.cuda.current_device() == self.dev.index:
+            go()
+        else:
+            with torch.cuda.device(self.dev):
+                go()
+        mode = self._mode.value
+        groups = [(idxs, CompressedBatch(t["data"], t["nbytes"], mode, t["h"], t["w"]), (t["ind"], t["mask"], mode))
+                  for (_, idxs), t in zip(self.groups, self._buf)]
+        self.decoded = [(t["dind"], t["dmask"], t["dz_q"], t["status"]) for t in self._buf] if self._decode else None
+        if N == 1:
+            return TiledImage((H, W), self.pad, self.tiles, groups)
+        out = []
+        for n in range(N):
+            mine = []
+            for idxs, comp, (ind, masks, mode_) in groups:
+                T = len(idxs)
+                sl = slice(n * T, (n + 1) * T)
+                per = ind.numel() // (N * T)
+                mine.append((idxs, CompressedBatch(comp.data[sl], comp.nbytes[sl], comp.mode, comp.h, comp.w),
+                             (ind.view(N * T, per)[sl].reshape(-1), [m[sl] for m in masks], mode_)))
+            out.append(TiledImage((H, W), self.pad, self.tiles, mine))
+        return out
+
+
 def decompress_tiled_batch(tiled_list, codec, concurrent=False, check=True, chain=False, decoder=None):
     """inverse of compress_tiled_batch for TiledImages of one geometry (from it, or from N compress_tiled calls on images
     of one size, or rebuilt from containers): ONE decompress per shape group over all the images

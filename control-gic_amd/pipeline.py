@@ -62,6 +62,94 @@ class HotPathPipeline:
         return [self._chain(x, z, hist, decode)]
 
 
+class HotCall:
+    """CGIC.compress (hot path: model.py:206-401 without the conv nets) for batches of ONE size as ONE foreign call per batch
+    (cgic_compress_image: entropy maps -> [VQ + per-image router] -> stream coder (+ usage histogram) -> prefix decoder + merge)
+    over buffers allocated ONCE -- the eager counterpart of a captured hipGraph: what a loop like inference.py:157-166 pays per
+    image is one ctypes call and the launches themselves, no Python per kernel and no allocation.
+    The results of a call (`out`: the same keys as HotPathPipeline.run) live in this object's buffers: valid until the next call."""
+
+    def __init__(self, quantizer, coarse_ratio, medium_ratio, B, H, W, frequency=None, decode=True, u8=False, hist=None,
+                 decoder=None, prepare=True, want_zq=True, want_loss=True):
+        import ctypes
+        from .codec import CompressedBatch, _decoder_flag
+        if H % 16 or W % 16:
+            raise ValueError("H and W must be multiples of 16")
+        w = quantizer.embedding.weight
+        dev = w.device
+        _lib.require_device(w)
+        self.vq, self.dev, self.shape, self.u8 = quantizer, dev, (B, H, W), bool(u8)
+        self.ratios = (float(coarse_ratio), float(medium_ratio))
+        self.codec = GrainCodec(frequency if frequency is not None else quantizer.embedding_counter, w)
+        self.prepared = prepare_codebook(w) if prepare else None
+        self.decoder = _decoder_flag(decoder)
+        h, ww = H // 4, W // 4
+        l = _lib.lib()
+        f32, i32, i64, u8t = torch.float32, torch.int32, torch.int64, torch.uint8
+        E = lambda shape, dt: torch.empty(shape, dtype=dt, device=dev)
+        slot = self.codec.slot_bytes(h, ww)
+        t = {"e8": E((B, H // 8, W // 8), f32), "e16": E((B, H // 16, W // 16), f32), "flat8": E((B, H // 8, W // 8), f32),
+             "x_out": E((B, 3, H, W), f32) if u8 else None,
+             "ind": E((B * h * ww,), i64), "z_q": E((B, 4, h, ww), f32) if want_zq else None, "loss": E((), f32) if want_loss else None,
+             "mask": [E((B, 1, h // 4, ww // 4), i32), E((B, 1, h // 2, ww // 2), i32), E((B, 1, h, ww), i32)],
+             "data": E((B, _lib.NUM_STREAMS, slot), u8t), "nbytes": E((B, _lib.NUM_STREAMS), i32), "hist": hist}
+        if decode:
+            t.update({"dind": E((B, h, ww), i64), "dmask": [E((B, 1, h // 4, ww // 4), i32), E((B, 1, h // 2, ww // 2), i32), E((B, 1, h, ww), i32)],
+                      "dz_q": E((B, 4, h, ww), f32), "status": E((B,), i32)})
+        ws = {"vq": E((l.cgic_vq_workspace_bytes(B * h * ww),), u8t) if want_loss else None,
+              "c": E((max(1, l.cgic_compress_workspace_bytes(B, h, ww)),), u8t),
+              "d": E((l.cgic_decompress_workspace_bytes(B, h, ww),), u8t) if decode else None}
+        self._t, self._ws, self._decode, self._slot = t, ws, bool(decode), slot
+        p = _lib.ptr
+        io = _lib.ImageIO()
+        io.x_is_u8 = int(self.u8)
+        io.x_out, io.e8, io.e16, io.flat8 = p(t["x_out"]), p(t["e8"]), p(t["e16"]), p(t["flat8"])
+        io.ind, io.z_q, io.loss = p(t["ind"]), p(t["z_q"]), p(t["loss"])
+        io.mask_c, io.mask_m, io.mask_f = (p(m) for m in t["mask"])
+        io.streams, io.slot, io.nbytes, io.hist = p(t["data"]), slot, p(t["nbytes"]), p(hist)
+        if decode:
+            io.dind, io.dz_q, io.status = p(t["dind"]), p(t["dz_q"]), p(t["status"])
+            io.dmask_c, io.dmask_m, io.dmask_f = (p(m) for m in t["dmask"])
+        io.ws_vq, io.ws_compress, io.ws_decompress = p(ws["vq"]), p(ws["c"]), p(ws["d"])
+        self._io = io
+        self._mode = ctypes.c_int(0)
+        self._CompressedBatch = CompressedBatch
+        self._fn = l.cgic_compress_image
+        self._bins = _lib.linspace_bins()
+        self.out = None
+
+    def refresh_codebook(self):
+        if self.prepared is not None:
+            self.prepared = prepare_codebook(self.vq.embedding.weight, out=self.prepared)
+
+    def __call__(self, x, z):
+        """x [B,3,H,W] fp32 (or uint8 frames [B,H,W,3] with u8=True), z [B,4,H/4,W/4] fp32, contiguous, on the device -> dict"""
+        import ctypes
+        B, H, W = self.shape
+        if tuple(x.shape) != ((B, H, W, 3) if self.u8 else (B, 3, H, W)) or x.dtype != (torch.uint8 if self.u8 else torch.float32) \
+                or tuple(z.shape) != (B, 4, H // 4, W // 4) or z.dtype != torch.float32 or not x.is_contiguous() or not z.is_contiguous() \
+                or x.device != self.dev or z.device != self.dev:
+            raise ValueError("HotCall: x / z do not have the shape, dtype, device or layout this object was built for")
+        io, t, vq = self._io, self._t, self.vq
+        io.x, io.z = x.data_ptr(), z.data_ptr()
+        w = vq.embedding.weight
+
+        def go():
+            _lib.check(self._fn(self.codec.huffman.table.handle, w.data_ptr(), w.shape[0], w.shape[1], _lib.ptr(self.prepared), B, H, W,
+                                self.ratios[0], self.ratios[1], float(vq.beta), int(bool(vq.legacy)), self._bins, 32, 0.01, self.decoder,
+                                ctypes.byref(io), ctypes.byref(self._mode), torch.cuda.current_stream(self.dev).cuda_stream))
+        if torch.cuda.current_device() == self.dev.index:      # (the torch device context manager costs ~10 us: only when it is needed)
+            go()
+        else:
+            with torch.cuda.device(self.dev):
+                go()
+        mode = self._mode.value
+        comp = self._CompressedBatch(t["data"], t["nbytes"], mode, H // 4, W // 4)
+        self.out = {"e8": t["e8"], "e16": t["e16"], "mask": t["mask"], "mode": mode, "z_q": t["z_q"], "loss": t["loss"], "ind": t["ind"],
+                    "comp": comp, "dec": (t["dind"], t["dmask"], t["dz_q"], t["status"]) if self._decode else None, "x": t["x_out"]}
+        return self.out
+
+
 class BatchSlot:
     """static buffers + two captured hipGraphs (encode side / decode side) for one batch of the stream"""
 

@@ -484,6 +484,60 @@ int cgic_decoder_blend_fine_f32(const float *h, const float *h_fine, const int32
 int cgic_embedding_gather_f32(const int64_t *ind, int64_t B, int64_t hw, const float *codebook, int K,
                               int e_dim, float *out, int32_t *status, cgic_stream_t stream);
 
+/* ---------------------------------------------------------------------------
+ * H'. One call per call the reference makes -- CGIC.compress for one image or a batch of images of one size, hot path only
+ * (CGIC/models/model.py:206-401 without the conv encoder / decoder; the loop of inference.py:157-166 calls it once per image):
+ *   Entropy(8), Entropy(16) on the pixels (model.py:99-101)  ->  [VectorQuantize2.forward + the per-image router, one launch]
+ *   (model.py:110-112, vqvae_blocks.py:355)  ->  Huffman / mask coding of the five streams (model.py:217-260)  ->  and, if any
+ *   decode output is given, the way back (model.py:269-397): prefix decoder, scatter / merge, codebook gather.
+ * Exactly the launches of cgic_entropy_maps_f32 / _u8, cgic_vq_forward_route_f32 (with the threshold-band refinement from these
+ * pixels), cgic_compress_streams and cgic_decompress_streams with the same arguments -- bit-identical results -- enqueued by
+ * ONE call on `stream`: an eager caller pays one foreign call instead of four (+ their Python around them: B = 1 eager
+ * 93 -> the time of the launches themselves).
+ *   x        device fp32 [B,3,H,W], or with x_is_u8 the uint8 frames [B,H,W,3]; H, W multiples of 16
+ *   z        device fp32 [B,4,H/4,W/4]: the latent behind quant_conv (the conv encoder is the caller's)
+ *   e8, e16, flat8   device fp32 [B,H/8,W/8], [B,H/16,W/16], [B,H/8,W/8]: written (the maps are results of the call)
+ *   x_out    device fp32 [B,3,H,W] or NULL (x_is_u8 only): ToTensor's output, as cgic_entropy_maps_u8
+ *   ind, mask_c/m/f, z_q (or NULL), loss (or NULL), streams [B,5,slot], nbytes [B,5], hist (or NULL): as the single calls
+ *   dind ... status: the decode side's outputs (cgic_decompress_streams); dind == NULL: encode only
+ *   ws_vq (cgic_vq_workspace_bytes(B*h*w); may be NULL iff loss is), ws_compress (cgic_compress_workspace_bytes),
+ *   ws_decompress (cgic_decompress_workspace_bytes; NULL iff dind is)
+ * ------------------------------------------------------------------------- */
+typedef struct cgic_image_io {
+    const void *x; int x_is_u8;
+    const float *z;
+    float *x_out, *e8, *e16, *flat8;
+    int64_t *ind; float *z_q, *loss;
+    int32_t *mask_c, *mask_m, *mask_f;
+    uint8_t *streams; int64_t slot; int32_t *nbytes; int64_t *hist;
+    int64_t *dind; int32_t *dmask_c, *dmask_m, *dmask_f; float *dz_q; int32_t *status;
+    void *ws_vq, *ws_compress, *ws_decompress;
+} cgic_image_io;
+int cgic_compress_image(const cgic_table *t, const float *codebook, int K, int e_dim, const void *prepared, int64_t B, int64_t H,
+                        int64_t W, double coarse_ratio, double medium_ratio, float beta, int legacy, const float *bins, int nbins,
+                        float sigma, int decoder, const cgic_image_io *io, int *mode_out, cgic_stream_t stream);
+
+/* The same for the tiled driver of high-resolution images (inference_high_resolution.py:112-173 pad + grid, :236-257 the
+ * per-tile compress loop): the tiles of N images of one size, grouped by shape (a 2040x1356 image: six tiles of four shapes),
+ * through ONE launch chain -- [pad + crop + both entropy maps] -> [VQ + per-tile router] -> stream coder -> (decoder + merge) --
+ * every link one launch for all shape groups (launch groups, cgic_group_begin / _launch).  One foreign call per image instead of
+ * ~30 recorded ones (eager: 0.54 ms -> the launches themselves).  Per group:
+ *   ntiles, th, tw, origins (host [ntiles][2]: (y0, x0) of the tiles in UNPADDED coordinates, may be negative / reach beyond
+ *   the image: the centred pad), share (of the chip: the group's pixels / all pixels), and io: the buffers of the group's batch
+ *   of N * ntiles tiles (image-major), as cgic_compress_image -- io.x / x_is_u8 are ignored (the tiles come from `src`),
+ *   io.x_out (the fp32 tile batch) is REQUIRED, io.z is the latent of the tiles.
+ * mode_out: the routing mode (the same for all groups).  At most cgic_group_max() groups. */
+typedef struct cgic_tile_group {
+    int ntiles, th, tw;
+    const int *origins;
+    double share;
+    cgic_image_io io;
+} cgic_tile_group;
+int cgic_compress_tiled(const cgic_table *t, const float *codebook, int K, int e_dim, const void *prepared, const void *src,
+                        int src_is_u8, int64_t N, int64_t H, int64_t W, int ngroups, const cgic_tile_group *groups,
+                        double coarse_ratio, double medium_ratio, float beta, int legacy, const float *bins, int nbins, float sigma,
+                        int decoder, int *mode_out, cgic_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -915,6 +915,47 @@ def test_pipeline_graph_replay_equals_eager(golden):
     assert rs[0]["comp"].to_host() == r1["comp"].to_host() and float(rs[0]["loss"]) == float(r1["loss"])
 
 
+@pytest.mark.parametrize("u8", [False, True])
+def test_one_call_driver_equals_the_four_calls(u8):
+    """cgic_compress_image (pipeline.HotCall): CGIC.compress's hot path for a batch as ONE foreign call over buffers allocated once
+    == entropy_maps / vq_forward_route / GrainCodec.compress / .decompress called one by one, bit for bit (maps, masks, indices,
+    z_q, loss, every stream byte, decoded indices and rows, usage histogram), fp32 pixels and uint8 frames, twice in a row"""
+    from control_gic_amd.quantize import vq_forward_route
+    from oracle.content_families import families
+    rng = np.random.default_rng(11)
+    B, H, W = 5, 128, 192
+    vq = _make_vq(rng.standard_normal((1024, 4), dtype=np.float32))
+    vq.usage_counter.copy_(torch.from_numpy(np.floor(1e6 / (1 + np.arange(1024)) ** 1.1).astype(np.float32)))
+    hist = torch.zeros(1024, dtype=torch.int64, device=DEV)
+    hc = cg.pipeline.HotCall(vq, 0.1, 0.8, B, H, W, u8=u8, hist=hist)
+    codec = cg.GrainCodec(vq.embedding_counter, vq.embedding.weight)
+    hsum = torch.zeros_like(hist)
+    for rep in range(2):
+        xf = families(n=B, H=H, W=W, seed=3 + rep)["smooth8" if rep else "noise8"]
+        z = _t(rng.standard_normal((B, 4, H // 4, W // 4), dtype=np.float32))
+        frames = torch.from_numpy(np.round(xf * 255.0).astype(np.uint8).transpose(0, 2, 3, 1).copy()).to(DEV)
+        x = frames if u8 else _t(xf)
+        out = hc(x, z)
+        torch.cuda.synchronize()
+        if u8:
+            xs, e8, e16 = cg.entropy_maps_u8(frames)
+            assert torch.equal(out["x"], xs) and torch.equal(xs, _t(xf))
+        else:
+            e8, e16 = cg.entropy_maps(x)
+        zq, loss, ind, mask, _, mode = vq_forward_route(z, vq.embedding.weight, 0.25, True, e16, e8, 0.1, 0.8, per_image=True, pixels=x)
+        h2 = torch.zeros_like(hist)
+        comp = codec.compress(ind, mask, mode, hist=h2)
+        dind, dmask, dq, status = codec.decompress(comp)
+        assert mode == out["mode"] and torch.equal(e8, out["e8"]) and torch.equal(e16, out["e16"])
+        assert torch.equal(ind, out["ind"]) and torch.equal(zq, out["z_q"]) and torch.equal(loss, out["loss"])
+        assert all(torch.equal(a, b) for a, b in zip(mask, out["mask"]))
+        assert comp.to_host() == out["comp"].to_host()
+        assert torch.equal(dind, out["dec"][0]) and torch.equal(dq, out["dec"][2]) and int(out["dec"][3].abs().max()) == 0
+        assert all(torch.equal(a, b) for a, b in zip(dmask, out["dec"][1]))
+        hsum += h2
+        assert torch.equal(hist, hsum)                            # the usage histogram accumulates over the calls
+
+
 def test_refreshed_codebook_reaches_captured_graphs():
     """advisor r3: refresh_codebook() used to allocate a NEW prepared image, so graphs captured earlier kept reading the old
     (freed) one.  The image is rewritten in place now: a replay after refresh_codebook() quantises against the new weights."""

@@ -105,6 +105,54 @@ def test_chain_of_ragged_tiles_equals_the_groups_one_by_one(H, W, content):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("frames,N,H,W", [(False, 1, 1356, 2040), (True, 1, 1356, 2040), (False, 3, 800, 1040), (False, 1, 512, 768)])
+def test_one_call_tiled_driver_equals_the_group_by_group_path(frames, N, H, W):
+    """cgic_compress_tiled (highres.TiledCall): the tiles of N images of one size through ONE foreign call -- cut + maps, VQ + router,
+    coder, decoder + merge as one launch chain over buffers allocated once -- == highres.compress_tiled / decompress_tiled group by
+    group (themselves pinned to the real reference's per-tile files): every stream byte, bpp, decoded index, mask and row; fp32
+    images and uint8 frames, a 2040x1356 image (four shape groups), three 1040x800 ones, a single-shape 768x512 one; twice in a row"""
+    from control_gic_amd import highres
+    from control_gic_amd.quantize import vq_forward_route
+    cg, dev, rng, vq, codec = _setup(7)
+    tc = highres.TiledCall(vq, 0.1, 0.8, N, H, W, frequency=codec.huffman, frames=frames)
+    zs = [torch.from_numpy(rng.standard_normal((N * len(idxs), 4, th // 4, tw // 4), dtype=np.float32)).to(dev) for (th, tw), idxs in tc.groups]
+    zmap = {(N * len(idxs), th, tw): z for ((th, tw), idxs), z in zip(tc.groups, zs)}
+
+    def encode(tiles):
+        if frames:
+            _, e8, e16 = cg.entropy_maps_u8(tiles, want_x=False)
+            key = (tiles.shape[0], tiles.shape[1], tiles.shape[2])
+        else:
+            e8, e16 = cg.entropy_maps(tiles)
+            key = (tiles.shape[0], tiles.shape[2], tiles.shape[3])
+        _, _, ind, mask, _, mode = vq_forward_route(zmap[key], vq.embedding.weight, 0.25, True, e16, e8, 0.1, 0.8, per_image=True, pixels=tiles)
+        return ind, mask, mode
+
+    for rep in range(2):
+        if frames:
+            x = torch.from_numpy(rng.integers(0, 256, (N, H, W, 3), dtype=np.uint8)).to(dev)
+        else:
+            x = torch.from_numpy((rng.integers(0, 256, (N, 3, H, W)) / 255.0).astype(np.float32)).to(dev)
+        got = tc(x, zs)
+        torch.cuda.synchronize()
+        ref = highres.compress_tiled_batch(x, encode, codec)
+        got = [got] if N == 1 else got
+        for g, r in zip(got, ref):
+            assert g.tiles == r.tiles and g.streams() == r.streams() and g.bpp() == r.bpp()
+        dref = highres.decompress_tiled_batch(ref, codec)
+        for k, ((th, tw), idxs) in enumerate(tc.groups):
+            dind, dmask, dzq, status = tc.decoded[k]
+            assert int(status.abs().max()) == 0
+            T = len(idxs)
+            for n in range(N):
+                for j, i in enumerate(idxs):
+                    ind_r, masks_r, zq_r = dref[n][i]
+                    b = n * T + j
+                    assert torch.equal(dind[b:b + 1], ind_r) and torch.equal(dzq[b:b + 1], zq_r)
+                    assert all(torch.equal(m[b:b + 1], q) for m, q in zip(dmask, masks_r))
+
+
+@pytest.mark.gpu
 def test_chain_launch_counts_and_uint8_frames():
     """a 2040x1356 image (6 tiles, 4 shape groups): the encode chain is 3 launches (2 + the tile cut inside the map launch), the decode chain 1; uint8 frames go through
     the grouped ToTensor + entropy launch"""
