@@ -1,12 +1,14 @@
 #!/bin/bash
-# profiles/r04_* from the output of tools/gpu_profile_r04.sh (gpurun_out/r04p)
+# profiles/<round>_* from the output of tools/gpu_profile.sh (gpurun_out/<round>p); usage: tools/assemble_profiles.sh [r05] ["what changed this round"]
+R=${1:-r05}
+WHAT=${2:-"refinement band by value, refinement queues in the stand-alone router launch, one-call drivers"}
 cd "$(dirname "$0")/.." || exit 1
-O=gpurun_out/r04p
-cp $O/r04_roofline.json profiles/r04_roofline.json; cp $O/pmc_hbm.json profiles/pmc_vq.json
+O=gpurun_out/${R}p
+cp $O/${R}_roofline.json profiles/${R}_roofline.json; cp $O/pmc_hbm.json profiles/pmc_vq.json
 {
-echo "# Kernel-trace summaries, round 4 (router with threshold-band refinement from the pixels, VQ waves taking priority turns, DPP histogram scans in the router, flat8 by-product of the entropy kernel)"
+echo "# Kernel-trace summaries, ${R} (${WHAT})"
 echo
-echo "Made by \`tools/gpu_profile_r04.sh\` on one MI355X (everything below is from ONE gpurun call; \`profiles/r04_roofline.json\` holds the same numbers machine-readable)."
+echo "Made by \`tools/gpu_profile.sh\` on one MI355X (everything below is from ONE gpurun call; \`profiles/${R}_roofline.json\` holds the same numbers machine-readable)."
 echo "Commands: \`rocprofv3 --kernel-trace --stats -- python bench.py --steps 96 --warmup 16 --no-report --lanes L\` for L = 1 and 4"
 echo "(\`--no-report\`: only the timed loop, so that the last 96 five-launch chains of the trace are the timed steps; tools/trace_concurrency.py),"
 echo "and \`rocprofv3 --kernel-trace --stats -- python tools/run_roofline_cmd.py fused|vq\` = the roofline command of bench.py on its own"
@@ -23,13 +25,13 @@ echo; cat $O/loop_lanes4.md; echo; echo '```'; head -9 $O/kernel_stats_lanes4.md
 echo
 echo "## the roofline command: the fused VQ + router launch alone, back to back (tools/run_roofline_cmd.py fused)"
 echo; grep HIP $O/alone.log; echo; echo '```'; head -5 $O/kernel_stats_alone.md; echo '```'
-echo "rocprofv3 average over the last 100 launches (the five timed replays): see r04_roofline.json \`rocprof_avg_us_alone_graph\`."
+echo "rocprofv3 average over the last 100 launches (the five timed replays): see ${R}_roofline.json \`rocprof_avg_us_alone_graph\`."
 echo
 echo "## the VQ kernel without the router workgroups (tools/run_roofline_cmd.py vq)"
 echo; grep HIP $O/alonevq.log; echo; echo '```'; head -5 $O/kernel_stats_alone_vq.md; echo '```'
-} > profiles/r04_kernel_stats.md
+} > profiles/${R}_kernel_stats.md
 {
-echo "# HBM traffic per launch, round 4 (rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in SEPARATE passes, --kernel-trace)"
+echo "# HBM traffic per launch, ${R} (rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in SEPARATE passes, --kernel-trace)"
 echo
 echo "Command per pass: \`rocprofv3 --pmc <C> --kernel-trace -- python bench.py --steps 40 --warmup 10 --no-report --lanes 1 --no-graph --no-dist\`;"
 echo "tools/pmc_summary.py: KiB x 1024; FETCH_SIZE doubled per the gfx950 note of MI355X_MICROARCH.md (a 128-byte request is tallied as 64)."
@@ -44,9 +46,9 @@ cat $O/pmc_hbm_lanes4.md 2>/dev/null
 echo
 echo "Algorithmic bytes per launch at B=64 of 256x256: entropy maps 50.33 MB read (the image, once) + 0.6 MB written (two maps + the flat8 by-product);"
 echo "VQ + router 4.2 MB read (latent) + 0.33 MB (entropy maps) + 0.26 MB (flat8) and 2.1 MB (int64 indices) + 4.2 MB (z_q) + 1.38 MB (int32 masks) written = 12.5 MB."
-} > profiles/r04_pmc_hbm.md
+} > profiles/${R}_pmc_hbm.md
 {
-echo "# SQ counters of the dominant kernel, round 4: the shipping fused VQ + router launch (vq_filter_router_kernel<true,false>, fp16 MFMA filter + exact fp32 resolve + router workgroups with refinement)"
+echo "# SQ counters of the dominant kernel, ${R}: the shipping fused VQ + router launch (vq_filter_router_kernel<true,false>, fp16 MFMA filter + exact fp32 resolve + router workgroups with refinement)"
 echo
 echo "Three passes of \`rocprofv3 --pmc <8 counters> --kernel-trace -- python tools/run_roofline_cmd.py fused\` (counters summed over all XCDs / SEs of a dispatch, averaged over the dispatches)."
 echo
@@ -54,7 +56,7 @@ cat $O/pmc_sq_vq_fused.md
 echo
 python - <<PY
 import json
-d = json.load(open("$O/r04_roofline.json")); m = d.get("mfma", {})
+d = json.load(open("$O/${R}_roofline.json")); m = d.get("mfma", {})
 dur = d["rocprof_avg_us_alone_graph"]
 cyc = dur * 1e-6 * 2.4e9
 print("Derived (launch duration %.2f us by rocprofv3 = %.0f cycles at 2.4 GHz; 1024 SIMDs):" % (dur, cyc))
@@ -72,6 +74,6 @@ cat $O/pmc_sq.md
 echo
 echo '### --lanes 4 (what the timed step launches: throughput decoder decode_image_kernel, one-band merge)'
 cat $O/pmc_sq_lanes4.md
-} > profiles/r04_pmc_sq_vq.md
+} > profiles/${R}_pmc_sq_vq.md
 python -c "
-import json; d=json.load(open('profiles/r04_roofline.json')); print({k: d[k] for k in ('rocprof_avg_us_alone_graph','hip_events_us_alone_graph_same_run','rocprof_avg_us_lanes1_loop','rocprof_avg_us_lanes4_loop','frac_alone_graph','frac_lanes1_loop','hbm_bytes_per_launch')}); print(d['mfma']['mfma_busy_frac'])"
+import json; d=json.load(open('profiles/${R}_roofline.json')); print({k: d[k] for k in ('rocprof_avg_us_alone_graph','hip_events_us_alone_graph_same_run','rocprof_avg_us_lanes1_loop','rocprof_avg_us_lanes4_loop','frac_alone_graph','frac_lanes1_loop','hbm_bytes_per_launch')}); print(d['mfma']['mfma_busy_frac'])"

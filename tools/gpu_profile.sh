@@ -1,8 +1,10 @@
 #!/bin/bash
-# round-4 profiling passes of the final build (kernel traces at --lanes 1 / 4, the roofline command alone, HBM and SQ counters)
+# the round's profiling passes of the final build (kernel traces at --lanes 1 / 4, the roofline command alone, HBM and SQ counters)
+# usage (on the GPU box, through gpurun): bash tools/gpu_profile.sh [r05]   -> gpurun_out/<round>p; then tools/assemble_profiles.sh <round> here
+R=${1:-r05}
 cd "$GRAFT_REPO_ROOT" || exit 1
 export TMPDIR=/tmp
-O=gpurun_out/r04p; rm -rf $O; mkdir -p $O
+O=gpurun_out/${R}p; rm -rf $O; mkdir -p $O
 for L in 1 4; do
   CMD="python $GRAFT_REPO_ROOT/bench.py --steps 96 --warmup 16 --no-report --lanes $L"
   (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/$O/stats$L -o t -- $CMD) > $O/stats$L.log 2>&1
@@ -48,7 +50,10 @@ for S in A B C; do
 done
 python tools/pmc_sq_summary.py --match vq_filter $(find $O/pmcf_A $O/pmcf_B $O/pmcf_C -name '*.db' | sort) > $O/pmc_sq_vq_fused.md 2>&1
 python tools/pmc_sq_summary.py --json --match vq_filter $(find $O/pmcf_A $O/pmcf_B $O/pmcf_C -name '*.db' | sort) > $O/pmc_sq_vq_fused.json 2>/dev/null
-python tools/roofline_json.py $O > $O/roofline.log 2>&1
+# the stand-alone router launch on tie-heavy content, refinement queues on / off (tools/probes/probe_refine_queue.py: its own HIP-event figures)
+(timeout 300 python tools/probes/probe_refine_queue.py smooth8 flat_edges tiles) > $O/refine_queue.log 2>&1
+(timeout 300 python tools/probes/probe_entropy_err.py) > $O/entropy_err.log 2>&1
+python tools/roofline_json.py $O $R > $O/roofline.log 2>&1
 find $O -name '*.db' -size +6M -delete
 find $O -name '*.csv' -size +2M -delete
 cat $O/loop_lanes1.md $O/loop_lanes4.md; tail -5 $O/alone.log; tail -30 $O/roofline.log; du -sh $O

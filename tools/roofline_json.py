@@ -1,7 +1,8 @@
-"""profiles/r04_roofline.json from the round-4 profiling passes (tools/gpu_profile_r04.sh): the ONE table bench.py's roofline line is
-computed from.  usage: python tools/roofline_json.py OUTDIR  (reads OUTDIR/loop_lanes1.json, loop_lanes4.json, alone.db, pmc_hbm.json)"""
+"""profiles/<round>_roofline.json from the round's profiling passes (tools/gpu_profile.sh): the ONE table bench.py's roofline line is
+computed from.  usage: python tools/roofline_json.py OUTDIR ROUND  (reads OUTDIR/loop_lanes1.json, loop_lanes4.json, alone.db, pmc_hbm.json)"""
 import json, os, sqlite3, sys
 O = sys.argv[1]
+R = sys.argv[2] if len(sys.argv) > 2 else "r05"
 dom = "vq_filter_router_kernel"
 out = {"kernel": dom + "<true, false> (VQ forward + the per-image router workgroups: the launch of the timed step)",
        "workload": "B=64 of 256x256: N = 262144 latent vectors, K = 1024, D = 4", "flops_per_launch": 2.0 * 262144 * 1024 * 4,
@@ -26,7 +27,7 @@ if os.path.exists(pm):
     out.update({k: v for k, v in json.load(open(pm)).items() if k in ("hbm_bytes_per_launch", "read_bytes_x2", "write_bytes")})
 out["frac_lanes1_loop"] = round(out["flops_per_launch"] / (out["rocprof_avg_us_lanes1_loop"] * 1e-6) / 1e12 / 157.3, 4)
 out["frac_alone_graph"] = round(out["flops_per_launch"] / (out["rocprof_avg_us_alone_graph"] * 1e-6) / 1e12 / 157.3, 4)
-# matrix-core counters of the same command (tools/gpu_profile_r04.sh, pmcf_* passes): busy fraction of the 1024 SIMDs' MFMA pipes
+# matrix-core counters of the same command (tools/gpu_profile.sh, pmcf_* passes): busy fraction of the 1024 SIMDs' MFMA pipes
 pj = os.path.join(O, "pmc_sq_vq_fused.json")
 if os.path.exists(pj):
     try:
@@ -45,5 +46,5 @@ out["commands"] = {
     "lanes L loop": "rocprofv3 --kernel-trace --stats -- python bench.py --steps 96 --warmup 16 --no-report --lanes L   (tools/trace_concurrency.py: the last 96 five-launch chains)",
     "alone graph": "rocprofv3 --kernel-trace --stats -- python tools/run_roofline_cmd.py fused   (bench.graph_kernel_time: 20 launches per hipGraph, the last 100 launches)",
     "hbm": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE --kernel-trace -- python bench.py --steps 40 --warmup 10 --no-report --lanes 1 --no-graph   (tools/pmc_summary.py)"}
-json.dump(out, open(os.path.join(O, "r04_roofline.json"), "w"), indent=1)
+json.dump(out, open(os.path.join(O, f"{R}_roofline.json"), "w"), indent=1)
 print(json.dumps(out, indent=1))
