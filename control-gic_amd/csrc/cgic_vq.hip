@@ -20,8 +20,10 @@
 
 #include <stdlib.h>
 
+#include <algorithm>
 #include <map>
 #include <mutex>
+#include <vector>
 #include <utility>
 
 namespace cgic {
@@ -531,8 +533,12 @@ __host__ __device__ constexpr size_t vqf_lds_bytes(int K) { return vqf_ees_off(K
 // The codebook's LDS image of the filter path: fp32 rows (at rowpos()), row norms (at eepos()), the split fp16 A operands
 // and, in s_max[0..1], the bit patterns of max |e_kj| and max ee_k (they fix the fp16 scaling).  Ends with a barrier.
 constexpr unsigned int kPreparedMagic = 0x43474951u;      // "CGIQ": last word of a prepared codebook image, after (Emax, EEmax, K)
+constexpr unsigned int kPreparedMagicPerm = 0x43474950u;  // "CGIP": a PERMUTED image (near-duplicate rows packed into tiles); K keys (orig << 16 | position) follow
+// perm (vq_prepare_kernel only): position k of the image holds ORIGINAL row perm[k] (near-duplicate rows packed into one tile:
+// cgic_vq_prepare_f32); nullptr: the identity.
 template <int NT>
-__device__ __forceinline__ void vqf_stage(const float *__restrict__ cb, const int K, unsigned char *smem, unsigned int *s_max)
+__device__ __forceinline__ void vqf_stage(const float *__restrict__ cb, const int K, unsigned char *smem, unsigned int *s_max,
+                                          const unsigned short *__restrict__ perm = nullptr)
 {
     uint4 *ldsA = reinterpret_cast<uint4 *>(smem);                                  // [K/32][64]
     float4 *cbs = reinterpret_cast<float4 *>(smem + vqf_rows_off(K));               // fp32 rows, at rowpos()
@@ -548,7 +554,7 @@ __device__ __forceinline__ void vqf_stage(const float *__restrict__ cb, const in
 #pragma unroll
         for (int q = 0; q < kRows; ++q) {
             const int k = tid + q * NT;
-            rows[q] = k < K ? reinterpret_cast<const float4 *>(cb)[k] : float4{0.f, 0.f, 0.f, 0.f};
+            rows[q] = k < K ? reinterpret_cast<const float4 *>(cb)[perm ? (int)perm[k] : k] : float4{0.f, 0.f, 0.f, 0.f};
         }
         __syncthreads();                    // s_max is zero
 #pragma unroll
@@ -599,7 +605,10 @@ __device__ __forceinline__ void vqf_stage(const float *__restrict__ cb, const in
 
 // ALIGNED: hw % 64 == 0 -- a group of 64 consecutive vectors never straddles two images, so (image, position) of a
 // group is wave-uniform and every address is a scalar base plus a per-lane offset that is computed once.
-template <int NT, bool ALIGNED, bool CONV, bool PROBE = false>
+// PERM: the prepared image is permuted -- near-duplicate rows (a trained codebook's clusters: quantize.py:22-26,78) sit in one tile,
+// so that the 32-code exact step resolves them instead of every vector running into the all-K scan; "index" below is then the key
+// (original index << 16 | position): ties go to the lowest ORIGINAL index like the reference's argmin, the position finds the row.
+template <int NT, bool ALIGNED, bool CONV, bool PROBE = false, bool PERM = false>
 __device__ __forceinline__ void vq_filter_body(const VqArgs &a, unsigned char *smem, const unsigned int vblk)
 {
     constexpr int NW = NT / 64, G = kVqfGroup;
@@ -611,7 +620,9 @@ __device__ __forceinline__ void vq_filter_body(const VqArgs &a, unsigned char *s
     uint4 *ldsA = reinterpret_cast<uint4 *>(smem);                                  // [K/32][64]
     float4 *cbs = reinterpret_cast<float4 *>(smem + vqf_rows_off(K));               // fp32 rows, at rowpos()
     float *ees = reinterpret_cast<float *>(smem + vqf_ees_off(K));                  // their squared norms, at eepos()
+    unsigned int *okey = reinterpret_cast<unsigned int *>(smem + vqf_lds_bytes(K));  // PERM: [K] (original index << 16) | position
     __shared__ unsigned int s_max[4];        // [2..3]: the prepared image's (K, magic) tag
+    __shared__ unsigned int s_key0;          // PERM: the key of original row 0
     __shared__ double s_wsum[NT / 64];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -696,12 +707,22 @@ __device__ __forceinline__ void vq_filter_body(const VqArgs &a, unsigned char *s
         __syncthreads();
         // the image carries (K, magic) behind the two maxima: an image of another K, or memory that is not an image at all,
         // is not trusted -- the workgroup derives its own from the fp32 rows (workgroup-uniform branch)
-        if (s_max[2] != (unsigned int)K || s_max[3] != kPreparedMagic) {
+        if (s_max[2] != (unsigned int)K || s_max[3] != (PERM ? kPreparedMagicPerm : kPreparedMagic)) {
             __syncthreads();
             vqf_stage<NT>(a.cb, K, smem, s_max);
+            if (PERM) { for (int c = tid; c < K; c += NT) okey[c] = ((unsigned int)c << 16) | (unsigned int)c; __syncthreads(); }
+        } else if (PERM) {
+            const unsigned int *ks = reinterpret_cast<const unsigned int *>(src + n16 + 1);
+            for (int c = tid; c < K; c += NT) okey[c] = ks[c];
+            __syncthreads();
         }
     } else {
         vqf_stage<NT>(a.cb, K, smem, s_max);
+        if (PERM) { for (int c = tid; c < K; c += NT) okey[c] = ((unsigned int)c << 16) | (unsigned int)c; __syncthreads(); }
+    }
+    if (PERM) {
+        for (int c = tid; c < K; c += NT) if ((okey[c] >> 16) == 0u) s_key0 = okey[c];
+        __syncthreads();
     }
     const float Emax = __uint_as_float(s_max[0]), EEmax = __uint_as_float(s_max[1]);
     // the filter needs a finite, non-zero codebook (an all-zero one ties everywhere: exact path)
@@ -865,18 +886,28 @@ __device__ __forceinline__ void vq_filter_body(const VqArgs &a, unsigned char *s
                 const float4 *rb = cbs + rowpos(cb0);          // (a set stays inside one tile: same padding for all 16)
                 const float *eb = ees + eepos(cb0);
                 int rs = 0;                                     // the winner's offset in the set: a select between inline constants
+                unsigned int kb = 0xFFFFFFFFu;                  // PERM: the winner's key
 #pragma unroll
                 for (int r4 = 3; r4 >= 0; --r4) {
                     const float4 en = *reinterpret_cast<const float4 *>(&eb[8 * r4]);
+                    uint4 k4 = make_uint4(0u, 0u, 0u, 0u);
+                    if (PERM) k4 = *reinterpret_cast<const uint4 *>(&okey[cb0 + 8 * r4]);
 #pragma unroll
                     for (int r = 3; r >= 0; --r) {
                         const float dd = dist_row(y0, y1, y2, y3, yy, rb[8 * r4 + r], r == 0 ? en.x : r == 1 ? en.y : r == 2 ? en.z : en.w);
-                        const bool take = dd <= d;
-                        d = take ? dd : d;
-                        rs = take ? 8 * r4 + r : rs;
+                        if (PERM) {
+                            const unsigned int kk = r == 0 ? k4.x : r == 1 ? k4.y : r == 2 ? k4.z : k4.w;
+                            const bool take = dd < d || (dd == d && kk < kb);
+                            d = take ? dd : d;
+                            kb = take ? kk : kb;
+                        } else {
+                            const bool take = dd <= d;
+                            d = take ? dd : d;
+                            rs = take ? 8 * r4 + r : rs;
+                        }
                     }
                 }
-                wi = cb0 + rs;
+                wi = PERM ? (int)kb : cb0 + rs;
             }
             // ... and on the other half's best tile where it is a candidate too (lexicographic merge)
             if (__ballot(valid && other && !flag)) {
@@ -889,11 +920,13 @@ __device__ __forceinline__ void vq_filter_body(const VqArgs &a, unsigned char *s
 #pragma unroll
                 for (int r4 = 3; r4 >= 0; --r4) {
                     const float4 en = *reinterpret_cast<const float4 *>(&eb[8 * r4]);
+                    uint4 k4 = make_uint4(0u, 0u, 0u, 0u);
+                    if (PERM) k4 = *reinterpret_cast<const uint4 *>(&okey[cb1 + 8 * r4]);
 #pragma unroll
                     for (int r = 3; r >= 0; --r) {
-                        const int c = cb1 + 8 * r4 + r;
+                        const int c = PERM ? (int)(r == 0 ? k4.x : r == 1 ? k4.y : r == 2 ? k4.z : k4.w) : cb1 + 8 * r4 + r;
                         const float dd = dist_row(y0, y1, y2, y3, yy, rb[8 * r4 + r], r == 0 ? en.x : r == 1 ? en.y : r == 2 ? en.z : en.w);
-                        const bool take = doit && (dd < d || (dd == d && c < wi));
+                        const bool take = doit && (dd < d || (dd == d && (unsigned int)c < (unsigned int)wi));
                         d = take ? dd : d;
                         wi = take ? c : wi;
                     }
@@ -915,19 +948,26 @@ __device__ __forceinline__ void vq_filter_body(const VqArgs &a, unsigned char *s
                     const float s3 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(y3), v));
                     const float ss = sumsq4(s0, s1, s2, s3);
                     float bd = __builtin_inff();
-                    int bi = 0;
+                    int bi = PERM ? 0x7FFFFFFF : 0;                      // (PERM: "none yet" sorts behind every key)
 #pragma unroll 4
                     for (int c = K - 64 + lane; c >= 0; c -= 64) {       // descending: the lowest index wins ties
                         const float dd = dist_row(s0, s1, s2, s3, ss, cbs[rowpos(c)], ees[eepos(c)]);
-                        const bool take = dd <= bd;
-                        bd = take ? dd : bd;
-                        bi = take ? c : bi;
+                        if (PERM) {
+                            const int kk = (int)okey[c];
+                            const bool take = dd < bd || (dd == bd && (unsigned int)kk < (unsigned int)bi);
+                            bd = take ? dd : bd;
+                            bi = take ? kk : bi;
+                        } else {
+                            const bool take = dd <= bd;
+                            bd = take ? dd : bd;
+                            bi = take ? c : bi;
+                        }
                     }
 #pragma unroll
                     for (int off = 1; off < 64; off <<= 1) {
                         const float od = __shfl_xor(bd, off, kWave);
                         const int oi = __shfl_xor(bi, off, kWave);
-                        const bool take = od < bd || (od == bd && oi < bi);
+                        const bool take = od < bd || (od == bd && (unsigned int)oi < (unsigned int)bi);
                         bd = take ? od : bd;
                         bi = take ? oi : bi;
                     }
@@ -948,7 +988,7 @@ __device__ __forceinline__ void vq_filter_body(const VqArgs &a, unsigned char *s
                     zb4[tt] = g4 == 0 ? z0[tt] : g4 == 1 ? z1[tt] : g4 == 2 ? z2[tt] : z3[tt];
                     zz[tt] = sumsq4(z0[tt], z1[tt], z2[tt], z3[tt]);
                     best[tt] = __builtin_inff();
-                    bt2[tt] = 0;
+                    bt2[tt] = PERM ? 0x7FFFFFFF : 0;                 // (PERM: the best KEY so far instead of its 16-code tile)
                 }
                 for (int ct = 0; ct < (K >> 4); ++ct) {
                     const float av = reinterpret_cast<const float *>(cbs)[rowpos(16 * ct + col) * 4 + g4];
@@ -961,21 +1001,38 @@ __device__ __forceinline__ void vq_filter_body(const VqArgs &a, unsigned char *s
                         const float d1 = __builtin_fmaf(-2.0f, acc[1], zz[tt] + e4[1]);
                         const float d2 = __builtin_fmaf(-2.0f, acc[2], zz[tt] + e4[2]);
                         const float d3 = __builtin_fmaf(-2.0f, acc[3], zz[tt] + e4[3]);
-                        const float q1 = __builtin_fminf(__builtin_fminf(best[tt], d0), d1);
-                        const float q2 = __builtin_fminf(__builtin_fminf(q1, d2), d3);
-                        bt2[tt] = q2 < best[tt] ? ct : bt2[tt];
-                        best[tt] = q2;
+                        if (PERM) {
+                            // ties across the whole codebook go to the lowest ORIGINAL index: the smallest key among this step's minima
+                            const uint4 k4 = *reinterpret_cast<const uint4 *>(&okey[16 * ct + 4 * g4]);
+                            const float m = __builtin_fminf(__builtin_fminf(d0, d1), __builtin_fminf(d2, d3));
+                            unsigned int kq = 0x7FFFFFFFu;
+                            kq = d0 == m && k4.x < kq ? k4.x : kq;
+                            kq = d1 == m && k4.y < kq ? k4.y : kq;
+                            kq = d2 == m && k4.z < kq ? k4.z : kq;
+                            kq = d3 == m && k4.w < kq ? k4.w : kq;
+                            const bool take = m < best[tt] || (m == best[tt] && kq < (unsigned int)bt2[tt]);
+                            best[tt] = take ? m : best[tt];
+                            bt2[tt] = take ? (int)kq : bt2[tt];
+                        } else {
+                            const float q1 = __builtin_fminf(__builtin_fminf(best[tt], d0), d1);
+                            const float q2 = __builtin_fminf(__builtin_fminf(q1, d2), d3);
+                            bt2[tt] = q2 < best[tt] ? ct : bt2[tt];
+                            best[tt] = q2;
+                        }
                     }
                 }
                 int w16[4];
 #pragma unroll
                 for (int tt = 0; tt < 4; ++tt) {
-                    const int c0 = 16 * bt2[tt] + 4 * g4;
                     float dq = best[tt];
-                    int i = c0;
+                    int i = bt2[tt];
+                    if (!PERM) {
+                        const int c0 = 16 * bt2[tt] + 4 * g4;
+                        i = c0;
 #pragma unroll
-                    for (int r = 3; r >= 0; --r)
-                        i = dist_row(z0[tt], z1[tt], z2[tt], z3[tt], zz[tt], cbs[rowpos(c0 + r)], ees[eepos(c0 + r)]) == dq ? c0 + r : i;
+                        for (int r = 3; r >= 0; --r)
+                            i = dist_row(z0[tt], z1[tt], z2[tt], z3[tt], zz[tt], cbs[rowpos(c0 + r)], ees[eepos(c0 + r)]) == dq ? c0 + r : i;
+                    }
                     colargmin(dq, i);
                     w16[tt] = i;
                 }
@@ -987,7 +1044,12 @@ __device__ __forceinline__ void vq_filter_body(const VqArgs &a, unsigned char *s
 
         // ---- outputs: lane (column j, half hf) owns channels 2 hf, 2 hf + 1 of vector (tile t, column j); lane L the
         // index of vector L
-        if (idx_out && base + lane < N) idx_out[base + lane] = (int64_t)wi;
+        if (PERM) {
+            // a key that never got set (every distance NaN: nothing wins) is original row 0, like the plain path's index 0
+            if ((unsigned int)wi >= ((unsigned int)K << 16)) wi = (int)s_key0;
+        }
+        if (idx_out && base + lane < N) idx_out[base + lane] = (int64_t)(PERM ? wi >> 16 : wi);
+        if (PERM) wi &= 0xFFFF;                                   // from here on: where the row sits
         if (zq_out || a.sq_partial) {
             const uint2 wt = rows32((unsigned int)wi);           // .x: tile 0's winners (lanes 0..31), .y: tile 1's
             int64_t gb = 0, gp0 = 0;
@@ -1069,6 +1131,15 @@ __global__ CGIC_VQF_BOUNDS void vq_filter_kernel(VqArgs a)
     vq_filter_body<kVqfThreads, ALIGNED, CONV>(a, smem_f, blockIdx.x);
 }
 
+// PERM instantiations (a prepared image whose rows were packed by cluster: cgic_vq_prepare_f32): kernels of their own, so that the
+// plain kernels' code and register allocation are untouched
+template <bool ALIGNED>
+__global__ CGIC_VQF_BOUNDS void vq_filter_perm_kernel(VqArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_f[];
+    vq_filter_body<kVqfThreads, ALIGNED, false, false, true>(a, smem_f, blockIdx.x);
+}
+
 // Telemetry instantiation (cgic_vq_filter_probe_f32): the SAME body, with every approximate score and every decision threshold
 // written out -- what tools/stress_vq.py --telemetry and tests/test_gpu_stress.py compare with the budgeted error bound.
 template <bool ALIGNED>
@@ -1099,6 +1170,18 @@ __global__ CGIC_VQF_BOUNDS void vq_filter_router_kernel(VqArgs a, RouterArgs r, 
     vq_filter_body<kVqfThreads, ALIGNED, CONV>(a, smem_f, blockIdx.x - vb);
 }
 
+template <bool ALIGNED>
+__global__ CGIC_VQF_BOUNDS void vq_filter_router_perm_kernel(VqArgs a, RouterArgs r, unsigned int nrouter, unsigned int router_behind)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_f[];
+    const unsigned int rb = router_behind ? a.nblk : 0u, vb = router_behind ? 0u : nrouter;
+    if (blockIdx.x - rb < nrouter) {
+        router_body<kVqfThreads>(r, (int64_t)(blockIdx.x - rb), smem_f);
+        return;
+    }
+    vq_filter_body<kVqfThreads, ALIGNED, false, false, true>(a, smem_f, blockIdx.x - vb);
+}
+
 // The same launch for several shape groups at once (cgic_common.h: launch groups): every group keeps its own VQ shares, router
 // workgroups and loss ticket; a workgroup's role is read off its block index inside its group.
 struct VqfrArgs {
@@ -1123,7 +1206,8 @@ __global__ CGIC_VQF_BOUNDS void vq_filter_router_grouped_kernel(Grouped<VqfrArgs
 // The codebook's LDS image, computed ONCE (cgic_vq_prepare_f32) instead of by every workgroup of every launch: inference
 // runs thousands of launches against one codebook, and deriving the image (two block-wide maxima, 11 fp16 splits per row, three
 // barriers) was ~3 us at the head of every ~23 us launch.  One workgroup; the image is followed by the two maxima.
-__global__ __launch_bounds__(kVqfThreads) void vq_prepare_kernel(const float *__restrict__ cb, int K, uint4 *__restrict__ out)
+__global__ __launch_bounds__(kVqfThreads) void vq_prepare_kernel(const float *__restrict__ cb, int K, uint4 *__restrict__ out,
+                                                                 const unsigned short *__restrict__ perm)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_f[];
     __shared__ unsigned int s_max[4];
@@ -1131,9 +1215,12 @@ __global__ __launch_bounds__(kVqfThreads) void vq_prepare_kernel(const float *__
     uint4 *img = reinterpret_cast<uint4 *>(smem_f);
     for (int i = threadIdx.x; i < n16; i += kVqfThreads) img[i] = make_uint4(0u, 0u, 0u, 0u);      // the padding rows: defined bytes
     __syncthreads();
-    vqf_stage<kVqfThreads>(cb, K, smem_f, s_max);
+    vqf_stage<kVqfThreads>(cb, K, smem_f, s_max, perm);
     for (int i = threadIdx.x; i < n16; i += kVqfThreads) out[i] = img[i];
-    if (threadIdx.x == 0) out[n16] = make_uint4(s_max[0], s_max[1], (unsigned int)K, kPreparedMagic);
+    if (threadIdx.x == 0) out[n16] = make_uint4(s_max[0], s_max[1], (unsigned int)K, perm ? kPreparedMagicPerm : kPreparedMagic);
+    // behind the tag: the keys of a permuted image, (original index << 16) | position (all zero otherwise: defined bytes)
+    unsigned int *keys = reinterpret_cast<unsigned int *>(out + n16 + 1);
+    for (int k = threadIdx.x; k < K; k += kVqfThreads) keys[k] = perm ? ((unsigned int)perm[k] << 16) | (unsigned int)k : 0u;
 }
 
 // Plain-VALU restatement: one latent vector per thread, codebook broadcast from
@@ -1334,6 +1421,8 @@ static int dev_knob(const char *name) { const char *v = getenv(name); return v ?
 static int dev_knob(const char *) { return 0; }      // the environment knobs exist in `make dbg` builds only
 #endif
 
+static bool prepared_is_perm(const void *prepared);      // (below, next to cgic_vq_prepare_f32)
+
 template <bool ALIGNED, bool CONV>
 static int launch_filter(const float *z, int64_t hw, int64_t N, const float *cb, int K, int64_t *idx, float *zq,
                          VqWs ws, float beta, int legacy, float *loss, hipStream_t s, const RouterArgs *router,
@@ -1389,13 +1478,35 @@ static int launch_filter(const float *z, int64_t hw, int64_t N, const float *cb,
     }
     a.n_early = (unsigned int)n_early; a.g_early = (unsigned int)g_early; a.g_late = (unsigned int)g_late;
     size_t lds = vqf_lds_bytes(K);
+    // a prepared image packed by cluster takes the PERM kernels (their own instantiations; inside a launch group and with a fused
+    // quant_conv the plain kernels run: they do not trust the permuted image's tag and derive their own)
+    const bool perm = !CONV && !group_recording() && prepared_is_perm(prepared);
+    if (perm) lds += 4 * (size_t)K;
     if (!router) {
+        if (perm) {
+            if constexpr (!CONV) {
+                rc = ensure_dynamic_lds((const void *)vq_filter_perm_kernel<ALIGNED>, lds);
+                if (rc) return rc;
+                hipLaunchKernelGGL((vq_filter_perm_kernel<ALIGNED>), dim3(a.nblk), dim3(kVqfThreads), lds, s, a);
+                return launch_check("vq_filter_perm_kernel");
+            }
+        }
         rc = ensure_dynamic_lds((const void *)vq_filter_kernel<ALIGNED, CONV>, lds);
         if (rc) return rc;
         hipLaunchKernelGGL((vq_filter_kernel<ALIGNED, CONV>), dim3(a.nblk), dim3(kVqfThreads), lds, s, a);
         return launch_check("vq_filter_kernel");
     }
     if (router_lds > lds) lds = router_lds;
+    if (perm) {
+        if constexpr (!CONV) {
+            rc = ensure_dynamic_lds((const void *)vq_filter_router_perm_kernel<ALIGNED>, lds);
+            if (rc) return rc;
+            const dim3 grid_p(a.nblk + (unsigned int)router_blocks);
+            const unsigned int behind = router_first ? 0u : 1u;
+            hipLaunchKernelGGL((vq_filter_router_perm_kernel<ALIGNED>), grid_p, dim3(kVqfThreads), lds, s, a, *router, (unsigned int)router_blocks, behind);
+            return launch_check("vq_filter_router_perm_kernel");
+        }
+    }
     rc = ensure_dynamic_lds((const void *)vq_filter_router_kernel<ALIGNED, CONV>, lds);
     if (rc) return rc;
     VqfrArgs p;
@@ -1501,9 +1612,84 @@ extern "C" int cgic_vq_stats(unsigned int *device_counters)
 
 extern "C" size_t cgic_vq_prepared_bytes(int K)
 {
-    // the filter path's LDS image + 16 bytes (the two maxima); 0: this K has no filter path (nothing to prepare)
-    return (K > 0 && K % 64 == 0 && K <= kVqfMaxK) ? vqf_lds_bytes(K) + 16 : 0;
+    // the filter path's LDS image + 16 bytes (the two maxima, K, magic) + K keys of a permuted image + K uint16 (the permutation as
+    // handed to the prepare kernel); 0: this K has no filter path (nothing to prepare)
+    return (K > 0 && K % 64 == 0 && K <= kVqfMaxK) ? vqf_lds_bytes(K) + 16 + 6 * (size_t)K : 0;
 }
+
+namespace cgic {
+// Which prepared images are permuted (the launch picks the PERM kernels for them).  A wrong answer is harmless: a kernel that finds
+// another magic than the one it was built for derives its own image from the fp32 rows.
+static std::mutex g_perm_mu;
+static std::map<const void *, bool> g_perm_images;
+static bool prepared_is_perm(const void *prepared)
+{
+    if (!prepared) return false;
+    std::lock_guard<std::mutex> lock(g_perm_mu);
+    auto it = g_perm_images.find(prepared);
+    return it != g_perm_images.end() && it->second;
+}
+
+// Near-duplicate rows -> one tile.  A trained codebook holds clusters of rows closer to each other than the candidate filter's
+// margin (quantize.py:22-26: rows that started within +-1/K of each other and were never pulled apart, dead codes): spread over the
+// tiles, every vector near such a cluster finds a runner-up TILE inside its margin and falls to the all-K exact scan (the whole
+// group to the exact loop: 2.2x the step).  Packed into one 32-code tile they are resolved by the exact step that looks at the best
+// tile anyway.  Greedy on the host (K <= 1024): first-fit leaders under the max-norm, clusters largest first into the tiles (never
+// split unless larger than a tile), singles fill up.  Returns false when there is nothing to pack (every cluster is a single row).
+static bool cluster_permutation(const float *cb, int K, std::vector<unsigned short> *perm)
+{
+    float emax = 0.f;
+    for (int i = 0; i < 4 * K; ++i) { const float v = fabsf(cb[i]); if (!(v <= emax)) emax = v; }      // (a NaN ends up in emax)
+    if (!(emax > 0.f) || !(emax < INFINITY)) return false;
+    const float tau = 3e-4f * emax;
+    std::vector<int> leader(K), leaders;
+    for (int i = 0; i < K; ++i) {
+        int L = i;
+        for (int j : leaders) {
+            const float *a = cb + 4 * i, *b = cb + 4 * j;
+            if (fabsf(a[0] - b[0]) <= tau && fabsf(a[1] - b[1]) <= tau && fabsf(a[2] - b[2]) <= tau && fabsf(a[3] - b[3]) <= tau) { L = j; break; }
+        }
+        leader[i] = L;
+        if (L == i) leaders.push_back(i);
+    }
+    if ((int)leaders.size() == K) return false;
+    std::map<int, std::vector<int>> members;
+    for (int i = 0; i < K; ++i) members[leader[i]].push_back(i);
+    std::vector<std::vector<int>> chunks;         // clusters cut into pieces of at most one tile
+    for (auto &kv : members)
+        for (size_t at = 0; at < kv.second.size(); at += 32)
+            chunks.emplace_back(kv.second.begin() + at, kv.second.begin() + (at + 32 < kv.second.size() ? at + 32 : kv.second.size()));
+    std::stable_sort(chunks.begin(), chunks.end(), [](const std::vector<int> &a, const std::vector<int> &b) { return a.size() > b.size(); });
+    const int ntile = K / 32;
+    std::vector<std::vector<int>> tiles(ntile);
+    for (const auto &c : chunks) {
+        // first fit (largest first: the singles go last and fill the gaps); a piece that fits nowhere whole is cut over the
+        // tiles with the most room (its rows then meet the all-K scan like before: rare, and only for that cluster)
+        size_t at = 0;
+        while (at < c.size()) {
+            int best = -1;
+            for (int t = 0; t < ntile; ++t)
+                if (tiles[t].size() + (c.size() - at) <= 32) { best = t; break; }
+            size_t take = c.size() - at;
+            if (best < 0) {
+                size_t room = 0;
+                for (int t = 0; t < ntile; ++t)
+                    if (32 - tiles[t].size() > room) { room = 32 - tiles[t].size(); best = t; }
+                if (best < 0 || room == 0) return false;          // (cannot happen: the pieces sum up to K = 32 ntile)
+                take = room;
+            }
+            tiles[best].insert(tiles[best].end(), c.begin() + at, c.begin() + at + take);
+            at += take;
+        }
+    }
+    perm->resize(K);
+    for (int t = 0; t < ntile; ++t) {
+        if ((int)tiles[t].size() != 32) return false;
+        for (int k = 0; k < 32; ++k) (*perm)[32 * t + k] = (unsigned short)tiles[t][k];
+    }
+    return true;
+}
+}  // namespace cgic
 
 extern "C" int cgic_vq_prepare_f32(const float *codebook, int K, int e_dim, void *prepared, cgic_stream_t stream)
 {
@@ -1515,7 +1701,28 @@ extern "C" int cgic_vq_prepare_f32(const float *codebook, int K, int e_dim, void
     const size_t lds = vqf_lds_bytes(K);
     int rc = ensure_dynamic_lds((const void *)vq_prepare_kernel, lds);
     if (rc) return rc;
-    hipLaunchKernelGGL(vq_prepare_kernel, dim3(1), dim3(kVqfThreads), lds, (hipStream_t)stream, codebook, K, (uint4 *)prepared);
+    // near-duplicate rows packed into tiles (cluster_permutation): needs the rows on the host -- one 16 KB copy and a wait, once per
+    // codebook; not while the stream is being captured (the image is then the plain one: same results, no packing)
+    hipStream_t s = (hipStream_t)stream;
+    const unsigned short *perm_dev = nullptr;
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    CGIC_HIP_TRY(hipStreamIsCapturing(s, &cap));
+    bool is_perm = false;
+    if (cap == hipStreamCaptureStatusNone) {
+        std::vector<float> host((size_t)4 * K);
+        CGIC_HIP_TRY(hipMemcpyAsync(host.data(), codebook, sizeof(float) * 4 * K, hipMemcpyDeviceToHost, s));
+        CGIC_HIP_TRY(hipStreamSynchronize(s));
+        std::vector<unsigned short> perm;
+        if (cluster_permutation(host.data(), K, &perm)) {
+            unsigned short *dst = reinterpret_cast<unsigned short *>(reinterpret_cast<unsigned char *>(prepared) + lds + 16 + 4 * (size_t)K);
+            CGIC_HIP_TRY(hipMemcpyAsync(dst, perm.data(), sizeof(unsigned short) * K, hipMemcpyHostToDevice, s));
+            CGIC_HIP_TRY(hipStreamSynchronize(s));          // (perm is about to go out of scope)
+            perm_dev = dst;
+            is_perm = true;
+        }
+    }
+    { std::lock_guard<std::mutex> lock(g_perm_mu); g_perm_images[prepared] = is_perm; }
+    hipLaunchKernelGGL(vq_prepare_kernel, dim3(1), dim3(kVqfThreads), lds, s, codebook, K, (uint4 *)prepared, perm_dev);
     return launch_check("vq_prepare_kernel");
 }
 

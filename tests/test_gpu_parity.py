@@ -1238,6 +1238,75 @@ def test_prepared_codebook_image_changes_nothing():
     assert vq._prepared is None
 
 
+@pytest.mark.parametrize("case", VQ_CASES)
+def test_vq_golden_through_the_prepared_image(golden, case):
+    """the reference's own outputs again, through cgic_vq_prepare_f32's image -- which packs near-duplicate rows into one tile when
+    there are any (dup_rows, codes_as_z, lattice_ties: exact ties go to the lowest ORIGINAL index like torch.argmin)"""
+    from control_gic_amd.quantize import _vq_forward, prepare_codebook
+    g = golden("vq")
+    cb = _t(g[case + "_cb"])
+    prep = prepare_codebook(cb)
+    with torch.no_grad():
+        zq, loss, idx = _vq_forward(_t(g[case + "_z"]), cb, 0.25, True, None, prepared=prep)
+    assert np.array_equal(idx.cpu().numpy(), g[case + "_idx"].astype(np.int64).ravel())
+    assert np.array_equal(zq.cpu().numpy(), g[case + "_zq"])
+    ref = float(g[case + "_loss"])
+    assert abs(float(loss) - ref) <= 1e-6 * abs(ref) + 1e-12
+
+
+def test_clustered_codebook_is_packed_into_tiles():
+    """A trained codebook holds clusters of near-duplicate rows and exact duplicates (quantize.py:22-26,78).  Spread over the tiles
+    they send every vector to the all-K exact scan; cgic_vq_prepare_f32 packs each cluster into one 32-code tile (keys =
+    original index << 16 | position; ties by ORIGINAL index).  Checks: results identical to the independent VALU kernel and to
+    the unprepared filter path -- N(0,1) latents, latents ON rows, on midpoints of duplicate rows (exact ties) --, fused with the
+    router, and the telemetry: groups rerun on the exact loop drop from ~all to a few per cent."""
+    from control_gic_amd.quantize import _vq_forward, vq_forward_route, prepare_codebook
+    rng = np.random.default_rng(21)
+    centres = rng.standard_normal((64, 4)).astype(np.float32)
+    cb = (centres[rng.integers(0, 64, 1024)] + np.float32(1e-4) * rng.standard_normal((1024, 4)).astype(np.float32)).astype(np.float32)
+    dup_src = rng.integers(0, 1024, 40)
+    dup_dst = rng.integers(0, 1024, 40)
+    cb[dup_dst] = cb[dup_src]                                   # exact duplicates at random places
+    z = rng.standard_normal((16, 4, 64, 64)).astype(np.float32)
+    zf = z.transpose(0, 2, 3, 1).reshape(-1, 4)
+    zf[:1024] = cb                                              # latents exactly on rows (duplicates: distance 0 twice)
+    zf[1024:1064] = (cb[dup_src] + cb[(dup_src + 1) % 1024]) / 2        # midpoints: whatever ties there are
+    z = np.ascontiguousarray(zf.reshape(16, 64, 64, 4).transpose(0, 3, 1, 2))
+    cbd, zd = _t(cb), _t(z)
+    lib = cg._lib.lib()
+    cnt = torch.zeros(8, dtype=torch.int32, device=DEV)
+    with torch.no_grad():
+        want = _vq_forward(zd, cbd, 0.25, True, None, kernel="valu")
+        assert lib.cgic_vq_stats(cnt.data_ptr()) == 0
+        try:
+            plain = _vq_forward(zd, cbd, 0.25, True, None)
+            torch.cuda.synchronize()
+            c_plain = cnt.cpu().numpy().copy()
+            cnt.zero_()
+            prep = prepare_codebook(cbd)
+            got = _vq_forward(zd, cbd, 0.25, True, None, prepared=prep)
+            torch.cuda.synchronize()
+            c_prep = cnt.cpu().numpy().copy()
+        finally:
+            lib.cgic_vq_stats(None)
+        for r in (plain, got):
+            assert torch.equal(r[2], want[2]) and torch.equal(r[0], want[0])
+            assert abs(float(r[1]) - float(want[1])) <= 1e-6 * abs(float(want[1]))
+        groups = 16 * 64 * 64 // 64
+        assert c_plain[1] > 0.9 * groups                        # without the packing: (nearly) every group falls back to the exact loop
+        assert c_prep[1] < 0.05 * groups, (c_prep, groups)       # with it: a few per cent
+        e16 = _t(rng.random((16, 16, 16)).astype(np.float32) * 2.6)
+        e8 = _t(rng.random((16, 32, 32)).astype(np.float32) * 2.6)
+        a = vq_forward_route(zd, cbd, 0.25, True, e16, e8, 0.1, 0.8)
+        b = vq_forward_route(zd, cbd, 0.25, True, e16, e8, 0.1, 0.8, prepared=prep)
+        assert torch.equal(a[2], b[2]) and torch.equal(a[0], b[0]) and all(torch.equal(x, y) for x, y in zip(a[3], b[3]))
+        assert torch.equal(b[2], want[2])
+        # an image that was made for another codebook (same address reused) or copied elsewhere is never trusted blindly
+        moved = prep.clone()
+        c = _vq_forward(zd, cbd, 0.25, True, None, prepared=moved)
+        assert torch.equal(c[2], want[2])
+
+
 def test_decoder_choice_is_per_call_two_threads():
     """the prefix decoder is an argument of each cgic_decompress_streams call (ABI 4), not a process-wide switch: two threads
     decode the same batch at the same time, one per decoder, on their own streams, and both match the one-thread result"""
