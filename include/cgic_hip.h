@@ -174,7 +174,11 @@ int cgic_vq_stats(unsigned int *device_counters);
 int cgic_vq_filter_probe_f32(const float *z, int64_t B, int64_t hw, const float *codebook, int K, int64_t *indices,
                              float *scores, float *aux, cgic_stream_t stream);
 size_t cgic_vq_workspace_bytes(int64_t n_vectors);
-/* bytes of the prepared codebook image (0: this K only has the exact loop, which needs none) / make it (one small launch) */
+/* bytes of the prepared codebook image (0: this K only has the exact loop, which needs none) / make it (one small launch).
+ * Near-duplicate rows -- a trained codebook's clusters and dead codes (quantize.py:22-26,78) -- are packed into one 32-code tile of
+ * the image each (keys = original index << 16 | position travel with it; ties still go to the lowest ORIGINAL index), so that they
+ * do not send every nearby vector to the all-K exact scan.  For that cgic_vq_prepare_f32 copies the K rows (16 KB) to the host and
+ * WAITS for `stream` -- once per codebook; while `stream` is being captured it makes the plain image instead (same results). */
 size_t cgic_vq_prepared_bytes(int K);
 int cgic_vq_prepare_f32(const float *codebook, int K, int e_dim, void *prepared, cgic_stream_t stream);
 int cgic_vq_forward_f32(const float *z, int64_t B, int64_t hw, const float *codebook, int K, int e_dim,

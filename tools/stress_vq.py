@@ -4,7 +4,7 @@ import os, sys, time
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import control_gic_amd as cg
-from control_gic_amd.quantize import _vq_forward
+from control_gic_amd.quantize import _vq_forward, prepare_codebook
 if "--telemetry" in sys.argv:
     # margin telemetry of the candidate filter (cgic_vq_filter_probe_f32): worst observed |f - F| against the budget and the share
     # of the candidate margin the reference's winners used, over the stress families (tests/test_gpu_stress.py holds both under 0.5)
@@ -35,8 +35,16 @@ while time.time() - t0 < float(sys.argv[2] if len(sys.argv) > 2 else 60):
         cb = torch.round(cb / cs * 2) * cs / 2; z = torch.round(z / zs * 2) * zs / 2
     if kind == 4:   # trained-VQGAN-like init
         cb = (torch.rand(K, 4, generator=g) * 2 - 1) / K
+    if rng.integers(0, 3) == 0:   # exact duplicates of rows at random places (ties go to the lowest original index)
+        m = int(rng.integers(1, max(2, K // 8)))
+        cb[torch.randint(0, K, (m,), generator=g)] = cb[torch.randint(0, K, (m,), generator=g)]
     z, cb = z.cuda(), cb.cuda()
     a = _vq_forward(z, cb, 0.25, True, None, kernel="mfma"); b = _vq_forward(z, cb, 0.25, True, None, kernel="valu")
+    # ... and through the prepared image (clusters of near-duplicate rows packed into tiles: the PERM kernels when there are any)
+    p = _vq_forward(z, cb, 0.25, True, None, prepared=prepare_codebook(cb))
+    if not (torch.equal(p[2], b[2]) and torch.equal(p[0], b[0])):
+        bad = (p[2] != b[2]).nonzero().flatten()[:5].tolist()
+        print("MISMATCH (prepared image)", dict(B=B, h=h, w=w, K=K, zs=zs, cs=cs, kind=kind), "first bad vectors", bad); sys.exit(1)
     if not (torch.equal(a[2], b[2]) and torch.equal(a[0], b[0])):
         bad = (a[2] != b[2]).nonzero().flatten()[:5].tolist()
         print("MISMATCH", dict(B=B, h=h, w=w, K=K, zs=zs, cs=cs, kind=kind), "first bad vectors", bad); sys.exit(1)
@@ -44,4 +52,4 @@ while time.time() - t0 < float(sys.argv[2] if len(sys.argv) > 2 else 60):
     if not (la == lb or abs(la - lb) <= 1e-6 * abs(lb)):
         print("LOSS MISMATCH", la, lb, dict(B=B, h=h, w=w, K=K, zs=zs, cs=cs, kind=kind)); sys.exit(1)
     n += 1; nvec += B * h * w
-print(f"{n} random cases, {nvec} vectors: filter path == VALU path everywhere")
+print(f"{n} random cases, {nvec} vectors: filter path == filter path through the prepared image == VALU path everywhere")
