@@ -49,7 +49,7 @@ class ImageIO(C.Structure):
                 ("ind", _vp), ("z_q", _vp), ("loss", _vp), ("mask_c", _vp), ("mask_m", _vp), ("mask_f", _vp),
                 ("streams", _vp), ("slot", _i64), ("nbytes", _vp), ("hist", _vp),
                 ("dind", _vp), ("dmask_c", _vp), ("dmask_m", _vp), ("dmask_f", _vp), ("dz_q", _vp), ("status", _vp),
-                ("ws_vq", _vp), ("ws_compress", _vp), ("ws_decompress", _vp)]
+                ("ws_vq", _vp), ("ws_compress", _vp), ("ws_decompress", _vp), ("ws_refine", _vp), ("ws_refine_bytes", _sz)]
 
 
 class TileGroup(C.Structure):
@@ -254,6 +254,10 @@ def linspace_bins():
 
 #: False: bands are evaluated inside the image's own router workgroup only (no refinement queues: the pre-ABI-7 behaviour; tests, A/B)
 REFINE_QUEUES = True
+#: the fused VQ + router launch: tiles of at least this many 16x16 patches get the scratch that lets their row bands SPLIT a long
+#: threshold band between them (a smooth 768x768 tile 251 -> 73 us; costs that launch ~4 us on an ordinary tile: its own kernel
+#: instantiation).  2304 = the 768x768 tile of the 2K path; Kodak-sized 768x512 images stay on the plain kernel
+REFINE_SPLIT_MIN_PATCHES = 2304
 
 
 def pixels_arg(pixels, B, h16, w16, per_image, sigma=0.01, flat8=None, queues=False, explicit=False):

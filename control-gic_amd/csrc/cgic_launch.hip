@@ -136,6 +136,7 @@ extern "C" int cgic_compress_image(const cgic_table *t, const float *codebook, i
     cgic_pixels px;
     memset(&px, 0, sizeof(px));
     px.x = io->x; px.is_u8 = io->x_is_u8 ? 1 : 0; px.bins = bins; px.nbins = nbins; px.sigma = sigma; px.flat8 = io->flat8;
+    px.scratch = io->ws_refine; px.scratch_bytes = io->ws_refine_bytes;
     const cgic_pixels *refine = cgic_router_refine_supported(B, H / 16, W / 16, 1) ? &px : nullptr;
     int mode = 0;
     rc = cgic_vq_forward_route_f32(io->z, B, h * w, codebook, K, e_dim, beta, legacy, io->ind, io->z_q, io->loss, io->ws_vq, io->e16, io->e8,
@@ -179,6 +180,7 @@ extern "C" int cgic_compress_tiled(const cgic_table *t, const float *codebook, i
         cgic_pixels px;
         memset(&px, 0, sizeof(px));
         px.x = io.x_out; px.is_u8 = 0; px.bins = bins; px.nbins = nbins; px.sigma = sigma; px.flat8 = io.flat8;
+        px.scratch = io.ws_refine; px.scratch_bytes = io.ws_refine_bytes;
         const cgic_pixels *refine = cgic_router_refine_supported(B, G.th / 16, G.tw / 16, 1) ? &px : nullptr;
         if (!rc) rc = cgic_vq_forward_route_f32(io.z, B, h * w, codebook, K, e_dim, beta, legacy, io.ind, io.z_q, io.loss, io.ws_vq, io.e16, io.e8,
                                                 G.th / 16, G.tw / 16, coarse_ratio, medium_ratio, 1, io.mask_c, io.mask_m, io.mask_f, nullptr, nullptr,

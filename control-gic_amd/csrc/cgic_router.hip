@@ -81,6 +81,7 @@ int router_prepare(const float *e16, const float *e8, int64_t B, int64_t h16, in
                  "router: threshold refinement needs a segment whose maps fit the workgroup's LDS (%lld + %lld patches here; "
                  "cgic_router_refine_supported): route per image / per tile of at most 768x768, or pass no pixels",
                  (long long)N16, (long long)N8);
+    CGIC_REQUIRE(!a.rf.x || N8 <= 64 * (int64_t)kRefBitWords, CGIC_ERR_UNSUPPORTED, "router: refinement of a segment of %lld patches", (long long)N8);
     // large per-image segments: several workgroups per image share the mask writing (every one repeats the selects, which
     // costs nothing while most CUs are idle): up to 8, while the launch stays within ~a quarter of the chip
     a.bands = 1;
@@ -92,7 +93,8 @@ int router_prepare(const float *e16, const float *e8, int64_t B, int64_t h16, in
     }
     CGIC_REQUIRE(lds <= 150 * 1024, CGIC_ERR_UNSUPPORTED, "router: segment of %lld coarse patches exceeds LDS", (long long)N16);
     // the launch's refinement queues: one header per (segment, select) + the board, in library-owned slots (a pool of their own); payload in the caller's scratch
-    if (queues && a.rf.x && refine->scratch && 2 * nseg <= 4096) {
+    // (the fused launch, queues == false, uses headers + scratch only for the row bands' exchange: segments with bands > 1)
+    if ((queues || a.bands > 1) && a.rf.x && refine->scratch && 2 * nseg <= 4096) {
         const size_t need = (size_t)nseg * refine_scratch_bytes_per_segment(N16, N8);
         CGIC_REQUIRE(refine->scratch_bytes >= need, CGIC_ERR_INVALID, "router: refinement scratch of %zu bytes, %zu needed (cgic_router_refine_scratch_bytes)",
                      refine->scratch_bytes, need);

@@ -188,6 +188,7 @@ constexpr int kRefWavesMax = 8;            // waves of a workgroup that evaluate
 constexpr int kRefListCap = 1024;          // band elements listed per sweep (a longer band is swept range by range)
 constexpr int kRefFlatSlots = 128;         // distinct grays of constant patches per select (more: the rest go patch by patch)
 constexpr unsigned int kRefEmpty = 0xFFFFFFFFu;      // (a NaN pattern: never the gray of a constant patch)
+constexpr int kRefBitWords = 176;          // 64-bit words of the band's member bitmap: 11264 elements, more than any segment whose maps fit kRouterFusedLds
 
 // ---- evaluating a band's patches with the whole chip -------------------------------------------------------------------------
 // A band of a few patches is evaluated where it was found (four waves per 16x16 patch, side by side).  A long one -- smooth or flat
@@ -244,6 +245,8 @@ struct RefineShared {
     unsigned int flat_key[kRefFlatSlots];                  // open-addressing set of the constant patches' grays (bit patterns)
     float flat_val[kRefFlatSlots];
     unsigned int small[64];                                // all band elements, when there are at most 64 (the final pick)
+    unsigned long long bits[kRefBitWords];                 // MANY: the band's members that are evaluated from their pixels, bit i = element i
+    unsigned int pre[kRefBitWords];                        //       members in front of each word
     float thr;
     unsigned int busy_held;                                // this workgroup has raised the board's busy count
     unsigned int tag;                                      // the current list's publication count
@@ -336,7 +339,13 @@ __device__ __forceinline__ unsigned long long granule(unsigned int tag, float v)
 #define CGIC_RQ_COUNT(k, n) atomicAdd((unsigned long long *)&g_phase_clk[20 + (k)], (unsigned long long)(n))
 // dev: per (segment, select) of the first 64 segments: [0] published [1] own rounds exhausted [2] all done [3] items published [4] of which this workgroup's own
 #define CGIC_RQ_STAMP(qid, k, v) do { if (threadIdx.x == 0 && (qid) < 128) g_blk_t[4096 + 8 * (qid) + (k)] = (v); } while (0)
+// dev: the MANY path of a select without queues, row band 0 (tools/probes/probe_tile_timeline.py): the same slots
+#define CGIC_RS_STAMP(k) do { if (!RQ && threadIdx.x == 0 && band == 0 && qid < 128) g_blk_t[4096 + 8 * qid + (k)] = wall_clock64(); } while (0)
+// dev: the front of a select's refinement, row band 0: [0] entry [1] past the histogram shortcut [2] counted [3] past the early returns
+#define CGIC_RE_STAMP(k) do { if (!RQ && threadIdx.x == 0 && band == 0 && qid < 128) g_blk_t[4096 + 1024 + 8 * qid + (k)] = wall_clock64(); } while (0)
 #else
+#define CGIC_RE_STAMP(k) do {} while (0)
+#define CGIC_RS_STAMP(k) do {} while (0)
 #define CGIC_RQ_COUNT(k, n) do {} while (0)
 #define CGIC_RQ_STAMP(qid, k, v) do {} while (0)
 #endif
@@ -483,8 +492,8 @@ struct ExactGate {
 // well, no refinement even running), a real function call is not an option (the callee's register count becomes the kernel's:
 // 248, one wave per SIMD), and the VQ workgroups' last waves as helpers bought nothing in a stream of batches (the long launch
 // overlaps the other lanes' work either way, and helpers hold CUs those lanes want: 68 vs 82 GPixel/s on smooth 8-bit batches).
-template <int NT, int P, bool RQ>
-__device__ __forceinline__ float refine_select(const RouterArgs &a, int qid, int nb, float *arr, int n, unsigned int rank, float t_a,
+template <int NT, int P, bool RQ, bool SPLIT>
+__device__ __forceinline__ float refine_select(const RouterArgs &a, int qid, int nb, int band, float *arr, int n, unsigned int rank, float t_a,
                                                        ExactGate is_exact, int64_t img0, int wP, int nP, RefineShared *rs_, RouterShared *sh,
                                                        const SelInfo &si)
 {
@@ -496,6 +505,7 @@ __device__ __forceinline__ float refine_select(const RouterArgs &a, int qid, int
     constexpr int UPP = P == 16 ? 4 : 1;              // units (64 pixels, one wave and step) per patch
     const int tid = threadIdx.x, lane = lane_id(), wave = tid >> 6;
     const float w = 2.f * refine_delta(t_a + kRefineBand);
+    CGIC_RE_STAMP(0);
     // 0. The usual image leaves here WITHOUT a pass over the map and without a barrier: the select's last pass counted the low
     // key byte of everything that shares the threshold's upper 24 key bits, and a band of +-4e-6 around a value in [0.13, 4) is
     // at most +-250 such steps -- when both band edges share those 24 bits with the threshold (most of the time for values
@@ -518,14 +528,30 @@ __device__ __forceinline__ float refine_select(const RouterArgs &a, int qid, int
             const unsigned int both = (unsigned int)__builtin_amdgcn_readlane((int)wave_inclusive_scan_u32((mall << 16) | before), 63);
             mall = both >> 16;
             before = (both & 0xFFFFu) + si.before;     // + the elements EQUAL to the threshold that sort before it
-            if (mall < 2u || before == 0u) return t_a;      // the threshold element alone / nothing of the band below it (see 1.)
+            if (__builtin_expect(mall < 2u || before == 0u, 1)) return t_a;      // the threshold element alone / nothing of the band below it (see 1.)
         }
     }
+    CGIC_RE_STAMP(1);
     {       // (cnt and the bin centres were set up when the router started: no barrier in front of the count)
         unsigned int minx = 0, below = 0;
         for (int i = tid; i < n; i += NT) {
             const float d = arr[i] - t_a;
-            if (fabsf(d) <= w) {                                  // (NaN: false)
+            const bool in = fabsf(d) <= w;                         // (NaN: false)
+            if constexpr (SPLIT || RQ) {
+                // (one atomic per wave: the 6408 constant patches of a flat tile's band were 8.7 us on this one counter)
+                const unsigned long long m = __ballot(in);
+                if (m) {
+                    const int first = __builtin_ctzll(m);
+                    unsigned int base = 0;
+                    if (lane == first) base = atomicAdd(&cnt[0], (unsigned int)__builtin_popcountll(m));
+                    base = (unsigned int)__shfl((int)base, first, kWave);
+                    const unsigned int s = base + (unsigned int)__builtin_popcountll(m & ((1ull << lane) - 1ull));
+                    if (in) {
+                        if (s < 64) rs->small[s] = (unsigned int)i;
+                        minx += is_exact(i) ? 0u : 1u;
+                    }
+                }
+            } else if (in) {
                 const unsigned int s = atomicAdd(&cnt[0], 1u);
                 if (s < 64) rs->small[s] = (unsigned int)i;
                 minx += is_exact(i) ? 0u : 1u;
@@ -538,21 +564,50 @@ __device__ __forceinline__ float refine_select(const RouterArgs &a, int qid, int
         if (minx) atomicAdd(&cnt[1], minx);
     }
     __syncthreads();
+    CGIC_RE_STAMP(2);
     const unsigned int m_all = cnt[0], m_inexact = cnt[1], c_below = cnt[3];
-    if (m_all < 2 || m_inexact == 0) return t_a;          // (workgroup-uniform) the threshold element alone: nothing can change
+    if (__builtin_expect(m_all < 2 || m_inexact == 0, 1)) return t_a;          // (workgroup-uniform) the threshold element alone: nothing can change
     // The band's members all rank at or above the threshold element (nothing of the band sorts before it): the true threshold is
     // the SMALLEST exact value of the band, and under the strict '<' no member of the band lies below that -- every one of them
     // gets 0 whatever the exact values are, everything outside the band keeps its side: t_a already gives the reference's mask.
     // (Half of the two-member bands of noise-like content.)
-    if (rank == c_below) return t_a;
+    if (__builtin_expect(rank == c_below, 1)) return t_a;
     // From here on this workgroup is the launch's critical path (in the fused launch it shares its CU with an issue-bound VQ
     // workgroup): its instructions go first.  Measured, 64 images of 256x256, fused launch: routers at priority 3 throughout
     // 25.4 -> 27.4 us when no image refines (the VQ workgroups pay), refining images 35.5 -> 30.3 us; raised only here: both.
     __builtin_amdgcn_s_setprio(3);
+    CGIC_RE_STAMP(3);
 
     const bool have_q = RQ && a.rq.nq != 0;
+    // Without the queues (the fused launch), the row bands of a tile -- nb workgroups that all find the same band -- at least
+    // SPLIT it: every band evaluates its share of the members (FEW: by a hash of the patch index; MANY: every nb-th in index
+    // order) and publishes the values (by patch index, write-through, drained, then its count on the select's header); every
+    // band waits for the count to reach the total and reads the others' values.  (They used to evaluate every member each: a
+    // smooth 768x768 tile 251 us of the fused launch.)
+    // The bands of a tile are all in the launch's grid in front of (or beside) VQ workgroups that wait for nobody: each gets a CU.
+    const bool split = SPLIT && !RQ && nb > 1 && a.rq.nq != 0;
     RefineQView qv;
-    if (have_q) qv = refine_qview(a.rq, a.per * a.h16 * a.w16, qid);
+    if (have_q || split) qv = refine_qview(a.rq, a.per * a.h16 * a.w16, qid);
+    float *xvals = reinterpret_cast<float *>(qv.vals);          // split: values by patch index
+    // (ownership by a multiplicative hash of the patch index: balanced for any nb, no division)
+    auto mine_of = [&](int e) { return !split || (((((unsigned int)e * 0x9E3779B1u) >> 16) * (unsigned int)nb) >> 16) == (unsigned int)band; };
+    // split: `total` members are evaluated by all bands together, `own` of them here -> wait for the rest, then leave the header clean
+    auto exchange = [&](unsigned int total, unsigned int own) {
+        drain_stores();
+        __syncthreads();
+        if (tid == 0) {
+            if (own) add_sc1(qv.hdr + QH_ARRIVE, own);
+            while (ld_sc1(qv.hdr + QH_ARRIVE) < total) __builtin_amdgcn_s_sleep(2);
+        }
+        __syncthreads();
+    };
+    auto exchange_leave = [&]() {
+        __syncthreads();
+        if (tid == 0 && add_sc1(qv.hdr + QH_LEFT, 1u) == (unsigned int)nb - 1u) {      // the last band out restores the header
+            st_sc1(qv.hdr + QH_ARRIVE, 0u);
+            st_sc1(qv.hdr + QH_LEFT, 0u);
+        }
+    };
     const RoundCtx rc = round_ctx(a);
     bool share = false;           // this workgroup owns a refinement whose outcome the segment's other row bands take over
 
@@ -692,6 +747,19 @@ __device__ __forceinline__ float refine_select(const RouterArgs &a, int qid, int
         return (f == q[1] && f == q[2 * wP] && f == q[2 * wP + 1]) ? __float_as_uint(f) : kRefEmpty;           // (NaN: never equal)
     };
 
+    // the same in two steps, for passes that load a batch of flags before they look at any: what to load (four flags of a 16x16
+    // patch; i < n), then the key
+    auto flat_raw = [&](int i, float (&r)[P == 16 ? 4 : 1]) {
+        if (P == 8) { r[0] = flat[i]; return; }
+        const int bi = i / nP, q = i - bi * nP, py = q / wP, px = q - py * wP;
+        const float *f = flat + (int64_t)bi * 4 * nP + (int64_t)(2 * py) * (2 * wP) + 2 * px;
+        r[0] = f[0]; r[1] = f[1]; r[2] = f[2 * wP]; r[3] = f[2 * wP + 1];
+    };
+    auto flat_key_raw = [&](const float (&r)[P == 16 ? 4 : 1]) -> unsigned int {
+        if (P == 8) return r[0] == r[0] ? __float_as_uint(r[0]) : kRefEmpty;
+        return (r[0] == r[1] && r[0] == r[2] && r[0] == r[3]) ? __float_as_uint(r[0]) : kRefEmpty;
+    };
+
     const bool few = m_all <= 64 && rank >= c_below && rank - c_below < m_all;
     // FEW: constant patches of one gray are one evaluation: member k is evaluated only if it is the first of its gray.  Every wave
     // works that out for itself (lane = member): no LDS, no barrier
@@ -703,9 +771,12 @@ __device__ __forceinline__ float refine_select(const RouterArgs &a, int qid, int
         my = lane < (int)m_all ? (int)rs->small[lane] : 0;
         exact_l = lane < (int)m_all ? is_exact(my) : true;
         if (flat && lane < (int)m_all && !exact_l) key = flat_key_of(my);
-        for (int j = (int)m_all - 1; j >= 0; --j) {
+        // (the member with the smallest PATCH INDEX of its gray: the same one in every row band, whatever order they listed them in)
+        int lead_e = my;
+        for (int j = 0; j < (int)m_all; ++j) {
             const unsigned int kj = (unsigned int)__builtin_amdgcn_readlane((int)key, j);
-            if (kj == key && key != kRefEmpty) lead = j;                  // ends at the smallest j of this gray
+            const int ej = __builtin_amdgcn_readlane(my, j);
+            if (kj == key && key != kRefEmpty && ej < lead_e) { lead = j; lead_e = ej; }
         }
         work = __ballot(lane < (int)m_all && !exact_l && lead == lane);      // bit k: member k is evaluated
     }
@@ -755,8 +826,16 @@ __device__ __forceinline__ float refine_select(const RouterArgs &a, int qid, int
     };
 
     if (few) {
-        sweep(rs->small, (int)m_all, __builtin_popcountll(work), [&](int k, int) { return (work >> k) & 1ull; },
-              [&](int, int e, float ent) { arr[e] = ent; });
+        // (a band that one round of this workgroup's waves evaluates is not worth the exchange -- two global round trips: every row band does it all)
+        const bool sf = split && __builtin_popcountll(work) * UPP > NWR;
+        sweep(rs->small, (int)m_all, __builtin_popcountll(work), [&](int k, int e) { return ((work >> k) & 1ull) && (!sf || mine_of(e)); },
+              [&](int, int e, float ent) { arr[e] = ent; if (sf) st_sc1(xvals + e, ent); });
+        if (sf) {
+            const unsigned long long own = __ballot(lane < (int)m_all && ((work >> lane) & 1ull) && mine_of(my));
+            exchange((unsigned int)__builtin_popcountll(work), (unsigned int)__builtin_popcountll(own));
+            if (wave == 0 && lane < (int)m_all && ((work >> lane) & 1ull) && !mine_of(my)) arr[my] = ld_sc1(xvals + my);
+            exchange_leave();
+        }
         // everything below the band is below the true threshold, everything above it above: it is the band's (rank - below)-th
         if (wave == 0) {
             float v = lane < (int)m_all ? arr[rs->small[lead]] : __builtin_inff();        // (a follower takes its leader's value)
@@ -780,65 +859,228 @@ __device__ __forceinline__ float refine_select(const RouterArgs &a, int qid, int
 
     // ---- MANY.  Membership of the band is decided on the values as they were when the select ran: every element is tested
     // before it is written, and written once.
-    auto in_band = [&](int i) { return fabsf(arr[i] - t_a) <= w && !is_exact(i); };
+    // Three things made this path slow on flat content (a 768x768 tile with 6408 constant patches in the medium band spent 54 us
+    // here, none of it evaluating): every pass over the map read the constant-patch flags one dependent global load per element
+    // and thread; whole waves inserted the same gray into the table (64 lanes on one LDS word); and the members were listed
+    // 1024 indices at a time, three barriers per range.  Now: a pass loads a batch of values AND flags before it looks at any;
+    // a wave whose members are all one gray inserts it once; the members that need their pixels go into a bitmap (a wave's 64
+    // consecutive elements are one word: a ballot, no atomics), which also puts them in index order -- the same order in every
+    // row band of a tile, so that the bands can take every nb-th one (SPLIT) -- and is listed 1024 MEMBERS at a time.
     auto put = [&](int i, float v) {
         arr[i] = v;
         if (share) { const unsigned int pos = atomicAdd(&cnt[5], 1u); st_sc1(qv.fidx + pos, (unsigned int)i); st_sc1(qv.fval + pos, v); }
     };
-    if (flat) {
-        // the distinct grays of the band's constant patches; the member with the smallest index stands for its gray
-        unsigned int *flat_rep = rs->list;               // [kRefFlatSlots] (the list is free until the ranges below)
-        for (int i = tid; i < kRefFlatSlots; i += NT) { rs->flat_key[i] = kRefEmpty; flat_rep[i] = kRefEmpty; }
-        __syncthreads();
-        for (int i = tid; i < n; i += NT)
-            if (in_band(i)) {
-                const unsigned int k = flat_key_of(i);
-                if (k != kRefEmpty) { const int slot = flat_insert(rs->flat_key, k); if (slot >= 0) atomicMin(&flat_rep[slot], (unsigned int)i); }
-            }
-        __syncthreads();
-        unsigned int used = 0;
-        for (int i = lane; i < kRefFlatSlots; i += 64) used += rs->flat_key[i] != kRefEmpty ? 1u : 0u;
+    if constexpr (!(SPLIT || RQ)) {
+        // (the fused launch's plain instantiation keeps the round-4 form of this path: the one below cost its ORDINARY path 2 us
+        // through register allocation, B = 64 x 256x256 24.0 -> 26.4 us, like every other addition to that kernel)
+        auto in_band = [&](int i) { return fabsf(arr[i] - t_a) <= w && !is_exact(i); };
+        if (flat) {
+            // the distinct grays of the band's constant patches; the member with the smallest index stands for its gray
+            unsigned int *flat_rep = rs->list;               // [kRefFlatSlots] (the list is free until the ranges below)
+            for (int i = tid; i < kRefFlatSlots; i += NT) { rs->flat_key[i] = kRefEmpty; flat_rep[i] = kRefEmpty; }
+            __syncthreads();
+            for (int i = tid; i < n; i += NT)
+                if (in_band(i)) {
+                    const unsigned int k = flat_key_of(i);
+                    if (k != kRefEmpty) { const int slot = flat_insert(rs->flat_key, k); if (slot >= 0) atomicMin(&flat_rep[slot], (unsigned int)i); }
+                }
+            __syncthreads();
+            unsigned int used = 0;
+            for (int i = lane; i < kRefFlatSlots; i += 64) used += rs->flat_key[i] != kRefEmpty ? 1u : 0u;
 #pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) used += __shfl_xor(used, d, kWave);
-        if (RQ && have_q && (int)used * UPP > 4 * NWR) {
-            // (evaluated from the pixels like any other patch -- 64 or 256 equal ones: the same bits as one evaluation of the gray)
-            sweep(flat_rep, kRefFlatSlots, (int)used, [&](int, int e) { return (unsigned int)e != kRefEmpty; },
-                  [&](int k, int, float ent) { rs->flat_val[k] = ent; });
-        } else {
-            if (wave < NWR) {
-                for (int s = wave; s < kRefFlatSlots; s += NWR) {
-                    const unsigned int k = rs->flat_key[s];              // (wave-uniform)
-                    if (k == kRefEmpty) continue;
-                    int j0;
-                    float v[kRefWin];
-                    ref_pixel(rs->tl.bins, rf.sigma, __uint_as_float(k), j0, v);        // every pixel of the patch is this one
-                    ref_unit_chunks(rs->tl.rec[wave], j0, v, rs->tl.T[wave]);
-                    float acc = 0.f;
-                    for (int q = 0; q < UPP; ++q) acc = ref_add_rows(acc, rs->tl.T[wave]);
-                    const float ent = ref_finalize(acc, P * P, rs->tl.P[wave]);
-                    if (lane == 0) rs->flat_val[s] = ent;
+            for (int d = 32; d >= 1; d >>= 1) used += __shfl_xor(used, d, kWave);
+            if (RQ && have_q && (int)used * UPP > 4 * NWR) {
+                // (evaluated from the pixels like any other patch -- 64 or 256 equal ones: the same bits as one evaluation of the gray)
+                sweep(flat_rep, kRefFlatSlots, (int)used, [&](int, int e) { return (unsigned int)e != kRefEmpty; },
+                      [&](int k, int, float ent) { rs->flat_val[k] = ent; });
+            } else {
+                if (wave < NWR) {
+                    for (int s = wave; s < kRefFlatSlots; s += NWR) {
+                        const unsigned int k = rs->flat_key[s];              // (wave-uniform)
+                        if (k == kRefEmpty) continue;
+                        int j0;
+                        float v[kRefWin];
+                        ref_pixel(rs->tl.bins, rf.sigma, __uint_as_float(k), j0, v);        // every pixel of the patch is this one
+                        ref_unit_chunks(rs->tl.rec[wave], j0, v, rs->tl.T[wave]);
+                        float acc = 0.f;
+                        for (int q = 0; q < UPP; ++q) acc = ref_add_rows(acc, rs->tl.T[wave]);
+                        const float ent = ref_finalize(acc, P * P, rs->tl.P[wave]);
+                        if (lane == 0) rs->flat_val[s] = ent;
+                    }
+                }
+                __syncthreads();
+            }
+        }
+        for (int base = 0; base < n; base += kRefListCap) {
+            if (tid == 0) cnt[2] = 0;
+            __syncthreads();
+            const int hi = base + kRefListCap < n ? base + kRefListCap : n;
+            for (int i = base + tid; i < hi; i += NT) {
+                if (!in_band(i)) continue;
+                int slot = -1;
+                if (flat) { const unsigned int k = flat_key_of(i); if (k != kRefEmpty) slot = flat_find(rs->flat_key, k); }
+                if (slot >= 0) put(i, rs->flat_val[slot]);
+                else rs->list[atomicAdd(&cnt[2], 1u)] = (unsigned int)i;
+            }
+            __syncthreads();
+            const int L = (int)cnt[2];
+            sweep(rs->list, L, L, [](int, int) { return true; }, [&](int, int e, float ent) { put(e, ent); });
+        }
+    } else {
+        CGIC_RS_STAMP(0);
+        const int W64 = (n + 63) >> 6;
+        unsigned int *flat_rep = rs->list;               // [kRefFlatSlots] (the list is free until the members are listed)
+        if (flat) {
+            for (int i = tid; i < kRefFlatSlots; i += NT) { rs->flat_key[i] = kRefEmpty; flat_rep[i] = kRefEmpty; }
+            __syncthreads();
+        }
+        constexpr int U = P == 8 ? 8 : 4;
+        // pass A: constant members -> the table of distinct grays (the member with the smallest index stands for its gray), the others -> the bitmap
+        for (int i0 = tid; i0 < 64 * W64; i0 += U * NT) {
+            float v[U];
+            float r[U][P == 16 ? 4 : 1];
+            unsigned int k[U];
+            // (unconditional loads from clamped indices, nothing looked at: a load inside a branch waits inside the branch, one
+            // global round trip per element -- what made these passes 10-14 us each)
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int i = i0 + u * NT, ic = i < n ? i : n - 1;
+                v[u] = arr[ic];
+                if (flat) flat_raw(ic, r[u]);
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int i = i0 + u * NT;                 // (a wave's lanes: 64 consecutive elements, one word of the bitmap; uniform trip count)
+                if (i - lane >= 64 * W64) break;
+                k[u] = (flat && i < n) ? flat_key_raw(r[u]) : kRefEmpty;
+                const bool member = i < n && fabsf(v[u] - t_a) <= w && !is_exact(i < n ? i : 0);
+                bool need = member && k[u] == kRefEmpty;
+                if (member && k[u] != kRefEmpty) {
+                    // (regions of one gray: the wave inserts it once)
+                    const unsigned int k0 = (unsigned int)__builtin_amdgcn_readfirstlane((int)k[u]);
+                    const unsigned long long act = __ballot(true);
+                    int slot;
+                    if (__ballot(k[u] == k0) == act) {
+                        slot = 0;
+                        if (lane == __builtin_ctzll(act)) { slot = flat_insert(rs->flat_key, k0); if (slot >= 0) atomicMin(&flat_rep[slot], (unsigned int)i); }
+                        slot = __builtin_amdgcn_readfirstlane(slot);
+                    } else {
+                        slot = flat_insert(rs->flat_key, k[u]);
+                        if (slot >= 0) atomicMin(&flat_rep[slot], (unsigned int)i);
+                    }
+                    need = slot < 0;                       // (table full: evaluated from its pixels like any other member)
+                }
+                const unsigned long long word = __ballot(need);
+                if (lane == 0) rs->bits[i >> 6] = word;
+            }
+        }
+        __syncthreads();
+        CGIC_RS_STAMP(1);
+        if (flat) {
+            unsigned int used = 0;
+            for (int i = lane; i < kRefFlatSlots; i += 64) used += rs->flat_key[i] != kRefEmpty ? 1u : 0u;
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) used += __shfl_xor(used, d, kWave);
+            if (RQ && have_q && (int)used * UPP > 4 * NWR) {
+                // (evaluated from the pixels like any other patch -- 64 or 256 equal ones: the same bits as one evaluation of the gray)
+                sweep(flat_rep, kRefFlatSlots, (int)used, [&](int, int e) { return (unsigned int)e != kRefEmpty; },
+                      [&](int k, int, float ent) { rs->flat_val[k] = ent; });
+            } else if (used) {
+                if (wave < NWR) {
+                    for (int s = wave; s < kRefFlatSlots; s += NWR) {
+                        const unsigned int k = rs->flat_key[s];              // (wave-uniform)
+                        if (k == kRefEmpty) continue;
+                        int j0;
+                        float v[kRefWin];
+                        ref_pixel(rs->tl.bins, rf.sigma, __uint_as_float(k), j0, v);        // every pixel of the patch is this one
+                        ref_unit_chunks(rs->tl.rec[wave], j0, v, rs->tl.T[wave]);
+                        float acc = 0.f;
+                        for (int q = 0; q < UPP; ++q) acc = ref_add_rows(acc, rs->tl.T[wave]);
+                        const float ent = ref_finalize(acc, P * P, rs->tl.P[wave]);
+                        if (lane == 0) rs->flat_val[s] = ent;
+                    }
+                }
+                __syncthreads();
+            }
+            CGIC_RS_STAMP(2);
+            // pass B: the constant members take their gray's value (the others are still untouched: the band test sees what the select saw)
+            if (used) {
+                for (int i0 = tid; i0 < n; i0 += U * NT) {
+                    float v[U];
+                    float r[U][P == 16 ? 4 : 1];
+#pragma unroll
+                    for (int u = 0; u < U; ++u) {
+                        const int i = i0 + u * NT, ic = i < n ? i : n - 1;
+                        v[u] = arr[ic];
+                        flat_raw(ic, r[u]);
+                    }
+#pragma unroll
+                    for (int u = 0; u < U; ++u) {
+                        const int i = i0 + u * NT;
+                        const unsigned int ku = i < n ? flat_key_raw(r[u]) : kRefEmpty;
+                        if (ku == kRefEmpty || !(fabsf(v[u] - t_a) <= w) || is_exact(i)) continue;
+                        const int slot = flat_find(rs->flat_key, ku);
+                        if (slot >= 0) put(i, rs->flat_val[slot]);
+                    }
+                }
+                __syncthreads();
+            }
+        }
+        // the members in index order: how many in front of each word
+        if (wave == 0) {
+            unsigned int carry = 0;
+            for (int c = 0; c < W64; c += 64) {
+                const unsigned int pc = c + lane < W64 ? (unsigned int)__builtin_popcountll(rs->bits[c + lane]) : 0u;
+                const unsigned int incl = wave_inclusive_scan_u32(pc);
+                if (c + lane < W64) rs->pre[c + lane] = carry + incl - pc;
+                carry += (unsigned int)__builtin_amdgcn_readlane((int)incl, 63);
+            }
+            if (lane == 0) cnt[2] = carry;
+        }
+        __syncthreads();
+        const unsigned int M = cnt[2];                               // members evaluated from their pixels, all row bands together
+        // SPLIT: member number o (in index order) is band (o mod nb)'s, its (o / nb)-th.  (o < 2^14, nb <= 8: the multiply is exact)
+        const unsigned int nbu = split ? (unsigned int)nb : 1u, inv = ((1u << 17) + nbu - 1u) / nbu;
+        const unsigned int own = M > (unsigned int)band * (split ? 1u : 0u) ? (split ? ((M - (unsigned int)band - 1u) * inv >> 17) + 1u : M) : 0u;
+        CGIC_RS_STAMP(3);
+        for (unsigned int c0 = 0; c0 < own; c0 += kRefListCap) {
+            for (int wd = tid; wd < W64; wd += NT) {
+                unsigned long long b = rs->bits[wd];
+                unsigned int o = rs->pre[wd];
+                while (b) {
+                    const int bit = __builtin_ctzll(b);
+                    b &= b - 1;
+                    const unsigned int q = o * inv >> 17;
+                    if (o - q * nbu == (split ? (unsigned int)band : 0u) && q - c0 < (unsigned int)kRefListCap) rs->list[q - c0] = (unsigned int)(64 * wd + bit);
+                    ++o;
                 }
             }
             __syncthreads();
+            const int L = (int)(own - c0 < (unsigned int)kRefListCap ? own - c0 : (unsigned int)kRefListCap);
+            sweep(rs->list, L, L, [](int, int) { return true; }, [&](int, int e, float ent) { put(e, ent); if (split) st_sc1(xvals + e, ent); });
         }
-    }
-    for (int base = 0; base < n; base += kRefListCap) {
-        if (tid == 0) cnt[2] = 0;
-        __syncthreads();
-        const int hi = base + kRefListCap < n ? base + kRefListCap : n;
-        for (int i = base + tid; i < hi; i += NT) {
-            if (!in_band(i)) continue;
-            int slot = -1;
-            if (flat) { const unsigned int k = flat_key_of(i); if (k != kRefEmpty) slot = flat_find(rs->flat_key, k); }
-            if (slot >= 0) put(i, rs->flat_val[slot]);
-            else rs->list[atomicAdd(&cnt[2], 1u)] = (unsigned int)i;
+        CGIC_RS_STAMP(4);
+        if (split && M) {
+            exchange(M, own);
+            CGIC_RS_STAMP(5);
+            for (int wd = tid; wd < W64; wd += NT) {                 // the other bands' members
+                unsigned long long b = rs->bits[wd];
+                unsigned int o = rs->pre[wd];
+                while (b) {
+                    const int bit = __builtin_ctzll(b);
+                    b &= b - 1;
+                    const unsigned int q = o * inv >> 17;
+                    if (o - q * nbu != (unsigned int)band) arr[64 * wd + bit] = ld_sc1(xvals + 64 * wd + bit);
+                    ++o;
+                }
+            }
+            exchange_leave();
         }
-        __syncthreads();
-        const int L = (int)cnt[2];
-        sweep(rs->list, L, L, [](int, int) { return true; }, [&](int, int e, float ent) { put(e, ent); });
+        CGIC_RS_STAMP(6);
     }
     const lds_cf32 arr_l = as_lds(arr);                  // (refinement only runs on staged maps)
     const float thr = radix_select<NT>([&](int64_t i) { return arr_l[i]; }, n, rank, sh);
+    CGIC_RS_STAMP(7);
     if (share) { __syncthreads(); hand_over(cnt[5], thr); }
     __builtin_amdgcn_s_setprio(0);
     return thr;
@@ -849,17 +1091,20 @@ __device__ __forceinline__ float refine_select(const RouterArgs &a, int qid, int
 // launches of the timed paths run, all element reads ds_read; the other copy serves the unstaged / half-staged segments.
 // HELP: the stand-alone launch -- with the refinement queues (refine_select's RQ), and a router workgroup that is done evaluates
 // other images' band patches while any is open.  The fused launch's routers refine inside their own workgroup only.
-template <int NT, bool ST, bool HELP>
+// SPLIT: the row bands of a tile split a threshold band between them (refine_select) -- its own instantiation: even this much more
+// code in the router costs its ordinary path 2-3 us (B = 64 x 256x256: 23.4 -> 26.5 us), so only launches whose segments HAVE row
+// bands take it.
+template <int NT, bool ST, bool HELP, bool SPLIT>
 __device__ __forceinline__ void router_team(const RouterArgs &a, int64_t blk, unsigned char *dyn);
 
-template <int NT, bool HELP = false>
+template <int NT, bool HELP = false, bool SPLIT = false>
 __device__ __forceinline__ void router_body(const RouterArgs &a, int64_t blk, unsigned char *dyn)
 {
-    if (a.stage == 1) router_team<NT, true, HELP>(a, blk, dyn);
-    else router_team<NT, false, false>(a, blk, dyn);
+    if (a.stage == 1) router_team<NT, true, HELP, SPLIT>(a, blk, dyn);
+    else router_team<NT, false, false, false>(a, blk, dyn);
 }
 
-template <int NT, bool ST, bool HELP>
+template <int NT, bool ST, bool HELP, bool SPLIT>
 __device__ __forceinline__ void router_team(const RouterArgs &a, int64_t blk, unsigned char *dyn)
 {
     const int nb = a.bands > 1 ? a.bands : 1;
@@ -920,7 +1165,7 @@ __device__ __forceinline__ void router_team(const RouterArgs &a, int64_t blk, un
         SelInfo si;
         thr_c = radix_select<NT>(rd16, N16, a.rank_c, sh, &si);
         if constexpr (ST) if (refine)
-            thr_c = refine_select<NT, 16, HELP>(a, (int)(2 * seg), nb, const_cast<float *>(e16), (int)N16, a.rank_c, thr_c, ExactGate{nullptr, 0, 0, 0, 0, 0, 0},
+            thr_c = refine_select<NT, 16, HELP, SPLIT>(a, (int)(2 * seg), nb, band, const_cast<float *>(e16), (int)N16, a.rank_c, thr_c, ExactGate{nullptr, 0, 0, 0, 0, 0, 0},
                                           seg * a.per, (int)w16, (int)n16, rs, sh, si);
     }
     CGIC_STAMP(2);
@@ -981,7 +1226,7 @@ __device__ __forceinline__ void router_team(const RouterArgs &a, int64_t blk, un
             SelInfo si;
             thr_m = radix_select<NT>(rd8, N8, a.rank_m, sh, &si);        // (stage 2: the masked copy through the generic pointer)
             if constexpr (ST) if (refine)       // (a gated element's 0 is exact: never re-evaluated, never overwritten)
-                thr_m = refine_select<NT, 8, HELP>(a, (int)(2 * seg + 1), nb, l8m, (int)N8, a.rank_m, thr_m,
+                thr_m = refine_select<NT, 8, HELP, SPLIT>(a, (int)(2 * seg + 1), nb, band, l8m, (int)N8, a.rank_m, thr_m,
                                              ExactGate{gc_bits, n8i, w8i, n16i, w16i, mg_n8, mg_w8}, seg * a.per, w8i, n8i, rs, sh, si);
         } else {
             thr_m = radix_select<NT>([&](int64_t i) { return e8[i] * (1.0f - (gc_of8(i) ? 1.0f : 0.0f)); }, N8, a.rank_m, sh);
@@ -991,7 +1236,7 @@ __device__ __forceinline__ void router_team(const RouterArgs &a, int64_t blk, un
         SelInfo si;
         thr_m = radix_select<NT>(rd8, N8, a.rank_m, sh, &si);
         if constexpr (ST) if (refine)
-            thr_m = refine_select<NT, 8, HELP>(a, (int)(2 * seg + 1), nb, const_cast<float *>(e8), (int)N8, a.rank_m, thr_m, ExactGate{nullptr, 0, 0, 0, 0, 0, 0},
+            thr_m = refine_select<NT, 8, HELP, SPLIT>(a, (int)(2 * seg + 1), nb, band, const_cast<float *>(e8), (int)N8, a.rank_m, thr_m, ExactGate{nullptr, 0, 0, 0, 0, 0, 0},
                                          seg * a.per, w8i, n8i, rs, sh, si);
     }
     auto gm_rule = [&](float v, bool gc) -> bool {

@@ -1153,7 +1153,7 @@ __global__ CGIC_VQF_BOUNDS void vq_filter_probe_kernel(VqArgs a)
 // dynamic LDS / the VGPR budget are per launch, so a router workgroup does not share a CU with one: behind the VQ
 // workgroups it only starts when the VQ is over.  The router workgroups therefore come FIRST (`nrouter` of them, one CU
 // each for ~11 us); the VQ workgroups that have to wait for those CUs own fewer groups, the others more.
-template <bool ALIGNED, bool CONV>
+template <bool ALIGNED, bool CONV, bool SPLIT = false>
 __global__ CGIC_VQF_BOUNDS void vq_filter_router_kernel(VqArgs a, RouterArgs r, unsigned int nrouter, unsigned int router_behind)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_f[];
@@ -1164,7 +1164,7 @@ __global__ CGIC_VQF_BOUNDS void vq_filter_router_kernel(VqArgs a, RouterArgs r, 
 #ifdef CGIC_ROUTER_PRIO
         __builtin_amdgcn_s_setprio(CGIC_ROUTER_PRIO);
 #endif
-        router_body<kVqfThreads>(r, (int64_t)(blockIdx.x - rb), smem_f);
+        router_body<kVqfThreads, false, SPLIT>(r, (int64_t)(blockIdx.x - rb), smem_f);
         return;
     }
     vq_filter_body<kVqfThreads, ALIGNED, CONV>(a, smem_f, blockIdx.x - vb);
@@ -1189,7 +1189,7 @@ struct VqfrArgs {
     RouterArgs r;
     unsigned int nrouter, router_behind;
 };
-template <bool ALIGNED>
+template <bool ALIGNED, bool SPLIT = false>
 __global__ CGIC_VQF_BOUNDS void vq_filter_router_grouped_kernel(Grouped<VqfrArgs> g)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_f[];
@@ -1197,7 +1197,7 @@ __global__ CGIC_VQF_BOUNDS void vq_filter_router_grouped_kernel(Grouped<VqfrArgs
     const VqfrArgs &p = g.a[group_locate(g, &blk)];
     const unsigned int rb = p.router_behind ? p.a.nblk : 0u, vb = p.router_behind ? 0u : p.nrouter;
     if (blk.x - rb < p.nrouter) {
-        router_body<kVqfThreads>(p.r, (int64_t)(blk.x - rb), smem_f);
+        router_body<kVqfThreads, false, SPLIT>(p.r, (int64_t)(blk.x - rb), smem_f);
         return;
     }
     vq_filter_body<kVqfThreads, ALIGNED, false>(p.a, smem_f, blk.x - vb);
@@ -1507,11 +1507,20 @@ static int launch_filter(const float *z, int64_t hw, int64_t N, const float *cb,
             return launch_check("vq_filter_router_perm_kernel");
         }
     }
-    rc = ensure_dynamic_lds((const void *)vq_filter_router_kernel<ALIGNED, CONV>, lds);
-    if (rc) return rc;
     VqfrArgs p;
     p.a = a; p.r = *router; p.nrouter = (unsigned int)router_blocks; p.router_behind = router_first ? 0u : 1u;
     const dim3 grid(a.nblk + (unsigned int)router_blocks);
+    // row bands that share a threshold band's re-evaluation run the SPLIT instantiation (cgic_router_dev.h: router_body)
+    const bool split = router->bands > 1 && router->rq.nq != 0;
+    if (split) {
+        rc = ensure_dynamic_lds((const void *)vq_filter_router_kernel<ALIGNED, CONV, true>, lds);
+        if (rc) return rc;
+        return launch_or_record(CONV ? KID_NONE : ALIGNED ? KID_VQF_ROUTER_AL : KID_VQF_ROUTER_UN, grid, dim3(kVqfThreads), lds, p, s, [=] {
+            hipLaunchKernelGGL((vq_filter_router_kernel<ALIGNED, CONV, true>), grid, dim3(kVqfThreads), lds, s, p.a, p.r, p.nrouter, p.router_behind);
+            return launch_check("vq_filter_router_kernel(split)"); });
+    }
+    rc = ensure_dynamic_lds((const void *)vq_filter_router_kernel<ALIGNED, CONV>, lds);
+    if (rc) return rc;
     return launch_or_record(CONV ? KID_NONE : ALIGNED ? KID_VQF_ROUTER_AL : KID_VQF_ROUTER_UN, grid, dim3(kVqfThreads), lds, p, s, [=] {
         hipLaunchKernelGGL((vq_filter_router_kernel<ALIGNED, CONV>), grid, dim3(kVqfThreads), lds, s, p.a, p.r, p.nrouter, p.router_behind);
         return launch_check("vq_filter_router_kernel"); });
@@ -1524,6 +1533,14 @@ static int vqfr_grouped_launch(const GroupRec *const *recs, int n, hipStream_t s
     size_t lds;
     int rc = fill_grouped(recs, n, &g, &lds);
     if (rc) return rc;
+    bool split = false;
+    for (int i = 0; i < n; ++i) split = split || (g.a[i].r.bands > 1 && g.a[i].r.rq.nq != 0);
+    if (split) {
+        rc = ensure_dynamic_lds((const void *)vq_filter_router_grouped_kernel<ALIGNED, true>, lds);
+        if (rc) return rc;
+        hipLaunchKernelGGL((vq_filter_router_grouped_kernel<ALIGNED, true>), dim3(g.start[kMaxGroups]), dim3(kVqfThreads), lds, s, g);
+        return launch_check("vq_filter_router_grouped_kernel(split)");
+    }
     rc = ensure_dynamic_lds((const void *)vq_filter_router_grouped_kernel<ALIGNED>, lds);
     if (rc) return rc;
     hipLaunchKernelGGL((vq_filter_router_grouped_kernel<ALIGNED>), dim3(g.start[kMaxGroups]), dim3(kVqfThreads), lds, s, g);

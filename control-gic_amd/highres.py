@@ -344,6 +344,8 @@ class TiledCall:
                           "dmask": [E((B, 1, h // 4, ww // 4), i32), E((B, 1, h // 2, ww // 2), i32), E((B, 1, h, ww), i32)]})
             ws_c = E((max(1, l.cgic_compress_workspace_bytes(B, h, ww)),), u8t)
             ws_d = E((l.cgic_decompress_workspace_bytes(B, h, ww),), u8t) if decode else None
+            nref = l.cgic_router_refine_scratch_bytes(B, th // 16, tw // 16, 1) if (th // 16) * (tw // 16) >= _lib.REFINE_SPLIT_MIN_PATCHES and _lib.REFINE_QUEUES else 0
+            ws_r = E((nref,), u8t) if nref else None                 # (large tiles: their row bands split a threshold band between them)
             org = (ctypes.c_int * (2 * T))(*[v for i in idxs for v in (self.tiles[i][0] - top, self.tiles[i][1] - left)])
             g = self._arr[k]
             g.ntiles, g.th, g.tw, g.origins, g.share = T, th, tw, org, len(idxs) * th * tw / total
@@ -355,8 +357,9 @@ class TiledCall:
                 io.dind, io.dz_q, io.status = p(t["dind"]), p(t["dz_q"]), p(t["status"])
                 io.dmask_c, io.dmask_m, io.dmask_f = (p(m) for m in t["dmask"])
             io.ws_compress, io.ws_decompress = p(ws_c), p(ws_d)
+            io.ws_refine, io.ws_refine_bytes = p(ws_r), nref
             self._buf.append(t)
-            self._keep += [org, ws_c, ws_d]
+            self._keep += [org, ws_c, ws_d, ws_r]
         self._mode = ctypes.c_int(0)
         self._fn = l.cgic_compress_tiled
         self._bins = _lib.linspace_bins()

@@ -175,7 +175,8 @@ def vq_forward_route(z, weight, beta, legacy, e16, e8, coarse_ratio, medium_rati
     gate = torch.empty((B, 1, 4 * h16, 12 * w16), dtype=torch.float32, device=dev) if want_gate else None
     mode = ctypes.c_int(0)
     qc, keep = _lib.conv_arg(quant_conv, conv_bias_first)
-    px, keep_px = _lib.pixels_arg(pixels, B, h16, w16, per_image, flat8=flat8, explicit=True)
+    px, keep_px = _lib.pixels_arg(pixels, B, h16, w16, per_image, flat8=flat8, explicit=True,
+                                   queues=bool(per_image) and h16 * w16 >= _lib.REFINE_SPLIT_MIN_PATCHES)      # (large tiles: their row bands split a band between them)
     with _lib.on_device(dev):
         _lib.call("cgic_vq_forward_route_f32", _lib.ptr(z), B, h * w, _lib.ptr(weight), weight.shape[0], C, float(beta),
                   int(bool(legacy)), _lib.ptr(idx), _lib.ptr(z_q), _lib.ptr(loss), _lib.ptr(ws), _lib.ptr(e16), _lib.ptr(e8),

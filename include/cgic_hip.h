@@ -505,7 +505,8 @@ int cgic_embedding_gather_f32(const int64_t *ind, int64_t B, int64_t hw, const f
  *   ind, mask_c/m/f, z_q (or NULL), loss (or NULL), streams [B,5,slot], nbytes [B,5], hist (or NULL): as the single calls
  *   dind ... status: the decode side's outputs (cgic_decompress_streams); dind == NULL: encode only
  *   ws_vq (cgic_vq_workspace_bytes(B*h*w); may be NULL iff loss is), ws_compress (cgic_compress_workspace_bytes),
- *   ws_decompress (cgic_decompress_workspace_bytes; NULL iff dind is)
+ *   ws_decompress (cgic_decompress_workspace_bytes; NULL iff dind is), ws_refine (optional: the row bands of large tiles then
+ *   split a threshold band between them instead of evaluating it each)
  * ------------------------------------------------------------------------- */
 typedef struct cgic_image_io {
     const void *x; int x_is_u8;
@@ -516,6 +517,7 @@ typedef struct cgic_image_io {
     uint8_t *streams; int64_t slot; int32_t *nbytes; int64_t *hist;
     int64_t *dind; int32_t *dmask_c, *dmask_m, *dmask_f; float *dz_q; int32_t *status;
     void *ws_vq, *ws_compress, *ws_decompress;
+    void *ws_refine; size_t ws_refine_bytes;     /* cgic_router_refine_scratch_bytes(B, H/16, W/16, 1) bytes or NULL: cgic_pixels.scratch of the call */
 } cgic_image_io;
 int cgic_compress_image(const cgic_table *t, const float *codebook, int K, int e_dim, const void *prepared, int64_t B, int64_t H,
                         int64_t W, double coarse_ratio, double medium_ratio, float beta, int legacy, const float *bins, int nbins,

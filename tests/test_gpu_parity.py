@@ -458,6 +458,70 @@ def test_refinement_queues_change_nothing_and_survive_concurrent_launches():
         _lib.REFINE_QUEUES = True
 
 
+def test_row_bands_split_a_band_in_the_fused_launch():
+    """The fused VQ + router launch has no refinement queues; the row bands of a large tile (up to eight workgroups that all find
+    the same band) split its re-evaluation between them instead -- FEW: by a hash of the patch index, MANY: every nb-th member in
+    index order -- and exchange the values through the scratch (cgic_pixels.scratch, _lib.REFINE_SPLIT_MIN_PATCHES).  Masks
+    identical to the launch without the scratch (every band evaluates everything) and to the routing on the reference-arithmetic
+    maps: all four families as 768x768 tiles, other tile shapes and band counts (8, 6, 3 row bands; 32 to 64 patch rows), uint8
+    frames, repeated launches over the same header slots, four streams at once."""
+    from control_gic_amd import _lib
+    from control_gic_amd.quantize import vq_forward_route
+    from oracle.content_families import families
+    rng = np.random.default_rng(77)
+    w = _t(rng.standard_normal((1024, 4), dtype=np.float32))
+    router = cg.TripleGrainFixedEntropyRouter(0.1, 0.8, per_image=True)
+    cases = {}
+    t = families(n=2, H=768, W=768, seed=11)
+    cases["768x768 x8"] = np.concatenate([t[k] for k in ("noise8", "smooth8", "flat_edges", "blocky8")])
+    t = families(n=5, H=512, W=1024, seed=12)
+    cases["512x1024 x10 (6 bands)"] = np.concatenate([t["smooth8"], t["flat_edges"]])
+    t = families(n=10, H=1024, W=512, seed=13)
+    cases["1024x512 x20 (3 bands)"] = np.concatenate([t["smooth8"], t["noise8"]])
+    t = families(n=1, H=640, W=656, seed=14)
+    cases["640x656 x2"] = np.concatenate([t["smooth8"], t["flat_edges"]])
+    keep = _lib.REFINE_SPLIT_MIN_PATCHES, _lib.REFINE_QUEUES
+    try:
+        _lib.REFINE_SPLIT_MIN_PATCHES = 1024
+        ready = {}
+        for name, x in cases.items():
+            xd = torch.from_numpy(x).to(DEV)
+            B, _, H, W = xd.shape
+            assert _lib.lib().cgic_router_refine_scratch_bytes(B, H // 16, W // 16, 1) > 0, name
+            e8, e16 = cg.entropy_maps(xd)
+            r8, r16 = cg.entropy_maps(xd, reference_order=True)
+            want = [m.clone() for m in router(r16, r8, want_gate=False, pixels=None)[0]]
+            z = _t(rng.standard_normal((B, 4, H // 4, W // 4), dtype=np.float32))
+            f = lambda z=z, e16=e16, e8=e8, xd=xd: vq_forward_route(z, w, 0.25, True, e16, e8, 0.1, 0.8, per_image=True, pixels=xd)[3]
+            _lib.REFINE_QUEUES = False
+            plain = f()
+            assert all(torch.equal(a, b) for a, b in zip(plain, want)), (name, "every band evaluates everything")
+            _lib.REFINE_QUEUES = True
+            for rep in range(4):
+                got = f()
+                assert all(torch.equal(a, b) for a, b in zip(got, want)), (name, "split", rep, [int((a != b).sum()) for a, b in zip(got, want)])
+            ready[name] = (f, want)
+        xd = torch.from_numpy(cases["768x768 x8"]).to(DEV)
+        frames = (xd * 255.0).round().to(torch.uint8).permute(0, 2, 3, 1).contiguous()
+        _, f8, f16 = cg.entropy_maps_u8(frames)
+        z = _t(rng.standard_normal((8, 4, 192, 192), dtype=np.float32))
+        got = vq_forward_route(z, w, 0.25, True, f16, f8, 0.1, 0.8, per_image=True, pixels=frames)[3]
+        assert all(torch.equal(a, b) for a, b in zip(got, ready["768x768 x8"][1])), "uint8 frames"
+        streams = [torch.cuda.Stream() for _ in range(4)]
+        torch.cuda.synchronize()
+        outs, names = [], list(ready)
+        for rnd in range(6):
+            for k, st in enumerate(streams):
+                name = names[(rnd + k) % len(names)]
+                with torch.cuda.stream(st):
+                    outs.append((name, ready[name][0]()))
+        torch.cuda.synchronize()
+        for name, got in outs:
+            assert all(torch.equal(a, b) for a, b in zip(got, ready[name][1])), (name, "concurrent streams")
+    finally:
+        _lib.REFINE_SPLIT_MIN_PATCHES, _lib.REFINE_QUEUES = keep
+
+
 def test_flat_map_and_constant_patch_shortcut():
     """entropy_maps' by-product flat8 (gray of an 8x8 patch whose 64 pixels agree bit for bit, else NaN) against numpy, fp32
     and uint8 input; with it the router evaluates constant band patches once per distinct gray -- same masks as without it

@@ -129,7 +129,12 @@ def test_one_call_tiled_driver_equals_the_group_by_group_path(frames, N, H, W):
         return ind, mask, mode
 
     for rep in range(2):
-        if frames:
+        if rep == 1:        # smooth 8-bit content: long threshold bands, which the row bands of the full 768x768 tiles split between them (ws_refine)
+            yy, xx = np.mgrid[0:H, 0:W].astype(np.float32)
+            sm = np.stack([np.stack([np.round(255.0 * np.clip(0.5 + 0.45 * np.sin((0.6 * xx + (0.8 + 0.1 * n) * yy) * 0.7 * 2 * np.pi / W) * (0.7 + 0.1 * c)
+                                                             + rng.integers(-1, 2, (H, W)) / 255.0, 0, 1)) for c in range(3)]) for n in range(N)]).astype(np.float32) / 255.0
+            x = torch.from_numpy(np.ascontiguousarray((sm * 255.0).round().astype(np.uint8).transpose(0, 2, 3, 1)) if frames else sm).to(dev)
+        elif frames:
             x = torch.from_numpy(rng.integers(0, 256, (N, H, W, 3), dtype=np.uint8)).to(dev)
         else:
             x = torch.from_numpy((rng.integers(0, 256, (N, 3, H, W)) / 255.0).astype(np.float32)).to(dev)

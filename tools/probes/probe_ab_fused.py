@@ -4,7 +4,8 @@ import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from control_gic_amd import _lib
 if os.environ.get("BASE"):
-    _lib.PROTOTYPES.pop("cgic_router_refine_scratch_bytes", None)
+    for _n in ("cgic_router_refine_scratch_bytes", "cgic_compress_image", "cgic_compress_tiled"):
+        _lib.PROTOTYPES.pop(_n, None)
     _lib.REFINE_QUEUES = False
 if os.environ.get("NOQ"):
     _lib.REFINE_QUEUES = False
