@@ -968,15 +968,28 @@ __device__ __forceinline__ float refine_select(const RouterArgs &a, int qid, int
                         slot = flat_insert(rs->flat_key, k[u]);
                         if (slot >= 0) atomicMin(&flat_rep[slot], (unsigned int)i);
                     }
-                    need = slot < 0;                       // (table full: evaluated from its pixels like any other member)
+                    need = slot < 0;                       // (table full: see below)
+                    if (slot < 0) cnt[6] = 1u;
                 }
                 const unsigned long long word = __ballot(need);
                 if (lane == 0) rs->bits[i >> 6] = word;
             }
         }
         __syncthreads();
+        // More distinct grays than the table holds (a blocky image whose quantile falls among its constant blocks): WHICH grays made
+        // it into the table depends on the order the waves came by -- not the same in every row band, and the bands must agree on
+        // the member list.  Then no gray is shared: every member is evaluated from its pixels.
+        const bool overflow = flat && cnt[6] != 0u;
+        if (overflow) {
+            for (int i0 = tid; i0 < 64 * W64; i0 += NT) {
+                const bool member = i0 < n && fabsf(arr[i0 < n ? i0 : 0] - t_a) <= w && !is_exact(i0 < n ? i0 : 0);
+                const unsigned long long word = __ballot(member);
+                if (lane == 0) rs->bits[i0 >> 6] = word;
+            }
+            __syncthreads();
+        }
         CGIC_RS_STAMP(1);
-        if (flat) {
+        if (flat && !overflow) {
             unsigned int used = 0;
             for (int i = lane; i < kRefFlatSlots; i += 64) used += rs->flat_key[i] != kRefEmpty ? 1u : 0u;
 #pragma unroll

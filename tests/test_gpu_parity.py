@@ -501,6 +501,19 @@ def test_row_bands_split_a_band_in_the_fused_launch():
                 got = f()
                 assert all(torch.equal(a, b) for a, b in zip(got, want)), (name, "split", rep, [int((a != b).sum()) for a, b in zip(got, want)])
             ready[name] = (f, want)
+        # blocky tiles, medium grain only, the quantile among the constant blocks: hundreds of distinct grays in the band -- more than
+        # the table of shared grays holds; the row bands must still agree on the member list (found by tools/stress_refine.py)
+        r2 = cg.TripleGrainFixedEntropyRouter(0.0, 0.25, per_image=True)
+        for seed in (21, 22):
+            blocks = np.random.default_rng(seed).integers(0, 256, (7, 3, 96, 96)).astype(np.float32) / 255.0        # every 8x8 block one colour
+            xd = torch.from_numpy(np.ascontiguousarray(np.repeat(np.repeat(blocks, 8, axis=2), 8, axis=3))).to(DEV)
+            e8, e16 = cg.entropy_maps(xd)
+            r8, r16 = cg.entropy_maps(xd, reference_order=True)
+            want = r2(r16, r8, want_gate=False, pixels=None)[0]
+            z = _t(rng.standard_normal((7, 4, 192, 192), dtype=np.float32))
+            for rep in range(3):
+                got = vq_forward_route(z, w, 0.25, True, e16, e8, 0.0, 0.25, per_image=True, pixels=xd)[3]
+                assert all(torch.equal(a, b) for a, b in zip(got, want)), ("blocky, more grays than table slots", seed, rep, [int((a != b).sum()) for a, b in zip(got, want)])
         xd = torch.from_numpy(cases["768x768 x8"]).to(DEV)
         frames = (xd * 255.0).round().to(torch.uint8).permute(0, 2, 3, 1).contiguous()
         _, f8, f16 = cg.entropy_maps_u8(frames)
