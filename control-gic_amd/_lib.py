@@ -257,7 +257,7 @@ REFINE_QUEUES = True
 #: the fused VQ + router launch: tiles of at least this many 16x16 patches get the scratch that lets their row bands SPLIT a long
 #: threshold band between them (a smooth 768x768 tile 251 -> 73 us; costs that launch ~4 us on an ordinary tile: its own kernel
 #: instantiation).  2304 = the 768x768 tile of the 2K path; Kodak-sized 768x512 images stay on the plain kernel
-REFINE_SPLIT_MIN_PATCHES = 2304
+REFINE_SPLIT_MIN_PATCHES = int(os.environ.get("CGIC_REFINE_SPLIT_MIN_PATCHES", "2304"))      # (a huge value: never)
 
 
 def pixels_arg(pixels, B, h16, w16, per_image, sigma=0.01, flat8=None, queues=False, explicit=False):

@@ -767,7 +767,7 @@ __device__ __forceinline__ float refine_select(const RouterArgs &a, int qid, int
     int my = 0, lead = lane;
     bool exact_l = true;
     unsigned long long work = 0;
-    if (few) {
+    if (__builtin_expect(few, 1)) {
         my = lane < (int)m_all ? (int)rs->small[lane] : 0;
         exact_l = lane < (int)m_all ? is_exact(my) : true;
         if (flat && lane < (int)m_all && !exact_l) key = flat_key_of(my);
@@ -825,12 +825,12 @@ __device__ __forceinline__ float refine_select(const RouterArgs &a, int qid, int
         }
     };
 
-    if (few) {
+    if (__builtin_expect(few, 1)) {
         // (a band that one round of this workgroup's waves evaluates is not worth the exchange -- two global round trips: every row band does it all)
         const bool sf = split && __builtin_popcountll(work) * UPP > NWR;
         sweep(rs->small, (int)m_all, __builtin_popcountll(work), [&](int k, int e) { return ((work >> k) & 1ull) && (!sf || mine_of(e)); },
               [&](int, int e, float ent) { arr[e] = ent; if (sf) st_sc1(xvals + e, ent); });
-        if (sf) {
+        if (__builtin_expect(sf, 0)) {
             const unsigned long long own = __ballot(lane < (int)m_all && ((work >> lane) & 1ull) && mine_of(my));
             exchange((unsigned int)__builtin_popcountll(work), (unsigned int)__builtin_popcountll(own));
             if (wave == 0 && lane < (int)m_all && ((work >> lane) & 1ull) && !mine_of(my)) arr[my] = ld_sc1(xvals + my);
@@ -934,7 +934,7 @@ __device__ __forceinline__ float refine_select(const RouterArgs &a, int qid, int
             for (int i = tid; i < kRefFlatSlots; i += NT) { rs->flat_key[i] = kRefEmpty; flat_rep[i] = kRefEmpty; }
             __syncthreads();
         }
-        constexpr int U = P == 8 ? 8 : 4;
+        constexpr int U = 4;
         // pass A: constant members -> the table of distinct grays (the member with the smallest index stands for its gray), the others -> the bitmap
         for (int i0 = tid; i0 < 64 * W64; i0 += U * NT) {
             float v[U];
@@ -951,7 +951,7 @@ __device__ __forceinline__ float refine_select(const RouterArgs &a, int qid, int
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const int i = i0 + u * NT;                 // (a wave's lanes: 64 consecutive elements, one word of the bitmap; uniform trip count)
-                if (i - lane >= 64 * W64) break;
+                if (i - lane >= 64 * W64) continue;        // (no break: the loop stays unrolled, the arrays stay registers)
                 k[u] = (flat && i < n) ? flat_key_raw(r[u]) : kRefEmpty;
                 const bool member = i < n && fabsf(v[u] - t_a) <= w && !is_exact(i < n ? i : 0);
                 bool need = member && k[u] == kRefEmpty;
