@@ -139,10 +139,13 @@ typedef struct cgic_pixels {
                          * Without it constant patches are re-evaluated one by one like any other (same result, slower on
                          * flat content) */
     void *scratch;      /* device, cgic_router_refine_scratch_bytes(...) bytes, or NULL (ABI 7).  With it a long band -- smooth or
-                         * flat 8-bit content puts tens to hundreds of patches within the band of a threshold -- is evaluated
-                         * by every idle workgroup of the launch (the other row bands of a tile, finished router workgroups,
-                         * the VQ workgroups of the fused launch once their own work is done) instead of by the image's one
-                         * router workgroup.  Same masks either way.  Uninitialised memory; one per launch in flight */
+                         * flat 8-bit content puts tens to hundreds of patches within the band of a threshold -- is not evaluated
+                         * by every router workgroup of the image on its own: cgic_router_f32 publishes it to every idle wave of
+                         * the launch (the other row bands of a tile, finished router workgroups); cgic_vq_forward_route_f32 has
+                         * the row bands of a large tile (>= 32x32 patches routed per image: up to 8 workgroups) split it between
+                         * them -- a smooth 768x768 tile 251 -> 73 us; that launch then runs its own kernel instantiation,
+                         * ~3.5 us slower on an ordinary tile: pass NULL to keep the plain one.  Same masks either way.
+                         * Uninitialised memory; one per launch in flight */
     size_t scratch_bytes;
 } cgic_pixels;
 /* scratch for cgic_pixels.scratch of a router / fused call with these arguments (0: the call takes none) */
