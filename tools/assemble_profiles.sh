@@ -56,7 +56,9 @@ cat $O/pmc_sq_vq_fused.md
 echo
 python - <<PY
 import json
-d = json.load(open("$O/${R}_roofline.json")); m = d.get("mfma", {})
+d = json.load(open("$O/${R}_roofline.json")); m = dict(d.get("mfma", {}))
+for k, v in json.load(open("$O/pmc_sq_vq_fused.json")).items():
+    if "vq_filter_router_kernel" in k: m.update(v)
 dur = d["rocprof_avg_us_alone_graph"]
 cyc = dur * 1e-6 * 2.4e9
 print("Derived (launch duration %.2f us by rocprofv3 = %.0f cycles at 2.4 GHz; 1024 SIMDs):" % (dur, cyc))
@@ -64,6 +66,7 @@ print("* matrix pipes busy: SQ_VALU_MFMA_BUSY_CYCLES / 1024 / cycles = **%.3f** 
 print("* %.0f %% of the matrix-busy cycles have a VALU instruction executing beside them (SQ_VALU_MFMA_COEXEC_CYCLES)" % (100 * m["SQ_VALU_MFMA_COEXEC_CYCLES"] / m["SQ_VALU_MFMA_BUSY_CYCLES"]))
 print("* VALU issue: %.0f instructions per SIMD x 4 cycles = %.2f us per SIMD" % (m["SQ_INSTS_VALU"] / 1024, m["SQ_INSTS_VALU"] / 1024 * 4 / 2.4e3))
 print("* waves wait (SQ_WAIT_ANY / SQ_WAVE_CYCLES): %.0f %%; LDS bank conflicts: %.0f %% of the LDS-active cycles" % (100 * m["SQ_WAIT_ANY"] / m["SQ_WAVE_CYCLES"], 100 * m["SQ_LDS_BANK_CONFLICT"] / m["SQ_LDS_IDX_ACTIVE"]))
+print("* the two levers round 4's verdict named, priced by these counters: (a) LDS bank conflicts -- %.0f conflict cycles per CU = %.2f us of the launch's %.1f if NONE of it were hidden behind the VALU scan (LDS is index-active %.0f %% of the busy CU cycles; waves wait on an LDS instruction %.1f %% of their wait cycles: SQ_WAIT_INST_LDS / SQ_WAIT_ANY): a swizzle of the ldsA tiles is worth <= %.1f us and costs address VALU in a loop that is VALU-issue-bound at the 128-VGPR cap -- not attempted; (b) the router workgroups as the launch's tail (they end at 21.0-21.7 us, the VQ workgroups at 18.5-19.5: NOTES 10.2) -- routers on 64 CUs of their own leave the VQ scan 192 CUs: its %.1f us x 256 CU of work take %.1f us there, more than the whole launch now (priced, not built); three waves per SIMD need <= 84 VGPRs where the kernel already spills at its 128 cap (uncapped it takes 144-150; ScratchSize 20 B/lane, 247 spilled SGPRs: llvm -Rpass-analysis=kernel-resource-usage) -- the scan loop's registers would go to scratch (priced, not built); measured and slower: router waves at raised priority throughout, 256- / 128-thread router teams, 1024-thread or two VQ workgroups per CU (NOTES 10.2, 10.3f)" % (m["SQ_LDS_BANK_CONFLICT"] / 256, m["SQ_LDS_BANK_CONFLICT"] / 256 / 2.4e3, dur, 100 * m["SQ_LDS_IDX_ACTIVE"] / m["SQ_BUSY_CU_CYCLES"], 100 * m["SQ_WAIT_INST_LDS"] / m["SQ_WAIT_ANY"], m["SQ_LDS_BANK_CONFLICT"] / 256 / 2.4e3, 19.0, 19.0 * 256 / 192))
 print("* fp16 MFMA work: %.2f GFLOP per launch = %.0f TFLOP/s = %.3f of the 2.5 PFLOP/s dense fp16 peak; algorithmic 2NKD = 2.147 GFLOP = %.1f TFLOP/s = %.3f of the 157.3 fp32 yardstick" % (m["SQ_INSTS_MFMA"] * 32768 / 1e9, m["SQ_INSTS_MFMA"] * 32768 / dur / 1e6, m["SQ_INSTS_MFMA"] * 32768 / dur / 1e6 / 2500, 2147.48 / dur, 2147.48 / dur / 157.3))
 PY
 echo
