@@ -254,10 +254,11 @@ def linspace_bins():
 
 #: False: bands are evaluated inside the image's own router workgroup only (no refinement queues: the pre-ABI-7 behaviour; tests, A/B)
 REFINE_QUEUES = True
-#: the fused VQ + router launch: tiles of at least this many 16x16 patches get the scratch that lets their row bands SPLIT a long
-#: threshold band between them (a smooth 768x768 tile 251 -> 73 us; costs that launch ~4 us on an ordinary tile: its own kernel
-#: instantiation).  2304 = the 768x768 tile of the 2K path; Kodak-sized 768x512 images stay on the plain kernel
-REFINE_SPLIT_MIN_PATCHES = int(os.environ.get("CGIC_REFINE_SPLIT_MIN_PATCHES", "2304"))      # (a huge value: never)
+#: the fused VQ + router launch: tiles of at least this many 16x16 patches (1024 = where a per-image segment gets row bands) get the
+#: scratch that lets their row bands SPLIT a long threshold band between them (a smooth 768x768 tile 251 -> 82 us).  The launch then
+#: runs the router in two attempts (plain first, the split instantiation only when a band is long: DESIGN.md 4.3): the ordinary
+#: tile pays nothing measurable for it
+REFINE_SPLIT_MIN_PATCHES = int(os.environ.get("CGIC_REFINE_SPLIT_MIN_PATCHES", "1024"))      # (a huge value: never)
 
 
 def pixels_arg(pixels, B, h16, w16, per_image, sigma=0.01, flat8=None, queues=False, explicit=False):

@@ -492,10 +492,12 @@ struct ExactGate {
 // well, no refinement even running), a real function call is not an option (the callee's register count becomes the kernel's:
 // 248, one wave per SIMD), and the VQ workgroups' last waves as helpers bought nothing in a stream of batches (the long launch
 // overlaps the other lanes' work either way, and helpers hold CUs those lanes want: 68 vs 82 GPixel/s on smooth 8-bit batches).
-template <int NT, int P, bool RQ, bool SPLIT>
+// BAIL (attempt one of a launch whose row bands can split a band, see router_body): a band with more than four rounds of this
+// workgroup's waves to evaluate from pixels is not done here -- *bail_out = true, and the caller starts over in the SPLIT instantiation.
+template <int NT, int P, bool RQ, bool SPLIT, bool BAIL = false>
 __device__ __forceinline__ float refine_select(const RouterArgs &a, int qid, int nb, int band, float *arr, int n, unsigned int rank, float t_a,
                                                        ExactGate is_exact, int64_t img0, int wP, int nP, RefineShared *rs_, RouterShared *sh,
-                                                       const SelInfo &si)
+                                                       const SelInfo &si, bool *bail_out = nullptr)
 {
     RefineShared *rs = rs_;
     const RefineSrc &rf = a.rf;
@@ -554,7 +556,23 @@ __device__ __forceinline__ float refine_select(const RouterArgs &a, int qid, int
             } else if (in) {
                 const unsigned int s = atomicAdd(&cnt[0], 1u);
                 if (s < 64) rs->small[s] = (unsigned int)i;
-                minx += is_exact(i) ? 0u : 1u;
+                const bool ex = is_exact(i);
+                minx += ex ? 0u : 1u;
+                if constexpr (BAIL) {       // cnt[7]: members that are evaluated from their pixels (not exact, not a constant patch)
+                    if (!ex) {
+                        bool constant = false;
+                        if (const float *fl = a.rf.flat8) {
+                            fl += img0 * (P == 16 ? 4 * (int64_t)nP : (int64_t)nP);
+                            if (P == 8) constant = fl[i] == fl[i];
+                            else {
+                                const int bi = i / nP, r = i - bi * nP, py = r / wP, px = r - py * wP;
+                                const float *q = fl + (int64_t)bi * 4 * nP + (int64_t)(2 * py) * (2 * wP) + 2 * px;
+                                constant = q[0] == q[1] && q[0] == q[2 * wP] && q[0] == q[2 * wP + 1];
+                            }
+                        }
+                        if (!constant) atomicAdd(&cnt[7], 1u);
+                    }
+                }
             }
             below += d < -w ? 1u : 0u;
         }
@@ -779,6 +797,17 @@ __device__ __forceinline__ float refine_select(const RouterArgs &a, int qid, int
             if (kj == key && key != kRefEmpty && ej < lead_e) { lead = j; lead_e = ej; }
         }
         work = __ballot(lane < (int)m_all && !exact_l && lead == lane);      // bit k: member k is evaluated
+    }
+    if constexpr (BAIL) {
+        // what there is to evaluate from pixels: FEW -- the members that are not a follower of their gray; MANY -- counted above.
+        // Up to four rounds of this workgroup's waves stay here (the restart costs as much); constant patches do not count: their
+        // passes cost the same in both instantiations.
+        const unsigned int heavy = few ? (unsigned int)__builtin_popcountll(work) : cnt[7];
+        if (nb > 1 && a.rq.nq != 0 && heavy * UPP > 4 * NWR) {      // (workgroup-uniform, and the same in every row band)
+            *bail_out = true;
+            __builtin_amdgcn_s_setprio(0);
+            return t_a;
+        }
     }
     // Row bands: does this refinement go to the queue?  (The same answer in every band: the counts do not depend on the order in
     // which a band's threads listed the members.)  Then the first band to arrive does it for all.
@@ -1107,18 +1136,34 @@ __device__ __forceinline__ float refine_select(const RouterArgs &a, int qid, int
 // SPLIT: the row bands of a tile split a threshold band between them (refine_select) -- its own instantiation: even this much more
 // code in the router costs its ordinary path 2-3 us (B = 64 x 256x256: 23.4 -> 26.5 us), so only launches whose segments HAVE row
 // bands take it.
-template <int NT, bool ST, bool HELP, bool SPLIT>
-__device__ __forceinline__ void router_team(const RouterArgs &a, int64_t blk, unsigned char *dyn);
+template <int NT, bool ST, bool HELP, bool SPLIT, bool BAIL>
+__device__ __forceinline__ bool router_team(const RouterArgs &a, int64_t blk, unsigned char *dyn);
 
+// A SPLIT launch runs the router in two attempts: first the plain instantiation, which leaves (BAIL) as soon as a select's band is
+// more than four rounds of work -- before anything but the coarse mask is written, and that is written again with the same values --
+// then, from the top, the instantiation in which the row bands split the band.  The ordinary tile never enters the second copy, and
+// nothing of the first is live across it: its path keeps the plain kernel's register allocation (with the split code inlined
+// into the one path an ordinary 768x768 tile paid 3.5 us, the 2040x1356 chain 8 us; NOTES 11.8).  A tile that does refine at
+// length pays the first attempt on top (7-20 us of 70-90).
 template <int NT, bool HELP = false, bool SPLIT = false>
 __device__ __forceinline__ void router_body(const RouterArgs &a, int64_t blk, unsigned char *dyn)
 {
-    if (a.stage == 1) router_team<NT, true, HELP, SPLIT>(a, blk, dyn);
-    else router_team<NT, false, false, false>(a, blk, dyn);
+    if (a.stage == 1) {
+        if constexpr (SPLIT) {
+            if (!router_team<NT, true, false, false, true>(a, blk, dyn)) return;
+            __syncthreads();
+            router_team<NT, true, false, true, false>(a, blk, dyn);
+        } else {
+            router_team<NT, true, HELP, false, false>(a, blk, dyn);
+        }
+    } else {
+        router_team<NT, false, false, false, false>(a, blk, dyn);
+    }
 }
 
-template <int NT, bool ST, bool HELP, bool SPLIT>
-__device__ __forceinline__ void router_team(const RouterArgs &a, int64_t blk, unsigned char *dyn)
+// (returns whether it left early: BAIL only)
+template <int NT, bool ST, bool HELP, bool SPLIT, bool BAIL>
+__device__ __forceinline__ bool router_team(const RouterArgs &a, int64_t blk, unsigned char *dyn)
 {
     const int nb = a.bands > 1 ? a.bands : 1;
     const int64_t seg = blk / nb;
@@ -1171,6 +1216,7 @@ __device__ __forceinline__ void router_team(const RouterArgs &a, int64_t blk, un
     int32_t *mf = a.mask_f + seg * N4;
     const int mode = a.mode;
     const bool has_thr_c = mode == 0 || mode == 2 || mode == 3;
+    bool bail = false;
 
     // ---- coarse gate (RouterTriple.py:21-25 / 52-56 / 63-66)
     float thr_c = 0.f;
@@ -1178,8 +1224,9 @@ __device__ __forceinline__ void router_team(const RouterArgs &a, int64_t blk, un
         SelInfo si;
         thr_c = radix_select<NT>(rd16, N16, a.rank_c, sh, &si);
         if constexpr (ST) if (refine)
-            thr_c = refine_select<NT, 16, HELP, SPLIT>(a, (int)(2 * seg), nb, band, const_cast<float *>(e16), (int)N16, a.rank_c, thr_c, ExactGate{nullptr, 0, 0, 0, 0, 0, 0},
-                                          seg * a.per, (int)w16, (int)n16, rs, sh, si);
+            thr_c = refine_select<NT, 16, HELP, SPLIT, BAIL>(a, (int)(2 * seg), nb, band, const_cast<float *>(e16), (int)N16, a.rank_c, thr_c, ExactGate{nullptr, 0, 0, 0, 0, 0, 0},
+                                          seg * a.per, (int)w16, (int)n16, rs, sh, si, &bail);
+        if (BAIL && bail) return true;
     }
     CGIC_STAMP(2);
     CGIC_RT_STAMP(1);
@@ -1239,8 +1286,9 @@ __device__ __forceinline__ void router_team(const RouterArgs &a, int64_t blk, un
             SelInfo si;
             thr_m = radix_select<NT>(rd8, N8, a.rank_m, sh, &si);        // (stage 2: the masked copy through the generic pointer)
             if constexpr (ST) if (refine)       // (a gated element's 0 is exact: never re-evaluated, never overwritten)
-                thr_m = refine_select<NT, 8, HELP, SPLIT>(a, (int)(2 * seg + 1), nb, band, l8m, (int)N8, a.rank_m, thr_m,
-                                             ExactGate{gc_bits, n8i, w8i, n16i, w16i, mg_n8, mg_w8}, seg * a.per, w8i, n8i, rs, sh, si);
+                thr_m = refine_select<NT, 8, HELP, SPLIT, BAIL>(a, (int)(2 * seg + 1), nb, band, l8m, (int)N8, a.rank_m, thr_m,
+                                             ExactGate{gc_bits, n8i, w8i, n16i, w16i, mg_n8, mg_w8}, seg * a.per, w8i, n8i, rs, sh, si, &bail);
+            if (BAIL && bail) return true;
         } else {
             thr_m = radix_select<NT>([&](int64_t i) { return e8[i] * (1.0f - (gc_of8(i) ? 1.0f : 0.0f)); }, N8, a.rank_m, sh);
         }
@@ -1249,8 +1297,9 @@ __device__ __forceinline__ void router_team(const RouterArgs &a, int64_t blk, un
         SelInfo si;
         thr_m = radix_select<NT>(rd8, N8, a.rank_m, sh, &si);
         if constexpr (ST) if (refine)
-            thr_m = refine_select<NT, 8, HELP, SPLIT>(a, (int)(2 * seg + 1), nb, band, const_cast<float *>(e8), (int)N8, a.rank_m, thr_m, ExactGate{nullptr, 0, 0, 0, 0, 0, 0},
-                                         seg * a.per, w8i, n8i, rs, sh, si);
+            thr_m = refine_select<NT, 8, HELP, SPLIT, BAIL>(a, (int)(2 * seg + 1), nb, band, const_cast<float *>(e8), (int)N8, a.rank_m, thr_m, ExactGate{nullptr, 0, 0, 0, 0, 0, 0},
+                                         seg * a.per, w8i, n8i, rs, sh, si, &bail);
+        if (BAIL && bail) return true;
     }
     auto gm_rule = [&](float v, bool gc) -> bool {
         switch (mode) {
@@ -1325,6 +1374,7 @@ __device__ __forceinline__ void router_team(const RouterArgs &a, int64_t blk, un
         __syncthreads();
         if (rs->flag) refine_help_while_busy(a, &rs->tl);
     }
+    return false;
 }
 
 

@@ -463,8 +463,9 @@ def test_row_bands_split_a_band_in_the_fused_launch():
     the same band) split its re-evaluation between them instead -- FEW: by a hash of the patch index, MANY: every nb-th member in
     index order -- and exchange the values through the scratch (cgic_pixels.scratch, _lib.REFINE_SPLIT_MIN_PATCHES).  Masks
     identical to the launch without the scratch (every band evaluates everything) and to the routing on the reference-arithmetic
-    maps: all four families as 768x768 tiles, other tile shapes and band counts (8, 6, 3 row bands; 32 to 64 patch rows), uint8
-    frames, repeated launches over the same header slots, four streams at once."""
+    maps: all four families as 768x768 tiles, other tile shapes and band counts (8, 6, 3, 2 row bands; 32 to 64 patch rows), uint8
+    frames, repeated launches over the same header slots, four streams at once.  (The launch runs the router in two attempts: the
+    plain instantiation first, which leaves when a band is long, then the split one from the top: both outcomes are exercised.)"""
     from control_gic_amd import _lib
     from control_gic_amd.quantize import vq_forward_route
     from oracle.content_families import families
@@ -480,6 +481,8 @@ def test_row_bands_split_a_band_in_the_fused_launch():
     cases["1024x512 x20 (3 bands)"] = np.concatenate([t["smooth8"], t["noise8"]])
     t = families(n=1, H=640, W=656, seed=14)
     cases["640x656 x2"] = np.concatenate([t["smooth8"], t["flat_edges"]])
+    t = families(n=12, H=512, W=768, seed=15)
+    cases["512x768 x24 (2 bands)"] = np.concatenate([t["smooth8"], t["flat_edges"]])
     keep = _lib.REFINE_SPLIT_MIN_PATCHES, _lib.REFINE_QUEUES
     try:
         _lib.REFINE_SPLIT_MIN_PATCHES = 1024
