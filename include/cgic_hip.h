@@ -143,8 +143,8 @@ typedef struct cgic_pixels {
                          * by every router workgroup of the image on its own: cgic_router_f32 publishes it to every idle wave of
                          * the launch (the other row bands of a tile, finished router workgroups); cgic_vq_forward_route_f32 has
                          * the row bands of a large tile (>= 32x32 patches routed per image: up to 8 workgroups) split it between
-                         * them -- a smooth 768x768 tile 251 -> 73 us; that launch then runs its own kernel instantiation,
-                         * ~3.5 us slower on an ordinary tile: pass NULL to keep the plain one.  Same masks either way.
+                         * them -- a smooth 768x768 tile 251 -> 82 us (the routers run the plain code first and start over in
+                         * the split code only when a band is long: nothing measurable on an ordinary tile).  Same masks either way.
                          * Uninitialised memory; one per launch in flight */
     size_t scratch_bytes;
 } cgic_pixels;
