@@ -1133,9 +1133,9 @@ __device__ __forceinline__ float refine_select(const RouterArgs &a, int qid, int
 // launches of the timed paths run, all element reads ds_read; the other copy serves the unstaged / half-staged segments.
 // HELP: the stand-alone launch -- with the refinement queues (refine_select's RQ), and a router workgroup that is done evaluates
 // other images' band patches while any is open.  The fused launch's routers refine inside their own workgroup only.
-// SPLIT: the row bands of a tile split a threshold band between them (refine_select) -- its own instantiation: even this much more
-// code in the router costs its ordinary path 2-3 us (B = 64 x 256x256: 23.4 -> 26.5 us), so only launches whose segments HAVE row
-// bands take it.
+// SPLIT: the row bands of a tile split a threshold band between them (refine_select) -- its own instantiation, entered only as a
+// launch's second attempt (router_body): even this much more code in the router's one path costs its ordinary path 2-3 us
+// (B = 64 x 256x256: 23.4 -> 26.5 us).  BAIL: the first attempt of such a launch (returns true when it left for the second).
 template <int NT, bool ST, bool HELP, bool SPLIT, bool BAIL>
 __device__ __forceinline__ bool router_team(const RouterArgs &a, int64_t blk, unsigned char *dyn);
 
