@@ -76,6 +76,33 @@ def main():
                 out[f"{name}_{b}_m{k}"] = np.packbits(m.numpy().astype(np.uint8).reshape(-1))
         d8 = float(np.abs(orc.entropy(x, 8) - e8.numpy()).max())
         print(f"  {name}: distinct e8 values {len(np.unique(e8.numpy()))} of {e8.numel()}, C oracle max |diff| {d8:.2e}")
+    # 3. (round 6) bands of realistic length for the GPU's pixels -> masks check: two 256x256 images per family and one smooth
+    # 768x768 tile, per-image masks of the REAL router on the REAL Entropy maps, and the real router's batch-global masks
+    # (the reference's encode() routes over the flattened batch: RouterTriple.py:21,40,52,63) of each pair.  Only inputs
+    # (uint8) and masks (bits) are stored.  The masks must also follow from the correctly rounded restatement
+    # (cgic_oracle_entropy_ref == the GPU's reference-order arithmetic, bit for bit): a fixture whose masks hang on MKL's
+    # last-bit exp / log rounding could not be demanded of any other implementation.
+    big = {name + "_256": x for name, x in families(n=2, H=256, W=256, seed=33).items()}
+    big["smooth8_768"] = families(n=1, H=768, W=768, seed=11)["smooth8"]
+    for name, x in big.items():
+        u8 = np.round(x * 255.0).astype(np.uint8)
+        check(np.array_equal(u8.astype(np.float32) / 255.0, x), f"{name}: not exactly 8-bit")
+        xt = torch.from_numpy(x)
+        e8, e16 = Entropy(8)(xt), Entropy(16)(xt)
+        a8, a16 = orc.entropy_ref(x, 8), orc.entropy_ref(x, 16)
+        out[name + "_u8"] = u8
+        nb = x.shape[0]
+        for b in list(range(nb)) + (["batch"] if nb > 1 else []):
+            sl = slice(0, nb) if b == "batch" else slice(b, b + 1)
+            mask, _, _, mode = router(e16[sl], e8[sl])
+            o = orc.router(a16[sl], a8[sl], 0.1, 0.8)
+            check(o[4] == mode and all(np.array_equal(m.numpy(), q) for m, q in zip(mask, o[:3])),
+                  f"{name}[{b}]: the masks of the correctly rounded restatement differ from the real router's")
+            for k, m in zip("cmf", mask):
+                out[f"{name}_{b}_m{k}"] = np.packbits(m.numpy().astype(np.uint8).reshape(-1))
+        t16 = np.sort(e16.numpy().reshape(-1))
+        print(f"  {name}: distinct e16 {len(np.unique(t16))} of {t16.size}, "
+              f"within 4e-6 of the coarse threshold: {int((np.abs(e16.numpy() - t16[max(round(t16.size / nb * 0.1) - 1, 0)]) < 4e-6).sum())}")
     path = os.path.join(HERE, "ties.npz")
     np.savez_compressed(path, **out)
     print(f"  wrote ties.npz ({os.path.getsize(path)} bytes)")

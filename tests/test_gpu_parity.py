@@ -409,6 +409,63 @@ def test_refined_router_equals_router_on_reference_arithmetic_maps(ratio):
             assert all(torch.equal(a, b) for a, b in zip(got, want)), (name, ratio, "uint8 frames")
 
 
+TIES_SMALL = ["noise8", "smooth8", "flat_edges", "blocky8"]
+TIES_BIG = ["noise8_256", "smooth8_256", "flat_edges_256", "blocky8_256", "smooth8_768"]
+
+
+@pytest.mark.parametrize("name", TIES_SMALL + TIES_BIG)
+def test_pixels_to_masks_equal_the_reference_routers_own_masks(golden, name):
+    """the GPU's pixels -> masks path against the masks the REAL TripleGrainFixedEntropyRouter produced from the
+    REAL Entropy maps (tests/golden/ties.npz, make_golden_ties.py) -- no host torch, no MKL slack, exact.  8-bit tie-heavy
+    families at 96x128 (round 4's fixture), two 256x256 images per family and one smooth 768x768 tile (bands of up to ~200
+    patches).  Every form the product offers: the stand-alone router with the pixels, the fused VQ + router launch, uint8 frames
+    (ToTensor inside the map kernel), the one-call driver (cgic_compress_image), and -- for the pairs -- the reference's
+    batch-global routing (encode(): RouterTriple.py:21,40,52,63)."""
+    from control_gic_amd.quantize import vq_forward_route
+    g = golden("ties")
+    u8 = g[name + "_u8"]
+    B, _, H, W = u8.shape
+    xd = torch.from_numpy(u8.astype(np.float32) / 255.0).to(DEV)
+    frames = torch.from_numpy(np.ascontiguousarray(u8.transpose(0, 2, 3, 1))).to(DEV)
+
+    def want(b):
+        shapes = [(H // 16, W // 16), (H // 8, W // 8), (H // 4, W // 4)]
+        n = B if b == "batch" else 1
+        return [np.unpackbits(g[f"{name}_{b}_m{k}"])[:n * h * w].reshape(n, 1, h, w).astype(np.int32) for k, (h, w) in zip("cmf", shapes)]
+
+    per = [want(b) for b in range(B)]
+    ref = [np.concatenate([per[b][k] for b in range(B)]) for k in range(3)]
+
+    def same(masks, ref_, what):
+        for k in range(3):
+            d = int((masks[k].cpu().numpy() != ref_[k]).sum())
+            assert d == 0, (name, what, "cmf"[k], d)
+
+    router = cg.TripleGrainFixedEntropyRouter(0.1, 0.8, per_image=True)
+    e8, e16 = cg.entropy_maps(xd)
+    same(router(e16, e8, want_gate=False, pixels=xd)[0], ref, "stand-alone router, fp32 pixels")
+    same(router(e16, e8, want_gate=False)[0], ref, "stand-alone router, pixels riding on the maps")
+    x2, f8, f16 = cg.entropy_maps_u8(frames)
+    assert torch.equal(x2, xd)
+    same(router(f16, f8, want_gate=False, pixels=frames)[0], ref, "stand-alone router, uint8 frames")
+    rng = np.random.default_rng(3)
+    w = _t(rng.standard_normal((1024, 4), dtype=np.float32))
+    z = _t(rng.standard_normal((B, 4, H // 4, W // 4), dtype=np.float32))
+    same(vq_forward_route(z, w, 0.25, True, e16, e8, 0.1, 0.8, per_image=True, pixels=xd)[3], ref, "fused launch, fp32 pixels")
+    same(vq_forward_route(z, w, 0.25, True, f16, f8, 0.1, 0.8, per_image=True, pixels=frames)[3], ref, "fused launch, uint8 frames")
+    # reference-order maps decide by themselves
+    r8, r16 = cg.entropy_maps(xd, reference_order=True)
+    plain = cg.TripleGrainFixedEntropyRouter(0.1, 0.8, per_image=True)
+    plain.refine = False
+    same(plain(r16, r8, want_gate=False)[0], ref, "reference-order maps")
+    if f"{name}_batch_mc" in g:
+        # the reference's own batch semantics: thresholds over the flattened batch
+        flat_router = cg.TripleGrainFixedEntropyRouter(0.1, 0.8, per_image=False)
+        same(flat_router(e16, e8, want_gate=False, pixels=xd)[0], want("batch"), "batch-global routing, fp32 pixels")
+        same(flat_router(f16, f8, want_gate=False, pixels=frames)[0], want("batch"), "batch-global routing, uint8 frames")
+        same(vq_forward_route(z, w, 0.25, True, e16, e8, 0.1, 0.8, per_image=False, pixels=xd)[3], want("batch"), "fused launch, batch-global")
+
+
 def test_refinement_queues_change_nothing_and_survive_concurrent_launches():
     """The stand-alone router launch evaluates long bands with every idle wave of the launch (refinement queues: the band's
     owner publishes its patch list; the other row bands of a tile and router workgroups that are done take patches; results as

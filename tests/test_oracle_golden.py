@@ -174,6 +174,27 @@ def test_reference_arithmetic_entropy_port_vs_reference_fixture(orc, golden, nam
             assert np.array_equal(np.packbits(m.astype(np.uint8).reshape(-1)), g[f"{name}_{b}_m{k}"])
 
 
+BIG_TIES = ["noise8_256", "smooth8_256", "flat_edges_256", "blocky8_256", "smooth8_768"]
+
+
+@pytest.mark.parametrize("name", BIG_TIES)
+def test_reference_masks_of_realistic_bands_follow_from_the_correctly_rounded_port(orc, golden, name):
+    """round 6: two 256x256 images per tie-heavy family + one smooth 768x768 tile (bands of up to ~200 patches around the coarse
+    threshold), masks of the REAL router on the REAL Entropy maps, per image and over the flattened batch (RouterTriple.py:21,
+    40,52,63): the correctly rounded restatement (cgic_oracle_entropy_ref == the GPU's reference-order arithmetic bit for bit)
+    gives exactly these masks -- what tests/test_gpu_parity.py then demands of the GPU's pixels -> masks path"""
+    g = golden("ties")
+    x = g[name + "_u8"].astype(np.float32) / 255.0
+    a8, a16 = orc.entropy_ref(x, 8), orc.entropy_ref(x, 16)
+    nb = x.shape[0]
+    for b in list(range(nb)) + (["batch"] if nb > 1 else []):
+        sl = slice(0, nb) if b == "batch" else slice(b, b + 1)
+        mc, mm, mf, _, mode = orc.router(a16[sl], a8[sl], 0.1, 0.8)
+        assert mode == 0
+        for k, m in zip("cmf", (mc, mm, mf)):
+            assert np.array_equal(np.packbits(m.astype(np.uint8).reshape(-1)), g[f"{name}_{b}_m{k}"]), (name, b, k)
+
+
 def test_fast_division_by_sigma_is_the_ieee_quotient(orc):
     """cgic_entropy_dev.h: div_by_sigma001 (x * 100 corrected once by the exact remainder) == x / 0.01f, bit for bit -- what the
     reference computes at model.py:454.  Sampled here (every 257th magnitude of [2^-100, 8] + whole binades around the bin
