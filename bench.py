@@ -215,6 +215,48 @@ def saturated_launch_time(hp, lanes=4, per_graph=20, reps=6):
     return best * 1e6 / (per_graph * lanes)
 
 
+def saturated_stage_times(hp, lanes=4, per_graph=20, reps=4):
+    """resource time of every launch of the step: microseconds per launch when `lanes` independent streams replay graphs of THAT
+    launch alone (its ramp and tail hide behind the other streams' launches).  Their sum is what a step costs the GPU when the
+    lanes overlap perfectly: the yardstick next to ms_per_step."""
+    from control_gic_amd.quantize import vq_forward_route, _vq_forward
+    from control_gic_amd.pipeline import GraphLanes
+    cg = hp.cg
+    e8, e16 = cg.entropy_maps(hp.x)
+    mask, _, _, mode = hp.router(e16, e8, want_gate=False)
+    _, _, ind = _vq_forward(hp.z, hp.vq.embedding.weight, 0.25, True, None)
+    comp = hp.codec.compress(ind, mask, mode)
+    w, prep = hp.vq.embedding.weight, hp.pipe.prepared
+    stages = {
+        "entropy_maps": lambda: cg.entropy_maps(hp.x),
+        "vq+router": lambda: vq_forward_route(hp.z, w, 0.25, True, e16, e8, hp.router.coarse_grain_ratio, hp.router.medium_grain_ratio,
+                                              prepared=prep, pixels=hp.x),
+        "compress_streams+hist": lambda: hp.codec.compress(ind, mask, mode, hist=hp.hist),
+    }
+    with cg.decoder_mode("throughput"):
+        stages["decode+merge"] = lambda: hp.codec.decompress(comp)
+        out = {}
+        for name, call in stages.items():
+            def make(call=call):
+                def fn():
+                    r = None
+                    for _ in range(per_graph):
+                        r = call()
+                    return r
+                return fn
+            gl = GraphLanes(hp.x.device, [make() for _ in range(lanes)])
+            best = 1e9
+            for _ in range(reps):
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                gl.replay(1)
+                gl.join()
+                torch.cuda.synchronize()
+                best = min(best, time.perf_counter() - t0)
+            out[name] = round(best * 1e6 / (per_graph * lanes), 2)
+    return out
+
+
 def cpu_baseline(x, z, cb, ratio, budget_s=12.0, threads=None):
     """the oracle (a scalar C port of the reference algorithm) on the HOST'S CORES: the same workload, images in parallel over
     `threads` worker threads (the C calls release the GIL; default: every core the process may run on, at most 64), bounded
@@ -1114,6 +1156,27 @@ def mixed_extra(dev, vq, codec, ratio, n_div2k=8, steps=10):
             "note": "python bench.py --workload mixed --gpus N shards the same stream over N ranks (strong scaling) with the histogram all-reduce under the last decode"}
 
 
+def device_identity(dev):
+    """(PCI bus id of this rank's GPU as HIP reports it, RCCL version) -- what a reader of an N-GPU line needs to see that the ranks
+    sat on N different devices of one node and which collective library carried the histogram"""
+    bus = None
+    try:
+        import ctypes
+        hip = ctypes.CDLL("libamdhip64.so")
+        buf = ctypes.create_string_buffer(64)
+        if hip.hipDeviceGetPCIBusId(buf, 64, int(dev.index or 0)) == 0:
+            bus = buf.value.decode()
+    except Exception:                                        # noqa: BLE001
+        bus = None
+    ver = None
+    try:
+        v = torch.cuda.nccl.version()
+        ver = ".".join(str(q) for q in v) if isinstance(v, tuple) else str(v)
+    except Exception:                                        # noqa: BLE001
+        ver = None
+    return bus, ver
+
+
 def run_rank(a, rank, world, local):
     stub = bool(a.stub)
     dist = None
@@ -1285,7 +1348,15 @@ def run_rank(a, rank, world, local):
     per_rank = [dt]
     per_rank_dev = [steps_ms * 1e-3]
     allreduce_us = None
+    bus_id, rccl_version = (None, None) if stub else device_identity(dev)
+    per_rank_bus = [bus_id]
     if dist is not None:
+        try:
+            every_bus = [None] * world
+            dist.all_gather_object(every_bus, bus_id)
+            per_rank_bus = every_bus
+        except Exception:                                    # noqa: BLE001 -- identity is a report field, never a reason to fail
+            per_rank_bus = [bus_id]
         mine = torch.tensor([dt, steps_ms * 1e-3], dtype=torch.float64, device=dev)
         every = [torch.zeros_like(mine) for _ in range(world)]
         dist.all_gather(every, mine)
@@ -1314,6 +1385,7 @@ def run_rank(a, rank, world, local):
                 "metric": "encode+decode MPixels/s at fixed granularity ratio; bpp match vs reference",
                 "value": round(a.steps * pix_all / dt / 1e6, 2), "unit": "MPixels/s",
                 "n_gpus": world, "rccl_ranks": ranks_seen, "steps": a.steps, "warmup": a.warmup,
+                "rank_pci_bus_ids": per_rank_bus, "rccl_version": rccl_version, "spawned_ranks": bool(a.dry_nccl or (world > 1 and "TORCHELASTIC_RUN_ID" not in os.environ)),
                 "per_rank_MPixels/s": [round(a.steps * p / t / 1e6, 2) for p, t in zip(pix, per_rank)],
                 "per_rank_MPixels/s_device_events": [round(a.steps * p / t / 1e6, 2) for p, t in zip(pix, per_rank_dev)],
                 "timed_collectives": timed_collectives,
@@ -1338,6 +1410,7 @@ def run_rank(a, rank, world, local):
             "value": round(world * a.steps * B * H * W / dt / 1e6, 2),
             "unit": "MPixels/s",
             "n_gpus": world, "rccl_ranks": ranks_seen, "steps": a.steps, "warmup": a.warmup,
+            "rank_pci_bus_ids": per_rank_bus, "rccl_version": rccl_version, "spawned_ranks": bool(a.dry_nccl or (world > 1 and "TORCHELASTIC_RUN_ID" not in os.environ)),
             "per_rank_MPixels/s": [round(a.steps * B * H * W / t / 1e6, 2) for t in per_rank],
             "per_rank_MPixels/s_device_events": [round(a.steps * B * H * W / t / 1e6, 2) for t in per_rank_dev],
             "timed_collectives": timed_collectives,
@@ -1360,7 +1433,7 @@ def run_rank(a, rank, world, local):
         if dist_note:
             res["config"]["distributed"] = dist_note
         if not stub and not a.no_report:
-            line, extras = report(a, dev, world, stream, slots_np, vq, codec, ratio, res["value"])
+            line, extras = report(a, dev, world, stream, slots_np, vq, codec, ratio, res["value"], res["ms_per_step"])
             res.update(line)
             try:
                 path = a.extras_file or os.path.join(ROOT, "gpurun_out", "bench_extras.json")
@@ -1382,7 +1455,7 @@ def slot_out(stream, k):
     return (e["e8"], e["e16"], e["mask"], e["mode"], e["z_q"], e["ind"], e["comp"], *s.dec)
 
 
-def report(a, dev, world, stream, slots_np, vq, codec, ratio, value):
+def report(a, dev, world, stream, slots_np, vq, codec, ratio, value, ms_per_step=None):
     """everything next to the headline value (outside the timed region) -> (what goes on the JSON line, the bulky rest).  The
     driver's record keeps the first ~2 KB of the line: roofline, cpu_baseline, the parity summary and the 8-bit-content figure
     sit there; every other extra goes to the side file (bench.py --extras-file, default gpurun_out/bench_extras.json)."""
@@ -1425,26 +1498,29 @@ def report(a, dev, world, stream, slots_np, vq, codec, ratio, value):
     flops = 2.0 * N * 1024 * 4                        # 2*N*K*D per launch (0.512 kFLOP/pixel)
     t_live = stages["vq+router_fused_launch"] * 1e-6  # HIP events around 20 launches in a hipGraph, on the stream they run on
     prof = None
-    pj = next((q for q in (os.path.join(ROOT, "profiles", f"r0{r}_roofline.json") for r in (5, 4)) if os.path.exists(q)), "")
+    pj = next((q for q in (os.path.join(ROOT, "profiles", f"r0{r}_roofline.json") for r in (6, 5, 4)) if os.path.exists(q)), "")
     if os.path.exists(pj) and (B, H) == (64, 256):
         try:
             prof = json.load(open(pj))
         except Exception:                             # noqa: BLE001
             prof = None
-    # `frac` is priced with the PROFILER's average duration of the kernel for the same command (tools/run_roofline_cmd.py = this
-    # measurement under rocprofv3 --kernel-trace --stats; profiles/rNN_roofline.json of the latest round, made by tools/gpu_profile.sh): the number a
-    # reader can recompute from profiles/.  The live HIP-event figure of this run stays next to it.
-    t_dom = prof["rocprof_avg_us_alone_graph"] * 1e-6 if prof else t_live
-    achieved = flops / t_dom / 1e12
+    # `frac` is THIS RUN'S own figure: HIP events around 100 launches of the dominant kernel (20 per hipGraph x 5 replays), on the
+    # stream they run on.  `frac_rocprof` is the same command under rocprofv3 --kernel-trace --stats (tools/run_roofline_cmd.py,
+    # profiles/rNN_roofline.json of the latest round, made by tools/gpu_profile.sh): the number a reader can recompute from
+    # profiles/.  The two agree within the boxes' spread (~2 %).
+    t_prof = prof["rocprof_avg_us_alone_graph"] * 1e-6 if prof else None
+    achieved = flops / t_live / 1e12
     res["roofline"] = {
         "kernel": "vq_filter_router_kernel (VQ forward + the per-image router workgroups, the launch of the timed step)",
         "bound": "mfma", "achieved": round(achieved, 3), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
         "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4),
         "traffic": prof.get("hbm_bytes_per_launch") if prof else None,
-        "duration_us": round(t_dom * 1e6, 3),
-        "duration_source": (os.path.relpath(pj, ROOT) + ": rocprofv3 --kernel-trace average over the 100 timed launches of tools/run_roofline_cmd.py "
-                            "(the same 20-launches-per-hipGraph command as the live measurement)") if prof else "live HIP events (no profile JSON found)",
-        "frac_hip_events": round(flops / t_live / 1e12 / PEAK_F32_MFMA_TFLOPS, 4), "hip_events_us": round(t_live * 1e6, 3),
+        "duration_us": round(t_live * 1e6, 3),
+        "duration_source": "live: HIP events on the launch stream, 20 launches per hipGraph x 5 replays (bench.graph_kernel_time)",
+        "frac_rocprof": round(flops / t_prof / 1e12 / PEAK_F32_MFMA_TFLOPS, 4) if t_prof else None,
+        "duration_rocprof_us": round(t_prof * 1e6, 3) if t_prof else None,
+        "rocprof_source": (os.path.relpath(pj, ROOT) + ": rocprofv3 --kernel-trace average over the 100 timed launches of tools/run_roofline_cmd.py "
+                           "(the same command as the live measurement); traffic and mfma_busy_frac are that profile's counter passes") if prof else None,
         "frac_one_lane_loop": prof.get("frac_lanes1_loop") if prof else None,
         "one_lane_loop_us": prof.get("rocprof_avg_us_lanes1_loop") if prof else None,
         "in_step_us": prof.get("rocprof_avg_us_lanes4_loop") if prof else None,
@@ -1453,12 +1529,32 @@ def report(a, dev, world, stream, slots_np, vq, codec, ratio, value):
         "mfma_counters": {k: v for k, v in (prof.get("mfma") or {}).items() if k.startswith("SQ_")} if prof else None,
         "note": "algorithmic flops = 2*N*K*D of the fp32 distance contraction per launch / the kernel's average duration, priced against the dense "
                 "fp32 MFMA peak (results are bit-identical to the fp32 sequence); the kernel issues fp16 MFMAs with 16 K-slots per 4-dim contraction "
-                f"({2.0 * N * 1024 * 16 / 1e9:.1f} GFLOP per launch = {2.0 * N * 1024 * 16 / t_dom / 2.5e15:.2f} of the 2.5 PFLOP/s fp16 peak) "
+                f"({2.0 * N * 1024 * 16 / 1e9:.1f} GFLOP per launch = {2.0 * N * 1024 * 16 / t_live / 2.5e15:.2f} of the 2.5 PFLOP/s fp16 peak) "
                 "and is bound by VALU + MFMA issue (one v_min3 per two scores), not by the matrix cores alone: mfma_busy_frac = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x "
                 "the launch's cycles), from the counter passes of the same command (profiles/rNN_pmc_sq_vq.md).  frac: the launch by itself, "
-                "back to back; frac_one_lane_loop: the same kernel inside the one-batch-in-flight step (behind the entropy kernel's 50 MB: cold "
+                "back to back, measured in this run; frac_one_lane_loop: the same kernel inside the one-batch-in-flight step (behind the entropy kernel's 50 MB: cold "
                 "L2); in_step_us: its duration while the kernels of three other batches share the GPU (not a kernel property; under the "
                 "profiler, which serialises part of the overlap); vq_alone_frac: the VQ kernel without the router workgroups, live"}
+    # the STEP against its own floors: counted HBM bytes of its five launches (the round's FETCH_SIZE / WRITE_SIZE passes) at 8 TB/s and
+    # 2NKD at the fp32 yardstick; next to them what each launch costs the GPU with four lanes in flight (measured here)
+    if ms_per_step is not None and (B, H) == (64, 256):
+        step_bytes = (prof or {}).get("step_hbm_bytes")
+        floor_hbm = step_bytes / (PEAK_HBM_GBS * 1e9) * 1e6 if step_bytes else None
+        floor_fp32 = flops / (PEAK_F32_MFMA_TFLOPS * 1e12) * 1e6
+        st = {"hbm_bytes": step_bytes, "hbm_bytes_by_kernel": (prof or {}).get("step_hbm_bytes_by_kernel"), "flops": flops,
+              "floor_hbm_us": round(floor_hbm, 2) if floor_hbm else None, "floor_fp32_us": round(floor_fp32, 2),
+              "ms_per_step": ms_per_step}
+        st["step_frac"] = round(max(floor_hbm or 0.0, floor_fp32) / (ms_per_step * 1e3), 4)
+        if not a.no_extra:
+            try:
+                st["resource_us"] = saturated_stage_times(hp)
+                st["resource_us_sum"] = round(sum(st["resource_us"].values()), 2)
+            except Exception as e:                               # an extra data point: never fail the bench line
+                st["resource_us"] = {"error": str(e)[:200]}
+        st["note"] = ("step = entropy maps -> VQ + router -> compress (+ histogram) -> decode -> merge of one batch; hbm_bytes = counted FETCH_SIZE x 2 + "
+                      "WRITE_SIZE of the four-lane step's kernels (profiles/rNN_pmc_hbm.md); step_frac = max(floor_hbm, floor_fp32) / ms_per_step; "
+                      "resource_us = each launch replayed alone by four streams at once (wall / launches): what it costs the GPU in flight")
+        res["roofline"]["step"] = st
     if not a.no_extra:
         try:
             t_sat = saturated_launch_time(hp)
@@ -1499,9 +1595,12 @@ def report(a, dev, world, stream, slots_np, vq, codec, ratio, value):
     # ---- the line: compact
     line["bpp"], line["bpp_match"] = res.pop("bpp"), res.pop("bpp_match")
     rf = res["roofline"]
-    line["roofline"] = {k: rf[k] for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "duration_us", "frac_hip_events", "in_step_us",
-                                           "mfma_busy_frac") if k in rf}
+    line["roofline"] = {k: rf[k] for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "duration_us", "frac_rocprof", "duration_rocprof_us",
+                                           "in_step_us", "mfma_busy_frac") if k in rf}
     line["roofline"]["kernel"] = "vq_filter_router_kernel"
+    if "step" in rf:
+        line["roofline"]["step"] = {k: rf["step"][k] for k in ("hbm_bytes", "flops", "floor_hbm_us", "floor_fp32_us", "step_frac", "resource_us",
+                                                               "resource_us_sum") if k in rf["step"]}
     if "cpu_baseline" in res:
         cbl = res.pop("cpu_baseline")
         line["cpu_baseline"] = {k: cbl[k] for k in ("value", "unit", "cores", "kind", "sample") if k in cbl}
@@ -1566,6 +1665,9 @@ def parse_args(argv=None):
     ap.add_argument("--no-report", action="store_true", help="only the timed loop and the headline fields (for kernel traces: the last K chains of the trace are the timed steps)")
     ap.add_argument("--no-extra", action="store_true", help="skip the extra data points (mask mismatch, ratio sweep, DIV2K, B=1)")
     ap.add_argument("--extras-file", default="", help="where the extras that do not go on the JSON line are written (default gpurun_out/bench_extras.json)")
+    ap.add_argument("--dry-nccl", action="store_true",
+                    help="N=1 only: run the single rank in a SPAWNED child process (torch.multiprocessing.spawn + init_process_group('nccl', device_id=...)), "
+                         "exactly as the ranks of --gpus N>1 are started, instead of in this process")
     ap.add_argument("--stub", action="store_true", help=argparse.SUPPRESS)      # CPU test of the launcher only (gloo, no kernels)
     return ap.parse_args(argv)
 
@@ -1582,7 +1684,7 @@ def main(argv=None):
             raise SystemExit(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={world}; refusing to report a {a.gpus}-GPU number")
         run_rank(a, rank, world, local)
         return
-    if a.gpus == 1:
+    if a.gpus == 1 and not a.dry_nccl:
         run_rank(a, 0, 1, 0)
         return
     # plain `python bench.py --gpus N`: start the N ranks here, one per GPU

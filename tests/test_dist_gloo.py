@@ -1,6 +1,8 @@
 """CPU, world_size 2, gloo: the N>1 path -- sharding covers every image exactly once, the int64 usage
 histogram all-reduce is exact, and the average-bpp reduction matches the serial value."""
 import os
+
+import pytest
 import socket
 
 import numpy as np
@@ -230,3 +232,43 @@ def test_training_usage_counter_is_reduced_over_ranks(tmp_path):
         assert torch.equal(r["late"], want)                      # sync_usage_counter_now(): the same table from one collective
         assert torch.equal(r["loaded"], r["ckpt"] + want)        # checkpoint base once + the ranks' deltas
     assert not torch.equal(res[0]["local"], res[1]["local"])
+
+
+def test_bench_dry_nccl_spawns_the_single_rank_like_n_ranks():
+    """`bench.py --gpus 1 --dry-nccl`: the one rank runs in a child started by torch.multiprocessing.spawn with RANK / WORLD_SIZE /
+    MASTER_* set by the parent -- the code path of `--gpus N` for N > 1 -- instead of in the calling process (here over gloo with
+    the CPU stand-in for the kernels; the GPU form of this test is below)"""
+    import json
+    r = _bench(["--gpus", "1", "--stub", "--steps", "3", "--warmup", "1", "--dry-nccl"])
+    assert r.returncode == 0, r.stdout + r.stderr
+    d = json.loads(r.stdout.strip())
+    assert d["n_gpus"] == 1 and d["rccl_ranks"] == 1 and d["spawned_ranks"] is True and d["timed_collectives"] == 0
+
+
+@pytest.mark.gpu
+def test_bench_dry_nccl_on_the_gpu():
+    """mp.spawn + init_process_group("nccl", device_id=...) + the RCCL all-reduce in a child process, exactly as
+    the ranks of an N > 1 run are started, exercised at N = 1 on whatever box runs the GPU tests; the line names the rank's PCI bus
+    id and the RCCL version"""
+    import json
+    r = _bench(["--gpus", "1", "--dry-nccl", "--steps", "6", "--warmup", "2", "--no-extra", "--no-cpu-baseline"], timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert d["n_gpus"] == 1 and d["rccl_ranks"] == 1 and d["spawned_ranks"] is True and d["bpp_match"] is True
+    assert d["rank_pci_bus_ids"][0] and d["rccl_version"] and d["histogram_allreduce_us"] > 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("workload", ["batch", "mixed"])
+def test_bench_two_gpus_for_real(workload):
+    """a NON-stub `--gpus 2` run of both workloads (RCCL over xGMI, one process per GPU) wherever two GPUs are visible; skipped on
+    the one-GPU boxes of the pool"""
+    import json
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("one GPU visible")
+    r = _bench(["--gpus", "2", "--workload", workload, "--steps", "6", "--warmup", "2", "--no-extra", "--no-cpu-baseline"], timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert d["n_gpus"] == 2 and d["rccl_ranks"] == 2 and d["timed_collectives"] == 1
+    assert len(set(d["rank_pci_bus_ids"])) == 2 and len(d["per_rank_MPixels/s"]) == 2

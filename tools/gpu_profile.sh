@@ -1,7 +1,7 @@
 #!/bin/bash
 # the round's profiling passes of the final build (kernel traces at --lanes 1 / 4, the roofline command alone, HBM and SQ counters)
 # usage (on the GPU box, through gpurun): bash tools/gpu_profile.sh [r05]   -> gpurun_out/<round>p; then tools/assemble_profiles.sh <round> here
-R=${1:-r05}
+R=${1:-r06}
 cd "$GRAFT_REPO_ROOT" || exit 1
 export TMPDIR=/tmp
 O=gpurun_out/${R}p; rm -rf $O; mkdir -p $O
@@ -28,6 +28,7 @@ for C in FETCH_SIZE WRITE_SIZE; do
   (cd /tmp && timeout 600 rocprofv3 --pmc $C --kernel-trace -d $GRAFT_REPO_ROOT/$O/pmc4_$C -o pmc -- $CMDP4) > $O/pmc4_$C.log 2>&1
 done
 python tools/pmc_summary.py $(find $O/pmc4_FETCH_SIZE -name '*.db' | head -1) $(find $O/pmc4_WRITE_SIZE -name '*.db' | head -1) > $O/pmc_hbm_lanes4.md 2>&1
+CGIC_PMC_STEP_JSON=$O/pmc_step.json python tools/pmc_summary.py $(find $O/pmc4_FETCH_SIZE -name '*.db' | head -1) $(find $O/pmc4_WRITE_SIZE -name '*.db' | head -1) > /dev/null 2>&1
 cp profiles/pmc_vq.json $O/pmc_vq_before.json 2>/dev/null
 python tools/pmc_summary.py $(find $O/pmc_FETCH_SIZE -name '*.db' | head -1) $(find $O/pmc_WRITE_SIZE -name '*.db' | head -1) > $O/pmc_hbm.md 2>&1
 cp profiles/pmc_vq.json $O/pmc_hbm.json

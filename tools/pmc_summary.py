@@ -20,6 +20,11 @@ for k, d in sorted(res.items(), key=lambda kv: -sum(x[0] for x in kv[1].values()
     f = d.get("FETCH_SIZE", (0, 0)); w = d.get("WRITE_SIZE", (0, 0))
     print(f"| {k} | {max(f[1], w[1])} | {f[0]:.1f} | {f[0]*1024*2:.0f} | {w[0]:.1f} | {w[0]*1024:.0f} |")
     out[k] = {"fetch_kib_raw": f[0], "read_bytes_x2": f[0] * 2048, "write_bytes": w[0] * 1024}
+import os
+if os.environ.get("CGIC_PMC_STEP_JSON"):            # the whole step's counted bytes (tools/gpu_profile.sh: the four-lane passes)
+    step = {k.replace("cgic::", ""): int(v["read_bytes_x2"] + v["write_bytes"]) for k, v in out.items() if "vq_prepare" not in k}
+    json.dump({"step_hbm_bytes": sum(step.values()), "step_hbm_bytes_by_kernel": step}, open(os.environ["CGIC_PMC_STEP_JSON"], "w"), indent=1)
+    raise SystemExit(0)
 name, vq = next(((k, v) for k, v in out.items() if "vq_filter_router_kernel" in k), (None, None))      # the launch of the timed step
 if vq is None:
     name, vq = next(((k, v) for k, v in out.items() if "vq_filter_kernel" in k), (None, None))

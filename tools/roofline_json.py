@@ -25,6 +25,9 @@ if hip:
 pm = os.path.join(O, "pmc_hbm.json")
 if os.path.exists(pm):
     out.update({k: v for k, v in json.load(open(pm)).items() if k in ("hbm_bytes_per_launch", "read_bytes_x2", "write_bytes")})
+ps = os.path.join(O, "pmc_step.json")
+if os.path.exists(ps):
+    out.update(json.load(open(ps)))
 out["frac_lanes1_loop"] = round(out["flops_per_launch"] / (out["rocprof_avg_us_lanes1_loop"] * 1e-6) / 1e12 / 157.3, 4)
 out["frac_alone_graph"] = round(out["flops_per_launch"] / (out["rocprof_avg_us_alone_graph"] * 1e-6) / 1e12 / 157.3, 4)
 # matrix-core counters of the same command (tools/gpu_profile.sh, pmcf_* passes): busy fraction of the 1024 SIMDs' MFMA pipes
