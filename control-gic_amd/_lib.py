@@ -101,6 +101,7 @@ PROTOTYPES = {
     "cgic_compress_tiled": (_int, [_vp, _vp, _int, _int, _vp, _vp, _int, _i64, _i64, _i64, _int, C.POINTER(TileGroup), _f64, _f64, _f32, _int,
                                   C.POINTER(_f32), _int, _f32, _int, C.POINTER(_int), _vp]),
     "cgic_router_refine_supported": (_int, [_i64, _i64, _i64, _int]),
+    "cgic_router_refine_in_lds": (_int, [_i64, _i64, _i64, _int]),
     "cgic_router_refine_scratch_bytes": (_sz, [_i64, _i64, _i64, _int]),
     "cgic_router_f32": (_int, [_vp, _vp, _i64, _i64, _i64, _f64, _f64, _int, _vp, _vp, _vp, _vp, C.POINTER(_int), _px, _vp]),
     "cgic_table_create": (_int, [C.POINTER(_i64), C.POINTER(_i32), _int, C.POINTER(_vp)]),
@@ -264,9 +265,9 @@ REFINE_SPLIT_MIN_PATCHES = int(os.environ.get("CGIC_REFINE_SPLIT_MIN_PATCHES", "
 def pixels_arg(pixels, B, h16, w16, per_image, sigma=0.01, flat8=None, queues=False, explicit=False):
     """(ctypes pointer or None, keep-alive) for the router's `refine` argument.  pixels: None, the fp32 [B,3,16 h16,16 w16] image
     batch the maps were made from, or the uint8 [B,16 h16,16 w16,3] frames; flat8: the constant-patch map the same entropy call
-    made (entropy_maps(...) attaches it to its maps as `_cgic_flat8`), optional.  None is also returned (no refinement, the maps
-    decide as given) when the routing segment does not fit the workgroup's LDS (cgic_router_refine_supported: flattened
-    batches / images beyond ~768x768 routed as one segment).  queues: also hand over the scratch of the launch's refinement
+    made (entropy_maps(...) attaches it to its maps as `_cgic_flat8`), optional.  A routing segment that does not fit the router
+    workgroup's LDS (flattened batches -- the reference's encode() semantics --, images beyond ~768x768 routed as one segment)
+    is refined too (ABI 8): through patched copies of the maps in a scratch this function allocates.  queues: also hand over the scratch of the launch's refinement
     queues (cgic_pixels.scratch: the stand-alone router launch evaluates long bands with every idle wave of the launch)."""
     if pixels is None:
         return None, ()
@@ -278,9 +279,7 @@ def pixels_arg(pixels, B, h16, w16, per_image, sigma=0.01, flat8=None, queues=Fa
         raise ValueError(f"pixels {pixels.dtype} {tuple(pixels.shape)} do not belong to entropy maps of {B} x {h16} x {w16} "
                          f"(expected fp32 [B,3,16 h16,16 w16] or uint8 [B,16 h16,16 w16,3])")
     if not lib().cgic_router_refine_supported(B, h16, w16, int(bool(per_image))):
-        # the routing segment (an image routed per image, or the WHOLE batch with per_image=False like the reference's encode())
-        # does not fit one workgroup's LDS: the band around a threshold cannot be re-evaluated, the maps decide as given --
-        # i.e. on tie-heavy content a few mask elements may differ from the CPU reference's.  Never silently:
+        # (a segment of 2^31 patches: not a practical case since ABI 8 -- segments beyond the LDS are refined through patched copies)
         msg = (f"threshold-band refinement is not available for a routing segment of {B if not per_image else 1} x {16 * h16}x{16 * w16} "
                "pixels (cgic_router_refine_supported): masks are made from the default entropy maps as given (within 2e-6 of the reference's "
                "arithmetic; under a strict '<' a tie-heavy image can get a few other mask elements).  Route per image "
@@ -298,7 +297,10 @@ def pixels_arg(pixels, B, h16, w16, per_image, sigma=0.01, flat8=None, queues=Fa
         flat8 = flat8.contiguous()
     # scratch of the launch's refinement queues (long bands are evaluated by every idle workgroup of the launch): an ordinary
     # temporary of the call -- the caching allocator keeps it alive for the stream, a captured graph keeps its own
-    nbytes = lib().cgic_router_refine_scratch_bytes(B, h16, w16, int(bool(per_image))) if (queues and REFINE_QUEUES) else 0
+    # ... and, for a segment that does not fit the router workgroup's LDS (the reference's flattened-batch routing, an untiled large
+    # image), the patched copies of the maps its refinement works on: required there
+    big = not lib().cgic_router_refine_in_lds(B, h16, w16, int(bool(per_image)))
+    nbytes = lib().cgic_router_refine_scratch_bytes(B, h16, w16, int(bool(per_image))) if ((queues and REFINE_QUEUES) or big) else 0
     scratch = torch.empty(nbytes, dtype=torch.uint8, device=px.device) if nbytes else None
     st = Pixels(ptr(px), int(u8), linspace_bins(), 32, float(sigma), ptr(flat8), ptr(scratch), nbytes)
     return C.byref(st), (st, px, flat8, scratch)

@@ -137,7 +137,9 @@ extern "C" int cgic_compress_image(const cgic_table *t, const float *codebook, i
     memset(&px, 0, sizeof(px));
     px.x = io->x; px.is_u8 = io->x_is_u8 ? 1 : 0; px.bins = bins; px.nbins = nbins; px.sigma = sigma; px.flat8 = io->flat8;
     px.scratch = io->ws_refine; px.scratch_bytes = io->ws_refine_bytes;
-    const cgic_pixels *refine = cgic_router_refine_supported(B, H / 16, W / 16, 1) ? &px : nullptr;
+    // (every segment is refined: in the router's workgroup up to 768x768, beyond that through patched copies in ws_refine --
+    // which cgic_vq_forward_route_f32 then REQUIRES: a call without it fails instead of routing from unrefined maps)
+    const cgic_pixels *refine = &px;
     int mode = 0;
     rc = cgic_vq_forward_route_f32(io->z, B, h * w, codebook, K, e_dim, beta, legacy, io->ind, io->z_q, io->loss, io->ws_vq, io->e16, io->e8,
                                    H / 16, W / 16, coarse_ratio, medium_ratio, 1, io->mask_c, io->mask_m, io->mask_f, nullptr, &mode, nullptr,
@@ -181,7 +183,8 @@ extern "C" int cgic_compress_tiled(const cgic_table *t, const float *codebook, i
         memset(&px, 0, sizeof(px));
         px.x = io.x_out; px.is_u8 = 0; px.bins = bins; px.nbins = nbins; px.sigma = sigma; px.flat8 = io.flat8;
         px.scratch = io.ws_refine; px.scratch_bytes = io.ws_refine_bytes;
-        const cgic_pixels *refine = cgic_router_refine_supported(B, G.th / 16, G.tw / 16, 1) ? &px : nullptr;
+        // (tiles beyond 768x768 cannot be refined inside a launch group: cgic_vq_forward_route_f32 refuses them -- never unrefined)
+        const cgic_pixels *refine = &px;
         if (!rc) rc = cgic_vq_forward_route_f32(io.z, B, h * w, codebook, K, e_dim, beta, legacy, io.ind, io.z_q, io.loss, io.ws_vq, io.e16, io.e8,
                                                 G.th / 16, G.tw / 16, coarse_ratio, medium_ratio, 1, io.mask_c, io.mask_m, io.mask_f, nullptr, nullptr,
                                                 nullptr, prepared, refine, stream);

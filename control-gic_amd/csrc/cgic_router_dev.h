@@ -1401,6 +1401,11 @@ int router_prepare(const float *e16, const float *e8, int64_t B, int64_t h16, in
                    RouterArgs *out, int64_t *nseg, size_t *lds, size_t lds_budget = 96 * 1024, const cgic_pixels *refine = nullptr,
                    hipStream_t stream = nullptr, bool queues = false);
 
+// segments whose maps do not fit the LDS budget below: refinement as a chain of launches over patched copies (cgic_router.hip)
+bool router_refine_in_lds(int64_t B, int64_t h16, int64_t w16, int per_image);
+int router_big(const float *e16, const float *e8, int64_t B, int64_t h16, int64_t w16, double c_ratio, double m_ratio, int per_image,
+               int32_t *mask_c, int32_t *mask_m, int32_t *mask_f, float *gate, const cgic_pixels *refine, hipStream_t stream);
+
 // LDS budget of a router workgroup in the fused VQ + router launch (two allocations per 160 KB CU); refinement is offered
 // for segments that fit THIS budget, in the stand-alone launch too, so that one answer holds for both
 constexpr size_t kRouterFusedLds = (size_t)78 * 1024;

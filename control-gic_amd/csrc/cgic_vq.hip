@@ -1783,6 +1783,19 @@ extern "C" int cgic_vq_forward_route_f32(const float *z, int64_t B, int64_t hw, 
     if (mode_out) *mode_out = cgic_router_mode(coarse_ratio, medium_ratio);
     const int64_t N = B * hw;
     if (N == 0) return CGIC_OK;
+    if (refine && refine->x && cgic_router_mode(coarse_ratio, medium_ratio) <= 3 && !router_refine_in_lds(B, h16, w16, per_image)) {
+        // a routing segment beyond the LDS (the reference's flattened-batch routing of encode(), an untiled large image): the VQ
+        // launch by itself, then the router's chain of launches over patched copies of the maps (cgic_router.hip: router_big)
+        CGIC_REQUIRE(!group_recording(), CGIC_ERR_UNSUPPORTED,
+                     "vq_forward_route: the refinement of a segment that does not fit the LDS is a chain of launches: not inside a launch group");
+        hipStream_t s0 = (hipStream_t)stream;
+        VqWs ws0;
+        rc = vq_ws(loss ? workspace : nullptr, s0, &ws0);
+        if (rc) return rc;
+        rc = vq_dispatch(z, hw, N, codebook, K, indices, z_q, ws0, beta, legacy, loss, s0, nullptr, 0, 0, quant_conv, prepared);
+        if (rc) return rc;
+        return router_big(e16, e8, B, h16, w16, coarse_ratio, medium_ratio, per_image, mask_c, mask_m, mask_f, gate, refine, s0);
+    }
     RouterArgs r;
     int64_t nseg;
     size_t rlds;

@@ -344,6 +344,10 @@ class TiledCall:
                           "dmask": [E((B, 1, h // 4, ww // 4), i32), E((B, 1, h // 2, ww // 2), i32), E((B, 1, h, ww), i32)]})
             ws_c = E((max(1, l.cgic_compress_workspace_bytes(B, h, ww)),), u8t)
             ws_d = E((l.cgic_decompress_workspace_bytes(B, h, ww),), u8t) if decode else None
+            if not l.cgic_router_refine_in_lds(B, th // 16, tw // 16, 1):
+                raise ValueError(f"TiledCall: tiles of {th}x{tw} are routed as one segment beyond the router workgroup's LDS; their refinement is a chain "
+                                 "of launches that a launch group cannot record (cgic_router_refine_in_lds): use tiles of at most 768x768 "
+                                 "(the reference's), or compress_tiled(..., chain=False)")
             nref = l.cgic_router_refine_scratch_bytes(B, th // 16, tw // 16, 1) if (th // 16) * (tw // 16) >= _lib.REFINE_SPLIT_MIN_PATCHES and _lib.REFINE_QUEUES else 0
             ws_r = E((nref,), u8t) if nref else None                 # (large tiles: their row bands split a threshold band between them)
             org = (ctypes.c_int * (2 * T))(*[v for i in idxs for v in (self.tiles[i][0] - top, self.tiles[i][1] - left)])

@@ -111,6 +111,11 @@ class HotCall:
             io.dind, io.dz_q, io.status = p(t["dind"]), p(t["dz_q"]), p(t["status"])
             io.dmask_c, io.dmask_m, io.dmask_f = (p(m) for m in t["dmask"])
         io.ws_vq, io.ws_compress, io.ws_decompress = p(ws["vq"]), p(ws["c"]), p(ws["d"])
+        if not l.cgic_router_refine_in_lds(B, H // 16, W // 16, 1):
+            # an image beyond ~768x768 routed as one segment: its threshold bands are refined through patched copies of the maps
+            nref = l.cgic_router_refine_scratch_bytes(B, H // 16, W // 16, 1)
+            ws["r"] = E((nref,), u8t)
+            io.ws_refine, io.ws_refine_bytes = p(ws["r"]), nref
         self._io = io
         self._mode = ctypes.c_int(0)
         self._CompressedBatch = CompressedBatch

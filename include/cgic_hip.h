@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define CGIC_ABI_VERSION 7
+#define CGIC_ABI_VERSION 8
 
 #define CGIC_OK 0
 #define CGIC_ERR_INVALID (-1)     /* bad argument (shape, ratio, NULL pointer ...) */
@@ -145,10 +145,14 @@ typedef struct cgic_pixels {
                          * the row bands of a large tile (>= 32x32 patches routed per image: up to 8 workgroups) split it between
                          * them -- a smooth 768x768 tile 251 -> 82 us (the routers run the plain code first and start over in
                          * the split code only when a band is long: nothing measurable on an ordinary tile).  Same masks either way.
+                         * REQUIRED (ABI 8) when the routing segment does not fit the workgroup's LDS (cgic_router_refine_in_lds == 0: the
+                         * flattened batch of the reference's encode(), RouterTriple.py:21,40,52,63, or an untiled image beyond
+                         * 768x768): the refinement then runs as a chain of launches over patched copies of the maps kept here.
                          * Uninitialised memory; one per launch in flight */
     size_t scratch_bytes;
 } cgic_pixels;
-/* scratch for cgic_pixels.scratch of a router / fused call with these arguments (0: the call takes none) */
+/* scratch for cgic_pixels.scratch of a router / fused call with these arguments (0: the call takes none; required when
+ * cgic_router_refine_in_lds(...) == 0) */
 size_t cgic_router_refine_scratch_bytes(int64_t B, int64_t h16, int64_t w16, int per_image);
 
 typedef struct cgic_conv1x1 {
@@ -285,13 +289,19 @@ int cgic_entropy_maps_u8(const unsigned char *x_hwc, int64_t B, int64_t H, int64
  *          4e-6 (>= twice the kernel's error) of a threshold is re-evaluated inside the router in the reference's own fp32
  *          operation order (the arithmetic of cgic_entropy_maps_ref_f32), and the k-th smallest is taken again: the result
  *          equals routing on cgic_entropy_maps_ref_f32's maps (tested), at the default kernel's cost whenever the band holds
- *          only the threshold element itself -- the typical image.  Needs a segment whose maps fit the workgroup's LDS:
- *          per-image routing of images / tiles up to 768x768 (cgic_router_refine_supported); otherwise
- *          CGIC_ERR_UNSUPPORTED.  The maps themselves are not modified.
+ *          only the threshold element itself -- the typical image.  A segment whose maps fit the workgroup's LDS
+ *          (per-image routing of images / tiles up to 768x768, batch-global routing of a few images:
+ *          cgic_router_refine_in_lds) is refined inside the router's workgroup; a larger one (ABI 8: the flattened batch of
+ *          the reference's encode(), RouterTriple.py:21,40,52,63; an untiled large image) through patched copies of the
+ *          maps in refine->scratch (five launches; not inside a launch group: CGIC_ERR_UNSUPPORTED).  The maps themselves
+ *          are not modified.
  * ------------------------------------------------------------------------- */
 int cgic_router_mode(double coarse_ratio, double medium_ratio);
-/* 1 if cgic_router_f32 / cgic_vq_forward_route_f32 accept `refine` for this shape, else 0 */
+/* 1 if cgic_router_f32 / cgic_vq_forward_route_f32 accept `refine` for this shape (ABI 8: every shape whose segment has fewer
+ * than 2^31 patches), else 0 */
 int cgic_router_refine_supported(int64_t B, int64_t h16, int64_t w16, int per_image);
+/* 1 if the segment is refined inside the router's workgroup (its maps fit the LDS); 0: through refine->scratch (see above) */
+int cgic_router_refine_in_lds(int64_t B, int64_t h16, int64_t w16, int per_image);
 int cgic_router_f32(const float *e16, const float *e8, int64_t B, int64_t h16, int64_t w16,
                     double coarse_ratio, double medium_ratio, int per_image, int32_t *mask_c,
                     int32_t *mask_m, int32_t *mask_f, float *gate, int *mode_out,

@@ -466,6 +466,77 @@ def test_pixels_to_masks_equal_the_reference_routers_own_masks(golden, name):
         same(vq_forward_route(z, w, 0.25, True, e16, e8, 0.1, 0.8, per_image=False, pixels=xd)[3], want("batch"), "fused launch, batch-global")
 
 
+@pytest.mark.parametrize("B", [16, 64])
+@pytest.mark.parametrize("ratio", [(0.1, 0.8), (0.0, 0.4), (0.4, 0.0), (0.3, 0.7)])
+def test_batch_global_routing_is_refined_beyond_one_workgroups_lds(B, ratio):
+    """the reference's encode() routes over the FLATTENED batch (RouterTriple.py:21,40,52,63).  64 images of
+    256x256 are one segment of 16 384 + 65 536 entropies -- beyond a workgroup's LDS -- and are refined through patched copies
+    of the maps (cgic_router.hip: router_big): masks equal to batch-global routing on the reference-arithmetic maps, on the
+    tie-heavy families, in every mode that compares, stand-alone and through the VQ + router entry point, fp32 pixels and
+    uint8 frames, and with maps perturbed within the kernel's error bound.  Also one untiled 1024x1280 image routed per image."""
+    from control_gic_amd.quantize import vq_forward_route
+    c, m = ratio
+    assert cg._lib.lib().cgic_router_refine_supported(B, 16, 16, 0) == 1 and cg._lib.lib().cgic_router_refine_in_lds(B, 16, 16, 0) == 0
+    router = cg.TripleGrainFixedEntropyRouter(c, m, per_image=False)
+    rng = np.random.default_rng(B + int(100 * c))
+    w = _t(rng.standard_normal((1024, 4), dtype=np.float32))
+    sets = _tie_sets(n=B, flat=B)
+    for name in ("smooth8", "flat_edges", "noise8"):
+        xd = torch.from_numpy(np.ascontiguousarray(sets[name][:B])).to(DEV)
+        e8, e16 = cg.entropy_maps(xd)
+        r8, r16 = cg.entropy_maps(xd, reference_order=True)
+        want, _, _, mode = router(r16, r8, want_gate=False)
+        got, gate, _, mode2 = router(e16, e8, pixels=xd)
+        assert mode == mode2 and all(torch.equal(a, b) for a, b in zip(got, want)), (name, ratio, [int((a != b).sum()) for a, b in zip(got, want)])
+        assert torch.equal(gate, router(r16, r8)[1])
+        z = _t(rng.standard_normal((B, 4, 64, 64), dtype=np.float32))
+        zq, loss, idx, fused, _, _ = vq_forward_route(z, w, 0.25, True, e16, e8, c, m, per_image=False, pixels=xd)
+        assert all(torch.equal(a, b) for a, b in zip(fused, want)), (name, ratio, "through cgic_vq_forward_route_f32")
+        zq0, loss0, idx0 = cg.quantize._vq_forward(z, w, 0.25, True, None)
+        assert torch.equal(idx, idx0) and torch.equal(zq, zq0) and torch.equal(loss, loss0)
+        dl = lambda r: torch.clamp(7e-7 + 0.01 * torch.clamp(r - 1e-4, min=0.0), max=2e-6)
+        n8 = (torch.rand(e8.shape, device=DEV) - 0.5) * 1.9 * dl(r8)
+        n16 = (torch.rand(e16.shape, device=DEV) - 0.5) * 1.9 * dl(r16)
+        got = router(r16 + n16, r8 + n8, want_gate=False, pixels=xd)[0]
+        assert all(torch.equal(a, b) for a, b in zip(got, want)), (name, ratio, "perturbed")
+        if name == "smooth8":
+            frames = (xd * 255.0).round().to(torch.uint8).permute(0, 2, 3, 1).contiguous()
+            _, f8, f16 = cg.entropy_maps_u8(frames)
+            got = router(f16, f8, want_gate=False, pixels=frames)[0]
+            assert all(torch.equal(a, b) for a, b in zip(got, want)), (name, ratio, "uint8 frames")
+    if B == 16:
+        from oracle.content_families import families
+        xl = torch.from_numpy(families(n=1, H=1024, W=1280, seed=5)["smooth8"]).to(DEV)
+        per = cg.TripleGrainFixedEntropyRouter(c, m, per_image=True)
+        assert cg._lib.lib().cgic_router_refine_in_lds(1, 64, 80, 1) == 0
+        e8, e16 = cg.entropy_maps(xl)
+        r8, r16 = cg.entropy_maps(xl, reference_order=True)
+        want = per(r16, r8, want_gate=False)[0]
+        got = per(e16, e8, want_gate=False, pixels=xl)[0]
+        assert all(torch.equal(a, b) for a, b in zip(got, want)), ("1024x1280", ratio)
+
+
+def test_hotcall_refines_images_beyond_768():
+    """cgic_compress_image on an image routed as one segment beyond the LDS used to route from the UNREFINED maps
+    without a word; it now refines through patched copies (HotCall allocates ws_refine) -- and a caller of the C entry point who
+    leaves ws_refine out is refused"""
+    from oracle.content_families import families
+    xl = torch.from_numpy(families(n=2, H=1024, W=1024, seed=9)["smooth8"]).to(DEV)
+    B, _, H, W = xl.shape
+    rng = np.random.default_rng(0)
+    vq = cg.VectorQuantizer(1024, 4, beta=0.25).to(DEV).eval()
+    vq.embedding.weight.data.copy_(_t(rng.standard_normal((1024, 4), dtype=np.float32)))
+    z = _t(rng.standard_normal((B, 4, H // 4, W // 4), dtype=np.float32))
+    hc = cg.pipeline.HotCall(vq, 0.1, 0.8, B, H, W)
+    out = hc(xl, z)
+    r8, r16 = cg.entropy_maps(xl, reference_order=True)
+    want = cg.TripleGrainFixedEntropyRouter(0.1, 0.8, per_image=True)(r16, r8, want_gate=False)[0]
+    assert all(torch.equal(a, b) for a, b in zip(out["mask"], want))
+    hc._io.ws_refine, hc._io.ws_refine_bytes = None, 0
+    with pytest.raises(cg.CgicError, match="scratch"):
+        hc(xl, z)
+
+
 def test_refinement_queues_change_nothing_and_survive_concurrent_launches():
     """The stand-alone router launch evaluates long bands with every idle wave of the launch (refinement queues: the band's
     owner publishes its patch list; the other row bands of a tile and router workgroups that are done take patches; results as
@@ -649,17 +720,16 @@ def test_refinement_plumbing_and_limits():
     want_flat = flat_router(r16, r8)[0]
     assert all(torch.equal(p, q) for p, q in zip(flat_router(e16m, e8m)[0], want_flat))
     assert all(torch.equal(p, q) for p, q in zip(flat_router(e16m.clone(), e8m.clone(), pixels=x)[0], want_flat))
-    # ... of 32 images it does not fit: never silently -- pixels found on the maps: a warning, and the maps decide as given;
-    # pixels handed over by the caller: refused
-    big = torch.rand(32, 3, 256, 256, device=DEV)
+    # ... of 32 images it does not fit the LDS: refined all the same (ABI 8: patched copies of the maps, a chain of launches) --
+    # pixels found on the maps or handed over, the masks are those of the reference-arithmetic maps
+    big = torch.from_numpy(np.ascontiguousarray(_tie_sets(n=32, flat=1)["smooth8"])).to(DEV)
     b8, b16 = cg.Entropy(8).to(DEV)(big), cg.Entropy(16).to(DEV)(big)
-    assert not cg._lib.lib().cgic_router_refine_supported(32, 16, 16, 0)
-    with pytest.warns(RuntimeWarning, match="refinement is not available"):
-        a = cg.TripleGrainFixedEntropyRouter(0.1, 0.8, per_image=False)(b16, b8)[0]
-    b = cg.TripleGrainFixedEntropyRouter(0.1, 0.8, per_image=False)(b16.clone(), b8.clone())[0]
-    assert all(torch.equal(p, q) for p, q in zip(a, b))
-    with pytest.raises(ValueError, match="refinement is not available"):
-        cg.TripleGrainFixedEntropyRouter(0.1, 0.8, per_image=False)(b16.clone(), b8.clone(), pixels=big)
+    assert cg._lib.lib().cgic_router_refine_supported(32, 16, 16, 0) and not cg._lib.lib().cgic_router_refine_in_lds(32, 16, 16, 0)
+    q8, q16 = cg.entropy_maps(big, reference_order=True)
+    want_big = cg.TripleGrainFixedEntropyRouter(0.1, 0.8, per_image=False)(q16, q8)[0]
+    a = cg.TripleGrainFixedEntropyRouter(0.1, 0.8, per_image=False)(b16, b8)[0]
+    b = cg.TripleGrainFixedEntropyRouter(0.1, 0.8, per_image=False)(b16.clone(), b8.clone(), pixels=big)[0]
+    assert all(torch.equal(p, q) for p, q in zip(a, want_big)) and all(torch.equal(p, q) for p, q in zip(b, want_big))
     # NaN pixels: the NaN patches sort last in both; nothing hangs
     xn = x.clone()
     xn[0, 0, 5, 7] = float("nan")

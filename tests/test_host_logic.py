@@ -139,10 +139,15 @@ def test_argument_validation_happens_before_any_launch():
     bad = (ctypes.c_float * 32)(*[v + (1e-7 if i == 20 else 0.0) for i, v in enumerate(tb)])
     assert l.cgic_router_f32(one, one, 1, 4, 4, 0.1, 0.8, 1, one, one, one, None, None, ctypes.byref(_lib.Pixels(16, 0, bad, 32, 0.01, None)), None) == _lib.ERR_UNSUPPORTED
     assert b"linspace" in l.cgic_last_error()
-    assert l.cgic_router_f32(one, one, 64, 16, 16, 0.1, 0.8, 0, one, one, one, None, None, ctypes.byref(px), None) == _lib.ERR_UNSUPPORTED   # flattened batch of 64
-    assert b"refine_supported" in l.cgic_last_error()
+    # a segment beyond the LDS (the flattened batch of 64: the reference's encode() semantics) is refined through patched copies of
+    # the maps (ABI 8) and REQUIRES the scratch: without it the call is refused, never routed from unrefined maps
+    assert l.cgic_router_f32(one, one, 64, 16, 16, 0.1, 0.8, 0, one, one, one, None, None, ctypes.byref(px), None) == _lib.ERR_INVALID
+    assert b"cgic_router_refine_scratch_bytes" in l.cgic_last_error()
     assert l.cgic_router_refine_supported(64, 16, 16, 1) == 1 and l.cgic_router_refine_supported(8, 48, 48, 1) == 1
-    assert l.cgic_router_refine_supported(64, 16, 16, 0) == 0 and l.cgic_router_refine_supported(1, 128, 85, 1) == 0
+    assert l.cgic_router_refine_supported(64, 16, 16, 0) == 1 and l.cgic_router_refine_supported(1, 128, 85, 1) == 1
+    assert l.cgic_router_refine_in_lds(64, 16, 16, 1) == 1 and l.cgic_router_refine_in_lds(8, 48, 48, 1) == 1 and l.cgic_router_refine_in_lds(8, 16, 16, 0) == 1
+    assert l.cgic_router_refine_in_lds(64, 16, 16, 0) == 0 and l.cgic_router_refine_in_lds(1, 128, 85, 1) == 0
+    assert l.cgic_router_refine_scratch_bytes(64, 16, 16, 0) == 20 * 64 * 256 + 16 + 64
     assert l.cgic_router_f32(one, one, 1, 4, 4, 1.0, 0.0, 1, one, one, one, None, None, ctypes.byref(_lib.Pixels(16, 0, bad, 32, 0.01, None)), None) in (_lib.ERR_HIP, _lib.OK)  # mode 4 compares nothing: pixels ignored
     assert l.cgic_entropy_maps_f32(one, 1, 24, 32, bins, 32, 0.01, one, one, None, None) == _lib.ERR_INVALID
     assert l.cgic_entropy_maps_f32(one, 1, 32, 32, bins, 32, 0.05, one, one, None, None) == _lib.ERR_UNSUPPORTED
