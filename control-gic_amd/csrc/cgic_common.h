@@ -158,6 +158,9 @@ extern __device__ long long g_blk_t[2 * 4096];   // per-workgroup (start, end) o
 #define CGIC_DBG_COUNT(which, n) do { if (lane_id() == 0 && blockIdx.x < 2048) atomicAdd((unsigned long long *)&g_blk_t[2 * (2048 + blockIdx.x) + (which)], (unsigned long long)(n)); } while (0)
 #define CGIC_STAMP(i) do { if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) g_phase_clk[i] = clock64(); \
         if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 192 && (i) >= 2 && (i) <= 7) g_phase_clk[8 + (i)] = clock64(); } while (0)
+// per-phase accumulation over the groups of a wave (workgroup 0: wave 0 -> g_phase_clk[16 + k], wave 4 -> [22 + k]; k < 6)
+#define CGIC_PHASE_T0() long long _ph_t = clock64()
+#define CGIC_PHASE_ACC(k) do { if (blockIdx.x == 0 && (threadIdx.x == 0 || threadIdx.x == 256)) { const long long _n = clock64(); g_phase_clk[(threadIdx.x ? 22 : 16) + (k)] += _n - _ph_t; _ph_t = _n; } } while (0)
 // span of a whole launch over ALL workgroups (constant 100 MHz clock): [28] = earliest start, [29] = latest end,
 // [30]/[31] = start/end of the workgroup that ended last (as block id pair packed)
 #define CGIC_SPAN_BEGIN() long long _span_t0 = 0; do { if (threadIdx.x == 0) { _span_t0 = wall_clock64(); atomicMin((unsigned long long *)&g_phase_clk[28], (unsigned long long)_span_t0); } } while (0)
@@ -168,6 +171,8 @@ extern __device__ long long g_blk_t[2 * 4096];   // per-workgroup (start, end) o
 #define CGIC_STAMP2(i) do { if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) g_phase_clk[i] = clock64(); } while (0)
 #else
 #define CGIC_STAMP(i) do {} while (0)
+#define CGIC_PHASE_T0() do {} while (0)
+#define CGIC_PHASE_ACC(k) do {} while (0)
 #define CGIC_DBG_COUNT(which, n) do {} while (0)
 #define CGIC_STAMP2(i) do {} while (0)
 #define CGIC_STAMP3(i) do {} while (0)

@@ -510,6 +510,27 @@ __device__ __forceinline__ void colargmin(float &d, int &i)
         i = take ? ib : ia;
     }
 }
+// lexicographic (d, i) minimum over all 64 lanes on the VALU: xor 1, 2 (quad_perm), 4 (row_half_mirror), 8 (row_mirror) on DPP
+// operands, then the 16- and 32-lane swaps of colargmin -- the minimum is idempotent, so mirrors do what xor shuffles do.  (The
+// all-K scan of a flagged vector used twelve ds_bpermute round trips here: ~0.3 of its ~0.5 us, and the workgroups that meet three
+// or four such vectors are the ones a launch waits for.)
+template <int CTRL>
+__device__ __forceinline__ void dpp_argmin_step(float &d, int &i)
+{
+    const float od = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(d), CTRL, 0xF, 0xF, true));
+    const int oi = __builtin_amdgcn_update_dpp(0, i, CTRL, 0xF, 0xF, true);
+    const bool take = od < d || (od == d && (unsigned int)oi < (unsigned int)i);
+    d = take ? od : d;
+    i = take ? oi : i;
+}
+__device__ __forceinline__ void wave_argmin(float &d, int &i)
+{
+    dpp_argmin_step<0xB1>(d, i);
+    dpp_argmin_step<0x4E>(d, i);
+    dpp_argmin_step<0x141>(d, i);
+    dpp_argmin_step<0x140>(d, i);
+    colargmin(d, i);
+}
 // the reference's rounding sequence for one codebook row
 __device__ __forceinline__ float dist_row(float z0, float z1, float z2, float z3, float zz, const float4 e, float ee)
 {
@@ -754,6 +775,7 @@ __device__ __forceinline__ void vq_filter_body(const VqArgs &a, unsigned char *s
 #endif
         const int64_t grp = cur;
         const int64_t base = grp * G;
+        CGIC_PHASE_T0();
         float zv[2][4];
         f16x8 bop[2];
         int qs[2];                      // scaled score = 2^qs x score
@@ -790,6 +812,7 @@ __device__ __forceinline__ void vq_filter_body(const VqArgs &a, unsigned char *s
         cur += NW;
         if (cur < blk_hi) load_group(cur, zn);
         CGIC_STAMP(2);
+        CGIC_PHASE_ACC(0);
 
         // ---- scan: tiles of 32 codes, ping-pong -- the MFMAs of one tile run while the VALU digests the other.
         float m1[2], m2[2];
@@ -815,8 +838,20 @@ __device__ __forceinline__ void vq_filter_body(const VqArgs &a, unsigned char *s
                             a.probe_scores[(base + 32 * t + j) * K + 32 * T + 8 * (r >> 2) + 4 * hf + (r & 3)] = ldexpf(D[t][r], -qs[t]);
                     }
                     float u = __builtin_inff();        // seeded with a constant: a two-operand fminf() canonicalises both operands first
+#ifdef CGIC_VQF_TREE
+                    {
+                        float ua = u, ub = u;
+#pragma unroll
+                        for (int r = 0; r < 8; r += 2) {
+                            ua = __builtin_fminf(__builtin_fminf(ua, D[t][r]), D[t][r + 1]);
+                            ub = __builtin_fminf(__builtin_fminf(ub, D[t][8 + r]), D[t][9 + r]);
+                        }
+                        u = __builtin_fminf(ua, ub);
+                    }
+#else
 #pragma unroll
                     for (int r = 0; r < 16; r += 2) u = __builtin_fminf(__builtin_fminf(u, D[t][r]), D[t][r + 1]);     // v_min3_f32 on the raw MFMA outputs
+#endif
                     // the tile's index rides in the low 5 mantissa bits of its minimum (one v_and_or_b32 instead of a
                     // compare + select per tile); the 2^-18 relative perturbation is part of the margin
                     u = __uint_as_float((__float_as_uint(u) & ~31u) | (unsigned int)T);
@@ -835,6 +870,7 @@ __device__ __forceinline__ void vq_filter_body(const VqArgs &a, unsigned char *s
             }
         }
         CGIC_STAMP(3);
+        CGIC_PHASE_ACC(1);
 
         // ---- decide: ONE LANE PER VECTOR.  Lane L = 32 t + j takes vector (tile t, column j): its own scaled
         // (smallest, second) of the row half it scanned, the other half's from lane L ^ 32 (v_permlane32_swap), and its
@@ -963,6 +999,9 @@ __device__ __forceinline__ void vq_filter_body(const VqArgs &a, unsigned char *s
                             bi = take ? c : bi;
                         }
                     }
+#ifndef CGIC_VQF_SHFLMIN
+                    wave_argmin(bd, bi);
+#else
 #pragma unroll
                     for (int off = 1; off < 64; off <<= 1) {
                         const float od = __shfl_xor(bd, off, kWave);
@@ -971,6 +1010,7 @@ __device__ __forceinline__ void vq_filter_body(const VqArgs &a, unsigned char *s
                         bd = take ? od : bd;
                         bi = take ? oi : bi;
                     }
+#endif
                     wi = lane == v ? bi : wi;
                 }
             } else if (nflag != 0) {
@@ -1041,6 +1081,7 @@ __device__ __forceinline__ void vq_filter_body(const VqArgs &a, unsigned char *s
             }
         }
         CGIC_STAMP(4);
+        CGIC_PHASE_ACC(2);
 
         // ---- outputs: lane (column j, half hf) owns channels 2 hf, 2 hf + 1 of vector (tile t, column j); lane L the
         // index of vector L
@@ -1048,7 +1089,14 @@ __device__ __forceinline__ void vq_filter_body(const VqArgs &a, unsigned char *s
             // a key that never got set (every distance NaN: nothing wins) is original row 0, like the plain path's index 0
             if ((unsigned int)wi >= ((unsigned int)K << 16)) wi = (int)s_key0;
         }
-        if (idx_out && base + lane < N) idx_out[base + lane] = (int64_t)(PERM ? wi >> 16 : wi);
+        // indices and z_q leave as nontemporal stores: 6.3 MB per launch that nobody in this launch reads again -- as ordinary stores they
+        // sat dirty in the L2s until the end-of-kernel write-back (fused launch 23.2 -> 22.4 us, same box A/B: profiles/r06_vq_ab.md)
+#ifndef CGIC_VQF_PLAIN_STORES
+#define CGIC_VQF_STORE(p, v) __builtin_nontemporal_store((v), (p))
+#else
+#define CGIC_VQF_STORE(p, v) (*(p) = (v))
+#endif
+        if (idx_out && base + lane < N) CGIC_VQF_STORE(&idx_out[base + lane], (int64_t)(PERM ? wi >> 16 : wi));
         if (PERM) wi &= 0xFFFF;                                   // from here on: where the row sits
         if (zq_out || a.sq_partial) {
             const uint2 wt = rows32((unsigned int)wi);           // .x: tile 0's winners (lanes 0..31), .y: tile 1's
@@ -1065,8 +1113,8 @@ __device__ __forceinline__ void vq_filter_body(const VqArgs &a, unsigned char *s
                     if (zq_out) {
                         if (ALIGNED) {
                             float *qb = zq_out + (gb * 4 * hw + gp0 + 32 * t) + out_off;
-                            qb[0] = za + da;
-                            qb[hw] = zb + db;
+                            CGIC_VQF_STORE(&qb[0], za + da);
+                            CGIC_VQF_STORE(&qb[hw], zb + db);
                         } else {
                             int64_t b, p;
                             divmod(n, &b, &p);
@@ -1079,6 +1127,7 @@ __device__ __forceinline__ void vq_filter_body(const VqArgs &a, unsigned char *s
                 }
             }
         }
+        CGIC_PHASE_ACC(3);
     }
 
 #ifndef CGIC_VQF_NO_TURNS

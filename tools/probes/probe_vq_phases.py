@@ -71,3 +71,11 @@ if "waves" in sys.argv:
         print(f"wg {g}: loop start per wave " + " ".join(f"{(wv[g, w, 0] - t0g) / 100:.1f}" for w in range(8)) + " | loop end " + " ".join(f"{(wv[g, w, 1] - t0g) / 100:.1f}" for w in range(8)) + f" | wg end {(wg[g, 1] - t0g) / 100:.1f}")
     le = (wv[:, :, 1] - wg[:, :1]) / 100.0
     print("loop end by wave index, median over 64 workgroups:", " ".join(f"{np.median(le[:, w]):.2f}" for w in range(8)), "| max over waves, median:", f"{np.median(le.max(1)):.2f}", "| min:", f"{np.median(le.min(1)):.2f}")
+if "acc" in sys.argv:
+    # per-phase clock sums over the groups of wave 0 / wave 4 of workgroup 0 (CGIC_PHASE_ACC): prep | scan | decide | outputs
+    l.cgic_debug_phase_clocks(ph); a0 = np.array(list(ph), dtype=np.int64).copy()
+    f(); torch.cuda.synchronize()
+    l.cgic_debug_phase_clocks(ph); a1 = np.array(list(ph), dtype=np.int64)
+    d = (a1 - a0) / ghz / 1e3
+    print("wave 0 of wg 0, us per launch: prep %.2f | scan %.2f | decide %.2f | outputs %.2f | sum %.2f" % (d[16], d[17], d[18], d[19], d[16:20].sum()))
+    print("wave 4 of wg 0, us per launch: prep %.2f | scan %.2f | decide %.2f | outputs %.2f | sum %.2f" % (d[22], d[23], d[24], d[25], d[22:26].sum()))
