@@ -436,9 +436,14 @@ def mask_flip_families(dev, z, cb, vq, codec, ratio):
         """the fused VQ + router launch on this content, with and without the refinement (what the band costs)"""
         xd, zd = torch.from_numpy(x).to(dev), torch.from_numpy(zz).to(dev)
         e8, e16 = cg_entropy(xd)
-        f = lambda px: graph_kernel_time(lambda: vq_forward_route(zd, vq.embedding.weight, 0.25, True, e16, e8, ratio[0], ratio[1], per_image=True,
-                                                                  pixels=px), per_graph=5, reps=3)
-        return {"vq+router_us": round(f(xd), 2), "vq+router_no_refinement_us": round(f(None), 2)}
+        f = lambda px, q=False: graph_kernel_time(lambda: vq_forward_route(zd, vq.embedding.weight, 0.25, True, e16, e8, ratio[0], ratio[1], per_image=True,
+                                                                           pixels=px, refine_queues=q), per_graph=5, reps=3)
+        import control_gic_amd as cg
+        auto = cg.pipeline.HotPathPipeline(vq, ratio[0], ratio[1], frequency=codec.huffman).decide(xd)
+        tq, tp = round(f(xd, True), 2), round(f(xd, False), 2)
+        # vq+router_us: what a stream of such batches runs (the variant refine_queues="auto" picks from the content at capture)
+        return {"vq+router_us": tq if auto else tp, "vq+router_plain_kernel_us": tp, "vq+router_refinement_queues_us": tq,
+                "auto_picks_queues": bool(auto), "vq+router_no_refinement_us": round(f(None), 2)}
 
     fam = families(n=64)
     for name, x in fam.items():

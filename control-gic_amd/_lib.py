@@ -259,6 +259,12 @@ REFINE_QUEUES = True
 #: scratch that lets their row bands SPLIT a long threshold band between them (a smooth 768x768 tile 251 -> 82 us).  The launch then
 #: runs the router in two attempts (plain first, the split instantiation only when a band is long: DESIGN.md 4.3): the ordinary
 #: tile pays nothing measurable for it
+#: the fused VQ + router launch with one workgroup per image (batches of 256x256 ...): images whose threshold band is long start over
+#: with the launch's refinement queues and the routers that are done help (round 6: a smooth 8-bit batch no longer waits for the
+#: image with the densest cluster).  False (the default for single calls): every image evaluates its band in its own workgroup -- the
+#: kernel variant with the queues costs the ORDINARY launch ~1.5 us by itself (two more router instantiations in one kernel), so
+#: it is chosen per stream of batches (pipeline.HotPathPipeline(refine_queues="auto"): from the content of the batches at capture)
+REFINE_FUSED_QUEUES = os.environ.get("CGIC_REFINE_FUSED_QUEUES", "0") != "0"
 REFINE_SPLIT_MIN_PATCHES = int(os.environ.get("CGIC_REFINE_SPLIT_MIN_PATCHES", "1024"))      # (a huge value: never)
 
 

@@ -497,7 +497,7 @@ struct ExactGate {
 template <int NT, int P, bool RQ, bool SPLIT, bool BAIL = false>
 __device__ __forceinline__ float refine_select(const RouterArgs &a, int qid, int nb, int band, float *arr, int n, unsigned int rank, float t_a,
                                                        ExactGate is_exact, int64_t img0, int wP, int nP, RefineShared *rs_, RouterShared *sh,
-                                                       const SelInfo &si, bool *bail_out = nullptr)
+                                                       const SelInfo &si, bool *bail_out = nullptr, bool *refined_out = nullptr)
 {
     RefineShared *rs = rs_;
     const RefineSrc &rf = a.rf;
@@ -595,6 +595,7 @@ __device__ __forceinline__ float refine_select(const RouterArgs &a, int qid, int
     // 25.4 -> 27.4 us when no image refines (the VQ workgroups pay), refining images 35.5 -> 30.3 us; raised only here: both.
     __builtin_amdgcn_s_setprio(3);
     CGIC_RE_STAMP(3);
+    if (refined_out) *refined_out = true;         // (this select's band is evaluated from pixels: the image is not an ordinary one)
 
     const bool have_q = RQ && a.rq.nq != 0;
     // Without the queues (the fused launch), the row bands of a tile -- nb workgroups that all find the same band -- at least
@@ -803,7 +804,9 @@ __device__ __forceinline__ float refine_select(const RouterArgs &a, int qid, int
         // Up to four rounds of this workgroup's waves stay here (the restart costs as much); constant patches do not count: their
         // passes cost the same in both instantiations.
         const unsigned int heavy = few ? (unsigned int)__builtin_popcountll(work) : cnt[7];
-        if (nb > 1 && a.rq.nq != 0 && heavy * UPP > 4 * NWR) {      // (workgroup-uniform, and the same in every row band)
+        // (row bands: more than four rounds, as before; an image with a workgroup of its own (round 6: the launch's queues): more than
+        // eight -- the restart and the queue's hand-offs cost ~15 us, and a band of a few rounds is done sooner where it was found)
+        if (a.rq.nq != 0 && heavy * UPP > (nb > 1 ? 4 : 8) * NWR) {      // (workgroup-uniform, and the same in every row band)
             *bail_out = true;
             __builtin_amdgcn_s_setprio(0);
             return t_a;
@@ -1137,7 +1140,7 @@ __device__ __forceinline__ float refine_select(const RouterArgs &a, int qid, int
 // launch's second attempt (router_body): even this much more code in the router's one path costs its ordinary path 2-3 us
 // (B = 64 x 256x256: 23.4 -> 26.5 us).  BAIL: the first attempt of such a launch (returns true when it left for the second).
 template <int NT, bool ST, bool HELP, bool SPLIT, bool BAIL>
-__device__ __forceinline__ bool router_team(const RouterArgs &a, int64_t blk, unsigned char *dyn);
+__device__ __forceinline__ int router_team(const RouterArgs &a, int64_t blk, unsigned char *dyn);
 
 // A SPLIT launch runs the router in two attempts: first the plain instantiation, which leaves (BAIL) as soon as a select's band is
 // more than four rounds of work -- before anything but the coarse mask is written, and that is written again with the same values --
@@ -1145,14 +1148,47 @@ __device__ __forceinline__ bool router_team(const RouterArgs &a, int64_t blk, un
 // nothing of the first is live across it: its path keeps the plain kernel's register allocation (with the split code inlined
 // into the one path an ordinary 768x768 tile paid 3.5 us, the 2040x1356 chain 8 us; NOTES 11.8).  A tile that does refine at
 // length pays the first attempt on top (7-20 us of 70-90).
+// where router_team keeps its RefineShared (stage 1, refinement on): behind the gate bits and the two staged maps
+__device__ __forceinline__ RefineShared *router_refine_shared(const RouterArgs &a, unsigned char *dyn)
+{
+    const int64_t N16 = a.per * a.h16 * a.w16, N8 = 4 * N16;
+    unsigned long long *gc_bits = reinterpret_cast<unsigned long long *>(dyn + kRouterSharedBytes);
+    float *l16 = reinterpret_cast<float *>(gc_bits + ((N16 + 63) >> 6));
+    return reinterpret_cast<RefineShared *>((reinterpret_cast<uintptr_t>(l16 + N16 + N8) + 15) & ~(uintptr_t)15);
+}
+
 template <int NT, bool HELP = false, bool SPLIT = false>
 __device__ __forceinline__ void router_body(const RouterArgs &a, int64_t blk, unsigned char *dyn)
 {
     if (a.stage == 1) {
         if constexpr (SPLIT) {
-            if (!router_team<NT, true, false, false, true>(a, blk, dyn)) return;
+            const int how = router_team<NT, true, false, false, true>(a, blk, dyn);
+            if (how != 1) {
+                // Done in the plain code.  One image per workgroup (round 6): the images of the launch whose bands ARE long have
+                // started over with the refinement queues -- while any of them holds a band open, the waves of a workgroup that had
+                // a (short) band of its own evaluate patches for them instead of leaving: tie-heavy content comes by the batch.  The
+                // ordinary image (how == 0: no band) leaves at once -- the look at the board is a memory round trip at the very end
+                // of the launch's critical path (measured: +1.9 us on every launch when every router took it).
+#ifndef CGIC_FUSED_Q_NOAFTER
+                if (how == 2 && a.bands <= 1 && a.rq.nq != 0 && a.rf.x != nullptr) {
+                    RefineShared *rs = router_refine_shared(a, dyn);
+                    __syncthreads();
+                    if (threadIdx.x == 0) rs->flag = ld_sc1(a.rq.board + QB_BUSY);
+                    __syncthreads();
+                    if (rs->flag) refine_help_while_busy(a, &rs->tl);
+                }
+#endif
+                return;
+            }
             __syncthreads();
+            // second attempt, from the top: the row bands of a large tile split the band between them; an image with a workgroup of
+            // its own publishes it to the launch's queues (the stand-alone launch's instantiation: owner + helpers)
+#ifdef CGIC_FUSED_Q_NOHELP      // dev A/B: without the queue instantiation in the kernel
             router_team<NT, true, false, true, false>(a, blk, dyn);
+#else
+            if (a.bands > 1) router_team<NT, true, false, true, false>(a, blk, dyn);
+            else router_team<NT, true, true, false, false>(a, blk, dyn);
+#endif
         } else {
             router_team<NT, true, HELP, false, false>(a, blk, dyn);
         }
@@ -1161,9 +1197,9 @@ __device__ __forceinline__ void router_body(const RouterArgs &a, int64_t blk, un
     }
 }
 
-// (returns whether it left early: BAIL only)
+// (returns 1 when it left early -- BAIL only --, 2 when it finished and one of its selects evaluated a band from the pixels, else 0)
 template <int NT, bool ST, bool HELP, bool SPLIT, bool BAIL>
-__device__ __forceinline__ bool router_team(const RouterArgs &a, int64_t blk, unsigned char *dyn)
+__device__ __forceinline__ int router_team(const RouterArgs &a, int64_t blk, unsigned char *dyn)
 {
     const int nb = a.bands > 1 ? a.bands : 1;
     const int64_t seg = blk / nb;
@@ -1216,7 +1252,7 @@ __device__ __forceinline__ bool router_team(const RouterArgs &a, int64_t blk, un
     int32_t *mf = a.mask_f + seg * N4;
     const int mode = a.mode;
     const bool has_thr_c = mode == 0 || mode == 2 || mode == 3;
-    bool bail = false;
+    bool bail = false, refined = false;
 
     // ---- coarse gate (RouterTriple.py:21-25 / 52-56 / 63-66)
     float thr_c = 0.f;
@@ -1225,8 +1261,8 @@ __device__ __forceinline__ bool router_team(const RouterArgs &a, int64_t blk, un
         thr_c = radix_select<NT>(rd16, N16, a.rank_c, sh, &si);
         if constexpr (ST) if (refine)
             thr_c = refine_select<NT, 16, HELP, SPLIT, BAIL>(a, (int)(2 * seg), nb, band, const_cast<float *>(e16), (int)N16, a.rank_c, thr_c, ExactGate{nullptr, 0, 0, 0, 0, 0, 0},
-                                          seg * a.per, (int)w16, (int)n16, rs, sh, si, &bail);
-        if (BAIL && bail) return true;
+                                          seg * a.per, (int)w16, (int)n16, rs, sh, si, &bail, &refined);
+        if (BAIL && bail) return 1;
     }
     CGIC_STAMP(2);
     CGIC_RT_STAMP(1);
@@ -1287,8 +1323,8 @@ __device__ __forceinline__ bool router_team(const RouterArgs &a, int64_t blk, un
             thr_m = radix_select<NT>(rd8, N8, a.rank_m, sh, &si);        // (stage 2: the masked copy through the generic pointer)
             if constexpr (ST) if (refine)       // (a gated element's 0 is exact: never re-evaluated, never overwritten)
                 thr_m = refine_select<NT, 8, HELP, SPLIT, BAIL>(a, (int)(2 * seg + 1), nb, band, l8m, (int)N8, a.rank_m, thr_m,
-                                             ExactGate{gc_bits, n8i, w8i, n16i, w16i, mg_n8, mg_w8}, seg * a.per, w8i, n8i, rs, sh, si, &bail);
-            if (BAIL && bail) return true;
+                                             ExactGate{gc_bits, n8i, w8i, n16i, w16i, mg_n8, mg_w8}, seg * a.per, w8i, n8i, rs, sh, si, &bail, &refined);
+            if (BAIL && bail) return 1;
         } else {
             thr_m = radix_select<NT>([&](int64_t i) { return e8[i] * (1.0f - (gc_of8(i) ? 1.0f : 0.0f)); }, N8, a.rank_m, sh);
         }
@@ -1298,8 +1334,8 @@ __device__ __forceinline__ bool router_team(const RouterArgs &a, int64_t blk, un
         thr_m = radix_select<NT>(rd8, N8, a.rank_m, sh, &si);
         if constexpr (ST) if (refine)
             thr_m = refine_select<NT, 8, HELP, SPLIT, BAIL>(a, (int)(2 * seg + 1), nb, band, const_cast<float *>(e8), (int)N8, a.rank_m, thr_m, ExactGate{nullptr, 0, 0, 0, 0, 0, 0},
-                                         seg * a.per, w8i, n8i, rs, sh, si, &bail);
-        if (BAIL && bail) return true;
+                                         seg * a.per, w8i, n8i, rs, sh, si, &bail, &refined);
+        if (BAIL && bail) return 1;
     }
     auto gm_rule = [&](float v, bool gc) -> bool {
         switch (mode) {
@@ -1374,7 +1410,7 @@ __device__ __forceinline__ bool router_team(const RouterArgs &a, int64_t blk, un
         __syncthreads();
         if (rs->flag) refine_help_while_busy(a, &rs->tl);
     }
-    return false;
+    return refined ? 2 : 0;
 }
 
 

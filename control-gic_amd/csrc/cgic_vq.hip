@@ -1560,7 +1560,8 @@ static int launch_filter(const float *z, int64_t hw, int64_t N, const float *cb,
     p.a = a; p.r = *router; p.nrouter = (unsigned int)router_blocks; p.router_behind = router_first ? 0u : 1u;
     const dim3 grid(a.nblk + (unsigned int)router_blocks);
     // row bands that share a threshold band's re-evaluation run the SPLIT instantiation (cgic_router_dev.h: router_body)
-    const bool split = router->bands > 1 && router->rq.nq != 0;
+    // ... and images with a workgroup of their own whose band is long start over with the launch's refinement queues (round 6)
+    const bool split = router->rq.nq != 0;
     if (split) {
         rc = ensure_dynamic_lds((const void *)vq_filter_router_kernel<ALIGNED, CONV, true>, lds);
         if (rc) return rc;
@@ -1583,7 +1584,7 @@ static int vqfr_grouped_launch(const GroupRec *const *recs, int n, hipStream_t s
     int rc = fill_grouped(recs, n, &g, &lds);
     if (rc) return rc;
     bool split = false;
-    for (int i = 0; i < n; ++i) split = split || (g.a[i].r.bands > 1 && g.a[i].r.rq.nq != 0);
+    for (int i = 0; i < n; ++i) split = split || g.a[i].r.rq.nq != 0;
     if (split) {
         rc = ensure_dynamic_lds((const void *)vq_filter_router_grouped_kernel<ALIGNED, true>, lds);
         if (rc) return rc;
@@ -1849,8 +1850,9 @@ extern "C" int cgic_vq_forward_route_f32(const float *z, int64_t B, int64_t hw, 
     int64_t nseg;
     size_t rlds;
     // (78 KB: a router workgroup of the fused launch shares its CU with a VQ workgroup -- two allocations per 160 KB)
+    // (with a scratch: the launch's refinement queues -- images with long threshold bands publish them, the routers that are done help)
     rc = router_prepare(e16, e8, B, h16, w16, coarse_ratio, medium_ratio, per_image, mask_c, mask_m, mask_f, gate, &r, &nseg, &rlds,
-                        kRouterFusedLds, refine, (hipStream_t)stream);
+                        kRouterFusedLds, refine, (hipStream_t)stream, per_image != 0 && refine && refine->scratch);
     if (rc) return rc;
     hipStream_t s = (hipStream_t)stream;
     VqWs ws;

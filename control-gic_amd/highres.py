@@ -348,7 +348,7 @@ class TiledCall:
                 raise ValueError(f"TiledCall: tiles of {th}x{tw} are routed as one segment beyond the router workgroup's LDS; their refinement is a chain "
                                  "of launches that a launch group cannot record (cgic_router_refine_in_lds): use tiles of at most 768x768 "
                                  "(the reference's), or compress_tiled(..., chain=False)")
-            nref = l.cgic_router_refine_scratch_bytes(B, th // 16, tw // 16, 1) if (th // 16) * (tw // 16) >= _lib.REFINE_SPLIT_MIN_PATCHES and _lib.REFINE_QUEUES else 0
+            nref = l.cgic_router_refine_scratch_bytes(B, th // 16, tw // 16, 1) if ((th // 16) * (tw // 16) >= _lib.REFINE_SPLIT_MIN_PATCHES or _lib.REFINE_FUSED_QUEUES) and _lib.REFINE_QUEUES else 0
             ws_r = E((nref,), u8t) if nref else None                 # (large tiles: their row bands split a threshold band between them)
             org = (ctypes.c_int * (2 * T))(*[v for i in idxs for v in (self.tiles[i][0] - top, self.tiles[i][1] - left)])
             g = self._arr[k]

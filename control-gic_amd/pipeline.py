@@ -16,8 +16,16 @@ class HotPathPipeline:
     (Cutting a batch into chunks on several streams and forking VQ next to entropy -> router were measured slower, NOTES.md;
     what overlaps well is WHOLE batches on independent queues: LaneStream.)"""
 
-    def __init__(self, quantizer, coarse_ratio, medium_ratio, frequency=None, fuse_router=True, prepare=False, refine=True):
+    def __init__(self, quantizer, coarse_ratio, medium_ratio, frequency=None, fuse_router=True, prepare=False, refine=True,
+                 refine_queues="auto"):
         self.vq = quantizer
+        # refine_queues: True / False / "auto".  The fused launch has a variant in which an image whose threshold band is long starts
+        # over with the launch's refinement queues and the router workgroups that are done help (quantize.vq_forward_route): worth
+        # ~17 % on batches of smooth 8-bit content, ~1.5 us of latency on the ordinary launch.  "auto": decide() looks at a batch
+        # of the stream once (LaneStream.capture does; a bare pipeline stays on the plain kernel until decide() is called) -- tie-heavy
+        # content comes by the stream.  The masks are the same either way.
+        self.refine_queues = refine_queues
+        self._queues = refine_queues is True
         # prepare=True: inference against a codebook that does not change -- the VQ kernel's codebook image is made once
         # (quantize.prepare_codebook, a snapshot of the weights NOW; refresh_codebook() after changing them) instead of by
         # every workgroup of every launch
@@ -39,6 +47,35 @@ class HotPathPipeline:
         if self.prepared is not None:
             self.prepared = prepare_codebook(self.vq.embedding.weight, out=self.prepared)
 
+    def decide(self, x):
+        """refine_queues="auto": look at one batch of the stream -- how many patches per image lie inside the threshold bands AND are
+        not constant (those are evaluated from their pixels) -- and choose the fused launch's variant for the batches to come.
+        Host-side, once per stream (a few torch kernels and one synchronisation: never inside a timed or captured region)."""
+        if self.refine_queues != "auto" or not self.refine or not self.fuse_router:
+            return self._queues
+        e8, e16 = entropy_maps(x)
+        flat8 = getattr(e8, "_cgic_flat8", None)
+        c, m = float(self.router.coarse_grain_ratio), float(self.router.medium_grain_ratio)
+        units = 0
+        # (the COARSE band decides: 16x16 patches are four units each, and a long coarse band -- the nearly constant patches of smooth
+        # content -- is where the queues pay, 71 -> 59 us per launch; a long MEDIUM band of 8x8 edge patches (flat regions with edges)
+        # is done sooner where it was found: 57 us against 62 with the restart and the queue's hand-offs)
+        for e, ratio, per_patch in ((e16, c, 4),):
+            B = e.shape[0]
+            v = e.reshape(B, -1)
+            k = max(int(round(v.shape[1] * ratio)), 1)
+            if ratio <= 0.0 or k > v.shape[1]:
+                continue
+            thr = torch.kthvalue(v, k, dim=1).values[:, None]
+            band = (v - thr).abs() <= 4e-6
+            if flat8 is not None:                       # constant patches cost one evaluation per gray, not one per patch
+                f = flat8 if per_patch == 1 else torch.nn.functional.max_pool2d(torch.isnan(flat8).float()[:, None], 2)[:, 0]
+                nonconst = torch.isnan(f) if per_patch == 1 else f > 0
+                band = band & nonconst.reshape(B, -1)
+            units = max(units, int(band.sum(dim=1).max().item()) * per_patch)
+        self._queues = units > 64                       # more than eight rounds of a router workgroup's eight waves
+        return self._queues
+
     def _chain(self, x, z, hist, decode, decoder=None):
         e8, e16 = entropy_maps(x)
         px = x if self.refine else None
@@ -50,7 +87,7 @@ class HotPathPipeline:
             zq, loss, ind, mask, _, mode = vq_forward_route(
                 z, self.vq.embedding.weight, self.vq.beta, self.vq.legacy, e16, e8,
                 self.router.coarse_grain_ratio, self.router.medium_grain_ratio, per_image=True, prepared=self.prepared,
-                pixels=px)
+                pixels=px, refine_queues=self._queues)
         comp = self.codec.compress(ind, mask, mode, hist=hist)      # usage histogram rides on the coder launch
         dec = self.codec.decompress(comp, decoder=decoder) if decode else None
         return {"e8": e8, "e16": e16, "mask": mask, "mode": mode, "z_q": zq, "loss": loss, "ind": ind,
@@ -111,9 +148,10 @@ class HotCall:
             io.dind, io.dz_q, io.status = p(t["dind"]), p(t["dz_q"]), p(t["status"])
             io.dmask_c, io.dmask_m, io.dmask_f = (p(m) for m in t["dmask"])
         io.ws_vq, io.ws_compress, io.ws_decompress = p(ws["vq"]), p(ws["c"]), p(ws["d"])
-        if not l.cgic_router_refine_in_lds(B, H // 16, W // 16, 1):
-            # an image beyond ~768x768 routed as one segment: its threshold bands are refined through patched copies of the maps
-            nref = l.cgic_router_refine_scratch_bytes(B, H // 16, W // 16, 1)
+        # the refinement scratch: the launch's queues (images with long threshold bands publish them, the other routers help; large
+        # tiles: their row bands split a band) -- or, for an image beyond ~768x768 routed as one segment, the patched copies of its maps
+        nref = l.cgic_router_refine_scratch_bytes(B, H // 16, W // 16, 1)
+        if nref and (_lib.REFINE_FUSED_QUEUES or not l.cgic_router_refine_in_lds(B, H // 16, W // 16, 1)):
             ws["r"] = E((nref,), u8t)
             io.ws_refine, io.ws_refine_bytes = p(ws["r"]), nref
         self._io = io
@@ -256,13 +294,13 @@ class LaneStream:
 
     def __init__(self, quantizer, coarse_ratio, medium_ratio, slots, lanes=4, frequency=None, hist=None, decode=True,
                  graph=True, ring=True, fuse_router=True, decoder=None, max_ring=8, prepare=True, native_launch=True,
-                 refine=True):
+                 refine=True, refine_queues="auto"):
         if not slots:
             raise ValueError("LaneStream needs at least one slot")
         # prepare: a stream of batches is inference against ONE codebook -- its image is made once, when capture() runs
         # (a captured launch holds a snapshot of the codebook either way: HotPathPipeline.prepare)
         self.pipe = HotPathPipeline(quantizer, coarse_ratio, medium_ratio, frequency=frequency, fuse_router=fuse_router, prepare=prepare,
-                                    refine=refine)
+                                    refine=refine, refine_queues=refine_queues)
         self.hist = hist
         self.decode = bool(decode)
         self.graph = bool(graph)
@@ -295,6 +333,7 @@ class LaneStream:
         side.wait_stream(cur)
         with torch.cuda.stream(side):
             self.pipe.refresh_codebook()                # the weights as they are now
+            self.pipe.decide(self.slots[0].x)           # refine_queues="auto": the stream's first batch chooses the fused launch's variant
             for s in self.slots:
                 for _ in range(warmup):
                     s.enc, s.dec = self._step(s)

@@ -143,15 +143,21 @@ def _vq_forward(z, weight, beta, legacy, hist, want_zq=True, want_loss=True, ker
 
 
 def vq_forward_route(z, weight, beta, legacy, e16, e8, coarse_ratio, medium_ratio, per_image=True, want_gate=False,
-                     want_zq=True, want_loss=True, quant_conv=None, conv_bias_first=False, prepared=None, pixels=None, flat8=None):
+                     want_zq=True, want_loss=True, quant_conv=None, conv_bias_first=False, prepared=None, pixels=None, flat8=None,
+                     refine_queues=None):
     """VectorQuantize2.forward and TripleGrainFixedEntropyRouter.forward in ONE launch (the router's per-image
     workgroups ride behind the VQ workgroups; see cgic_vq_forward_route_f32).  Returns
     (z_q, loss, indices, [mask_c, mask_m, mask_f], gate, mode) -- identical to the two separate calls.
     pixels: the image batch the maps were made from (fp32 [B,3,H,W] or uint8 [B,H,W,3]) -> the router's threshold-band
     refinement (router.TripleGrainFixedEntropyRouter.forward); flat8: its constant-patch map (default: the one entropy_maps
-    left on the maps)."""
+    left on the maps).  refine_queues (images with a router workgroup of their own: per_image, up to 32x32 patches): True -- an image
+    whose threshold band is long starts over with the launch's refinement queues and the routers that are done help (tie-heavy
+    batches: 71 -> 59 us on smooth 8-bit content; that kernel variant costs the ordinary launch ~1.5 us alone); None: the process
+    default (_lib.REFINE_FUSED_QUEUES, off); pipeline.HotPathPipeline decides per stream of batches.  Same masks either way."""
     import ctypes
     _lib.require_device(z, weight, e16, e8)
+    if refine_queues is None:
+        refine_queues = _lib.REFINE_FUSED_QUEUES
     if flat8 is None and pixels is not None:
         from .router import _flat_of
         flat8 = _flat_of(pixels, e8, e16)
@@ -175,8 +181,10 @@ def vq_forward_route(z, weight, beta, legacy, e16, e8, coarse_ratio, medium_rati
     gate = torch.empty((B, 1, 4 * h16, 12 * w16), dtype=torch.float32, device=dev) if want_gate else None
     mode = ctypes.c_int(0)
     qc, keep = _lib.conv_arg(quant_conv, conv_bias_first)
+    # (the scratch of the launch's refinement queues: images whose threshold band is long publish it and the router workgroups
+    # that are done evaluate patches for them; the row bands of a large tile split a band between them)
     px, keep_px = _lib.pixels_arg(pixels, B, h16, w16, per_image, flat8=flat8, explicit=True,
-                                   queues=bool(per_image) and h16 * w16 >= _lib.REFINE_SPLIT_MIN_PATCHES)      # (large tiles: their row bands split a band between them)
+                                   queues=bool(per_image) and (bool(refine_queues) or h16 * w16 >= _lib.REFINE_SPLIT_MIN_PATCHES))
     with _lib.on_device(dev):
         _lib.call("cgic_vq_forward_route_f32", _lib.ptr(z), B, h * w, _lib.ptr(weight), weight.shape[0], C, float(beta),
                   int(bool(legacy)), _lib.ptr(idx), _lib.ptr(z_q), _lib.ptr(loss), _lib.ptr(ws), _lib.ptr(e16), _lib.ptr(e8),

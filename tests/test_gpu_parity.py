@@ -537,6 +537,40 @@ def test_hotcall_refines_images_beyond_768():
         hc(xl, z)
 
 
+def test_fused_launch_with_refinement_queues_gives_the_same_masks():
+    """round 6: the fused VQ + router launch's variant in which an image with a long threshold band starts over with the launch's
+    refinement queues (published patch lists, the routers that are done help): masks == the plain variant's == routing on the
+    reference-arithmetic maps, on every tie-heavy family, repeated launches over the same header slots, fp32 pixels and uint8
+    frames; VQ outputs untouched.  HotPathPipeline(refine_queues="auto") picks the variant from a batch of the stream: the
+    smooth family (dozens of non-constant patches inside a band) takes the queues, noise does not."""
+    from control_gic_amd.quantize import vq_forward_route
+    rng = np.random.default_rng(11)
+    w = _t(rng.standard_normal((1024, 4), dtype=np.float32))
+    vq = cg.VectorQuantizer(1024, 4, beta=0.25).to(DEV).eval()
+    vq.embedding.weight.data.copy_(w)
+    picks = {}
+    for name, x in _tie_sets(n=64, flat=16).items():
+        xd = torch.from_numpy(np.ascontiguousarray(x)).to(DEV)
+        B, _, H, W = xd.shape
+        e8, e16 = cg.entropy_maps(xd)
+        r8, r16 = cg.entropy_maps(xd, reference_order=True)
+        want = cg.TripleGrainFixedEntropyRouter(0.1, 0.8, per_image=True)(r16, r8, want_gate=False)[0]
+        z = _t(rng.standard_normal((B, 4, H // 4, W // 4), dtype=np.float32))
+        plain = vq_forward_route(z, w, 0.25, True, e16, e8, 0.1, 0.8, per_image=True, pixels=xd, refine_queues=False)
+        for rep in range(3):
+            q = vq_forward_route(z, w, 0.25, True, e16, e8, 0.1, 0.8, per_image=True, pixels=xd, refine_queues=True)
+            assert all(torch.equal(a, b) for a, b in zip(q[3], want)), (name, rep, [int((a != b).sum()) for a, b in zip(q[3], want)])
+            assert torch.equal(q[0], plain[0]) and torch.equal(q[1], plain[1]) and torch.equal(q[2], plain[2])
+        assert all(torch.equal(a, b) for a, b in zip(plain[3], want)), name
+        if name == "smooth8":
+            frames = (xd * 255.0).round().to(torch.uint8).permute(0, 2, 3, 1).contiguous()
+            _, f8, f16 = cg.entropy_maps_u8(frames)
+            q = vq_forward_route(z, w, 0.25, True, f16, f8, 0.1, 0.8, per_image=True, pixels=frames, refine_queues=True)
+            assert all(torch.equal(a, b) for a, b in zip(q[3], want)), (name, "uint8 frames")
+        picks[name] = cg.pipeline.HotPathPipeline(vq, 0.1, 0.8).decide(xd)
+    assert picks["smooth8"] is True and picks["noise8"] is False and picks["flat_edges"] is False, picks
+
+
 def test_refinement_queues_change_nothing_and_survive_concurrent_launches():
     """The stand-alone router launch evaluates long bands with every idle wave of the launch (refinement queues: the band's
     owner publishes its patch list; the other row bands of a tile and router workgroups that are done take patches; results as
