@@ -92,6 +92,10 @@ int router_prepare(const float *e16, const float *e8, int64_t B, int64_t h16, in
     CGIC_REQUIRE(!a.rf.x || N8 <= 64 * (int64_t)kRefBitWords, CGIC_ERR_UNSUPPORTED, "router: refinement of a segment of %lld patches", (long long)N8);
     // large per-image segments: several workgroups per image share the mask writing (every one repeats the selects, which
     // costs nothing while most CUs are idle): up to 8, while the launch stays within ~a quarter of the chip
+    // (The row bands of a tile that split a threshold band WAIT for each other (refine_select's exchange()): every band of every launch
+    // in flight has to be resident.  nseg x bands <= 64 workgroups per launch = a quarter of the chip's CUs, two such workgroups fit a
+    // CU: up to FOUR launches in flight -- the pipeline's four hardware queues -- are resident together whatever else runs; more
+    // concurrent launches than that are outside the contract of cgic_pixels.scratch, see include/cgic_hip.h.)
     a.bands = 1;
     if (per_image && h16 * w16 >= 32 * 32) {
         int64_t nb = 64 / nseg;

@@ -354,9 +354,13 @@ extern "C" int cgic_ticket_slots_in_use(void)
     int dev = 0;
     CGIC_HIP_TRY(hipGetDevice(&dev));
     std::lock_guard<std::mutex> lock(g_ticket_mu);
-    const TicketPool &p = g_ticket_pools[2 * dev];
-    size_t used = p.chunk_next;
-    for (const TicketRange &r : p.free_ranges) used -= r.count;
+    // both pools of the device (kind 0: tickets; kind 1: the router's refinement headers): cgic_ticket_scope_release frees across both
+    size_t used = 0;
+    for (int kind = 0; kind < 2; ++kind) {
+        const TicketPool &p = g_ticket_pools[2 * dev + kind];
+        used += p.chunk_next;
+        for (const TicketRange &r : p.free_ranges) used -= r.count;
+    }
     return (int)used;
 }
 

@@ -315,6 +315,7 @@ class TiledCall:
         self.ratios = (float(coarse_ratio), float(medium_ratio))
         self.codec = GrainCodec(frequency if frequency is not None else quantizer.embedding_counter, w)
         self.prepared = prepare_codebook(w) if prepare else None
+        self._prepared_version = w._version
         self.decoder = _decoder_flag(decoder)
         self.pad, _ = compute_padding(H, W)
         left, right, top, bottom = self.pad
@@ -370,6 +371,14 @@ class TiledCall:
         self._decode = bool(decode)
         self.decoded = None
 
+    def refresh_codebook(self):
+        """after changing embedding.weight: rewrite the codebook image in place (HotCall / HotPathPipeline have the same method; __call__
+        does it by itself when the weight tensor's version counter moved)"""
+        from .quantize import prepare_codebook
+        if self.prepared is not None:
+            self.prepared = prepare_codebook(self.vq.embedding.weight, out=self.prepared)
+            self._prepared_version = self.vq.embedding.weight._version
+
     def __call__(self, x, zs):
         import ctypes
         from .codec import CompressedBatch
@@ -382,6 +391,8 @@ class TiledCall:
                 raise ValueError(f"TiledCall: latent of shape group {k} must be fp32 [{N * len(idxs)},4,{th // 4},{tw // 4}]")
             self._arr[k].io.z = z.data_ptr()
         w = self.vq.embedding.weight
+        if self.prepared is not None and w._version != self._prepared_version:
+            self.refresh_codebook()                 # the weights were modified in place since the image was made: a stale image gives wrong indices
 
         def go():
             _lib.check(self._fn(self.codec.huffman.table.handle, w.data_ptr(), w.shape[0], w.shape[1], _lib.ptr(self.prepared), x.data_ptr(),

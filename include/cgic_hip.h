@@ -148,7 +148,8 @@ typedef struct cgic_pixels {
                          * REQUIRED (ABI 8) when the routing segment does not fit the workgroup's LDS (cgic_router_refine_in_lds == 0: the
                          * flattened batch of the reference's encode(), RouterTriple.py:21,40,52,63, or an untiled image beyond
                          * 768x768): the refinement then runs as a chain of launches over patched copies of the maps kept here.
-                         * Uninitialised memory; one per launch in flight */
+                         * Uninitialised memory; one per launch in flight, and at most FOUR launches that carry one in flight on a
+                         * device at a time (the row bands of a tile wait for each other: all of them must be resident) */
     size_t scratch_bytes;
 } cgic_pixels;
 /* scratch for cgic_pixels.scratch of a router / fused call with these arguments (0: the call takes none; required when
