@@ -77,6 +77,7 @@ struct DecodeArgs {
 #define CGIC_SS_THREADS_SMALL 256
 #endif
 __global__ void decode_image_kernel(DecodeArgs a, int stage_cap, int chunk_cap);
+__global__ void decode_image_stream_kernel(DecodeArgs a, int stage_cap, int chunk_cap);
 struct DecodeImageArgs { DecodeArgs a; int stage_cap, chunk_cap; };      // its argument block in a grouped launch
 
 static const int kModeStreams[7] = {0x1f, 0x16, 0x0d, 0x0b, 0x01, 0x02, 0x04};  // model.py:225-260

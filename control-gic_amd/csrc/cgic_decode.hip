@@ -1441,6 +1441,12 @@ extern "C" int cgic_decompress_streams(const cgic_table *t, const uint8_t *in, i
             const int sc_ = (int)stage_cap, cc_ = (int)chunk_cap;
             DecodeImageArgs dia;
             dia.a = d; dia.stage_cap = sc_; dia.chunk_cap = cc_;
+            static const bool per_stream = getenv("CGIC_SS_PER_STREAM") && atoi(getenv("CGIC_SS_PER_STREAM")) != 0;      // dev A/B, round 6
+            if (per_stream && !group_recording()) {
+                { int rc_ = ensure_dynamic_lds((const void *)decode_image_stream_kernel, lds_ss); if (rc_) return rc_; }
+                hipLaunchKernelGGL(decode_image_stream_kernel, dim3((unsigned)B, 3u), dim3(T), lds_ss, s, d, sc_, cc_);
+                rc = launch_check("decode_image_stream_kernel");
+            } else
             rc = launch_or_record(KID_DECODE_IMAGE, dim3((unsigned)B), dim3(T), lds_ss, dia, s, [=] {
                 hipLaunchKernelGGL(decode_image_kernel, dim3((unsigned)B), dim3(T), lds_ss, s, d, sc_, cc_);
                 return launch_check("decode_image_kernel"); });

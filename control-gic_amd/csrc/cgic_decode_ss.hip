@@ -248,7 +248,9 @@ __device__ __forceinline__ MeFn me_walk_all(const TableDev &t, const uint32_t *l
     return f;
 }
 
-__device__ __forceinline__ void decode_image_body(const DecodeArgs &a, const int stage_cap, const int chunk_cap, const Blk blk)
+// only: -1 = this workgroup decodes the image's three index streams (the shipping form); 0..2 = that one stream (dev A/B of round 6:
+// one workgroup per (image, stream), grid (B, 3) -- fewer sweeps per workgroup, three LUT stagings per image)
+__device__ __forceinline__ void decode_image_body(const DecodeArgs &a, const int stage_cap, const int chunk_cap, const Blk blk, const int only = -1)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t sm[];
     __shared__ int s_scan[kDecWaves + 1];
@@ -264,6 +266,11 @@ __device__ __forceinline__ void decode_image_body(const DecodeArgs &a, const int
     int nb[3];
 #pragma unroll
     for (int s = 0; s < 3; ++s) nb[s] = (a.stream_mask >> s & 1) ? a.nbytes[b * CGIC_NUM_STREAMS + s] : -2;
+    const bool own_s[3] = {only < 0 || only == 0, only < 0 || only == 1, only < 0 || only == 2};
+    int nb_all[3];
+#pragma unroll
+    for (int s = 0; s < 3; ++s) { nb_all[s] = nb[s]; if (!own_s[s]) nb[s] = -2; }
+    (void)nb_all;
     const int pad[3] = {in0[0], in0[a.slot], in0[2 * a.slot]};      // (slot memory is always readable)
     {   // LUT -> LDS: eight 16-byte loads in flight per thread (a plain strided loop pays one memory round trip per trip:
         // 32 trips of a 256-thread workgroup = 25 us)
@@ -310,9 +317,11 @@ __device__ __forceinline__ void decode_image_body(const DecodeArgs &a, const int
     if (tid == 0) {
         if (a.status) a.status[b] = 0;
 #pragma unroll
-        for (int s = 0; s < 3; ++s)
+        for (int s = 0; s < 3; ++s) {
+            if (!own_s[s]) continue;
             if (nb[s] <= 0) a.dcount[b * 3 + s] = nb[s] == 0 ? -1 : -2;             // empty file (None) / not sent
             else if (!fits) a.dcount[b * 3 + s] = -3;
+        }
     }
     if (!fits) return;
     CGIC_STAMP3(1);
@@ -464,7 +473,7 @@ __device__ __forceinline__ void decode_image_body(const DecodeArgs &a, const int
         run += n;
     }
     CGIC_STAMP3(6);
-    if (tid < 3 && sel3(tid, nb[0], nb[1], nb[2]) > 0) {
+    if (tid < 3 && (only < 0 || only == tid) && sel3(tid, nb[0], nb[1], nb[2]) > 0) {
         const int n = s_base[tid + 1] - s_base[tid];
         a.dcount[b * 3 + tid] = n > sel3(tid, cap[0], cap[1], cap[2]) ? -3 : n;
     }
@@ -473,6 +482,11 @@ __device__ __forceinline__ void decode_image_body(const DecodeArgs &a, const int
 __global__ __launch_bounds__(kDecThreads) void decode_image_kernel(DecodeArgs a, int stage_cap, int chunk_cap)
 {
     decode_image_body(a, stage_cap, chunk_cap, own_blk());
+}
+// dev A/B (CGIC_SS_PER_STREAM=1): grid (B, 3), blockIdx.y = the stream
+__global__ __launch_bounds__(kDecThreads) void decode_image_stream_kernel(DecodeArgs a, int stage_cap, int chunk_cap)
+{
+    decode_image_body(a, stage_cap, chunk_cap, own_blk(), (int)blockIdx.y);
 }
 
 // several shape groups in one launch (cgic_common.h: launch groups); the groups share the workgroup size (checked by

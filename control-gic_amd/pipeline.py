@@ -56,7 +56,7 @@ class HotPathPipeline:
         e8, e16 = entropy_maps(x)
         flat8 = getattr(e8, "_cgic_flat8", None)
         c, m = float(self.router.coarse_grain_ratio), float(self.router.medium_grain_ratio)
-        units = 0
+        units, mean_units = 0, 0.0
         # (the COARSE band decides: 16x16 patches are four units each, and a long coarse band -- the nearly constant patches of smooth
         # content -- is where the queues pay, 71 -> 59 us per launch; a long MEDIUM band of 8x8 edge patches (flat regions with edges)
         # is done sooner where it was found: 57 us against 62 with the restart and the queue's hand-offs)
@@ -72,8 +72,13 @@ class HotPathPipeline:
                 f = flat8 if per_patch == 1 else torch.nn.functional.max_pool2d(torch.isnan(flat8).float()[:, None], 2)[:, 0]
                 nonconst = torch.isnan(f) if per_patch == 1 else f > 0
                 band = band & nonconst.reshape(B, -1)
-            units = max(units, int(band.sum(dim=1).max().item()) * per_patch)
-        self._queues = units > 64                       # more than eight rounds of a router workgroup's eight waves
+            per_image = band.sum(dim=1).float() * per_patch
+            units, mean_units = max(units, int(per_image.max().item())), float(per_image.mean().item())
+        # more than eight rounds of a router workgroup's eight waves in SOME image while the batch as a whole has routers to spare:
+        # when every image carries about the same band, every router is busy with its own and the restart is pure cost (flat regions
+        # with edges: 57 us plain, 62 with the queues)
+        self._decide_stats = (units, mean_units)
+        self._queues = units > 64 and units >= 1.6 * mean_units
         return self._queues
 
     def _chain(self, x, z, hist, decode, decoder=None):
