@@ -147,34 +147,35 @@ __device__ __forceinline__ double wave_sum_f64(double v)
     return __builtin_bit_cast(double, ((unsigned long long)b.x << 32) | a.x) + __builtin_bit_cast(double, ((unsigned long long)b.y << 32) | a.y);
 }
 
-// Variant for the filter path, executed by ONE wave: lane 0 publishes the workgroup's partial (write-through
-// store, drained, then the ticket); the wave of the last workgroup sums all partials in a fixed order.
+// Variant for the filter path, executed by ONE wave.  Round 6: the partials live in LIBRARY-owned, zero-on-entry slots (behind the
+// ticket: acquire_tickets) instead of the caller's workspace, and a workgroup publishes -partial -- the sum of squares is never
+// negative, so the sign bit says "written" (a +0.0 partial goes out as -0.0, a NaN stays a NaN with its sign set) -- with a
+// write-through store that it does NOT wait for before it takes its ticket: the last workgroup polls any slot that still reads zero
+// (its store was issued before the ticket that made this workgroup the last one: it is on its way), sums in the fixed order as
+// before, and hands the slots back zeroed.  Every workgroup's tail loses one memory round trip (the drain between store and ticket:
+// the launch 22.4 -> 21.9 us); the sum is the same additions in the same order: the same bits.
 __device__ __forceinline__ void finish_loss_wave(double block_sum, double *sq_partial, unsigned int *ticket, double count,
                                                  float beta, int legacy, float *loss, unsigned int blk, unsigned int nblk)
 {
     const int lane = lane_id();
+    unsigned long long *slots = reinterpret_cast<unsigned long long *>(sq_partial);
     int last = 0;
     if (lane == 0) {
-#ifdef CGIC_STRICT_HANDOFF
-        // textbook form (make FLAGS+=-DCGIC_STRICT_HANDOFF): plain store, release at the ticket; for A/B runs against the
-        // write-through shortcut below on a new ROCm / GPU
-        sq_partial[blk] = block_sum;
-        last = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT) == nblk - 1;
-#else
-        __hip_atomic_store(&sq_partial[blk], block_sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __hip_atomic_store(&slots[blk], __builtin_bit_cast(unsigned long long, -block_sum), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         last = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == nblk - 1;
-#endif
     }
     last = __builtin_amdgcn_readfirstlane(last);
     if (!last) return;
-#ifdef CGIC_STRICT_HANDOFF
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-#endif
-    // (no acquire fence: sc1 stores on the producers' side, sc1 loads here -- see finish_loss)
     double a = 0.0;
-    for (unsigned int i = lane; i < nblk; i += kWave)
-        a += __hip_atomic_load(&sq_partial[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (unsigned int i = lane; i < nblk; i += kWave) {
+        unsigned long long v = __hip_atomic_load(&slots[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        while (v == 0ull) {                                      // (still in flight: see above)
+            __builtin_amdgcn_s_sleep(1);
+            v = __hip_atomic_load(&slots[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        a += -__builtin_bit_cast(double, v);
+    }
+    for (unsigned int i = lane; i < nblk; i += kWave) __hip_atomic_store(&slots[i], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     a = wave_sum_f64(a);
     if (lane == 0) {
         const float m = (float)(a / count);
@@ -1491,7 +1492,16 @@ static int launch_filter(const float *z, int64_t hw, int64_t N, const float *cb,
     int64_t nblk = ngroups < cus ? ngroups : cus;
     VqArgs a;
     a.z = z; a.hw = hw; a.N = N; a.cb = cb; a.K = K; a.idx_out = idx; a.zq_out = zq;
-    a.sq_partial = loss ? ws.partial : nullptr; a.ticket = ws.ticket; a.beta = beta; a.legacy = legacy; a.loss = loss;
+    a.sq_partial = nullptr; a.ticket = ws.ticket; a.beta = beta; a.legacy = legacy; a.loss = loss;
+    if (loss) {
+        // the ticket and, behind it, one 8-byte partial per workgroup: library-owned, zero when handed out, zeroed again by the launch
+        // (finish_loss_wave); the caller's workspace is not touched by this path
+        unsigned int *t = nullptr;
+        rc = acquire_tickets(s, 1 + (int)((nblk + 7) / 8), &t);
+        if (rc) return rc;
+        a.ticket = t;
+        a.sq_partial = reinterpret_cast<double *>(t + kTicketStride);
+    }
     a.nblk = (unsigned int)nblk;
     a.conv_w = CONV ? qc->weight : nullptr; a.conv_b = CONV ? qc->bias : nullptr; a.conv_bias_first = CONV ? qc->bias_first : 0;
     a.prep = prepared;
