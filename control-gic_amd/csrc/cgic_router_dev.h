@@ -806,7 +806,9 @@ __device__ __forceinline__ float refine_select(const RouterArgs &a, int qid, int
         const unsigned int heavy = few ? (unsigned int)__builtin_popcountll(work) : cnt[7];
         // (row bands: more than four rounds, as before; an image with a workgroup of its own (round 6: the launch's queues): more than
         // eight -- the restart and the queue's hand-offs cost ~15 us, and a band of a few rounds is done sooner where it was found)
-        if (a.rq.nq != 0 && heavy * UPP > (nb > 1 ? 4 : 8) * NWR) {      // (workgroup-uniform, and the same in every row band)
+        // (... and only a band of at most 64 members, the FEW form: a band of hundreds of mostly constant patches -- flat regions with
+        // edges -- spends its time in passes over the map that the restart would repeat: 57 us where it was found, 62 with the queues)
+        if (a.rq.nq != 0 && heavy * UPP > (nb > 1 ? 4 : 8) * NWR && (nb > 1 || few)) {      // (workgroup-uniform, and the same in every row band)
             *bail_out = true;
             __builtin_amdgcn_s_setprio(0);
             return t_a;

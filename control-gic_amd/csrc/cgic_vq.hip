@@ -147,6 +147,44 @@ __device__ __forceinline__ double wave_sum_f64(double v)
     return __builtin_bit_cast(double, ((unsigned long long)b.x << 32) | a.x) + __builtin_bit_cast(double, ((unsigned long long)b.y << 32) | a.y);
 }
 
+#ifdef CGIC_VQF_DRAIN_HANDOFF      // dev A/B: round 5's hand-off (partials in the caller's workspace, drained before the ticket)
+// Variant for the filter path, executed by ONE wave: lane 0 publishes the workgroup's partial (write-through
+// store, drained, then the ticket); the wave of the last workgroup sums all partials in a fixed order.
+__device__ __forceinline__ void finish_loss_wave(double block_sum, double *sq_partial, unsigned int *ticket, double count,
+                                                 float beta, int legacy, float *loss, unsigned int blk, unsigned int nblk)
+{
+    const int lane = lane_id();
+    int last = 0;
+    if (lane == 0) {
+#ifdef CGIC_STRICT_HANDOFF
+        // textbook form (make FLAGS+=-DCGIC_STRICT_HANDOFF): plain store, release at the ticket; for A/B runs against the
+        // write-through shortcut below on a new ROCm / GPU
+        sq_partial[blk] = block_sum;
+        last = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT) == nblk - 1;
+#else
+        __hip_atomic_store(&sq_partial[blk], block_sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        last = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == nblk - 1;
+#endif
+    }
+    last = __builtin_amdgcn_readfirstlane(last);
+    if (!last) return;
+#ifdef CGIC_STRICT_HANDOFF
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+#endif
+    // (no acquire fence: sc1 stores on the producers' side, sc1 loads here -- see finish_loss)
+    double a = 0.0;
+    for (unsigned int i = lane; i < nblk; i += kWave)
+        a += __hip_atomic_load(&sq_partial[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    a = wave_sum_f64(a);
+    if (lane == 0) {
+        const float m = (float)(a / count);
+        *loss = legacy ? (m + beta * m) : (beta * m + m);
+        __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
+    }
+}
+
+#else
 // Variant for the filter path, executed by ONE wave.  Round 6: the partials live in LIBRARY-owned, zero-on-entry slots (behind the
 // ticket: acquire_tickets) instead of the caller's workspace, and a workgroup publishes -partial -- the sum of squares is never
 // negative, so the sign bit says "written" (a +0.0 partial goes out as -0.0, a NaN stays a NaN with its sign set) -- with a
@@ -184,6 +222,7 @@ __device__ __forceinline__ void finish_loss_wave(double block_sum, double *sq_pa
     }
 }
 
+#endif
 // ZT = latent tiles (of 16 vectors) per wave; a wave owns 16*ZT vectors and scans all K codes;
 // a block owns 4 * 16 * ZT vectors.  __launch_bounds__(256, 2): a <=256-VGPR budget makes hipcc
 // pick the VGPR-destination MFMA form (no v_accvgpr_read per output).
@@ -1493,7 +1532,12 @@ static int launch_filter(const float *z, int64_t hw, int64_t N, const float *cb,
     VqArgs a;
     a.z = z; a.hw = hw; a.N = N; a.cb = cb; a.K = K; a.idx_out = idx; a.zq_out = zq;
     a.sq_partial = nullptr; a.ticket = ws.ticket; a.beta = beta; a.legacy = legacy; a.loss = loss;
+#ifdef CGIC_VQF_DRAIN_HANDOFF
+    a.sq_partial = loss ? ws.partial : nullptr;
+    if (false) {
+#else
     if (loss) {
+#endif
         // the ticket and, behind it, one 8-byte partial per workgroup: library-owned, zero when handed out, zeroed again by the launch
         // (finish_loss_wave); the caller's workspace is not touched by this path
         unsigned int *t = nullptr;

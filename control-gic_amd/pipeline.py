@@ -68,11 +68,13 @@ class HotPathPipeline:
                 continue
             thr = torch.kthvalue(v, k, dim=1).values[:, None]
             band = (v - thr).abs() <= 4e-6
+            band_all = band
             if flat8 is not None:                       # constant patches cost one evaluation per gray, not one per patch
                 f = flat8 if per_patch == 1 else torch.nn.functional.max_pool2d(torch.isnan(flat8).float()[:, None], 2)[:, 0]
                 nonconst = torch.isnan(f) if per_patch == 1 else f > 0
                 band = band & nonconst.reshape(B, -1)
-            per_image = band.sum(dim=1).float() * per_patch
+            members = band_all.sum(dim=1)                  # (the kernel takes the queues only for bands of at most 64 members)
+            per_image = band.sum(dim=1).float() * per_patch * (members <= 64).float()
             units, mean_units = max(units, int(per_image.max().item())), float(per_image.mean().item())
         # more than eight rounds of a router workgroup's eight waves in SOME image while the batch as a whole has routers to spare:
         # when every image carries about the same band, every router is busy with its own and the restart is pure cost (flat regions
