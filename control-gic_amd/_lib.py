@@ -84,6 +84,7 @@ PROTOTYPES = {
     "cgic_vq_workspace_bytes": (_sz, [_i64]),
     "cgic_conv1x1_rows_f32": (_int, [_vp, _i64, _cv, _vp, _vp]),
     "cgic_vq_prepared_bytes": (_sz, [_int]),
+    "cgic_vq_cluster_permutation_host": (_int, [_vp, _int, _vp]),
     "cgic_vq_prepare_f32": (_int, [_vp, _int, _int, _vp, _vp]),
     "cgic_vq_forward_f32": (_int, [_vp, _i64, _i64, _vp, _int, _int, _f32, _int, _vp, _vp, _vp, _vp, _vp, _cv, _vp, _vp]),
     "cgic_vq_forward_valu_f32": (_int, [_vp, _i64, _i64, _vp, _int, _int, _f32, _int, _vp, _vp, _vp, _vp, _vp, _cv, _vp]),

@@ -1868,6 +1868,16 @@ static bool cluster_permutation(const float *cb, int K, std::vector<unsigned sho
 }
 }  // namespace cgic
 
+extern "C" int cgic_vq_cluster_permutation_host(const float *codebook_host, int K, uint16_t *perm_out)
+{
+    CGIC_REQUIRE(codebook_host && perm_out, CGIC_ERR_INVALID, "vq_cluster_permutation_host: NULL argument");
+    CGIC_REQUIRE(cgic_vq_prepared_bytes(K) != 0, CGIC_ERR_UNSUPPORTED, "vq_cluster_permutation_host: K=%d has no filter path", K);
+    std::vector<unsigned short> perm;
+    if (!cluster_permutation(codebook_host, K, &perm)) return 0;
+    for (int i = 0; i < K; ++i) perm_out[i] = perm[i];
+    return 1;
+}
+
 extern "C" int cgic_vq_prepare_f32(const float *codebook, int K, int e_dim, void *prepared, cgic_stream_t stream)
 {
     CGIC_NOT_IN_GROUP("cgic_vq_prepare_f32");

@@ -188,6 +188,10 @@ size_t cgic_vq_workspace_bytes(int64_t n_vectors);
  * do not send every nearby vector to the all-K exact scan.  For that cgic_vq_prepare_f32 copies the K rows (16 KB) to the host and
  * WAITS for `stream` -- once per codebook; while `stream` is being captured it makes the plain image instead (same results). */
 size_t cgic_vq_prepared_bytes(int K);
+/* the packing itself, host only (no GPU involved; what cgic_vq_prepare_f32 computes from its host copy of the rows): perm[p] = the
+ * ORIGINAL row that sits at position p of the image.  Returns 1 and fills perm[0..K), 0 when there is nothing to pack (no two rows
+ * within 3e-4 x the largest |entry| of each other under the max-norm: the image is the plain one), CGIC_ERR_* on bad arguments. */
+int cgic_vq_cluster_permutation_host(const float *codebook_host, int K, uint16_t *perm_out);
 int cgic_vq_prepare_f32(const float *codebook, int K, int e_dim, void *prepared, cgic_stream_t stream);
 int cgic_vq_forward_f32(const float *z, int64_t B, int64_t hw, const float *codebook, int K, int e_dim,
                         float beta, int legacy, int64_t *indices, float *z_q, float *loss,

@@ -107,11 +107,31 @@ def test_spawn_ranks_helper(tmp_path):
 
 
 def _bench(args, env_extra=None, timeout=300):
+    """bench.py in a process GROUP of its own, output through files: on a timeout the whole group is killed -- ranks that bench.py
+    spawned included -- and nothing waits for a pipe a stray grandchild still holds (subprocess.run(capture_output=True, timeout=...)
+    kills the child and then blocks on exactly that)"""
+    import signal
     import subprocess
     import sys
+    import tempfile
+    import types
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     env.update(env_extra or {})
-    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, capture_output=True, text=True, timeout=timeout, env=env)
+    with tempfile.TemporaryFile("w+") as out, tempfile.TemporaryFile("w+") as err:
+        p = subprocess.Popen([sys.executable, os.path.join(ROOT, "bench.py")] + args, stdout=out, stderr=err, text=True, env=env,
+                             start_new_session=True)
+        try:
+            rc = p.wait(timeout=timeout)
+        except subprocess.TimeoutExpired:
+            os.killpg(p.pid, signal.SIGKILL)
+            p.wait()
+            rc = -9
+        try:
+            os.killpg(p.pid, signal.SIGKILL)          # (whatever the group still holds: a rank stuck in its teardown)
+        except ProcessLookupError:
+            pass
+        out.seek(0); err.seek(0)
+        return types.SimpleNamespace(returncode=rc, stdout=out.read(), stderr=err.read())
 
 
 def test_bench_spawns_its_own_ranks():
@@ -251,7 +271,7 @@ def test_bench_dry_nccl_on_the_gpu():
     the ranks of an N > 1 run are started, exercised at N = 1 on whatever box runs the GPU tests; the line names the rank's PCI bus
     id and the RCCL version"""
     import json
-    r = _bench(["--gpus", "1", "--dry-nccl", "--steps", "6", "--warmup", "2", "--no-extra", "--no-cpu-baseline"], timeout=600)
+    r = _bench(["--gpus", "1", "--dry-nccl", "--steps", "6", "--warmup", "2", "--no-extra", "--no-cpu-baseline"], timeout=240)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
     assert d["n_gpus"] == 1 and d["rccl_ranks"] == 1 and d["spawned_ranks"] is True and d["bpp_match"] is True
@@ -267,7 +287,7 @@ def test_bench_two_gpus_for_real(workload):
     import torch
     if torch.cuda.device_count() < 2:
         pytest.skip("one GPU visible")
-    r = _bench(["--gpus", "2", "--workload", workload, "--steps", "6", "--warmup", "2", "--no-extra", "--no-cpu-baseline"], timeout=900)
+    r = _bench(["--gpus", "2", "--workload", workload, "--steps", "6", "--warmup", "2", "--no-extra", "--no-cpu-baseline"], timeout=400)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
     assert d["n_gpus"] == 2 and d["rccl_ranks"] == 2 and d["timed_collectives"] == 1

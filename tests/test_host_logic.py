@@ -269,3 +269,34 @@ def test_codec_follows_the_counters_and_refuses_a_foreign_table():
         cm._codec_for(m, other)
     with pytest.raises(ValueError, match="code table"):
         cm._codec_for(m, object())
+
+
+def test_cluster_packing_fills_tiles_exactly_where_the_sizes_allow():
+    """round 6: cgic_vq_prepare_f32 packs near-duplicate rows (a trained codebook's clusters, quantize.py:22-26) into 32-code tiles;
+    the packing itself is host code (cgic_vq_cluster_permutation_host).  On the bench's clustered codebook (64 centres, cluster
+    sizes 9..25) every tile is filled to exactly 32 rows and at most 2 clusters are cut (first fit, largest first, cut 7); a
+    codebook without near-duplicates has nothing to pack; K=1024 singles + a few pairs stay whole."""
+    import ctypes
+    from control_gic_amd import _lib
+    l = _lib.lib()
+    rng = np.random.default_rng(77)
+    centres = rng.standard_normal((64, 4), dtype=np.float32)
+    assign = rng.integers(0, 64, 1024)
+    cb = (centres[assign] + np.float32(1e-4) * rng.standard_normal((1024, 4), dtype=np.float32)).astype(np.float32)
+    perm = np.zeros(1024, np.uint16)
+    rc = l.cgic_vq_cluster_permutation_host(cb.ctypes.data_as(ctypes.c_void_p), 1024, perm.ctypes.data_as(ctypes.c_void_p))
+    assert rc == 1 and sorted(perm.tolist()) == list(range(1024))
+    tile_of = np.empty(1024, np.int64)
+    tile_of[perm] = np.arange(1024) // 32
+    cut = [c for c in range(64) if len(set(tile_of[assign == c].tolist())) > 1]
+    assert len(cut) <= 2, cut
+    # nothing to pack
+    plain = np.random.default_rng(1).standard_normal((1024, 4)).astype(np.float32)
+    assert l.cgic_vq_cluster_permutation_host(plain.ctypes.data_as(ctypes.c_void_p), 1024, perm.ctypes.data_as(ctypes.c_void_p)) == 0
+    # a few duplicated rows among singles: every pair / triple ends up inside one tile
+    dup = plain.copy()
+    dup[100] = dup[7]; dup[900] = dup[7]; dup[512] = dup[33]
+    assert l.cgic_vq_cluster_permutation_host(dup.ctypes.data_as(ctypes.c_void_p), 1024, perm.ctypes.data_as(ctypes.c_void_p)) == 1
+    tile_of[perm] = np.arange(1024) // 32
+    assert tile_of[100] == tile_of[7] == tile_of[900] and tile_of[512] == tile_of[33] and sorted(perm.tolist()) == list(range(1024))
+    assert l.cgic_vq_cluster_permutation_host(None, 1024, perm.ctypes.data_as(ctypes.c_void_p)) == _lib.ERR_INVALID
