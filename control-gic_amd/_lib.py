@@ -79,6 +79,8 @@ PROTOTYPES = {
     "cgic_ticket_scope_end": (_int, []),
     "cgic_ticket_scope_release": (_int, [_int]),
     "cgic_ticket_slots_in_use": (_int, []),
+    "cgic_ticket_pool_dirty_words": (C.c_longlong, []),
+    "cgic_ticket_pool_dirty_dump": (_int, [_vp, _int]),
     "cgic_vq_stats": (_int, [_vp]),
     "cgic_vq_filter_probe_f32": (_int, [_vp, _i64, _i64, _vp, _int, _vp, _vp, _vp, _vp]),
     "cgic_vq_workspace_bytes": (_sz, [_i64]),

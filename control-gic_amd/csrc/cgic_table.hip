@@ -95,14 +95,23 @@ int acquire_tickets(hipStream_t s, int n, unsigned int **ptr, int kind)
     std::lock_guard<std::mutex> lock(g_ticket_mu);
     TicketPool &p = g_ticket_pools[2 * dev + (kind ? 1 : 0)];      // (kind 1: the router's refinement headers -- their own memory, their own contract)
     if (cap == hipStreamCaptureStatusNone) {
+        // The zero-fill has to be ORDERED in front of the first launch that uses the memory.  hipMemset() of device memory returns
+        // before the fill has run and runs on the null stream, which the (non-blocking) streams of the callers do not wait for:
+        // the first launch on a NEW stream could start ahead of its ring's fill and have its tickets wiped under it -- a lost
+        // "last workgroup" (a loss that is never written, a slot left dirty for whoever gets it next) or, for kernels whose
+        // workgroups wait for each other's flags, a launch that never ends.  Found in round 6 (tests/conftest.py checks after every
+        // GPU test that the pools are all-zero: a tiled image's shape groups on fresh parallel streams left 285 dirty words; the
+        // two fresh threads + streams of test_captured_ticket_slots_are_recycled... hung once in ~15 runs of the suite).
+        // Ring: filled on the caller's own stream (stream order).  Capture pool: filled once, then the device is synchronised.
         if (!p.chunk) {
             CGIC_HIP_TRY(hipMalloc((void **)&p.chunk, sizeof(unsigned int) * kTicketStride * kChunkSlots));
             CGIC_HIP_TRY(hipMemset(p.chunk, 0, sizeof(unsigned int) * kTicketStride * kChunkSlots));
+            CGIC_HIP_TRY(hipDeviceSynchronize());
         }
         auto &ring = p.rings[s];
         if (!ring.first) {
             CGIC_HIP_TRY(hipMalloc((void **)&ring.first, sizeof(unsigned int) * kTicketStride * kRingSlots));
-            CGIC_HIP_TRY(hipMemset(ring.first, 0, sizeof(unsigned int) * kTicketStride * kRingSlots));
+            CGIC_HIP_TRY(hipMemsetAsync(ring.first, 0, sizeof(unsigned int) * kTicketStride * kRingSlots, s));
             ring.second = 0;
         }
         if (ring.second % kRingSlots + (size_t)n > kRingSlots) ring.second += kRingSlots - ring.second % kRingSlots;   // no wrap inside a range
@@ -347,6 +356,61 @@ extern "C" int cgic_ticket_scope_release(int scope)
         kv.second.scopes.erase(it);
     }
     return freed;
+}
+
+// Test tool: how many 32-bit words of the ticket memory of the current device (kind 0: the ring of every stream that has one, and the
+// used part of the pool for captured launches) are NOT zero once the device is idle.  Every user hands its slots back all-zero, so the
+// answer is 0 whenever no launch is in flight; anything else is a slot a later launch will trip over (wrong bytes, or workgroups that
+// wait forever).  tests/conftest.py checks it after every GPU test.  Synchronises the device.
+// (dev) the first `cap` dirty words as (where, slot, word, value): where = -1 the capture pool, k >= 0 the k-th ring
+extern "C" int cgic_ticket_pool_dirty_dump(unsigned int *out4, int cap)
+{
+    int dev = 0;
+    CGIC_HIP_TRY(hipGetDevice(&dev));
+    CGIC_HIP_TRY(hipDeviceSynchronize());
+    std::lock_guard<std::mutex> lock(g_ticket_mu);
+    auto it = g_ticket_pools.find(2 * dev);
+    if (it == g_ticket_pools.end()) return 0;
+    const TicketPool &p = it->second;
+    int n = 0;
+    std::vector<unsigned int> host;
+    auto scan = [&](const unsigned int *devp, size_t slots, int where) -> int {
+        if (!devp || !slots) return CGIC_OK;
+        host.resize(slots * kTicketStride);
+        CGIC_HIP_TRY(hipMemcpy(host.data(), devp, host.size() * sizeof(unsigned int), hipMemcpyDeviceToHost));
+        for (size_t i = 0; i < host.size() && n < cap; ++i)
+            if (host[i]) { out4[4 * n] = (unsigned int)where; out4[4 * n + 1] = (unsigned int)(i / kTicketStride); out4[4 * n + 2] = (unsigned int)(i % kTicketStride); out4[4 * n + 3] = host[i]; ++n; }
+        return CGIC_OK;
+    };
+    int rc = scan(p.chunk, p.chunk_next, -1);
+    if (rc) return rc;
+    int k = 0;
+    for (const auto &kv : p.rings) { rc = scan(kv.second.first, kRingSlots, k++); if (rc) return rc; }
+    return n;
+}
+
+extern "C" long long cgic_ticket_pool_dirty_words(void)
+{
+    int dev = 0;
+    CGIC_HIP_TRY(hipGetDevice(&dev));
+    CGIC_HIP_TRY(hipDeviceSynchronize());
+    std::lock_guard<std::mutex> lock(g_ticket_mu);
+    auto it = g_ticket_pools.find(2 * dev);
+    if (it == g_ticket_pools.end()) return 0;
+    const TicketPool &p = it->second;
+    long long dirty = 0;
+    std::vector<unsigned int> host;
+    auto scan = [&](const unsigned int *devp, size_t slots) -> int {
+        if (!devp || !slots) return CGIC_OK;
+        host.resize(slots * kTicketStride);
+        CGIC_HIP_TRY(hipMemcpy(host.data(), devp, host.size() * sizeof(unsigned int), hipMemcpyDeviceToHost));
+        for (unsigned int v : host) dirty += v != 0u;
+        return CGIC_OK;
+    };
+    int rc = scan(p.chunk, p.chunk_next);
+    if (rc) return rc;
+    for (const auto &kv : p.rings) { rc = scan(kv.second.first, kRingSlots); if (rc) return rc; }
+    return dirty;
 }
 
 extern "C" int cgic_ticket_slots_in_use(void)

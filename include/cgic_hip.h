@@ -63,6 +63,11 @@ int cgic_ticket_scope_begin(void);
 int cgic_ticket_scope_end(void);
 int cgic_ticket_scope_release(int scope);
 int cgic_ticket_slots_in_use(void);
+/* test tool: synchronises the device and counts the 32-bit words of the current device's ticket memory (every stream's ring + the used
+ * part of the pool for captured launches) that are not zero -- 0 whenever nothing is in flight (every user hands its slots back zeroed);
+ * < 0: CGIC_ERR_* */
+long long cgic_ticket_pool_dirty_words(void);
+int cgic_ticket_pool_dirty_dump(unsigned int *out4, int cap);      /* (dev) the first `cap` of them as (where, slot, word, value) */
 /* Launch n captured hipGraphs in one call: graph_execs[i] (hipGraphExec_t) on streams[i] (hipStream_t), in order, back to back on the
  * calling thread.  For runtimes of several independent streams of batches (pipeline.LaneStream): from Python every launch is an
  * interpreter round trip and the last lane starts ~100 us after the first. */

@@ -50,6 +50,27 @@ def decoder_under_test(request):
         yield mode
 
 
+@pytest.fixture(autouse=True)
+def ticket_slots_come_back_zeroed(request):
+    """after every GPU test: the library's ticket memory (zero-on-entry slots that every kernel hands back zeroed) is all zero once
+    the device is idle -- a slot left dirty breaks whichever launch gets it next, possibly many tests later (wrong bytes, or
+    workgroups that wait forever): this check names the test that left it"""
+    yield
+    if "gpu" not in request.keywords:
+        return
+    import torch
+    if not torch.cuda.is_available():
+        return
+    import control_gic_amd as cg
+    dirty = cg._lib.lib().cgic_ticket_pool_dirty_words()
+    if dirty:
+        import ctypes
+        buf = (ctypes.c_uint * (4 * 48))()
+        n = cg._lib.lib().cgic_ticket_pool_dirty_dump(buf, 48)
+        where = [tuple(buf[4 * i + j] for j in range(4)) for i in range(max(n, 0))]
+        assert dirty == 0, f"{dirty} words of the ticket pools are not zero after this test: (where, slot, word, value) {where}"
+
+
 def load_golden(name):
     return dict(np.load(os.path.join(GOLDEN, name + ".npz")))
 
