@@ -826,6 +826,27 @@ __device__ __forceinline__ void wait_decoded(unsigned int *done, unsigned int ne
 // WAIT: the workgroup shares its launch with the image's decoder workgroups: everything that does not depend on the decoded
 // symbols (mask streams -> bitsets, popcount prefixes, the fine symbols consumed above the band, the codebook) runs while
 // the decoder works; the symbol counts and the symbols themselves are fetched after wait_decoded()
+// 16 / 8-byte nontemporal stores (round 6): the merge's outputs -- 7.7 MB per launch at B = 64 that nobody in this launch reads again --
+// leave as streaming stores, like the VQ launch's indices and z_q, instead of sitting dirty in the L2s until the end-of-kernel write-back
+typedef unsigned int cgic_u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int cgic_u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void nt_store16(void *p, const void *v)
+{
+#ifndef CGIC_MERGE_PLAIN_STORES
+    __builtin_nontemporal_store(*reinterpret_cast<const cgic_u32x4 *>(v), reinterpret_cast<cgic_u32x4 *>(p));
+#else
+    *reinterpret_cast<cgic_u32x4 *>(p) = *reinterpret_cast<const cgic_u32x4 *>(v);
+#endif
+}
+__device__ __forceinline__ void nt_store8(void *p, const void *v)
+{
+#ifndef CGIC_MERGE_PLAIN_STORES
+    __builtin_nontemporal_store(*reinterpret_cast<const cgic_u32x2 *>(v), reinterpret_cast<cgic_u32x2 *>(p));
+#else
+    *reinterpret_cast<cgic_u32x2 *>(p) = *reinterpret_cast<const cgic_u32x2 *>(v);
+#endif
+}
+
 template <int NT, bool WAIT = false>
 __device__ __forceinline__ void merge_body(const MergeArgs &a, const Blk blk, unsigned int *done = nullptr, unsigned int need = 0,
                                            unsigned int total = 0)
@@ -1108,8 +1129,8 @@ __device__ __forceinline__ void merge_body(const MergeArgs &a, const Blk blk, un
             v[2] = v[3] = vc + vb;
             const int64_t i = (int64_t)y * w + 4 * xq;
             if (a.mc_out && (y & 3) == 0) a.mc_out[b * n_c + j4] = bc;
-            if (a.mm_out && (y & 1) == 0) *reinterpret_cast<int2 *>(a.mm_out + b * n_m + j2) = make_int2(bma, bmb);
-            if (a.mf_out) *reinterpret_cast<int4 *>(a.mf_out + b * n_f + i) = make_int4(bfa, bfa, bfb, bfb);
+            if (a.mm_out && (y & 1) == 0) { const int2 t2 = make_int2(bma, bmb); nt_store8(a.mm_out + b * n_m + j2, &t2); }
+            if (a.mf_out) { const int4 t4 = make_int4(bfa, bfa, bfb, bfb); nt_store16(a.mf_out + b * n_f + i, &t4); }
         }
         uint32_t ftotal;
         uint32_t frank = block_exclusive_scan((bfa ? 2u : 0u) + (bfb ? 2u : 0u), scan_smem, &ftotal) + fcarry;
@@ -1127,8 +1148,8 @@ __device__ __forceinline__ void merge_body(const MergeArgs &a, const Blk blk, un
             }
             const int64_t i = (int64_t)y * w + 4 * xq;
             if (ind_out) {                                                      // sum of the three grids (:293)
-                reinterpret_cast<longlong2 *>(ind_out + i)[0] = make_longlong2(v[0], v[1]);
-                reinterpret_cast<longlong2 *>(ind_out + i)[1] = make_longlong2(v[2], v[3]);
+                nt_store16(ind_out + i, &v[0]);
+                nt_store16(ind_out + i + 2, &v[2]);
             }
             if (zq || zq2) {
 #pragma unroll
@@ -1139,10 +1160,12 @@ __device__ __forceinline__ void merge_body(const MergeArgs &a, const Blk blk, un
                 float4 e[4];
 #pragma unroll
                 for (int k = 0; k < 4; ++k) e[k] = a.stage_cb ? cbk[v[k]] : reinterpret_cast<const float4 *>(a.codebook)[v[k]];   // exact rows (:391-392)
-                *reinterpret_cast<float4 *>(zq + i) = make_float4(e[0].x, e[1].x, e[2].x, e[3].x);
-                *reinterpret_cast<float4 *>(zq + n_f + i) = make_float4(e[0].y, e[1].y, e[2].y, e[3].y);
-                *reinterpret_cast<float4 *>(zq + 2 * n_f + i) = make_float4(e[0].z, e[1].z, e[2].z, e[3].z);
-                *reinterpret_cast<float4 *>(zq + 3 * n_f + i) = make_float4(e[0].w, e[1].w, e[2].w, e[3].w);
+                const float4 o0 = make_float4(e[0].x, e[1].x, e[2].x, e[3].x), o1 = make_float4(e[0].y, e[1].y, e[2].y, e[3].y);
+                const float4 o2 = make_float4(e[0].z, e[1].z, e[2].z, e[3].z), o3 = make_float4(e[0].w, e[1].w, e[2].w, e[3].w);
+                nt_store16(zq + i, &o0);
+                nt_store16(zq + n_f + i, &o1);
+                nt_store16(zq + 2 * n_f + i, &o2);
+                nt_store16(zq + 3 * n_f + i, &o3);
             }
             if (zq2) {
                 float4 e[4];
