@@ -151,7 +151,7 @@ __device__ __forceinline__ double wave_sum_f64(double v)
 // Variant for the filter path, executed by ONE wave: lane 0 publishes the workgroup's partial (write-through
 // store, drained, then the ticket); the wave of the last workgroup sums all partials in a fixed order.
 __device__ __forceinline__ void finish_loss_wave(double block_sum, double *sq_partial, unsigned int *ticket, double count,
-                                                 float beta, int legacy, float *loss, unsigned int blk, unsigned int nblk)
+                                                 float beta, int legacy, float *loss, unsigned int blk, unsigned int nblk, unsigned int = 0)
 {
     const int lane = lane_id();
     int last = 0;
@@ -188,26 +188,18 @@ __device__ __forceinline__ void finish_loss_wave(double block_sum, double *sq_pa
 // Variant for the filter path, executed by ONE wave.  Round 6: the partials live in LIBRARY-owned, zero-on-entry slots (behind the
 // ticket: acquire_tickets) instead of the caller's workspace, and a workgroup publishes -partial -- the sum of squares is never
 // negative, so the sign bit says "written" (a +0.0 partial goes out as -0.0, a NaN stays a NaN with its sign set) -- with a
-// write-through store that it does NOT wait for before it takes its ticket: the last workgroup polls any slot that still reads zero
-// (its store was issued before the ticket that made this workgroup the last one: it is on its way), sums in the fixed order as
-// before, and hands the slots back zeroed.  Every workgroup's tail loses one memory round trip (the drain between store and ticket:
-// the launch 22.4 -> 21.9 us); the sum is the same additions in the same order: the same bits.
-__device__ __forceinline__ void finish_loss_wave(double block_sum, double *sq_partial, unsigned int *ticket, double count,
-                                                 float beta, int legacy, float *loss, unsigned int blk, unsigned int nblk)
+// write-through store that it does NOT wait for before it takes its ticket: whoever sums polls any slot that still reads zero
+// (its store was issued before its workgroup left: it is on its way), sums in the fixed order as before, and hands the slots back
+// zeroed.  The sum is the same additions in the same order whoever makes it: the same bits.
+// loss_collect: the caller is the last to arrive (one wave): wait for every partial, sum, write the loss, hand everything back zeroed
+__device__ __forceinline__ void loss_collect(unsigned long long *slots, unsigned int *ticket, double count, float beta, int legacy,
+                                             float *loss, unsigned int nblk)
 {
     const int lane = lane_id();
-    unsigned long long *slots = reinterpret_cast<unsigned long long *>(sq_partial);
-    int last = 0;
-    if (lane == 0) {
-        __hip_atomic_store(&slots[blk], __builtin_bit_cast(unsigned long long, -block_sum), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        last = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == nblk - 1;
-    }
-    last = __builtin_amdgcn_readfirstlane(last);
-    if (!last) return;
     double a = 0.0;
     for (unsigned int i = lane; i < nblk; i += kWave) {
         unsigned long long v = __hip_atomic_load(&slots[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        while (v == 0ull) {                                      // (still in flight: see above)
+        while (v == 0ull) {                                      // (still in flight, or its workgroup is still working: see above)
             __builtin_amdgcn_s_sleep(1);
             v = __hip_atomic_load(&slots[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
@@ -221,7 +213,22 @@ __device__ __forceinline__ void finish_loss_wave(double block_sum, double *sq_pa
         __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
     }
 }
-
+__device__ __forceinline__ void finish_loss_wave(double block_sum, double *sq_partial, unsigned int *ticket, double count,
+                                                 float beta, int legacy, float *loss, unsigned int blk, unsigned int nblk,
+                                                 unsigned int tail_mode = 0)
+{
+    const int lane = lane_id();
+    unsigned long long *slots = reinterpret_cast<unsigned long long *>(sq_partial);
+    int last = 0;
+    if (lane == 0) {
+        __hip_atomic_store(&slots[blk], __builtin_bit_cast(unsigned long long, -block_sum), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (tail_mode == 0) last = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == nblk - 1;
+        if (tail_mode == 2) last = blk == 0;          // the COLLECTOR: no tickets at all -- workgroup 0 waits for everybody's partial
+    }
+    last = __builtin_amdgcn_readfirstlane(last);
+    if (!last) return;
+    loss_collect(slots, ticket, count, beta, legacy, loss, nblk);
+}
 #endif
 // ZT = latent tiles (of 16 vectors) per wave; a wave owns 16*ZT vectors and scans all K codes;
 // a block owns 4 * 16 * ZT vectors.  __launch_bounds__(256, 2): a <=256-VGPR budget makes hipcc
@@ -249,6 +256,11 @@ struct VqArgs {
     // filter path: groups per workgroup.  Workgroups [0, n_early) own `g_early` groups each, the rest `g_late`
     // (router workgroups in front of a fused launch delay the VQ workgroups that have to wait for their CUs)
     unsigned int n_early, g_early, g_late;
+    // loss hand-off of the filter path: 0 = the VQ workgroups take a ticket, the last one sums (finish_loss_wave); 2 (round 6) = a VQ
+    // workgroup only PUBLISHES its partial and workgroup 0 waits for all of them and sums -- 256 returning atomics on one word at the
+    // end of every VQ workgroup were 2.3 us of the launch; 1 = dev A/B: the router workgroups of the fused launch take the ticket among
+    // themselves and the last ROUTER sums (loss_collect_by_routers: slower, the routers are the launch's tail)
+    unsigned int tail_mode;
     // quant_conv fused in front of the quantiser (model.py:51,110): z = W h (+ b), 4 -> 4, or NULL
     const float *conv_w, *conv_b;
     int conv_bias_first;
@@ -263,6 +275,25 @@ struct VqArgs {
     // the filter saw, [N, K], and per vector (f_min, margin M, threshold, flagged, scale exponent q, S) in unscaled score units
     float *probe_scores, *probe_aux;
 };
+
+#ifndef CGIC_VQF_DRAIN_HANDOFF
+// tail_mode 1, called by every thread of a ROUTER workgroup of the fused launch when its routing is done: the routers take the ticket
+// among themselves (64 atomics spread over ~1 us instead of 256 within the VQ workgroups' last microsecond) and the last one sums
+// the VQ workgroups' partials -- which were published long before in the usual launch (the routers are its tail), and are simply
+// waited for otherwise (the VQ workgroups wait for nobody)
+__device__ __forceinline__ void loss_collect_by_routers(const VqArgs &a, unsigned int nrouter)
+{
+    if (a.tail_mode != 1 || !a.sq_partial) return;
+    if (threadIdx.x >= kWave) return;
+    int last = 0;
+    if (lane_id() == 0) last = __hip_atomic_fetch_add(a.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == nrouter - 1;
+    last = __builtin_amdgcn_readfirstlane(last);
+    if (!last) return;
+    loss_collect(reinterpret_cast<unsigned long long *>(a.sq_partial), a.ticket, (double)a.N * 4.0, a.beta, a.legacy, a.loss, a.nblk);
+}
+#else
+__device__ __forceinline__ void loss_collect_by_routers(const VqArgs &, unsigned int) {}
+#endif
 
 // The reference's quant_conv is a torch.nn.Conv2d(4, 4, 1) on the CPU.  Its fp32 rounding sequence is an fma chain over
 // the input channels in order, with the bias either seeding the accumulator or added at the end -- oneDNN picks one or
@@ -1177,7 +1208,11 @@ __device__ __forceinline__ void vq_filter_body(const VqArgs &a, unsigned char *s
     if (lane == 0 && vblk < 64 && wave < 8) g_blk_t[2 * (512 + 8 * vblk + wave) + 1] = wall_clock64();
 #endif
     CGIC_STAMP(5);
+#ifdef CGIC_VQF_NO_TAIL           // dev: no reduction, no barrier, no hand-off (the loss is garbage): what the tail costs
+    if (false) {
+#else
     if (a.sq_partial) {
+#endif
         // Only wave 0 stays for the hand-off: the other waves leave at the barrier WITHOUT draining their z_q /
         // index stores (an s_waitcnt vmcnt(0) in every wave before the barrier cost ~4 us at the end of every
         // workgroup); wave 0's own stores are long complete by the time it has waited for the others.
@@ -1188,7 +1223,11 @@ __device__ __forceinline__ void vq_filter_body(const VqArgs &a, unsigned char *s
             double bs = 0.0;
 #pragma unroll
             for (int w = 0; w < NW; ++w) bs += s_wsum[w];
-            finish_loss_wave(bs, a.sq_partial, a.ticket, (double)N * 4.0, a.beta, a.legacy, a.loss, vblk, a.nblk);
+#ifndef CGIC_VQF_NO_HANDOFF      // dev: reduction + barrier, but no store / ticket / last-workgroup sum
+            finish_loss_wave(bs, a.sq_partial, a.ticket, (double)N * 4.0, a.beta, a.legacy, a.loss, vblk, a.nblk, a.tail_mode);
+#else
+            if (bs == 12345.678) a.loss[0] = (float)bs;
+#endif
         }
     }
     CGIC_STAMP(6);
@@ -1254,6 +1293,7 @@ __global__ CGIC_VQF_BOUNDS void vq_filter_router_kernel(VqArgs a, RouterArgs r, 
         __builtin_amdgcn_s_setprio(CGIC_ROUTER_PRIO);
 #endif
         router_body<kVqfThreads, false, SPLIT>(r, (int64_t)(blockIdx.x - rb), smem_f);
+        loss_collect_by_routers(a, nrouter);
         return;
     }
     vq_filter_body<kVqfThreads, ALIGNED, CONV>(a, smem_f, blockIdx.x - vb);
@@ -1266,6 +1306,7 @@ __global__ CGIC_VQF_BOUNDS void vq_filter_router_perm_kernel(VqArgs a, RouterArg
     const unsigned int rb = router_behind ? a.nblk : 0u, vb = router_behind ? 0u : nrouter;
     if (blockIdx.x - rb < nrouter) {
         router_body<kVqfThreads>(r, (int64_t)(blockIdx.x - rb), smem_f);
+        loss_collect_by_routers(a, nrouter);
         return;
     }
     vq_filter_body<kVqfThreads, ALIGNED, false, false, true>(a, smem_f, blockIdx.x - vb);
@@ -1287,6 +1328,7 @@ __global__ CGIC_VQF_BOUNDS void vq_filter_router_grouped_kernel(Grouped<VqfrArgs
     const unsigned int rb = p.router_behind ? p.a.nblk : 0u, vb = p.router_behind ? 0u : p.nrouter;
     if (blk.x - rb < p.nrouter) {
         router_body<kVqfThreads, false, SPLIT>(p.r, (int64_t)(blk.x - rb), smem_f);
+        loss_collect_by_routers(p.a, p.nrouter);
         return;
     }
     vq_filter_body<kVqfThreads, ALIGNED, false>(p.a, smem_f, blk.x - vb);
@@ -1468,7 +1510,7 @@ static int launch_mfma(const float *z, int64_t hw, int64_t N, const float *cb, i
     a.z = z; a.hw = hw; a.N = N; a.cb = cb; a.K = K; a.idx_out = idx; a.zq_out = zq;
     a.sq_partial = loss ? ws.partial : nullptr; a.ticket = ws.ticket; a.beta = beta; a.legacy = legacy; a.loss = loss;
     a.nblk = (unsigned int)((N + per_block - 1) / per_block);
-    a.n_early = a.g_early = a.g_late = 0; a.conv_w = a.conv_b = nullptr; a.conv_bias_first = 0; a.prep = nullptr; a.stats = nullptr; a.probe_scores = a.probe_aux = nullptr;
+    a.n_early = a.g_early = a.g_late = 0; a.tail_mode = 0; a.conv_w = a.conv_b = nullptr; a.conv_bias_first = 0; a.prep = nullptr; a.stats = nullptr; a.probe_scores = a.probe_aux = nullptr;
     size_t lds = sizeof(float) * (size_t)K * 5;
     if (!router) {
         int rc = ensure_dynamic_lds((const void *)vq_mfma_kernel<ZT>, lds);
@@ -1547,6 +1589,13 @@ static int launch_filter(const float *z, int64_t hw, int64_t N, const float *cb,
         a.sq_partial = reinterpret_cast<double *>(t + kTicketStride);
     }
     a.nblk = (unsigned int)nblk;
+#if defined(CGIC_VQF_ROUTER_TAIL)
+    a.tail_mode = (router && loss) ? 1u : 0u;       // dev A/B: the routers sum the loss
+#elif !defined(CGIC_VQF_TICKET_TAIL) && !defined(CGIC_VQF_DRAIN_HANDOFF)
+    a.tail_mode = loss ? 2u : 0u;                   // workgroup 0 collects (VqArgs::tail_mode)
+#else
+    a.tail_mode = 0u;
+#endif
     a.conv_w = CONV ? qc->weight : nullptr; a.conv_b = CONV ? qc->bias : nullptr; a.conv_bias_first = CONV ? qc->bias_first : 0;
     a.prep = prepared;
     a.stats = g_vq_stats.load(std::memory_order_relaxed);
@@ -1708,7 +1757,7 @@ extern "C" int cgic_vq_filter_probe_f32(const float *z, int64_t B, int64_t hw, c
     a.z = z; a.hw = hw; a.N = N; a.cb = codebook; a.K = K; a.idx_out = indices; a.zq_out = nullptr;
     a.sq_partial = nullptr; a.ticket = nullptr; a.beta = 0.f; a.legacy = 1; a.loss = nullptr;
     a.nblk = (unsigned int)nblk; a.n_early = (unsigned int)nblk; a.g_early = a.g_late = (unsigned int)per;
-    a.conv_w = a.conv_b = nullptr; a.conv_bias_first = 0; a.prep = nullptr; a.stats = nullptr;
+    a.tail_mode = 0; a.conv_w = a.conv_b = nullptr; a.conv_bias_first = 0; a.prep = nullptr; a.stats = nullptr;
     a.probe_scores = scores; a.probe_aux = aux;
     const size_t lds = vqf_lds_bytes(K);
     hipStream_t s = (hipStream_t)stream;
