@@ -620,6 +620,32 @@ def test_refinement_queues_change_nothing_and_survive_concurrent_launches():
         _lib.REFINE_QUEUES = True
 
 
+def test_vq_loss_collector_on_sixteen_streams_at_once():
+    """The VQ launch's loss: every workgroup stores its partial, workgroup 0 of the launch collects them (no ticket; cgic_vq.hip
+    loss_collect).  Launches of many streams in flight together -- more streams than hardware queues, launches of a few workgroups
+    and of thousands, eager -- give the loss, indices and z_q of the same call alone, bit for bit, and hand every slot back zeroed."""
+    from control_gic_amd import _lib
+    from control_gic_amd.quantize import _vq_forward
+    rng = np.random.default_rng(2026)
+    w = _t(rng.standard_normal((1024, 4), dtype=np.float32))
+    shapes = [(1, 4, 16, 16), (3, 4, 40, 24), (64, 4, 64, 64), (16, 4, 192, 192)]
+    zs = [_t(rng.standard_normal(sh, dtype=np.float32)) for sh in shapes]
+    alone = [_vq_forward(z, w, 0.25, True, None) for z in zs]
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream() for _ in range(16)]
+    outs = []
+    for rnd in range(12):
+        for k, st in enumerate(streams):
+            i = (rnd + k) % len(zs)
+            with torch.cuda.stream(st):
+                outs.append((i, _vq_forward(zs[i], w, 0.25, True, None)))
+    torch.cuda.synchronize()
+    for i, (zq, loss, idx) in outs:
+        assert torch.equal(idx, alone[i][2]) and torch.equal(zq, alone[i][0])
+        assert loss.view(torch.int32).item() == alone[i][1].view(torch.int32).item(), (i, float(loss), float(alone[i][1]))
+    assert _lib.lib().cgic_ticket_pool_dirty_words() == 0
+
+
 def test_row_bands_split_a_band_in_the_fused_launch():
     """The fused VQ + router launch has no refinement queues; the row bands of a large tile (up to eight workgroups that all find
     the same band) split its re-evaluation between them instead -- FEW: by a hash of the patch index, MANY: every nb-th member in
