@@ -47,7 +47,40 @@ struct SelInfo {
     unsigned int digit, before;
 };
 
-template <int NT, typename F>
+// A lane's pending run of equal digits (see the comment in radix_select's counting loop), for callers that count a select's FIRST pass
+// inside a sweep of their own (router_team: the medium map is masked and its exponent byte counted in one go -- COUNTED0 below).
+struct RunCount {
+    unsigned int run_d = 0, run_n = 0;
+    __device__ __forceinline__ void take(unsigned int *h, unsigned int digit)
+    {
+        if (digit != run_d && run_n) { atomicAdd(&h[run_d], run_n); run_n = 0; }
+        run_d = digit;
+        ++run_n;
+    }
+    // pass 0 (the exponent byte): lanes that share the first pending lane's digit hand their counts to it, twice; then what is left
+    __device__ __forceinline__ void finish_pass0(unsigned int *h, int lane);
+    __device__ __forceinline__ void finish(unsigned int *h) { if (run_n) atomicAdd(&h[run_d], run_n); run_n = 0; }
+};
+
+__device__ __forceinline__ void RunCount::finish_pass0(unsigned int *h, int lane)
+{
+#pragma unroll 1
+    for (int round = 0; round < 2; ++round) {
+        const unsigned long long pend = __ballot(run_n != 0);
+        if (!pend) break;
+        const int first = __builtin_ctzll(pend);
+        const unsigned int d0 = (unsigned int)__builtin_amdgcn_readlane((int)run_d, first);
+        const bool same = run_n != 0 && run_d == d0;
+        const unsigned int tot = wave_inclusive_scan_u32(same ? run_n : 0u);
+        const unsigned int all = (unsigned int)__builtin_amdgcn_readlane((int)tot, 63);
+        if (lane == first) atomicAdd(&h[d0], all);
+        if (same) run_n = 0;
+    }
+    finish(h);
+}
+
+// COUNTED0: the caller has counted pass 0 (the top key byte of every element) into hist[0], cleared hist[1], and passed a barrier
+template <int NT, bool COUNTED0 = false, typename F>
 __device__ float radix_select(F val, int64_t n, unsigned int rank0, RouterShared *sh, SelInfo *info = nullptr)
 {
     const int tid = threadIdx.x;
@@ -57,6 +90,7 @@ __device__ float radix_select(F val, int64_t n, unsigned int rank0, RouterShared
 #pragma unroll 1
     for (int shift = 24; shift >= 0; shift -= 8, ++pass) {
         unsigned int *h = sh->hist[pass];
+        if (!(COUNTED0 && pass == 0)) {
         // Same-address LDS atomics serialise across the whole workgroup, and entropy values crowd into 2-3 bins of a pass
         // (all of them in the exponent byte): at 9216 values per 768x768 tile a pass spent ~4 us incrementing ONE
         // counter.  Every lane therefore merges equal digits of its own consecutive slots before it touches LDS: a
@@ -106,6 +140,7 @@ __device__ float radix_select(F val, int64_t n, unsigned int rank0, RouterShared
             for (int i = tid; i < 256; i += NT) hz[i] = 0;
         }
         __syncthreads();
+        }
         // every wave: lane handles 4 consecutive digits; find the digit holding `rank`
         // (a router wave of the fused launch only gets the issue slots the VQ workgroup on its CU leaves over: what counts below is
         // the length of the dependent chain -- one 16-byte LDS read, a DPP scan, mask arithmetic, v_readlane -- not the lane count)
@@ -1276,7 +1311,9 @@ __device__ __forceinline__ int router_team(const RouterArgs &a, int64_t blk, uns
         if (lane == 0) gc_bits[i >> 6] = bal;
         if (i < N16 && band == 0) mc[i] = g ? 1 : 0;
     }
-    __syncthreads();
+    // (both maps staged, mode 0: the sweep that masks the medium map takes the coarse gate from the coarse map itself, not from
+    // these bits -- nothing reads them before that sweep's barrier)
+    if (!(ST && mode == 0)) __syncthreads();
     // 32-bit index math throughout (N8 < 2^31 is checked on the host): a 64-bit divide is ~100 instructions
     const int n8i = (int)n8, w8i = (int)w8, n16i = (int)n16, w16i = (int)w16;
     // n / d as one v_mul_hi_u32 with m = ceil(2^32 / d): exact while n * d < 2^32 (n < 2^31 / 4 here, d <= 2^13: the host checks);
@@ -1314,6 +1351,36 @@ __device__ __forceinline__ int router_team(const RouterArgs &a, int64_t blk, uns
             // (v < thr) && !gate_coarse whatever v is -- 4 N8 bytes of LDS less.)
             float *l8m = const_cast<float *>(e8);
             __attribute__((address_space(3))) float *l8w = (__attribute__((address_space(3))) float *)l8m;
+            SelInfo si;
+            if constexpr (ST) {
+                // One sweep: the parent's gate straight from the coarse map (the same comparison the gate bits were made with), the
+                // masked value back into the copy, and its exponent byte counted -- the select's first pass.  Two barriers and a pass
+                // over the map less than gate bits | barrier | mask | barrier | pass 0: each is 1.2-1.7 us of dependent latency for a
+                // router that shares its SIMDs with the VQ waves, and the routers are the fused launch's tail.
+                // (hist[0] is clear: the coarse select's last pass did that, in front of its barrier.)
+                unsigned int *h0 = sh->hist[0];
+                RunCount rc;
+                auto one = [&](int at, int parent) {
+                    const float g = rd16(parent) < thr_c ? 1.0f : 0.0f;
+                    const float m = l8w[at] * (1.0f - g);
+                    l8w[at] = m;
+                    rc.take(h0, f2key(m) >> 24);
+                };
+                if (rows2d) {
+                    for (int y = wv; y < (int)h8; y += NWV)
+                        for (int x = lane; x < w8i; x += 64) one(y * w8i + x, (y >> 1) * w16i + (x >> 1));
+                } else {
+                    for (int i = tid; i < (int)N8; i += NT) {
+                        const int b = fdiv(i, mg_n8, n8i), r = i - b * n8i;
+                        const int y = fdiv(r, mg_w8, w8i), x = r - y * w8i;
+                        one(i, b * n16i + (y >> 1) * w16i + (x >> 1));
+                    }
+                }
+                rc.finish_pass0(h0, lane);
+                for (int i = tid; i < 256; i += NT) sh->hist[1][i] = 0;
+                __syncthreads();
+                thr_m = radix_select<NT, true>(rd8, N8, a.rank_m, sh, &si);
+            } else {
             if (rows2d) {
                 for (int y = wv; y < (int)h8; y += NWV)
                     for (int x = lane; x < w8i; x += 64) l8w[y * w8i + x] = l8w[y * w8i + x] * (1.0f - (gc_at(0, y, x) ? 1.0f : 0.0f));
@@ -1321,8 +1388,8 @@ __device__ __forceinline__ int router_team(const RouterArgs &a, int64_t blk, uns
                 for (int64_t i = tid; i < N8; i += NT) l8w[i] = l8w[i] * (1.0f - (gc_of8(i) ? 1.0f : 0.0f));
             }
             __syncthreads();
-            SelInfo si;
             thr_m = radix_select<NT>(rd8, N8, a.rank_m, sh, &si);        // (stage 2: the masked copy through the generic pointer)
+            }
             if constexpr (ST) if (refine)       // (a gated element's 0 is exact: never re-evaluated, never overwritten)
                 thr_m = refine_select<NT, 8, HELP, SPLIT, BAIL>(a, (int)(2 * seg + 1), nb, band, l8m, (int)N8, a.rank_m, thr_m,
                                              ExactGate{gc_bits, n8i, w8i, n16i, w16i, mg_n8, mg_w8}, seg * a.per, w8i, n8i, rs, sh, si, &bail, &refined);

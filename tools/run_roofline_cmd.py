@@ -15,7 +15,16 @@ hp = bench.HotPath(dev, x, z, cb, (0.1, 0.8))
 e8, e16 = cg.entropy_maps(hp.x)
 w, prep = hp.vq.embedding.weight, hp.pipe.prepared
 which = sys.argv[1] if len(sys.argv) > 1 else "fused"
-fn = (lambda: vq_forward_route(hp.z, w, 0.25, True, e16, e8, 0.1, 0.8, prepared=prep, pixels=hp.x)) if which == "fused" else \
-     (lambda: _vq_forward(hp.z, w, 0.25, True, None, prepared=prep))
+if which == "fused":
+    fn = lambda: vq_forward_route(hp.z, w, 0.25, True, e16, e8, 0.1, 0.8, prepared=prep, pixels=hp.x)
+elif which == "router":            # the stand-alone router launch on the same batch (refinement from the pixels)
+    fn = lambda: hp.router(e16, e8, want_gate=False, pixels=hp.x)
+elif which == "router768":         # ... on eight 768x768 tiles (eight row bands each)
+    import numpy as np
+    xt = torch.from_numpy(np.random.default_rng(3).random((8, 3, 768, 768), dtype=np.float32)).to(dev)
+    t8, t16 = cg.entropy_maps(xt)
+    fn = lambda: hp.router(t16, t8, want_gate=False, pixels=xt)
+else:
+    fn = lambda: _vq_forward(hp.z, w, 0.25, True, None, prepared=prep)
 t = bench.graph_kernel_time(fn)
 print(f"{which}: HIP events, 20 launches per graph x 5 replays: {t:.2f} us per launch", flush=True)
