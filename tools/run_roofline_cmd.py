@@ -17,6 +17,8 @@ w, prep = hp.vq.embedding.weight, hp.pipe.prepared
 which = sys.argv[1] if len(sys.argv) > 1 else "fused"
 if which == "fused":
     fn = lambda: vq_forward_route(hp.z, w, 0.25, True, e16, e8, 0.1, 0.8, prepared=prep, pixels=hp.x)
+elif which == "fusedplain":        # ... without the pixels: no refinement (what the band evaluation of the batch's one or two images costs the launch)
+    fn = lambda: vq_forward_route(hp.z, w, 0.25, True, e16, e8, 0.1, 0.8, prepared=prep, pixels=None)
 elif which == "router":            # the stand-alone router launch on the same batch (refinement from the pixels)
     fn = lambda: hp.router(e16, e8, want_gate=False, pixels=hp.x)
 elif which == "router768":         # ... on eight 768x768 tiles (eight row bands each)
