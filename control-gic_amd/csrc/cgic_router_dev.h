@@ -47,6 +47,14 @@ struct SelInfo {
     unsigned int digit, before;
 };
 
+// What the first attempt of a two-attempt launch (router_body) hands to the second when it leaves at its COARSE select: both staged maps
+// are untouched in LDS, the approximate threshold and the select's last histogram are what the second attempt would compute again
+struct RouterResume {
+    int at;                     // 0: start from the top; 1: the coarse select's approximate threshold is `thr`, `si` describes its last pass
+    float thr;
+    SelInfo si;
+};
+
 // A lane's pending run of equal digits (see the comment in radix_select's counting loop), for callers that count a select's FIRST pass
 // inside a sweep of their own (router_team: the medium map is masked and its exponent byte counted in one go -- COUNTED0 below).
 struct RunCount {
@@ -480,10 +488,12 @@ static __device__ __forceinline__ bool refine_help_wave(const RoundCtx &c, float
 
 // The waves of a router workgroup that is done evaluate other images' band patches while a router holds a band open (stand-alone
 // launch).  `tl`: the workgroup's evaluator LDS (bins are set).  Waves beyond the LDS scratch leave at once.
-__device__ __forceinline__ void refine_help_while_busy(const RouterArgs &a, RefineTeamLds *tl)
+// max_waves: how many waves of this workgroup look for work (every claim is a fetch-and-add on the queue's one word: the eight waves of
+// each of a launch's ~60 finished routers, all after the same few dozen items, spent more time in line at that word than evaluating)
+__device__ __forceinline__ void refine_help_while_busy(const RouterArgs &a, RefineTeamLds *tl, int max_waves = kRefWavesMax)
 {
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    if (wave >= kRefWavesMax) return;
+    if (wave >= kRefWavesMax || wave >= max_waves) return;
     const RoundCtx c = round_ctx(a);
 #pragma unroll 1
     for (;;) {
@@ -532,7 +542,7 @@ struct ExactGate {
 template <int NT, int P, bool RQ, bool SPLIT, bool BAIL = false>
 __device__ __forceinline__ float refine_select(const RouterArgs &a, int qid, int nb, int band, float *arr, int n, unsigned int rank, float t_a,
                                                        ExactGate is_exact, int64_t img0, int wP, int nP, RefineShared *rs_, RouterShared *sh,
-                                                       const SelInfo &si, bool *bail_out = nullptr, bool *refined_out = nullptr)
+                                                       const SelInfo &si, bool *bail_out = nullptr, bool *refined_out = nullptr, bool precounted = false)
 {
     RefineShared *rs = rs_;
     const RefineSrc &rf = a.rf;
@@ -543,6 +553,9 @@ __device__ __forceinline__ float refine_select(const RouterArgs &a, int qid, int
     const int tid = threadIdx.x, lane = lane_id(), wave = tid >> 6;
     const float w = 2.f * refine_delta(t_a + kRefineBand);
     CGIC_RE_STAMP(0);
+    // (precounted: the first attempt of a two-attempt launch left at this select AFTER the count below -- the counters and the list of
+    // the first 64 members are as it left them, router_team did not reset them)
+    if (!precounted) {
     // 0. The usual image leaves here WITHOUT a pass over the map and without a barrier: the select's last pass counted the low
     // key byte of everything that shares the threshold's upper 24 key bits, and a band of +-4e-6 around a value in [0.13, 4) is
     // at most +-250 such steps -- when both band edges share those 24 bits with the threshold (most of the time for values
@@ -615,6 +628,7 @@ __device__ __forceinline__ float refine_select(const RouterArgs &a, int qid, int
         for (int d = 32; d >= 1; d >>= 1) below += __shfl_xor(below, d, kWave);
         if (lane == 0 && below) atomicAdd(&cnt[3], below);
         if (minx) atomicAdd(&cnt[1], minx);
+    }
     }
     __syncthreads();
     CGIC_RE_STAMP(2);
@@ -1177,7 +1191,7 @@ __device__ __forceinline__ float refine_select(const RouterArgs &a, int qid, int
 // launch's second attempt (router_body): even this much more code in the router's one path costs its ordinary path 2-3 us
 // (B = 64 x 256x256: 23.4 -> 26.5 us).  BAIL: the first attempt of such a launch (returns true when it left for the second).
 template <int NT, bool ST, bool HELP, bool SPLIT, bool BAIL>
-__device__ __forceinline__ int router_team(const RouterArgs &a, int64_t blk, unsigned char *dyn);
+__device__ __forceinline__ int router_team(const RouterArgs &a, int64_t blk, unsigned char *dyn, unsigned int pre_held = 0, RouterResume *res = nullptr);
 
 // A SPLIT launch runs the router in two attempts: first the plain instantiation, which leaves (BAIL) as soon as a select's band is
 // more than four rounds of work -- before anything but the coarse mask is written, and that is written again with the same values --
@@ -1199,7 +1213,13 @@ __device__ __forceinline__ void router_body(const RouterArgs &a, int64_t blk, un
 {
     if (a.stage == 1) {
         if constexpr (SPLIT) {
+            RouterResume rr;
+            rr.at = 0; rr.thr = 0.f; rr.si.h = nullptr; rr.si.digit = 0; rr.si.before = 0;
+#ifdef CGIC_FUSED_Q_NORESUME      // dev A/B: the second attempt starts from the top
             const int how = router_team<NT, true, false, false, true>(a, blk, dyn);
+#else
+            const int how = router_team<NT, true, false, false, true>(a, blk, dyn, 0u, &rr);
+#endif
             if (how != 1) {
                 // Done in the plain code.  One image per workgroup (round 6): the images of the launch whose bands ARE long have
                 // started over with the refinement queues -- while any of them holds a band open, the waves of a workgroup that had
@@ -1207,12 +1227,23 @@ __device__ __forceinline__ void router_body(const RouterArgs &a, int64_t blk, un
                 // ordinary image (how == 0: no band) leaves at once -- the look at the board is a memory round trip at the very end
                 // of the launch's critical path (measured: +1.9 us on every launch when every router took it).
 #ifndef CGIC_FUSED_Q_NOAFTER
+#ifdef CGIC_FUSED_Q_REFINERS_ONLY      // dev A/B: only the routers that refined look at the board (the form of the first half of round 6)
                 if (how == 2 && a.bands <= 1 && a.rq.nq != 0 && a.rf.x != nullptr) {
+#else
+                // (a launch WITH queues is one the caller chose for tie-heavy batches -- pipeline.HotPathPipeline.decide: there every
+                // router looks, and an image that starts over says so on the board BEFORE it does (below): the ordinary images'
+                // routers are done 2-3 us before its list is out and used to be gone by then -- smooth 8-bit batches: two images of
+                // 64 with 30-40 patches each and ~12 helpers that arrived 5-15 us late)
+                if (a.bands <= 1 && a.rq.nq != 0 && a.rf.x != nullptr) {
+#endif
                     RefineShared *rs = router_refine_shared(a, dyn);
                     __syncthreads();
                     if (threadIdx.x == 0) rs->flag = ld_sc1(a.rq.board + QB_BUSY);
                     __syncthreads();
-                    if (rs->flag) refine_help_while_busy(a, &rs->tl);
+#ifndef CGIC_FUSED_HELP_WAVES
+#define CGIC_FUSED_HELP_WAVES 2
+#endif
+                    if (rs->flag) refine_help_while_busy(a, &rs->tl, how == 2 ? kRefWavesMax : CGIC_FUSED_HELP_WAVES);
                 }
 #endif
                 return;
@@ -1224,7 +1255,14 @@ __device__ __forceinline__ void router_body(const RouterArgs &a, int64_t blk, un
             router_team<NT, true, false, true, false>(a, blk, dyn);
 #else
             if (a.bands > 1) router_team<NT, true, false, true, false>(a, blk, dyn);
-            else router_team<NT, true, true, false, false>(a, blk, dyn);
+            else {
+#ifndef CGIC_FUSED_Q_REFINERS_ONLY
+                if (threadIdx.x == 0) add_sc1(a.rq.board + QB_BUSY, 1u);        // held until this image's last select (router_team: busy_held)
+                router_team<NT, true, true, false, false>(a, blk, dyn, 1u, &rr);
+#else
+                router_team<NT, true, true, false, false>(a, blk, dyn);
+#endif
+            }
 #endif
         } else {
             router_team<NT, true, HELP, false, false>(a, blk, dyn);
@@ -1236,7 +1274,7 @@ __device__ __forceinline__ void router_body(const RouterArgs &a, int64_t blk, un
 
 // (returns 1 when it left early -- BAIL only --, 2 when it finished and one of its selects evaluated a band from the pixels, else 0)
 template <int NT, bool ST, bool HELP, bool SPLIT, bool BAIL>
-__device__ __forceinline__ int router_team(const RouterArgs &a, int64_t blk, unsigned char *dyn)
+__device__ __forceinline__ int router_team(const RouterArgs &a, int64_t blk, unsigned char *dyn, unsigned int pre_held, RouterResume *res)
 {
     const int nb = a.bands > 1 ? a.bands : 1;
     const int64_t seg = blk / nb;
@@ -1259,22 +1297,25 @@ __device__ __forceinline__ int router_team(const RouterArgs &a, int64_t blk, uns
     const float *e16 = a.e16 + seg * N16;
     const float *e8 = a.e8 + seg * N8;
     RefineShared *rs = nullptr;
-    for (int i = tid; i < 256; i += NT) sh->hist[0][i] = 0;        // (radix_select: the first select's first buffer)
+    // (second attempt after a first one that left at its coarse select: the maps' copies, that select's last histogram and hist[0],
+    // cleared by its last pass, are as it left them)
+    const bool resume = !BAIL && ST && res != nullptr && res->at == 1;
+    if (!resume) for (int i = tid; i < 256; i += NT) sh->hist[0][i] = 0;        // (radix_select: the first select's first buffer)
     if (!a.stage) __syncthreads();
     if (a.stage) {
         // one round trip to HBM/L2 instead of one per radix pass (8 passes + 3 elementwise sweeps)
         float *l16 = reinterpret_cast<float *>(gc_bits + ((N16 + 63) >> 6));
         float *l8 = a.stage == 1 ? l16 + N16 : l16;               // stage 2: e16 stays in global memory
         if (a.stage == 1) {
-            for (int64_t i = tid; i < N16; i += NT) l16[i] = e16[i];
+            if (!resume) for (int64_t i = tid; i < N16; i += NT) l16[i] = e16[i];
             e16 = l16;
         }
-        for (int64_t i = tid; i < N8; i += NT) l8[i] = e8[i];
+        if (!resume) for (int64_t i = tid; i < N8; i += NT) l8[i] = e8[i];
         e8 = l8;
         if (a.rf.x) {
             rs = reinterpret_cast<RefineShared *>((reinterpret_cast<uintptr_t>(l8 + N8) + 15) & ~(uintptr_t)15);
-            if (tid < 16) rs->cnt[tid] = 0;
-            if (tid == 0) rs->busy_held = 0;
+            if (tid < 16 && !(resume && tid < 8)) rs->cnt[tid] = 0;       // (resume: the coarse select's counts stay, see refine_select's `precounted`)
+            if (tid == 0) rs->busy_held = pre_held;          // (router_body: a second attempt announced itself on the board before it started over)
             if (tid < kBins) rs->tl.bins[tid] = linspace_bin(tid);
         }
         __syncthreads();
@@ -1295,11 +1336,15 @@ __device__ __forceinline__ int router_team(const RouterArgs &a, int64_t blk, uns
     float thr_c = 0.f;
     if (has_thr_c) {
         SelInfo si;
-        thr_c = radix_select<NT>(rd16, N16, a.rank_c, sh, &si);
+        if (resume) { thr_c = res->thr; si = res->si; }
+        else thr_c = radix_select<NT>(rd16, N16, a.rank_c, sh, &si);
         if constexpr (ST) if (refine)
             thr_c = refine_select<NT, 16, HELP, SPLIT, BAIL>(a, (int)(2 * seg), nb, band, const_cast<float *>(e16), (int)N16, a.rank_c, thr_c, ExactGate{nullptr, 0, 0, 0, 0, 0, 0},
-                                          seg * a.per, (int)w16, (int)n16, rs, sh, si, &bail, &refined);
-        if (BAIL && bail) return 1;
+                                          seg * a.per, (int)w16, (int)n16, rs, sh, si, &bail, &refined, resume);
+        if (BAIL && bail) {
+            if (res) { res->at = 1; res->thr = thr_c; res->si = si; }       // (refine_select returned the approximate threshold as it got it)
+            return 1;
+        }
     }
     CGIC_STAMP(2);
     CGIC_RT_STAMP(1);

@@ -58,7 +58,7 @@ class HotPathPipeline:
         c, m = float(self.router.coarse_grain_ratio), float(self.router.medium_grain_ratio)
         units, mean_units = 0, 0.0
         # (the COARSE band decides: 16x16 patches are four units each, and a long coarse band -- the nearly constant patches of smooth
-        # content -- is where the queues pay, 71 -> 59 us per launch; a long MEDIUM band of 8x8 edge patches (flat regions with edges)
+        # content -- is where the queues pay, 71 -> 50 us per launch; a long MEDIUM band of 8x8 edge patches (flat regions with edges)
         # is done sooner where it was found: 57 us against 62 with the restart and the queue's hand-offs)
         for e, ratio, per_patch in ((e16, c, 4),):
             B = e.shape[0]

@@ -152,7 +152,7 @@ def vq_forward_route(z, weight, beta, legacy, e16, e8, coarse_ratio, medium_rati
     refinement (router.TripleGrainFixedEntropyRouter.forward); flat8: its constant-patch map (default: the one entropy_maps
     left on the maps).  refine_queues (images with a router workgroup of their own: per_image, up to 32x32 patches): True -- an image
     whose threshold band is long starts over with the launch's refinement queues and the routers that are done help (tie-heavy
-    batches: 71 -> 59 us on smooth 8-bit content; that kernel variant costs the ordinary launch ~1.5 us alone); None: the process
+    batches: 71 -> 50 us on smooth 8-bit content; that kernel variant costs the ordinary launch ~2 us alone); None: the process
     default (_lib.REFINE_FUSED_QUEUES, off); pipeline.HotPathPipeline decides per stream of batches.  Same masks either way."""
     import ctypes
     _lib.require_device(z, weight, e16, e8)
