@@ -857,7 +857,12 @@ __device__ __forceinline__ float refine_select(const RouterArgs &a, int qid, int
         // eight -- the restart and the queue's hand-offs cost ~15 us, and a band of a few rounds is done sooner where it was found)
         // (... and only a band of at most 64 members, the FEW form: a band of hundreds of mostly constant patches -- flat regions with
         // edges -- spends its time in passes over the map that the restart would repeat: 57 us where it was found, 62 with the queues)
-        if (a.rq.nq != 0 && heavy * UPP > (nb > 1 ? 4 : 8) * NWR && (nb > 1 || few)) {      // (workgroup-uniform, and the same in every row band)
+#ifdef CGIC_FUSED_Q_MANY        // dev A/B: long bands of more than 64 members of an image with a workgroup of its own go to the queues too
+        const bool many_ok = true;
+#else
+        const bool many_ok = false;
+#endif
+        if (a.rq.nq != 0 && heavy * UPP > (nb > 1 ? 4 : 8) * NWR && (nb > 1 || few || many_ok)) {      // (workgroup-uniform, and the same in every row band)
             *bail_out = true;
             __builtin_amdgcn_s_setprio(0);
             return t_a;
