@@ -862,7 +862,10 @@ __device__ __forceinline__ float refine_select(const RouterArgs &a, int qid, int
 #else
         const bool many_ok = false;
 #endif
-        if (a.rq.nq != 0 && heavy * UPP > (nb > 1 ? 4 : 8) * NWR && (nb > 1 || few || many_ok)) {      // (workgroup-uniform, and the same in every row band)
+#ifndef CGIC_FUSED_Q_ROUNDS
+#define CGIC_FUSED_Q_ROUNDS 8
+#endif
+        if (a.rq.nq != 0 && heavy * UPP > (nb > 1 ? 4 : CGIC_FUSED_Q_ROUNDS) * NWR && (nb > 1 || few || many_ok)) {      // (workgroup-uniform, and the same in every row band)
             *bail_out = true;
             __builtin_amdgcn_s_setprio(0);
             return t_a;
